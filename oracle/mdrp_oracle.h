@@ -1,0 +1,90 @@
+/* mdrp_oracle.h — CPU restatement of the RePoseD RANSAC hot path (PoseLib 2.0.5 monodepth estimators).
+ *
+ * TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported baseline — never as the product path.
+ *
+ * The algorithm lives in a third-party dependency that is NOT vendored under /root/reference:
+ * PoseLib 2.0.5, kocurvik/PoseLib@pr-mdrp (pinned by /root/reference/README.md:52-55 and
+ * demo/reposed_demo.ipynb cell 4).  Only its compiled binary ships (demo/poselib-2.0.5-cp312-*.whl).
+ * Every function here restates the published/observed algorithm of one exported symbol of that
+ * binary (ELF addresses as in SURVEY.md §2/§8a) and is PINNED against outputs of that very binary
+ * run in the build container (oracle/refshim + tools/gen_golden.py -> tests/golden/ fixtures).
+ */
+#ifndef MDRP_ORACLE_H
+#define MDRP_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* MonoDepthTwoViewGeometry (+ the two focals of MonoDepthImagePair): q = (w,x,y,z), x_cam2 = R x_cam1 + t,
+ * R (d1+shift1) x1 + t = scale (d2+shift2) x2   (wheel METADATA:264-272). */
+typedef struct {
+    double q[4];
+    double t[3];
+    double scale, shift1, shift2;
+    double f1, f2;
+} orc_model;
+
+typedef struct { /* RansacOptions, wheel METADATA:72-91 */
+    uint64_t max_iterations, min_iterations;
+    double dyn_num_trials_mult, success_prob, max_reproj_error, max_epipolar_error;
+    uint64_t seed;
+    int estimate_shift; /* monodepth_estimate_shift */
+    double weight_sampson; /* monodepth_weight_sampson (float in the reference) */
+} orc_ransac_opt;
+
+typedef struct { /* BundleOptions, wheel METADATA:94-106 */
+    uint64_t max_iterations;
+    int loss_type; /* 0 TRIVIAL 1 TRUNCATED 2 HUBER 3 CAUCHY 4 TRUNCATED_CAUCHY 5 TRUNCATED_LE_ZACH */
+    double loss_scale, gradient_tol, step_tol, initial_lambda, min_lambda, max_lambda;
+} orc_bundle_opt;
+
+typedef struct { uint64_t refinements, iterations, num_inliers; double inlier_ratio, model_score; } orc_ransac_stats;
+typedef struct { uint64_t iterations; double initial_cost, cost, lambda; uint64_t invalid_steps; double step_norm, grad_norm; } orc_bundle_stats;
+
+enum { ORC_CALIB = 0, ORC_SHARED = 1, ORC_VARYING = 2 };
+
+/* a-3 sampler */
+int32_t orc_random_int(uint64_t *state);
+void orc_draw_sample(uint64_t n, uint64_t *state, uint64_t out[3]);
+
+/* geometry helpers */
+void orc_quat_to_rotmat(const double q[4], double R[9] /*row-major*/);
+void orc_rotmat_to_quat(const double R[9], double q[4]);
+void orc_essential(const orc_model *m, double E[9] /*row-major*/);
+void orc_fundamental(const orc_model *m, double F[9] /*row-major: diag(1,1,f2) E diag(1,1,f1)*/);
+
+/* a-7 / a-9 scoring */
+int orc_check_cheirality(const orc_model *m, const double x1[3], const double x2[3], double min_depth);
+double orc_msac_pose(const orc_model *m, const double *x1, const double *x2, int n, double sq_thr, uint64_t *cnt);
+double orc_msac_F(const double F[9], const double *x1, const double *x2, int n, double sq_thr, uint64_t *cnt);
+int orc_inliers_pose(const orc_model *m, const double *x1, const double *x2, int n, double sq_thr, uint8_t *mask);
+int orc_inliers_F(const double F[9], const double *x1, const double *x2, int n, double sq_thr, uint8_t *mask);
+
+/* a-4..a-6' minimal solvers; inputs 3x3 row-major point arrays; return number of models written (<=4) */
+int orc_p3p(const double x[9] /*unit bearings*/, const double X[9], orc_model out[4]);
+int orc_solver_calib_shift(const double x1h[9], const double x2h[9], const double d1[3], const double d2[3], orc_model out[4]);
+int orc_solver_calib_p3p(const double x1h[9], const double x2h[9], const double d1[3], const double d2[3], orc_model out[4]);
+int orc_solver_shared(const double x1h[9], const double x2h[9], const double d1[3], const double d2[3], orc_model out[4]);
+int orc_solver_varying(const double x1h[9], const double x2h[9], const double d1[3], const double d2[3], orc_model out[4]);
+
+/* a-8 refinement (hybrid Sampson + forward/backward reprojection LM).  weights may be NULL. */
+orc_bundle_stats orc_refine(int kind, const double *x1, const double *x2, const double *d1, const double *d2, int n,
+                            orc_model *m, double scale_reproj, double weight_sampson, const orc_bundle_opt *opt,
+                            int estimate_shift, const double *weights);
+
+/* a-2 LO-RANSAC on normalised inputs, a-1 full estimators */
+orc_ransac_stats orc_ransac(int kind, const double *x1, const double *x2, const double *d1, const double *d2, int n,
+                            const orc_ransac_opt *opt, orc_model *best, uint8_t *mask);
+/* cam: {model_id, nparams, params...} only for ORC_CALIB (SIMPLE_PINHOLE=0 [f,cx,cy], PINHOLE=1 [fx,fy,cx,cy]) */
+orc_ransac_stats orc_estimate(int kind, const double *x1, const double *x2, const double *d1, const double *d2, int n,
+                              const double *cam1, const double *cam2, const orc_ransac_opt *ropt,
+                              const orc_bundle_opt *bopt, orc_model *best, uint8_t *mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
