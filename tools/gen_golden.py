@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own compiled PoseLib (via oracle/_ref/librefshim.so).
+
+Runs only in the build container (needs /root/reference/demo/poselib-2.0.5-*.whl; `make -C oracle ref`
+first).  The fixtures are data only: inputs and the reference binary's outputs.  Re-running reproduces the
+files bit for bit (all randomness is seeded).
+
+    python3 tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, ".."))
+import refshim as rs  # noqa: E402
+from mdrp_amd import synth  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+
+def rodrigues(w):
+    return synth.rodrigues(np.asarray(w, dtype=np.float64))
+
+
+def pad(sols, width):
+    out = np.full((4, width), np.nan)
+    out[: len(sols), : sols.shape[1]] = sols
+    return out
+
+
+def gen_sampler():
+    d = {}
+    for n in (7, 200, 2000, 5000):
+        for seed in (0, 5):
+            d[f"n{n}_s{seed}"] = rs.draw_samples(seed, n, 64).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **d)
+
+
+def minimal_problem(rng, kind, noisy):
+    R = rodrigues(rng.normal(0, 0.3, 3))
+    t = rng.normal(0, 0.5, 3)
+    X = np.stack([rng.uniform(-2, 2, 3), rng.uniform(-1.5, 1.5, 3), rng.uniform(2, 8, 3)], 1)
+    Y = X @ R.T + t
+    s = rng.uniform(0.3, 3)
+    u = rng.uniform(-0.5, 0.5) if kind == "calib_shift" else 0.0
+    v = rng.uniform(-0.5, 0.5) if kind == "calib_shift" else 0.0
+    f1 = f2 = 1.0
+    if kind == "shared":
+        f1 = f2 = rng.uniform(0.3, 2)
+    if kind == "varying":
+        f1, f2 = rng.uniform(0.3, 2, 2)
+    x1 = X / X[:, 2:]
+    x2 = Y / Y[:, 2:]
+    x1[:, :2] *= f1
+    x2[:, :2] *= f2
+    d1 = X[:, 2] - u
+    d2 = Y[:, 2] / s - v
+    if noisy:
+        x2[:, :2] += rng.normal(0, 0.1, (3, 2))
+        d2 = d2 * (1 + rng.normal(0, 0.1, 3))
+    return x1, x2, d1, d2
+
+
+def gen_solvers(count=96):
+    rng = np.random.default_rng(20240)
+    d = {}
+    # p3p: unit bearings + 3D points
+    xs, Xs, sols, ns = [], [], [], []
+    for i in range(count):
+        R = rodrigues(rng.normal(0, 0.8, 3))
+        t = rng.normal(size=3)
+        X = rng.uniform(-2, 2, (3, 3))
+        X[:, 2] += 5
+        Y = X @ R.T + t
+        if i % 2:
+            Y = rng.uniform(-2, 2, (3, 3)) + [0, 0, 4]
+        x = Y / np.linalg.norm(Y, axis=1, keepdims=True)
+        s = rs.p3p(x, X)
+        xs.append(x); Xs.append(X); sols.append(pad(s, 7)); ns.append(len(s))
+    d.update(p3p_x=np.array(xs), p3p_X=np.array(Xs), p3p_sols=np.array(sols), p3p_n=np.array(ns, dtype=np.int32))
+    for kind, fn, w in (("calib_shift", rs.solver_calib, 10), ("shared", rs.solver_shared, 12), ("varying", rs.solver_varying, 12)):
+        a, b, c, e, sols, ns = [], [], [], [], [], []
+        for i in range(count):
+            x1, x2, d1, d2 = minimal_problem(rng, kind, i % 2)
+            s = fn(x1, x2, d1, d2)
+            a.append(x1); b.append(x2); c.append(d1); e.append(d2); sols.append(pad(s, w)); ns.append(len(s))
+        d.update({f"{kind}_x1": np.array(a), f"{kind}_x2": np.array(b), f"{kind}_d1": np.array(c), f"{kind}_d2": np.array(e),
+                  f"{kind}_sols": np.array(sols), f"{kind}_n": np.array(ns, dtype=np.int32)})
+    np.savez_compressed(os.path.join(OUT, "solvers.npz"), **d)
+
+
+def quat_of(R):
+    from scipy.spatial.transform import Rotation as Rot
+    q = Rot.from_matrix(R).as_quat()
+    return np.array([q[3], q[0], q[1], q[2]])
+
+
+def gen_scoring():
+    d = {}
+    rng = np.random.default_rng(7)
+    for i in range(6):
+        p = synth.make_pair(500 + i, 256, noise_px=1.0, outlier_frac=0.3)
+        x1, x2 = p["x1"] / 800.0, p["x2"] / 800.0
+        R = p["R"] if i % 2 == 0 else rodrigues(rng.normal(0, 1.0, 3))
+        t = p["t"] if i % 3 else rng.normal(size=3)
+        m = np.zeros(12)
+        m[:4] = quat_of(R); m[4:7] = t; m[7] = 1.0; m[10] = 1.3; m[11] = 0.7
+        thr = (2.0 / 800.0) ** 2
+        s, c = rs.msac_pose(m[:7], x1, x2, thr)
+        mask = rs.inliers_pose(m[:7], x1, x2, thr)
+        # F of the model with the oracle convention diag(1,1,f2) E diag(1,1,f1), computed here independently
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+        F = np.diag([1, 1, m[11]]) @ (tx @ R) @ np.diag([1, 1, m[10]])
+        sF, cF = rs.msac_F(F, x1, x2, thr)
+        maskF = rs.inliers_F(F, x1, x2, thr)
+        d.update({f"x1_{i}": x1, f"x2_{i}": x2, f"model_{i}": m, f"R_{i}": R, f"F_{i}": F, f"thr_{i}": thr,
+                  f"pose_score_{i}": s, f"pose_cnt_{i}": c, f"pose_mask_{i}": mask,
+                  f"F_score_{i}": sF, f"F_cnt_{i}": cF, f"F_mask_{i}": maskF})
+    np.savez_compressed(os.path.join(OUT, "scoring.npz"), **d)
+
+
+def gen_refine():
+    d = {}
+    cases = []
+    for i in range(9):
+        kind = i % 3
+        es = (i // 3) % 2 if kind == 0 else 0
+        p = synth.make_pair(700 + i, 160, noise_px=1.0, depth_noise=0.05, outlier_frac=0.25,
+                            random_focal=[None, "shared", "varying"][kind], shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
+        sc = 800.0 if kind == 0 else 700.0
+        x1, x2 = p["x1"] / sc, p["x2"] / sc
+        rng = np.random.default_rng(i)
+        Rn = p["R"] @ rodrigues(rng.normal(0, 0.02, 3))
+        m = np.zeros(12)
+        m[:4] = quat_of(Rn); m[4:7] = p["t"] + rng.normal(0, 0.02, 3); m[7] = p["scale"] * 1.03
+        m[10] = p["f1"] / sc * 1.02 if kind else 1.0
+        m[11] = (p["f2"] / sc * 0.97) if kind == 2 else m[10]
+        d.update({f"x1_{i}": x1, f"x2_{i}": x2, f"d1_{i}": p["d1"], f"d2_{i}": p["d2"], f"model_{i}": m})
+        for lt in (0, 1, 2, 3, 4):
+            for its in (0, 1, 25):
+                thr = 2.0 / sc
+                bo = rs.bopt(max_iterations=its, loss_type=lt, loss_scale=thr, gradient_tol=1e-10)
+                if kind == 0:
+                    g, st = rs.refine_calib(x1, x2, p["d1"], p["d2"], m[:10], 1 / 64.0, 1.0, bo, es)
+                    g = np.r_[g, 1.0, 1.0]
+                else:
+                    g, st = rs.refine_focal(kind == 2, x1, x2, p["d1"], p["d2"], m, 1 / 64.0, 1.0, bo)
+                cases.append([i, kind, es, lt, its, thr])
+                d[f"out_{len(cases) - 1}"] = np.r_[g, st]
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "refine.npz"), **d)
+
+
+def gen_estimate():
+    d = {}
+    cases = []
+    for i in range(18):
+        kind = i % 3
+        es = (i // 3) % 2 if kind == 0 else 0
+        noise = 0.0 if i % 6 >= 3 else 0.5
+        n = [200, 300, 400][i % 3]
+        of = [0.0, 0.33, 0.5][(i // 2) % 3] if noise else 0.0
+        pp = (640.0, 480.0) if kind == 0 else (0.0, 0.0)
+        p = synth.make_pair(900 + i, n, noise_px=noise, depth_noise=0.02 if noise else 0.0, outlier_frac=of,
+                            random_focal=[None, "shared", "varying"][kind], shift1=0.2 if es else 0.0,
+                            shift2=-0.1 if es else 0.0, pp=pp, f1=800.0, f2=650.0)
+        iters = 1000
+        kw = dict(max_iterations=iters if i % 2 else 100000, min_iterations=iters, max_epipolar_error=2.0,
+                  max_reproj_error=16.0, seed=i % 4, estimate_shift=es)
+        lt = 4 if i % 4 else 3
+        c1 = c2 = None
+        cam1 = cam2 = np.zeros(6)
+        if kind == 0:
+            if i % 2:
+                cam1 = np.array([0, 3, 800, 640, 480, 0.0]); cam2 = np.array([1, 4, 640, 660, 640, 480.0])
+            else:
+                cam1 = np.array([0, 3, 800, 640, 480, 0.0]); cam2 = np.array([0, 3, 650, 640, 480, 0.0])
+            c1 = rs.cam_flat(int(cam1[0]), 1280, 960, list(cam1[2:2 + int(cam1[1])]))
+            c2 = rs.cam_flat(int(cam2[0]), 1280, 960, list(cam2[2:2 + int(cam2[1])]))
+        m, st, mask = rs.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], rs.ropt(**kw), rs.bopt(loss_type=lt), c1, c2)
+        m12 = np.r_[m, 1.0, 1.0] if kind == 0 else m
+        d.update({f"x1_{i}": p["x1"], f"x2_{i}": p["x2"], f"d1_{i}": p["d1"], f"d2_{i}": p["d2"], f"cam1_{i}": cam1,
+                  f"cam2_{i}": cam2, f"model_{i}": m12, f"stats_{i}": st, f"mask_{i}": mask,
+                  f"gt_R_{i}": p["R"], f"gt_t_{i}": p["t"], f"gt_{i}": np.array([p["scale"], p["shift1"], p["shift2"], p["f1"], p["f2"]])})
+        cases.append([i, kind, es, noise, of, kw["max_iterations"], kw["min_iterations"], kw["seed"], lt])
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "estimate.npz"), **d)
+
+
+if __name__ == "__main__":
+    if not rs.available():
+        sys.exit("reference shim not built: run `make -C oracle ref` in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    gen_sampler()
+    gen_solvers()
+    gen_scoring()
+    gen_refine()
+    gen_estimate()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
