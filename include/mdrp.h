@@ -1,0 +1,144 @@
+/* mdrp.h — C ABI of the MI355X-native RePoseD RANSAC hot path (libmdrp_hip.so).
+ *
+ * Drop-in boundary.  The reference reaches this path through pybind11
+ * (wheel poselib/_core.pyi:446-501) into PoseLib's C++:
+ *     estimate_monodepth_relative_pose                @0x224170   (README.md:86, make_pair.py:111, make_video.py:284)
+ *     estimate_shared_focal_monodepth_relative_pose   @0x223300   (README.md:90)
+ *     estimate_varying_focal_monodepth_relative_pose  @0x223a40   (README.md:96)
+ * one image pair per call.  The entry points below bind the same three estimators, batched: B image pairs per
+ * call, each pair an independent unit (that is how the reference itself parallelises, eval.py:355-359).
+ * mdrp_amd/_capi.py is the ctypes binding; INTEGRATION.md shows the stub a PoseLib maintainer would add.
+ *
+ * Conventions: plain pointers + sizes, caller owns every buffer, the library never frees caller memory,
+ * int return codes (0 = ok), no exceptions cross the boundary.  One HIP stream per handle; calls on different
+ * handles may run concurrently from different host threads.
+ */
+#ifndef MDRP_H
+#define MDRP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MDRP_CALIB = 0, MDRP_SHARED_FOCAL = 1, MDRP_VARYING_FOCAL = 2 };
+
+enum { /* return codes */
+    MDRP_OK = 0,
+    MDRP_ERR_INVALID = 1,   /* bad argument */
+    MDRP_ERR_HIP = 2,       /* a HIP runtime call failed; mdrp_last_error() has the text */
+    MDRP_ERR_NO_DEVICE = 3  /* no usable gfx950 device */
+};
+
+enum { /* where the caller's buffers live */
+    MDRP_MEM_HOST = 0,
+    MDRP_MEM_DEVICE = 1
+};
+
+/* MonoDepthTwoViewGeometry + the two focals of MonoDepthImagePair (wheel _core.pyi:134-204):
+ * q = (w,x,y,z);  R (d1+shift1) K1^-1 x1 + t = scale (d2+shift2) K2^-1 x2 */
+typedef struct {
+    double q[4];
+    double t[3];
+    double scale, shift1, shift2;
+    double f1, f2; /* 1.0 for the calibrated estimator */
+} mdrp_model;
+
+/* RansacOptions (wheel METADATA:72-91; defaults as the pybind wrapper @0x8ab59-0x8ac44) */
+typedef struct {
+    uint64_t max_iterations;   /* 100000 */
+    uint64_t min_iterations;   /* 1000 */
+    double dyn_num_trials_mult; /* 3.0 */
+    double success_prob;        /* 0.9999 */
+    double max_reproj_error;    /* 12.0 (pixels) */
+    double max_epipolar_error;  /* 1.0 (pixels) */
+    uint64_t seed;              /* 0 */
+    int32_t monodepth_estimate_shift; /* calibrated estimator only; ignored elsewhere exactly like the reference */
+    float monodepth_weight_sampson;   /* 1.0 */
+} mdrp_ransac_opt;
+
+/* BundleOptions (wheel METADATA:94-106) */
+typedef struct {
+    uint64_t max_iterations; /* 100 */
+    int32_t loss_type;       /* 0 TRIVIAL 1 TRUNCATED 2 HUBER 3 CAUCHY 4 TRUNCATED_CAUCHY 5 TRUNCATED_LE_ZACH */
+    double loss_scale;       /* 1.0 */
+    double gradient_tol;     /* 1e-10 */
+    double step_tol;         /* 1e-8 */
+    double initial_lambda;   /* 1e-3 */
+    double min_lambda;       /* 1e-10 */
+    double max_lambda;       /* 1e10 */
+} mdrp_bundle_opt;
+
+/* Pinhole intrinsics of one image (Camera, _core.pyi:76-132; only the models the reference callers use):
+ * model_id 0 SIMPLE_PINHOLE params {f,cx,cy,-} ; 1 PINHOLE params {fx,fy,cx,cy} */
+typedef struct {
+    int32_t model_id;
+    int32_t pad_;
+    double params[4];
+} mdrp_camera;
+
+/* One record per image pair: the estimator's return value + RansacStats */
+typedef struct {
+    mdrp_model model;
+    uint64_t refinements, iterations, num_inliers;
+    double inlier_ratio, model_score;
+} mdrp_result;
+
+typedef struct mdrp_handle mdrp_handle;
+
+/* Library/handle management.  device = HIP device ordinal.  stream = a hipStream_t created by the caller (e.g.
+ * torch's current stream) or NULL to let the handle create its own. */
+int mdrp_create(int device, void *stream, mdrp_handle **out);
+void mdrp_destroy(mdrp_handle *h);
+const char *mdrp_last_error(void);
+const char *mdrp_version(void);
+/* block the calling thread until all work queued on the handle's stream is done */
+int mdrp_synchronize(mdrp_handle *h);
+
+/* Batched estimators.  x1,x2: [B][n_max][2] pixel coordinates; d1,d2: [B][n_max] depths; n_per_pair: [B] valid
+ * correspondences per pair (host memory always; NULL = all n_max).  cam1/cam2: [B] cameras (host memory; calibrated
+ * estimator only — the focal estimators take principal-point-centred pixels, README.md:88-96).  out: [B] results
+ * (host memory).  inlier_mask: [B][n_max] bytes or NULL (same memory space as the inputs).
+ * Pairs with fewer than 3 correspondences return zeroed stats with model_score = DBL_MAX and the identity model,
+ * like ransac<> @0x22f087.  The call is synchronous with respect to `out`. */
+int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x1, const double *x2, const double *d1,
+                        const double *d2, int batch, int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1,
+                        const mdrp_camera *cam2, const mdrp_ransac_opt *ropt, const mdrp_bundle_opt *bopt,
+                        mdrp_result *out, uint8_t *inlier_mask);
+
+/* Same work, but nothing is copied back: results stay in the handle's device buffers until mdrp_fetch_results.
+ * Used by bench.py so that the timed region holds device work only (inputs resident in HBM). */
+int mdrp_estimate_batch_async(mdrp_handle *h, int kind, const double *x1_dev, const double *x2_dev, const double *d1_dev,
+                              const double *d2_dev, int batch, int n_max, const int32_t *n_per_pair_host,
+                              const mdrp_camera *cam1_host, const mdrp_camera *cam2_host, const mdrp_ransac_opt *ropt,
+                              const mdrp_bundle_opt *bopt, uint8_t *inlier_mask_dev);
+int mdrp_fetch_results(mdrp_handle *h, mdrp_result *out_host, int batch);
+
+/* ---- unit-parity entry points (the reference exposes the same pieces: _core.pyi:614-619, 871-876, 914-919) ---- */
+/* Minimal solvers on `count` independent 3-point problems (host memory).  x1h,x2h: [count][3][3] homogeneous points
+ * (z = 1), d1,d2: [count][3].  out: [count][4] models, n_out: [count] number of valid models.
+ * solver: 0 calibrated P3P path (shift off), 1 calibrated with shifts, 2 shared focal, 3 varying focal. */
+int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const double *x2h, const double *d1,
+                      const double *d2, int count, mdrp_model *out, int32_t *n_out);
+
+/* Sampson/MSAC sweep only (compute_sampson_msac_score @0x4f61d0 / @0x4f65d0): `num_models` models against the n
+ * normalised correspondences of ONE pair.  kind selects pose scoring with cheirality (MDRP_CALIB) or F scoring.
+ * All pointers in `mem_space`.  scores: [num_models], counts: [num_models]. */
+int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model *models, int num_models,
+                      const double *x1, const double *x2, int n, double sq_threshold, double *scores, int32_t *counts);
+
+/* Hybrid LM refinement of `count` models, each over the correspondences of ONE pair (refine_monodepth_*relpose
+ * @0x261030/@0x2592e0/@0x260fa0).  Host memory.  models in/out. */
+int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,
+                       const double *d1, const double *d2, int n, double scale_reproj, double weight_sampson,
+                       const mdrp_bundle_opt *opt, int estimate_shift, double *final_cost /*[count] or NULL*/);
+
+/* Timing of the last mdrp_estimate_batch* call on this handle, measured with HIP events on the handle's stream:
+ * total milliseconds in the scoring-sweep kernel, number of its launches, and (model x correspondence) evaluations. */
+int mdrp_last_sweep_stats(mdrp_handle *h, double *sweep_ms, int64_t *launches, int64_t *evaluations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,259 @@
+"""ctypes binding of libmdrp_hip.so (include/mdrp.h) — the only route from Python to the HIP kernels.
+
+There is no CPU fallback: if the shared library is missing or no gfx950 device is usable, every entry point
+raises.  Build with `python -c "import __graft_entry__ as g; g.build()"` (or mdrp_amd/build.py).
+"""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmdrp_hip.so")
+
+CALIB, SHARED_FOCAL, VARYING_FOCAL = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
+
+EXPORTS = (
+    "mdrp_create", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
+    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_solver_batch", "mdrp_score_models", "mdrp_refine_models",
+    "mdrp_last_sweep_stats",
+)
+
+
+class Model(C.Structure):
+    _fields_ = [("q", C.c_double * 4), ("t", C.c_double * 3), ("scale", C.c_double), ("shift1", C.c_double),
+                ("shift2", C.c_double), ("f1", C.c_double), ("f2", C.c_double)]
+
+
+class RansacOpt(C.Structure):
+    _fields_ = [("max_iterations", C.c_uint64), ("min_iterations", C.c_uint64), ("dyn_num_trials_mult", C.c_double),
+                ("success_prob", C.c_double), ("max_reproj_error", C.c_double), ("max_epipolar_error", C.c_double),
+                ("seed", C.c_uint64), ("monodepth_estimate_shift", C.c_int32), ("monodepth_weight_sampson", C.c_float)]
+
+
+class BundleOpt(C.Structure):
+    _fields_ = [("max_iterations", C.c_uint64), ("loss_type", C.c_int32), ("loss_scale", C.c_double),
+                ("gradient_tol", C.c_double), ("step_tol", C.c_double), ("initial_lambda", C.c_double),
+                ("min_lambda", C.c_double), ("max_lambda", C.c_double)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("model_id", C.c_int32), ("pad_", C.c_int32), ("params", C.c_double * 4)]
+
+
+class Result(C.Structure):
+    _fields_ = [("model", Model), ("refinements", C.c_uint64), ("iterations", C.c_uint64), ("num_inliers", C.c_uint64),
+                ("inlier_ratio", C.c_double), ("model_score", C.c_double)]
+
+
+MODEL_DTYPE = np.dtype([("q", "f8", 4), ("t", "f8", 3), ("scale", "f8"), ("shift1", "f8"), ("shift2", "f8"), ("f1", "f8"), ("f2", "f8")])
+RESULT_DTYPE = np.dtype([("model", MODEL_DTYPE), ("refinements", "u8"), ("iterations", "u8"), ("num_inliers", "u8"),
+                         ("inlier_ratio", "f8"), ("model_score", "f8")])
+CAMERA_DTYPE = np.dtype([("model_id", "i4"), ("pad_", "i4"), ("params", "f8", 4)])
+assert MODEL_DTYPE.itemsize == C.sizeof(Model) and RESULT_DTYPE.itemsize == C.sizeof(Result) and CAMERA_DTYPE.itemsize == C.sizeof(Camera)
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+class MdrpError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libmdrp_hip.so and declare prototypes.  Raises MdrpError if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise MdrpError(f"{LIB_PATH} is not built (run __graft_entry__.build()); mdrp_amd has no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
+        lib.mdrp_last_error.restype = C.c_char_p
+        lib.mdrp_version.restype = C.c_char_p
+        lib.mdrp_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+        lib.mdrp_destroy.argtypes = [vp]
+        lib.mdrp_destroy.restype = None
+        lib.mdrp_synchronize.argtypes = [vp]
+        lib.mdrp_estimate_batch.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, ip, vp, vp,
+                                            C.POINTER(RansacOpt), C.POINTER(BundleOpt), vp, vp]
+        lib.mdrp_estimate_batch_async.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, ip, vp, vp,
+                                                  C.POINTER(RansacOpt), C.POINTER(BundleOpt), vp]
+        lib.mdrp_fetch_results.argtypes = [vp, vp, C.c_int]
+        lib.mdrp_solver_batch.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int, vp, vp]
+        lib.mdrp_score_models.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp, vp]
+        lib.mdrp_refine_models.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, dp, dp, C.c_int, C.c_double, C.c_double,
+                                           C.POINTER(BundleOpt), C.c_int, vp]
+        lib.mdrp_last_sweep_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        _lib = lib
+        return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise MdrpError(f"mdrp error {rc}: {lib.mdrp_last_error().decode(errors='replace')}")
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def ransac_opt_from_dict(d=None):
+    """RansacOptions from a poselib-style dict; defaults as the reference's pybind wrapper;
+    unknown keys are ignored like the reference does."""
+    d = d or {}
+    return RansacOpt(int(d.get("max_iterations", 100000)), int(d.get("min_iterations", 1000)),
+                     float(d.get("dyn_num_trials_mult", 3.0)), float(d.get("success_prob", 0.9999)),
+                     float(d.get("max_reproj_error", 12.0)), float(d.get("max_epipolar_error", 1.0)),
+                     int(d.get("seed", 0)), int(bool(d.get("monodepth_estimate_shift", False))),
+                     float(d.get("monodepth_weight_sampson", 1.0)))
+
+
+LOSS_TYPES = {"TRIVIAL": 0, "TRUNCATED": 1, "HUBER": 2, "CAUCHY": 3, "TRUNCATED_CAUCHY": 4, "TRUNCATED_LE_ZACH": 5}
+
+
+def bundle_opt_from_dict(d=None):
+    d = d or {}
+    lt = d.get("loss_type", "CAUCHY")
+    if isinstance(lt, str):
+        if lt.upper() not in LOSS_TYPES:
+            raise ValueError(f"unknown loss_type {lt!r}")
+        lt = LOSS_TYPES[lt.upper()]
+    return BundleOpt(int(d.get("max_iterations", 100)), int(lt), float(d.get("loss_scale", 1.0)),
+                     float(d.get("gradient_tol", 1e-10)), float(d.get("step_tol", 1e-8)), float(d.get("initial_lambda", 1e-3)),
+                     float(d.get("min_lambda", 1e-10)), float(d.get("max_lambda", 1e10)))
+
+
+class Handle:
+    """One handle = one HIP device + one stream + its scratch buffers."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib, self._lib.mdrp_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mdrp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._lib, self._lib.mdrp_synchronize(self._h))
+
+    # ---- batched estimators, host (numpy) buffers
+    def estimate_batch(self, kind, x1, x2, d1, d2, ropt, bopt, n_per_pair=None, cam1=None, cam2=None, want_mask=True):
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        d1 = np.ascontiguousarray(d1, dtype=np.float64)
+        d2 = np.ascontiguousarray(d2, dtype=np.float64)
+        if x1.ndim != 3 or x1.shape[2] != 2 or x2.shape != x1.shape or d1.shape != x1.shape[:2] or d2.shape != d1.shape:
+            raise ValueError("expected x1,x2 (B,N,2) and d1,d2 (B,N)")
+        B, N = d1.shape
+        npp = None if n_per_pair is None else np.ascontiguousarray(n_per_pair, dtype=np.int32)
+        out = np.zeros(B, dtype=RESULT_DTYPE)
+        mask = np.zeros((B, N), dtype=np.uint8) if want_mask else None
+        c1 = None if cam1 is None else np.ascontiguousarray(cam1, dtype=CAMERA_DTYPE)
+        c2 = None if cam2 is None else np.ascontiguousarray(cam2, dtype=CAMERA_DTYPE)
+        _check(self._lib, self._lib.mdrp_estimate_batch(self._h, kind, MEM_HOST, _ptr(x1), _ptr(x2), _ptr(d1), _ptr(d2), B, N,
+                                                        _ptr(npp), _ptr(c1), _ptr(c2), C.byref(ropt), C.byref(bopt),
+                                                        _ptr(out), _ptr(mask)))
+        return out, mask
+
+    # ---- batched estimators, device pointers (ints), results fetched separately
+    def estimate_batch_device(self, kind, x1_ptr, x2_ptr, d1_ptr, d2_ptr, batch, n_max, ropt, bopt, n_per_pair=None,
+                              cam1=None, cam2=None, mask_ptr=None):
+        npp = None if n_per_pair is None else np.ascontiguousarray(n_per_pair, dtype=np.int32)
+        c1 = None if cam1 is None else np.ascontiguousarray(cam1, dtype=CAMERA_DTYPE)
+        c2 = None if cam2 is None else np.ascontiguousarray(cam2, dtype=CAMERA_DTYPE)
+        _check(self._lib, self._lib.mdrp_estimate_batch_async(self._h, kind, C.c_void_p(x1_ptr), C.c_void_p(x2_ptr),
+                                                              C.c_void_p(d1_ptr), C.c_void_p(d2_ptr), int(batch), int(n_max),
+                                                              _ptr(npp), _ptr(c1), _ptr(c2), C.byref(ropt), C.byref(bopt),
+                                                              C.c_void_p(mask_ptr) if mask_ptr else None))
+
+    def fetch_results(self, batch):
+        out = np.zeros(batch, dtype=RESULT_DTYPE)
+        _check(self._lib, self._lib.mdrp_fetch_results(self._h, _ptr(out), int(batch)))
+        return out
+
+    def last_sweep_stats(self):
+        ms, launches, evals = C.c_double(0), C.c_int64(0), C.c_int64(0)
+        _check(self._lib, self._lib.mdrp_last_sweep_stats(self._h, C.byref(ms), C.byref(launches), C.byref(evals)))
+        return ms.value, launches.value, evals.value
+
+    # ---- unit-parity entry points
+    def solver_batch(self, solver, x1h, x2h, d1, d2):
+        x1h = np.ascontiguousarray(x1h, dtype=np.float64).reshape(-1, 3, 3)
+        x2h = np.ascontiguousarray(x2h, dtype=np.float64).reshape(-1, 3, 3)
+        d1 = np.ascontiguousarray(d1, dtype=np.float64).reshape(-1, 3)
+        d2 = np.ascontiguousarray(d2, dtype=np.float64).reshape(-1, 3)
+        count = len(d1)
+        out = np.zeros((count, 4), dtype=MODEL_DTYPE)
+        n_out = np.zeros(count, dtype=np.int32)
+        _check(self._lib, self._lib.mdrp_solver_batch(self._h, int(solver), _ptr(x1h), _ptr(x2h), _ptr(d1), _ptr(d2), count,
+                                                      _ptr(out), _ptr(n_out)))
+        return out, n_out
+
+    def score_models(self, kind, models, x1, x2, sq_threshold):
+        models = np.ascontiguousarray(models, dtype=MODEL_DTYPE).reshape(-1)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        scores = np.zeros(len(models))
+        counts = np.zeros(len(models), dtype=np.int32)
+        _check(self._lib, self._lib.mdrp_score_models(self._h, int(kind), MEM_HOST, _ptr(models), len(models), _ptr(x1), _ptr(x2),
+                                                      len(x1), float(sq_threshold), _ptr(scores), _ptr(counts)))
+        return scores, counts
+
+    def score_models_device(self, kind, models_ptr, num_models, x1_ptr, x2_ptr, n, sq_threshold, scores_ptr, counts_ptr):
+        _check(self._lib, self._lib.mdrp_score_models(self._h, int(kind), MEM_DEVICE, C.c_void_p(models_ptr), int(num_models),
+                                                      C.c_void_p(x1_ptr), C.c_void_p(x2_ptr), int(n), float(sq_threshold),
+                                                      C.c_void_p(scores_ptr), C.c_void_p(counts_ptr)))
+
+    def refine_models(self, kind, models, x1, x2, d1, d2, scale_reproj, weight_sampson, bopt, estimate_shift=False):
+        models = np.ascontiguousarray(models, dtype=MODEL_DTYPE).reshape(-1).copy()
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        d1 = np.ascontiguousarray(d1, dtype=np.float64)
+        d2 = np.ascontiguousarray(d2, dtype=np.float64)
+        cost = np.zeros(len(models))
+        _check(self._lib, self._lib.mdrp_refine_models(self._h, int(kind), _ptr(models), len(models), _ptr(x1), _ptr(x2), _ptr(d1),
+                                                       _ptr(d2), len(x1), float(scale_reproj), float(weight_sampson), C.byref(bopt),
+                                                       int(bool(estimate_shift)), _ptr(cost)))
+        return models, cost
+
+
+_default_handles = {}
+_default_lock = threading.Lock()
+
+
+def default_handle(device=0):
+    with _default_lock:
+        h = _default_handles.get(device)
+        if h is None:
+            h = Handle(device)
+            _default_handles[device] = h
+        return h
+
+
+def model_to_array(m):
+    """structured MODEL_DTYPE scalar -> flat (12,) float64 [q t scale shift1 shift2 f1 f2]"""
+    return np.concatenate([m["q"], m["t"], [m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]]).astype(np.float64)
+
+
+def array_to_models(a):
+    a = np.asarray(a, dtype=np.float64).reshape(-1, 12)
+    out = np.zeros(len(a), dtype=MODEL_DTYPE)
+    out["q"] = a[:, :4]; out["t"] = a[:, 4:7]; out["scale"] = a[:, 7]; out["shift1"] = a[:, 8]; out["shift2"] = a[:, 9]
+    out["f1"] = a[:, 10]; out["f2"] = a[:, 11]
+    return out

@@ -1,0 +1,496 @@
+// mdrp_capi.hip — C ABI (include/mdrp.h) and host orchestration of the chunked, phase-split LO-RANSAC.
+// Everything numerical runs in the gfx950 kernels of mdrp_kernels.h; the host only sizes buffers, groups pairs by
+// correspondence count (one sample table per distinct N) and reads back one 16-byte progress record per chunk.
+#include "../../include/mdrp.h"
+#include "mdrp_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mdrp;
+
+static_assert(sizeof(mdrp_model) == sizeof(Model), "model layout");
+static_assert(sizeof(mdrp_camera) == sizeof(CamDev), "camera layout");
+static_assert(sizeof(mdrp_result) == sizeof(ResultDev), "result layout");
+
+namespace {
+
+thread_local std::string g_err;
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            char buf_[512];                                                                                \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            g_err = buf_;                                                                                  \
+            return MDRP_ERR_HIP;                                                                           \
+        }                                                                                                  \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MDRP_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        // grow with headroom so alternating sizes do not thrash
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { g_err = std::string("hipMalloc failed: ") + hipGetErrorString(e); p = nullptr; return MDRP_ERR_HIP; }
+        cap = want;
+        return MDRP_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct Progress { int32_t n_active; int32_t pad; unsigned long long max_needed; unsigned long long evals; };
+
+} // namespace
+
+struct mdrp_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int num_cu = 256;
+    // persistent device buffers
+    DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
+    DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, work_pos, counters, results, mask;
+    DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
+    DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
+    Progress *progress_host = nullptr; // pinned
+    // sweep timing
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+    double sweep_ms = 0.0;
+    int64_t sweep_launches = 0, sweep_evals = 0;
+    int last_batch = 0;
+};
+
+namespace {
+
+int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b) {
+    if (h->ev_used == h->ev_pool.size()) {
+        hipEvent_t x, y;
+        HIPCHK(hipEventCreate(&x));
+        HIPCHK(hipEventCreate(&y));
+        h->ev_pool.emplace_back(x, y);
+    }
+    *a = h->ev_pool[h->ev_used].first;
+    *b = h->ev_pool[h->ev_used].second;
+    h->ev_used++;
+    return MDRP_OK;
+}
+
+int solver_for(int kind, int est_shift) {
+    if (kind == MDRP_CALIB) return est_shift ? SOLVER_SHIFT : SOLVER_P3P;
+    return kind == MDRP_SHARED_FOCAL ? SOLVER_SHARED : SOLVER_VARYING;
+}
+
+// one pass = a contiguous range of pairs that fits the scratch budget
+int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
+             int n_max, const int32_t *n_host, const mdrp_camera *cam1, const mdrp_camera *cam2, const mdrp_ransac_opt *ro,
+             const mdrp_bundle_opt *bo, int chunk_cap, uint8_t *mask_dev, ResultDev *results_dev) {
+    hipStream_t s = h->stream;
+    const int est_shift = (kind == MDRP_CALIB && ro->monodepth_estimate_shift) ? 1 : 0;
+
+    // ---- group pairs by correspondence count: one sample table per distinct N
+    std::vector<int32_t> table_of(batch), tab_n;
+    {
+        std::map<int32_t, int32_t> ids;
+        for (int i = 0; i < batch; ++i) {
+            auto it = ids.find(n_host[i]);
+            if (it == ids.end()) { it = ids.emplace(n_host[i], (int32_t)tab_n.size()).first; tab_n.push_back(n_host[i]); }
+            table_of[i] = it->second;
+        }
+    }
+    const int n_tables = (int)tab_n.size();
+    std::vector<uint64_t> tab_state(n_tables, ro->seed);
+
+    const size_t slots = (size_t)batch * chunk_cap * 4;
+    int rc;
+    if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * batch * n_max))) return rc;
+    if ((rc = h->dep.ensure(sizeof(double) * 2 * batch * n_max))) return rc;
+    if ((rc = h->st.ensure(sizeof(PairState) * batch))) return rc;
+    if ((rc = h->samples.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
+    if ((rc = h->table_n.ensure(sizeof(int32_t) * n_tables))) return rc;
+    if ((rc = h->table_state.ensure(sizeof(uint64_t) * n_tables))) return rc;
+    if ((rc = h->table_of_pair.ensure(sizeof(int32_t) * batch))) return rc;
+    if ((rc = h->nper.ensure(sizeof(int32_t) * batch))) return rc;
+    if ((rc = h->cams1.ensure(sizeof(CamDev) * batch))) return rc;
+    if ((rc = h->cams2.ensure(sizeof(CamDev) * batch))) return rc;
+    if ((rc = h->models.ensure(sizeof(Model) * slots))) return rc;
+    if ((rc = h->slot_score.ensure(sizeof(double) * slots))) return rc;
+    if ((rc = h->slot_inl.ensure(sizeof(int32_t) * slots))) return rc;
+    if ((rc = h->tags.ensure(sizeof(uint32_t) * slots))) return rc;
+    if ((rc = h->model_count.ensure(sizeof(int32_t) * batch))) return rc;
+    const int trig_cap = chunk_cap;
+    if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
+    if ((rc = h->work_pair.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
+    if ((rc = h->work_pos.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
+    if ((rc = h->counters.ensure(64))) return rc; // [0] work_count, [1] work_head, [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64)
+
+    HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->table_of_pair.p, table_of.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->nper.p, n_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    if (kind == MDRP_CALIB) {
+        HIPCHK(hipMemcpyAsync(h->cams1.p, cam1, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->cams2.p, cam2, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
+    }
+
+    RunParams rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.kind = kind; rp.solver = solver_for(kind, est_shift); rp.est_shift = est_shift;
+    rp.batch = batch; rp.n_max = n_max;
+    rp.max_iterations = ro->max_iterations; rp.min_iterations = ro->min_iterations;
+    rp.dyn_mult = ro->dyn_num_trials_mult; rp.log_prob_missing = std::log(1.0 - ro->success_prob);
+    rp.weight_sampson = (double)ro->monodepth_weight_sampson;
+    rp.final_max_it = (int)std::min<uint64_t>(bo->max_iterations, 1u << 30); rp.final_loss = bo->loss_type;
+    rp.grad_tol = bo->gradient_tol; rp.step_tol = bo->step_tol; rp.lambda0 = bo->initial_lambda;
+    rp.lambda_min = bo->min_lambda; rp.lambda_max = bo->max_lambda;
+    rp.chunk_len = chunk_cap; rp.chunk_start = 0;
+
+    hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, h->nper.as<int32_t>(),
+                       h->table_of_pair.as<int32_t>(), h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error,
+                       ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>());
+    HIPCHK(hipGetLastError());
+
+    int32_t *cnt = h->counters.as<int32_t>();
+    const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
+    int64_t sum_n = 0;
+    for (int i = 0; i < batch; ++i) sum_n += n_host[i] >= 3 ? n_host[i] : 0;
+    (void)sum_n;
+
+    uint64_t it0 = 0;
+    uint64_t next_len = std::min<uint64_t>(ro->max_iterations, std::max<uint64_t>(ro->min_iterations + 1, 1));
+    if (ro->max_iterations == 0) next_len = 1; // the reference's do-while runs one iteration even then
+    while (true) {
+        const int len = (int)std::min<uint64_t>(next_len, (uint64_t)chunk_cap);
+        rp.chunk_len = len; rp.chunk_start = it0;
+        HIPCHK(hipMemsetAsync(h->model_count.p, 0, sizeof(int32_t) * batch, s));
+        HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
+        hipLaunchKernelGGL(k_samples, dim3((n_tables + 63) / 64), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
+                           h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
+        hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
+                           h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(),
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>());
+        {
+            hipEvent_t e0, e1;
+            if ((rc = get_events(h, &e0, &e1))) return rc;
+            HIPCHK(hipEventRecord(e0, s));
+            const dim3 grid((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS, batch);
+            if (kind == MDRP_CALIB)
+                hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                                   h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
+                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+            else
+                hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                                   h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
+                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+            HIPCHK(hipEventRecord(e1, s));
+            h->sweep_launches++;
+        }
+        hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
+                           h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0, h->work_pair.as<uint32_t>(),
+                           h->work_pos.as<uint32_t>(), h->model_count.as<int32_t>(), reinterpret_cast<unsigned long long *>(cnt + 6));
+        hipLaunchKernelGGL(k_lo, dim3(h->num_cu * 2), dim3(LM_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                           h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0,
+                           h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1);
+        hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
+                           h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
+        HIPCHK(hipGetLastError());
+        // evaluations of this chunk's sweep: sum over pairs of models * n  (read back with the progress record)
+        HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        h->sweep_evals += (int64_t)h->progress_host->evals;
+        it0 += (uint64_t)len;
+        if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
+        next_len = std::max<uint64_t>(h->progress_host->max_needed, 256);
+        next_len = std::min<uint64_t>(next_len, ro->max_iterations - it0);
+    }
+
+    hipLaunchKernelGGL(k_final, dim3(batch), dim3(LM_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                       h->dep.as<double>(), mask_dev, results_dev);
+    HIPCHK(hipGetLastError());
+    return MDRP_OK;
+}
+
+int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
+                    int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1, const mdrp_camera *cam2,
+                    const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
+    if (!h || batch < 0 || n_max < 0 || kind < 0 || kind > 2 || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (kind == MDRP_CALIB && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->last_batch = batch;
+    int rc;
+    if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
+    if (batch == 0) return MDRP_OK;
+    std::vector<int32_t> n_host(batch);
+    for (int i = 0; i < batch; ++i) {
+        n_host[i] = n_per_pair ? n_per_pair[i] : n_max;
+        if (n_host[i] < 0 || n_host[i] > n_max) { g_err = "n_per_pair out of range"; return MDRP_ERR_INVALID; }
+    }
+    uint8_t *mask = mask_dev;
+    if (!mask) {
+        if ((rc = h->mask.ensure((size_t)batch * std::max(n_max, 1)))) return rc;
+        mask = h->mask.as<uint8_t>();
+    }
+    // chunk capacity and pairs per pass from the scratch budget
+    uint64_t chunk_cap64 = std::min<uint64_t>(std::max<uint64_t>(ro->max_iterations, 1), std::max<uint64_t>(ro->min_iterations + 1, 4096));
+    chunk_cap64 = std::min<uint64_t>(chunk_cap64, 16384);
+    const int chunk_cap = (int)chunk_cap64;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    const size_t per_pair = (size_t)chunk_cap * 4 * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t)) +
+                            (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
+    size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
+    int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair));
+    for (int p0 = 0; p0 < batch; p0 += per_pass) {
+        const int nb = std::min(per_pass, batch - p0);
+        rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 + (size_t)p0 * n_max, d2 + (size_t)p0 * n_max, nb,
+                      n_max, n_host.data() + p0, cam1 ? cam1 + p0 : nullptr, cam2 ? cam2 + p0 : nullptr, ro, bo, chunk_cap,
+                      mask + (size_t)p0 * n_max, h->results.as<ResultDev>() + p0);
+        if (rc) return rc;
+    }
+    return MDRP_OK;
+}
+
+int finish_timing(mdrp_handle *h) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double ms = 0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
+        ms += t;
+    }
+    h->sweep_ms = ms;
+    return MDRP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *mdrp_last_error(void) { return g_err.c_str(); }
+const char *mdrp_version(void) { return "mdrp-hip 0.1 (gfx950)"; }
+
+int mdrp_create(int device, void *stream, mdrp_handle **out) {
+    if (!out) return MDRP_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        g_err = "no usable HIP device";
+        return MDRP_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    mdrp_handle *h = new mdrp_handle();
+    h->device = device;
+    if (stream) { h->stream = (hipStream_t)stream; h->owns_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->owns_stream = true; }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
+    const int tile_bytes = (int)(sizeof(double) * TILE_PTS * PT_STRIDE);
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
+    *out = h;
+    return MDRP_OK;
+}
+
+void mdrp_destroy(mdrp_handle *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
+                      &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
+                      &h->work_pos, &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
+                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f};
+    for (DevBuf *b : bufs) b->release();
+    for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (h->progress_host) (void)hipHostFree(h->progress_host);
+    if (h->owns_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int mdrp_synchronize(mdrp_handle *h) {
+    if (!h) return MDRP_ERR_INVALID;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MDRP_OK;
+}
+
+int mdrp_estimate_batch_async(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2,
+                              int batch, int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1, const mdrp_camera *cam2,
+                              const mdrp_ransac_opt *ropt, const mdrp_bundle_opt *bopt, uint8_t *inlier_mask_dev) {
+    return estimate_device(h, kind, x1, x2, d1, d2, batch, n_max, n_per_pair, cam1, cam2, ropt, bopt, inlier_mask_dev);
+}
+
+int mdrp_fetch_results(mdrp_handle *h, mdrp_result *out, int batch) {
+    if (!h || !out || batch < 0 || batch > h->last_batch) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, h->results.p, sizeof(ResultDev) * batch, hipMemcpyDeviceToHost, h->stream));
+    return finish_timing(h);
+}
+
+int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x1, const double *x2, const double *d1,
+                        const double *d2, int batch, int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1,
+                        const mdrp_camera *cam2, const mdrp_ransac_opt *ropt, const mdrp_bundle_opt *bopt, mdrp_result *out,
+                        uint8_t *inlier_mask) {
+    if (!h || !out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    HIPCHK(hipSetDevice(h->device));
+    const size_t np = (size_t)batch * n_max;
+    int rc;
+    uint8_t *mask_dev = inlier_mask;
+    if (mem_space == MDRP_MEM_HOST) {
+        if ((rc = h->in_x1.ensure(sizeof(double) * 2 * np + 16)) || (rc = h->in_x2.ensure(sizeof(double) * 2 * np + 16)) ||
+            (rc = h->in_d1.ensure(sizeof(double) * np + 16)) || (rc = h->in_d2.ensure(sizeof(double) * np + 16)))
+            return rc;
+        HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->in_d1.p, d1, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->in_d2.p, d2, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+        x1 = h->in_x1.as<double>(); x2 = h->in_x2.as<double>(); d1 = h->in_d1.as<double>(); d2 = h->in_d2.as<double>();
+        mask_dev = nullptr; // handle-owned device mask, copied back below
+    }
+    rc = estimate_device(h, kind, x1, x2, d1, d2, batch, n_max, n_per_pair, cam1, cam2, ropt, bopt, mask_dev);
+    if (rc) return rc;
+    if (mem_space == MDRP_MEM_HOST && inlier_mask && np > 0)
+        HIPCHK(hipMemcpyAsync(inlier_mask, h->mask.p, np, hipMemcpyDeviceToHost, h->stream));
+    return mdrp_fetch_results(h, out, batch);
+}
+
+int mdrp_last_sweep_stats(mdrp_handle *h, double *sweep_ms, int64_t *launches, int64_t *evaluations) {
+    if (!h) return MDRP_ERR_INVALID;
+    if (sweep_ms) *sweep_ms = h->sweep_ms;
+    if (launches) *launches = h->sweep_launches;
+    if (evaluations) *evaluations = h->sweep_evals;
+    return MDRP_OK;
+}
+
+int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const double *x2h, const double *d1, const double *d2,
+                      int count, mdrp_model *out, int32_t *n_out) {
+    if (!h || count < 0 || solver < 0 || solver > 3 || !out || !n_out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (count == 0) return MDRP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    int rc;
+    if ((rc = h->unit_a.ensure(sizeof(double) * 9 * count)) || (rc = h->unit_b.ensure(sizeof(double) * 9 * count)) ||
+        (rc = h->unit_c.ensure(sizeof(double) * 3 * count)) || (rc = h->unit_d.ensure(sizeof(double) * 3 * count)) ||
+        (rc = h->unit_e.ensure(sizeof(Model) * 4 * count)) || (rc = h->unit_f.ensure(sizeof(int32_t) * count)))
+        return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->unit_a.p, x1h, sizeof(double) * 9 * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->unit_b.p, x2h, sizeof(double) * 9 * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->unit_c.p, d1, sizeof(double) * 3 * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->unit_d.p, d2, sizeof(double) * 3 * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->unit_e.p, 0, sizeof(Model) * 4 * count, s));
+    hipLaunchKernelGGL(k_solver_unit, dim3((count + 63) / 64), dim3(64), 0, s, solver, count, h->unit_a.as<double>(),
+                       h->unit_b.as<double>(), h->unit_c.as<double>(), h->unit_d.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->unit_e.p, sizeof(Model) * 4 * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_out, h->unit_f.p, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MDRP_OK;
+}
+
+int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model *models, int num_models, const double *x1,
+                      const double *x2, int n, double sq_threshold, double *scores, int32_t *counts) {
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 2 || !scores || !counts) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (num_models == 0) return MDRP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int chunk = (num_models + 3) / 4;
+    const size_t slots = (size_t)chunk * 4;
+    int rc;
+    if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * std::max(n, 1))) || (rc = h->st.ensure(sizeof(PairState))) ||
+        (rc = h->models.ensure(sizeof(Model) * slots)) || (rc = h->slot_score.ensure(sizeof(double) * slots)) ||
+        (rc = h->slot_inl.ensure(sizeof(int32_t) * slots)) || (rc = h->tags.ensure(sizeof(uint32_t) * slots)) ||
+        (rc = h->model_count.ensure(sizeof(int32_t))))
+        return rc;
+    const double *x1d = x1, *x2d = x2;
+    const Model *md = reinterpret_cast<const Model *>(models);
+    if (mem_space == MDRP_MEM_HOST) {
+        if ((rc = h->in_x1.ensure(sizeof(double) * 2 * std::max(n, 1))) || (rc = h->in_x2.ensure(sizeof(double) * 2 * std::max(n, 1)))) return rc;
+        HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->models.p, models, sizeof(Model) * num_models, hipMemcpyHostToDevice, s));
+        x1d = h->in_x1.as<double>(); x2d = h->in_x2.as<double>();
+        md = h->models.as<Model>();
+    } else {
+        HIPCHK(hipMemcpyAsync(h->models.p, models, sizeof(Model) * num_models, hipMemcpyDeviceToDevice, s));
+        md = h->models.as<Model>();
+    }
+    std::vector<uint32_t> tags(num_models);
+    for (int i = 0; i < num_models; ++i) tags[i] = (uint32_t)i;
+    HIPCHK(hipMemcpyAsync(h->tags.p, tags.data(), sizeof(uint32_t) * num_models, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->model_count.p, &num_models, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    PairState ps;
+    std::memset(&ps, 0, sizeof ps);
+    ps.n = n; ps.active = 1; ps.sq_thr = sq_threshold; ps.eps = std::sqrt(sq_threshold);
+    HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, x1d, x2d, (const double *)nullptr,
+                       (const double *)nullptr, h->pts.as<double>(), (double *)nullptr);
+    RunParams rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk;
+    const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
+    const dim3 grid((num_models + SCORE_THREADS - 1) / SCORE_THREADS, 1);
+    h->ev_used = 0; h->sweep_launches = 1; h->sweep_evals = (int64_t)num_models * n;
+    hipEvent_t e0, e1;
+    if ((rc = get_events(h, &e0, &e1))) return rc;
+    HIPCHK(hipEventRecord(e0, s));
+    if (kind == MDRP_CALIB)
+        hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+    else
+        hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+    HIPCHK(hipEventRecord(e1, s));
+    HIPCHK(hipGetLastError());
+    const hipMemcpyKind back = mem_space == MDRP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPCHK(hipMemcpyAsync(scores, h->slot_score.p, sizeof(double) * num_models, back, s));
+    HIPCHK(hipMemcpyAsync(counts, h->slot_inl.p, sizeof(int32_t) * num_models, back, s));
+    return finish_timing(h);
+}
+
+int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,
+                       const double *d1, const double *d2, int n, double scale_reproj, double weight_sampson,
+                       const mdrp_bundle_opt *opt, int estimate_shift, double *final_cost) {
+    if (!h || count < 0 || n < 0 || kind < 0 || kind > 2 || !opt || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (count == 0) return MDRP_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    const int nn = std::max(n, 1);
+    if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * nn)) || (rc = h->dep.ensure(sizeof(double) * 2 * nn)) ||
+        (rc = h->in_x1.ensure(sizeof(double) * 2 * nn)) || (rc = h->in_x2.ensure(sizeof(double) * 2 * nn)) ||
+        (rc = h->in_d1.ensure(sizeof(double) * nn)) || (rc = h->in_d2.ensure(sizeof(double) * nn)) ||
+        (rc = h->unit_e.ensure(sizeof(Model) * count)) || (rc = h->unit_a.ensure(sizeof(double) * count)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->in_d1.p, d1, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->in_d2.p, d2, sizeof(double) * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->unit_e.p, models, sizeof(Model) * count, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, h->in_x1.as<double>(), h->in_x2.as<double>(),
+                       h->in_d1.as<double>(), h->in_d2.as<double>(), h->pts.as<double>(), h->dep.as<double>());
+    LmOpt o;
+    o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
+    o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
+    o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
+    hipLaunchKernelGGL(k_refine_unit, dim3(count), dim3(LM_THREADS), 0, s, kind, (kind == MDRP_CALIB && estimate_shift) ? 1 : 0, count,
+                       h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
+                       h->unit_a.as<double>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(models, h->unit_e.p, sizeof(Model) * count, hipMemcpyDeviceToHost, s));
+    if (final_cost) HIPCHK(hipMemcpyAsync(final_cost, h->unit_a.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MDRP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,813 @@
+// mdrp_kernels.h — gfx950 kernels of the RePoseD RANSAC hot path.
+//
+// The reference runs LO-RANSAC sequentially per image pair (ransac<> @0x22f030).  Its structure
+// is exactly parallelisable: the sample sequence depends only on (seed, N); LO triggers depend only
+// on the running records of the MINIMAL models; every LO starts from the triggering minimal model.  So per chunk
+// of iterations:
+//   k_samples  one lane per distinct N      splitmix64 sample table for the chunk                       (a-3)
+//   k_solve    one lane per minimal sample  solver -> <=4 models, compacted tag list per pair            (a-4..a-6')
+//   k_score    one lane per hypothesis      Sampson/MSAC (+cheirality) sweep over all N correspondences,
+//                                           correspondences staged through LDS, broadcast reads         (a-7)  HOT
+//   k_scan     one wave per pair            ordered prefix scan of (count,score) records -> LO triggers (a-2)
+//   k_lo       one workgroup per trigger    LM refinement (<=25 it, TRUNCATED) + rescoring              (a-8)
+//   k_walk     one lane per pair            replays the reference's bookkeeping over the triggers,
+//                                           dynamic stopping                                            (a-2)
+//   k_final    one workgroup per pair       final LO, inlier mask, inlier-only LM, result record        (a-1, a-9)
+// HBM layout (all fp64 unless noted): pts[B][n_max][6] = (x1.x, x1.y, x2.x, x2.y, 1/|(x1,1)|, 1/|(x2,1)|)
+// normalised; dep[B][n_max][2] = (d1, d2); models[B][chunk][4] (96 B each); slot_score/slot_inl[B][chunk][4];
+// tags[B][4*chunk] u32 compact list of live slots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "mdrp_math.h"
+
+namespace mdrp {
+
+constexpr int PT_STRIDE = 6;       // doubles per correspondence record
+constexpr int TILE_PTS = 2048;     // correspondences per LDS tile (96 KiB)
+constexpr int SCORE_THREADS = 512; // 8 waves: 2 per SIMD share one tile
+constexpr int LM_THREADS = 256;
+constexpr int MAX_NP = 9;
+constexpr int MAX_ACC = MAX_NP * (MAX_NP + 1) / 2 + MAX_NP; // 54
+
+struct PairState {
+    int32_t n;          // correspondences (0 if the pair is degenerate: n < 3)
+    int32_t table;      // sample table id (one per distinct n)
+    int32_t active;     // still iterating
+    int32_t n_triggers; // triggers found in the current chunk
+    double eps;         // normalised max_epipolar_error
+    double sq_thr;      // eps^2
+    double scale_reproj;
+    double lo_loss_scale;   // loss_scale of the LO refinement (eps; 1.0 for varying focal — reference quirk)
+    double final_loss_scale; // user bundle loss_scale, normalised
+    double norm;        // un-normalisation factor of the focals (1 for calibrated)
+    uint64_t best_min_cnt;
+    double best_min_score;
+    uint64_t dyn_max_iter;
+    uint64_t iterations, refinements, num_inliers;
+    double inlier_ratio, model_score;
+    Model best;
+};
+
+struct Trigger {
+    uint32_t iter;   // iteration index inside the chunk
+    int32_t k_ref;   // slot refined by LO (last record breaker of the iteration)
+    int32_t k_min;   // slot that set a new best minimal score in this iteration, or -1
+    int32_t cnt_min;
+    double score_min;
+    double ref_score; // filled by k_lo
+    int32_t ref_cnt;
+    int32_t pad_;
+    Model refined;
+};
+
+struct RunParams {
+    int kind;           // MDRP_CALIB / SHARED / VARYING
+    int solver;         // SOLVER_*
+    int est_shift;
+    int batch, n_max;
+    int chunk_len;      // iterations in this chunk
+    uint64_t chunk_start;
+    uint64_t max_iterations, min_iterations;
+    double dyn_mult, log_prob_missing;
+    double weight_sampson;
+    // user bundle options (final refinement)
+    int final_max_it, final_loss;
+    double grad_tol, step_tol, lambda0, lambda_min, lambda_max;
+};
+
+// ------------------------------------------------------------------------------------------------ reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sums NV per-thread values over the workgroup; every thread gets the totals.  scratch: NWAVES*NV doubles of LDS.
+template <int NV, int NTHREADS>
+__device__ __forceinline__ void block_sum(double *vals, double *scratch) {
+    constexpr int NW = NTHREADS / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const double s = wave_sum(vals[i]);
+        if (lane == 0) scratch[wave * NV + i] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += scratch[w * NV + i];
+        vals[i] = s;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------ prep
+// One workgroup per pair: normalise the correspondences into the pts/dep records and set up the pair state.
+// calibrated: Camera::unproject + thresholds * (1/f1 + 1/f2)/2 (estimate_monodepth_relative_pose @0x2242bf-0x224348)
+// focal:      x / scale, scale = sum(|x1_i| + |x2_i|) / (sqrt2 N) (normalize_points @0x4f6ae0), thresholds / scale
+struct CamDev { int32_t model_id, pad_; double p[4]; };
+
+__global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
+                                              const double *__restrict__ d1, const double *__restrict__ d2,
+                                              const int32_t *__restrict__ n_per_pair, const int32_t *__restrict__ table_of_pair,
+                                              const CamDev *__restrict__ cam1, const CamDev *__restrict__ cam2,
+                                              double max_epi, double max_reproj, double bundle_loss_scale,
+                                              double *__restrict__ pts, double *__restrict__ dep, PairState *__restrict__ st) {
+    __shared__ double red[4];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n = n_per_pair[pair];
+    const size_t base = (size_t)pair * rp.n_max;
+    double k = 1.0, norm = 1.0;
+    double fx1 = 1, fy1 = 1, cx1 = 0, cy1 = 0, fx2 = 1, fy2 = 1, cx2 = 0, cy2 = 0;
+    if (rp.kind == 0) {
+        const CamDev a = cam1[pair], b = cam2[pair];
+        if (a.model_id == 1) { fx1 = a.p[0]; fy1 = a.p[1]; cx1 = a.p[2]; cy1 = a.p[3]; } else { fx1 = fy1 = a.p[0]; cx1 = a.p[1]; cy1 = a.p[2]; }
+        if (b.model_id == 1) { fx2 = b.p[0]; fy2 = b.p[1]; cx2 = b.p[2]; cy2 = b.p[3]; } else { fx2 = fy2 = b.p[0]; cx2 = b.p[1]; cy2 = b.p[2]; }
+        k = 0.5 * (1.0 / (0.5 * (fx1 + fy1)) + 1.0 / (0.5 * (fx2 + fy2)));
+    } else {
+        double acc = 0;
+        for (int i = tid; i < n; i += 256) {
+            const double a = x1[2 * (base + i)], b = x1[2 * (base + i) + 1], c = x2[2 * (base + i)], d = x2[2 * (base + i) + 1];
+            acc += sqrt(a * a + b * b) + sqrt(c * c + d * d);
+        }
+        acc = wave_sum(acc);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        norm = (red[0] + red[1] + red[2] + red[3]) / (1.4142135623730951 * (double)(n > 0 ? n : 1));
+        k = 1.0 / norm;
+    }
+    for (int i = tid; i < n; i += 256) {
+        double a = x1[2 * (base + i)], b = x1[2 * (base + i) + 1], c = x2[2 * (base + i)], d = x2[2 * (base + i) + 1];
+        if (rp.kind == 0) { a = (a - cx1) / fx1; b = (b - cy1) / fy1; c = (c - cx2) / fx2; d = (d - cy2) / fy2; }
+        else { a /= norm; b /= norm; c /= norm; d /= norm; }
+        double *p = pts + (base + i) * PT_STRIDE;
+        p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+        p[4] = 1.0 / sqrt(a * a + b * b + 1.0);
+        p[5] = 1.0 / sqrt(c * c + d * d + 1.0);
+        dep[2 * (base + i)] = d1[base + i];
+        dep[2 * (base + i) + 1] = d2[base + i];
+    }
+    if (tid == 0) {
+        PairState s;
+        s.n = n >= 3 ? n : 0;
+        s.table = table_of_pair[pair];
+        s.active = n >= 3;
+        s.n_triggers = 0;
+        s.eps = max_epi * k;
+        s.sq_thr = s.eps * s.eps;
+        const double rep = max_reproj * k;
+        s.scale_reproj = rep > 0.0 ? (s.eps * s.eps) / (rep * rep) : 0.0;
+        s.lo_loss_scale = rp.kind == 2 ? 1.0 : s.eps;
+        s.final_loss_scale = bundle_loss_scale * k;
+        s.norm = norm;
+        s.best_min_cnt = 0; s.best_min_score = DBL_MAX;
+        s.dyn_max_iter = rp.max_iterations;
+        s.iterations = 0; s.refinements = 0; s.num_inliers = 0;
+        s.inlier_ratio = 0.0; s.model_score = DBL_MAX;
+        model_identity(s.best);
+        st[pair] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ samples
+// One lane per distinct N: the sample sequence is a pure function of (seed, N) (RandomSampler @0x4f8970).
+__global__ void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state, int chunk_len,
+                          uint32_t *__restrict__ samples /*[n_tables][chunk_len][3]*/) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tables) return;
+    uint64_t s = table_state[t];
+    const uint64_t n = (uint64_t)table_n[t];
+    uint32_t *out = samples + (size_t)t * chunk_len * 3;
+    if (n >= 3) {
+        for (int i = 0; i < chunk_len; ++i) {
+            uint32_t a, b, c;
+            draw_sample3(n, s, a, b, c);
+            out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+        }
+    }
+    table_state[t] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ solve
+// One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
+// with ONE atomic per wave (wave-aggregated prefix sum).
+__global__ __launch_bounds__(256) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+                                               const double *__restrict__ pts, const double *__restrict__ dep,
+                                               Model *__restrict__ models, int32_t *__restrict__ slot_inl,
+                                               uint32_t *__restrict__ tags, int32_t *__restrict__ model_count) {
+    const int pair = blockIdx.y;
+    const int it = blockIdx.x * 256 + threadIdx.x;
+    const PairState &ps = st[pair];
+    if (!ps.active) return;
+    const bool live = it < rp.chunk_len;
+    int n = 0;
+    Model out[4];
+    if (live) {
+        const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it) * 3;
+        Sample3 s;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t idx = (size_t)pair * rp.n_max + sm[k];
+            const double *p = pts + idx * PT_STRIDE;
+            s.x1[k][0] = p[0]; s.x1[k][1] = p[1]; s.x2[k][0] = p[2]; s.x2[k][1] = p[3];
+            s.d1[k] = dep[2 * idx]; s.d2[k] = dep[2 * idx + 1];
+        }
+        n = run_solver(rp.solver, s, out);
+        // a NaN hypothesis can never become a record (its score is N*thr, count 0) except as the very first model;
+        // drop it (the reference's own P3P emits NaN poses for ~2% of garbage samples)
+    }
+    // wave-aggregated append
+    const int lane = threadIdx.x & 63;
+    int pre = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
+    const int total = __shfl(pre, 63, 64);
+    int basepos = 0;
+    if (lane == 63 && total > 0) basepos = atomicAdd(&model_count[pair], total);
+    basepos = __shfl(basepos, 63, 64);
+    if (!live) return;
+    const size_t slot0 = ((size_t)pair * rp.chunk_len + it) * 4;
+    int pos = basepos + pre - n;
+    const size_t tag_base = (size_t)pair * rp.chunk_len * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            models[slot0 + k] = out[k];
+            tags[tag_base + pos] = (uint32_t)(it * 4 + k);
+            ++pos;
+        } else {
+            slot_inl[slot0 + k] = -1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ score (HOT)
+// One lane per hypothesis; the pair's correspondences are staged through LDS in tiles and read as wave-wide
+// broadcasts (every lane reads the same record), so a tile is fetched from HBM/L2 once per workgroup and each
+// (model x correspondence) evaluation costs ~20 fp64 VALU ops + 3 broadcast ds_read_b128.
+// Algorithmic bytes: 32 B per evaluation (x1, x2 as four fp64 — what the CPU loop reads).
+template <bool POSE>
+__device__ __forceinline__ void score_tile(const double *__restrict__ tile, int npts, const double E[9], const double R[9],
+                                           const double t[3], double thr, double &score, int &cnt) {
+    const double thr_hi = thr * (1.0 + 1e-12);
+#pragma unroll 2
+    for (int p = 0; p < npts; ++p) {
+        const double2 *P = reinterpret_cast<const double2 *>(tile + p * PT_STRIDE);
+        const double2 p01 = P[0], p23 = P[1];
+        const double a = p01.x, b = p01.y, c = p23.x, d = p23.y;
+        const double e0 = fma(E[0], a, fma(E[1], b, E[2]));
+        const double e1 = fma(E[3], a, fma(E[4], b, E[5]));
+        const double e2 = fma(E[6], a, fma(E[7], b, E[8]));
+        const double g0 = fma(E[0], c, fma(E[3], d, E[6]));
+        const double g1 = fma(E[1], c, fma(E[4], d, E[7]));
+        const double C = fma(c, e0, fma(d, e1, e2));
+        const double den = fma(e0, e0, fma(e1, e1, fma(g0, g0, g1 * g1)));
+        const double C2 = C * C;
+        if (C2 < thr_hi * den) { // candidate inlier; exact test on the quotient like the reference
+            const double r2 = C2 / den;
+            if (r2 < thr) {
+                bool ok = true;
+                if (POSE) { // check_cheirality on unit bearings, min depth 0.01 (@0x1dce00)
+                    const double2 p45 = P[2];
+                    const double u0 = fma(R[0], a, fma(R[1], b, R[2]));
+                    const double u1 = fma(R[3], a, fma(R[4], b, R[5]));
+                    const double u2 = fma(R[6], a, fma(R[7], b, R[8]));
+                    const double uh = fma(u0, c, fma(u1, d, u2));
+                    const double ut = fma(u0, t[0], fma(u1, t[1], u2 * t[2]));
+                    const double ht = fma(c, t[0], fma(d, t[1], t[2]));
+                    const double A = -uh * p45.x * p45.y;
+                    const double b1 = -ut * p45.x, b2 = ht * p45.y;
+                    const double l1 = fma(-A, b2, b1), l2 = fma(-A, b1, b2);
+                    const double md = 0.01 * fma(-A, A, 1.0);
+                    ok = (l1 > md) && (l2 > md);
+                }
+                if (ok) { score += r2; ++cnt; }
+            }
+        }
+    }
+}
+
+template <bool POSE>
+__global__ __launch_bounds__(SCORE_THREADS) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                         const Model *__restrict__ models, const uint32_t *__restrict__ tags,
+                                                         const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
+                                                         int32_t *__restrict__ slot_inl) {
+    extern __shared__ double tile[]; // TILE_PTS * PT_STRIDE doubles
+    const int pair = blockIdx.y;
+    const int count = model_count[pair];
+    const int base = blockIdx.x * SCORE_THREADS;
+    if (base >= count) return;
+    const PairState &ps = st[pair];
+    const int n = ps.n;
+    const double thr = ps.sq_thr;
+    const int tid = threadIdx.x;
+    const bool live = base + tid < count;
+    const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+    uint32_t slot = 0;
+    double E[9], R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { E[i] = 0; R[i] = 0; }
+    t[0] = t[1] = t[2] = 0;
+    if (live) {
+        slot = tags[slot_base + base + tid];
+        const Model m = models[slot_base + slot];
+        quat_to_R(m.q, R);
+        t[0] = m.t[0]; t[1] = m.t[1]; t[2] = m.t[2];
+        double Em[9];
+        essential_from_Rt(R, t, Em);
+        if (POSE) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) E[i] = Em[i];
+        } else {
+            fundamental_from_E(Em, m.f1, m.f2, E);
+        }
+    }
+    double score = 0;
+    int cnt = 0;
+    const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    for (int t0 = 0; t0 < n; t0 += TILE_PTS) {
+        const int npts = min(TILE_PTS, n - t0);
+        __syncthreads();
+        { // cooperative, coalesced 16-B loads of the tile
+            const double2 *src = reinterpret_cast<const double2 *>(gp + (size_t)t0 * PT_STRIDE);
+            double2 *dst = reinterpret_cast<double2 *>(tile);
+            const int nvec = npts * (PT_STRIDE / 2);
+            for (int i = tid; i < nvec; i += SCORE_THREADS) dst[i] = src[i];
+        }
+        __syncthreads();
+        score_tile<POSE>(tile, npts, E, R, t, thr, score, cnt);
+    }
+    if (live) {
+        slot_score[slot_base + slot] = score + thr * (double)(n - cnt);
+        slot_inl[slot_base + slot] = cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scan
+// One wave per pair walks the chunk's slots in iteration order, 64 iterations per step: per-lane local records ->
+// wave exclusive prefix (max count, min score) -> per-lane replay against the true running records.
+__global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict__ st, const double *__restrict__ slot_score,
+                                             const int32_t *__restrict__ slot_inl, Trigger *__restrict__ triggers,
+                                             int trig_cap, int32_t *__restrict__ work_count, uint32_t *__restrict__ work_pair,
+                                             uint32_t *__restrict__ work_pos, const int32_t *__restrict__ model_count,
+                                             unsigned long long *__restrict__ evals) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    PairState &ps = st[pair];
+    if (!ps.active) { if (lane == 0) ps.n_triggers = 0; return; }
+    if (lane == 0) atomicAdd(evals, (unsigned long long)model_count[pair] * (unsigned long long)ps.n);
+    long long run_cnt = (long long)ps.best_min_cnt;
+    double run_score = ps.best_min_score;
+    int ntrig = 0;
+    const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+    for (int it0 = 0; it0 < rp.chunk_len; it0 += 64) {
+        const int it = it0 + lane;
+        const bool live = it < rp.chunk_len;
+        int c[4];
+        double s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            c[k] = live ? slot_inl[slot_base + (size_t)it * 4 + k] : -1;
+            s[k] = (live && c[k] >= 0) ? slot_score[slot_base + (size_t)it * 4 + k] : DBL_MAX;
+        }
+        long long lc = -1;
+        double ls = DBL_MAX;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (c[k] >= 0) { lc = max(lc, (long long)c[k]); ls = fmin(ls, s[k]); }
+        // exclusive prefix over lanes
+        long long pc = lc;
+        double psn = ls;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long vc = __shfl_up(pc, o, 64);
+            const double vs = __shfl_up(psn, o, 64);
+            if (lane >= o) { pc = max(pc, vc); psn = fmin(psn, vs); }
+        }
+        const long long tot_c = __shfl(pc, 63, 64);
+        const double tot_s = __shfl(psn, 63, 64);
+        long long ec = __shfl_up(pc, 1, 64);
+        double es = __shfl_up(psn, 1, 64);
+        if (lane == 0) { ec = -1; es = DBL_MAX; }
+        long long bc = max(run_cnt, ec);
+        double bs = fmin(run_score, es);
+        // replay this iteration's models in order against the true running records
+        int k_ref = -1, k_min = -1, cnt_min = 0;
+        double score_min = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (c[k] >= 0) {
+                const bool more = (long long)c[k] > bc, better = s[k] < bs;
+                if (more || better) {
+                    if (more) bc = c[k];
+                    if (better) { bs = s[k]; k_min = k; score_min = s[k]; cnt_min = c[k]; }
+                    k_ref = k;
+                }
+            }
+        }
+        const unsigned long long ball = __ballot(k_ref >= 0);
+        if (k_ref >= 0) {
+            const int pos = ntrig + __popcll(ball & ((1ull << lane) - 1ull));
+            if (pos < trig_cap) {
+                Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+                tr.iter = (uint32_t)it; tr.k_ref = k_ref; tr.k_min = k_min; tr.cnt_min = cnt_min; tr.score_min = score_min;
+                tr.ref_score = DBL_MAX; tr.ref_cnt = 0;
+                const int w = atomicAdd(work_count, 1);
+                work_pair[w] = (uint32_t)pair;
+                work_pos[w] = (uint32_t)pos;
+            }
+        }
+        ntrig += __popcll(ball);
+        run_cnt = max(run_cnt, tot_c);
+        run_score = fmin(run_score, tot_s);
+    }
+    if (lane == 0) {
+        ps.best_min_cnt = (uint64_t)(run_cnt < 0 ? 0 : run_cnt);
+        ps.best_min_score = run_score;
+        ps.n_triggers = min(ntrig, trig_cap);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LM (workgroup)
+template <int KIND, bool SHIFT> struct LmTraits;
+template <> struct LmTraits<0, false> { static constexpr int NP = 7; };
+template <> struct LmTraits<0, true> { static constexpr int NP = 9; };
+template <> struct LmTraits<1, false> { static constexpr int NP = 8; };
+template <> struct LmTraits<2, false> { static constexpr int NP = 9; };
+
+// active parameter p -> column of the full 11-wide Jacobian
+template <int KIND, bool SHIFT>
+__device__ __forceinline__ constexpr int lm_col(int p) {
+    return p < 7 ? p : (KIND == 0 ? p /*7,8 = shifts*/ : p + 2 /*9,10 = focals*/);
+}
+
+struct LmOpt {
+    int max_it, loss;
+    double loss_scale, grad_tol, step_tol, lambda0, lambda_min, lambda_max;
+};
+
+template <int KIND>
+__device__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+                          const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *scratch) {
+    LmState stt;
+    lm_state_from_model(m, KIND != 0, stt);
+    double cost = 0;
+    for (int i = threadIdx.x; i < n; i += LM_THREADS) {
+        if (mask && !mask[i]) continue;
+        const double *p = pts + (size_t)i * PT_STRIDE;
+        double r[5], zf, zb;
+        point_residuals<false>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, nullptr);
+        cost += ws * loss_value(o.loss, o.loss_scale, r[0] * r[0]);
+        if (!(zf < 0)) cost += loss_value(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2]);
+        if (!(zb < 0)) cost += loss_value(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4]);
+    }
+    double v[1] = {cost};
+    block_sum<1, LM_THREADS>(v, scratch);
+    return v[0];
+}
+
+template <int KIND, bool SHIFT>
+__device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+                              const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, double *scratch) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NA = NP * (NP + 1) / 2 + NP;
+    LmState stt;
+    lm_state_from_model(m, KIND != 0, stt);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0;
+    for (int i = threadIdx.x; i < n; i += LM_THREADS) {
+        if (mask && !mask[i]) continue;
+        const double *p = pts + (size_t)i * PT_STRIDE;
+        double r[5], zf, zb, J[5][LM_NPAR];
+        point_residuals<true>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, J);
+        const double wS = ws * loss_weight(o.loss, o.loss_scale, r[0] * r[0]);
+        const double wF = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2]);
+        const double wB = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4]);
+        const double wr[5] = {wS, wF, wF, wB, wB};
+#pragma unroll
+        for (int row = 0; row < 5; ++row) {
+            double Ja[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                Ja[q] = J[row][lm_col<KIND, SHIFT>(q)];
+                if (KIND == 1 && q == 7) Ja[q] += J[row][10]; // shared focal: f1 = f2 = f
+            }
+            const double w = wr[row];
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+                const double wa = w * Ja[a];
+#pragma unroll
+                for (int b = 0; b <= a; ++b) acc[idx++] += wa * Ja[b];
+            }
+#pragma unroll
+            for (int a = 0; a < NP; ++a) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r[row];
+        }
+    }
+    block_sum<NA, LM_THREADS>(acc, scratch);
+}
+
+// lm_impl<> loop of the reference (upstream PoseLib convention): executed redundantly and uniformly by every
+// thread of the workgroup; only the two sweeps over the correspondences are distributed.
+template <int KIND, bool SHIFT>
+__device__ void lm_refine(Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o, double *scratch) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NT = NP * (NP + 1) / 2;
+    const double sqrt_sr = sqrt(scale_reproj);
+    double cost = lm_cost<KIND>(m, pts, dep, n, mask, sqrt_sr, ws, o, scratch);
+    double lambda = o.lambda0;
+    bool recompute = true;
+    double acc[NT + NP];
+    double A[NP * NP], g[NP], sol[NP];
+    for (int it = 0; it < o.max_it; ++it) {
+        if (recompute) {
+            lm_accumulate<KIND, SHIFT>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, scratch);
+            double gn = 0;
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+#pragma unroll
+                for (int b = 0; b <= a; ++b) A[a * NP + b] = acc[idx++];
+            }
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { g[a] = acc[NT + a]; gn += g[a] * g[a]; }
+            if (sqrt(gn) < o.grad_tol) break;
+        }
+        double Ad[NP * NP];
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) Ad[a * NP + b] = A[a * NP + b] + (a == b ? lambda : 0.0);
+        chol_solve<NP>(Ad, g, sol);
+        double sn = 0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { sol[a] = -sol[a]; sn += sol[a] * sol[a]; }
+        if (sqrt(sn) < o.step_tol) break;
+        double full[LM_NPAR];
+#pragma unroll
+        for (int q = 0; q < LM_NPAR; ++q) full[q] = 0;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) full[lm_col<KIND, SHIFT>(q)] = sol[q];
+        if (KIND == 1) full[10] = full[9];
+        Model cand;
+        lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
+        const double cost_new = lm_cost<KIND>(cand, pts, dep, n, mask, sqrt_sr, ws, o, scratch);
+        if (cost_new < cost) {
+            m = cand;
+            lambda = fmax(o.lambda_min, lambda / 10.0);
+            cost = cost_new;
+            recompute = true;
+        } else {
+            lambda = fmin(o.lambda_max, lambda * 10.0);
+            recompute = false;
+        }
+    }
+}
+
+__device__ __forceinline__ void lm_dispatch(int kind, int est_shift, Model &m, const double *pts, const double *dep, int n,
+                                            const uint8_t *mask, double scale_reproj, double ws, const LmOpt &o, double *scratch) {
+    if (kind == 0) {
+        if (est_shift) lm_refine<0, true>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
+        else lm_refine<0, false>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
+    } else if (kind == 1) lm_refine<1, false>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
+    else lm_refine<2, false>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
+}
+
+// workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask output
+__device__ void block_score(int kind, const Model &m, const double *__restrict__ pts, int n, double thr, double *scratch,
+                            double &score_out, int &cnt_out, uint8_t *__restrict__ mask_out) {
+    double R[9], E[9], Em[9];
+    quat_to_R(m.q, R);
+    essential_from_Rt(R, m.t, Em);
+    if (kind == 0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) E[i] = Em[i];
+    } else fundamental_from_E(Em, m.f1, m.f2, E);
+    double score = 0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += LM_THREADS) {
+        double s1 = 0;
+        int c1 = 0;
+        if (kind == 0) score_tile<true>(pts + (size_t)i * PT_STRIDE, 1, E, R, m.t, thr, s1, c1);
+        else score_tile<false>(pts + (size_t)i * PT_STRIDE, 1, E, R, m.t, thr, s1, c1);
+        score += s1; cnt += c1;
+        if (mask_out) mask_out[i] = (uint8_t)c1;
+    }
+    double v[2] = {score, (double)cnt};
+    block_sum<2, LM_THREADS>(v, scratch);
+    cnt_out = (int)v[1];
+    score_out = v[0] + thr * (double)(n - cnt_out);
+}
+
+// ------------------------------------------------------------------------------------------------ LO
+// Persistent workgroups pop (pair, trigger) items; each refines the triggering minimal model (refine_model
+// @0x4fa550/@0x4fad60/@0x4fb0a0: 25 it, TRUNCATED) and rescoring it.
+__global__ __launch_bounds__(LM_THREADS) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                   const double *__restrict__ dep, const Model *__restrict__ models,
+                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ work_count,
+                                                   const uint32_t *__restrict__ work_pair, const uint32_t *__restrict__ work_pos,
+                                                   int32_t *__restrict__ work_head) {
+    __shared__ double scratch[4 * MAX_ACC];
+    __shared__ int s_item;
+    const int total = *work_count;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(work_head, 1);
+        __syncthreads();
+        const int w = s_item;
+        if (w >= total) break;
+        const int pos = (int)work_pos[w];
+        const int pair = (int)work_pair[w];
+        const PairState &ps = st[pair];
+        Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+        const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+        Model m = models[slot_base + (size_t)tr.iter * 4 + tr.k_ref];
+        LmOpt o;
+        o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+        o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+        const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+        const double *dd = dep + (size_t)pair * rp.n_max * 2;
+        lm_dispatch(rp.kind, rp.est_shift, m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, scratch);
+        double sc;
+        int cn;
+        block_score(rp.kind, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+        if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ walk
+// One lane per pair replays score_models<> / ransac<> bookkeeping (@0x22ebc0, @0x22f030) over the ordered triggers
+// and applies the dynamic stopping rule.
+__global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__restrict__ models, const Trigger *__restrict__ triggers,
+                       int trig_cap, int32_t *__restrict__ n_active, unsigned long long *__restrict__ max_needed) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= rp.batch) return;
+    PairState &ps = st[pair];
+    if (!ps.active) return;
+    const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+    const uint64_t c0 = rp.chunk_start, c1 = rp.chunk_start + (uint64_t)rp.chunk_len;
+    uint64_t it = c0; // iterations completed so far
+    bool stopped = false;
+    // stop test applied after each completed iteration: it >= max -> stop; it > min && it > dyn -> stop
+    auto first_stop = [&](uint64_t lo /*first candidate value of it*/) -> uint64_t {
+        uint64_t s = lo;
+        if (s < ps.dyn_max_iter + 1) s = ps.dyn_max_iter + 1;
+        if (s < rp.min_iterations + 1) s = rp.min_iterations + 1;
+        if (s > rp.max_iterations) s = rp.max_iterations;
+        if (lo > s) s = lo;
+        return s;
+    };
+    for (int k = 0; k < ps.n_triggers && !stopped; ++k) {
+        const Trigger &tr = triggers[(size_t)pair * trig_cap + k];
+        const uint64_t ti = c0 + tr.iter; // absolute index of the triggering iteration
+        // iterations it .. ti-1 complete without bookkeeping changes; would the loop stop at a value in (it, ti] ?
+        if (ti > it) {
+            const uint64_t s = first_stop(it + 1);
+            if (s <= ti) { it = s; stopped = true; break; }
+        }
+        // execute iteration ti
+        if (tr.k_min >= 0 && tr.score_min < ps.model_score) {
+            ps.model_score = tr.score_min;
+            ps.best = models[slot_base + (size_t)tr.iter * 4 + tr.k_min];
+            ps.num_inliers = (uint64_t)tr.cnt_min;
+        }
+        ps.refinements++;
+        if (tr.ref_score < ps.model_score) {
+            ps.model_score = tr.ref_score;
+            ps.num_inliers = (uint64_t)tr.ref_cnt;
+            ps.best = tr.refined;
+        }
+        ps.inlier_ratio = (double)ps.num_inliers / (double)ps.n;
+        if (ps.inlier_ratio >= 0.9999) ps.dyn_max_iter = rp.min_iterations;
+        else if (ps.inlier_ratio <= 0.0001) ps.dyn_max_iter = rp.max_iterations;
+        else {
+            const double prob_outlier = 1.0 - ps.inlier_ratio * ps.inlier_ratio * ps.inlier_ratio;
+            ps.dyn_max_iter = (uint64_t)ceil(rp.log_prob_missing / log(prob_outlier) * rp.dyn_mult);
+        }
+        it = ti + 1;
+        if (it >= rp.max_iterations || (it > rp.min_iterations && it > ps.dyn_max_iter)) { stopped = true; break; }
+    }
+    if (!stopped) {
+        // remaining iterations of the chunk
+        if (c1 > it) {
+            const uint64_t s = first_stop(it + 1);
+            if (s <= c1) { it = s; stopped = true; } else it = c1;
+        }
+    }
+    ps.iterations = it;
+    if (stopped) ps.active = 0;
+    else {
+        atomicAdd(n_active, 1);
+        uint64_t need = first_stop(it + 1) - it; // iterations still certainly needed with the current dyn_max_iter
+        atomicMax(max_needed, (unsigned long long)need);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ final
+// ransac<> tail (@0x22f1d0-0x22f295) + get_inliers (@0x4f7a10/@0x4f77f0) + the estimator's inlier-only refinement
+// (@0x2247c3 / @0x223815) + focal un-normalisation.
+struct ResultDev {
+    Model model;
+    uint64_t refinements, iterations, num_inliers;
+    double inlier_ratio, model_score;
+};
+
+__global__ __launch_bounds__(LM_THREADS) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
+                                                      const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
+                                                      ResultDev *__restrict__ results) {
+    __shared__ double scratch[4 * MAX_ACC];
+    const int pair = blockIdx.x;
+    PairState &ps = st[pair];
+    ResultDev res;
+    res.model = ps.best;
+    res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
+    res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
+    uint8_t *mask = mask_all + (size_t)pair * rp.n_max;
+    if (ps.n < 3) {
+        for (int i = threadIdx.x; i < rp.n_max; i += LM_THREADS) mask[i] = 0;
+        if (threadIdx.x == 0) results[pair] = res;
+        return;
+    }
+    const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    const double *dd = dep + (size_t)pair * rp.n_max * 2;
+    Model m = ps.best;
+    LmOpt o;
+    o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+    o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+    lm_dispatch(rp.kind, rp.est_shift, m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, scratch);
+    res.refinements++;
+    double sc;
+    int cn;
+    block_score(rp.kind, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+    Model best = ps.best;
+    if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
+    for (int i = ps.n + threadIdx.x; i < rp.n_max; i += LM_THREADS) mask[i] = 0;
+    block_score(rp.kind, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
+    __syncthreads();
+    if (res.num_inliers > 3) {
+        LmOpt f;
+        f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
+        f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
+        lm_dispatch(rp.kind, rp.est_shift, best, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, f, scratch);
+    }
+    if (rp.kind != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
+    res.model = best;
+    if (threadIdx.x == 0) results[pair] = res;
+}
+
+// ------------------------------------------------------------------------------------------------ unit-parity kernels
+__global__ void k_solver_unit(int solver, int count, const double *__restrict__ x1h, const double *__restrict__ x2h,
+                              const double *__restrict__ d1, const double *__restrict__ d2, Model *__restrict__ out, int32_t *__restrict__ n_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    Sample3 s;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        s.x1[k][0] = x1h[9 * i + 3 * k]; s.x1[k][1] = x1h[9 * i + 3 * k + 1];
+        s.x2[k][0] = x2h[9 * i + 3 * k]; s.x2[k][1] = x2h[9 * i + 3 * k + 1];
+        s.d1[k] = d1[3 * i + k]; s.d2[k] = d2[3 * i + k];
+    }
+    Model m[4];
+    const int n = run_solver(solver, s, m);
+    n_out[i] = n;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < n) out[4 * i + k] = m[k];
+}
+
+// pack raw normalised correspondences of ONE pair into pts records (for mdrp_score_models / mdrp_refine_models)
+__global__ void k_pack_unit(int n, const double *__restrict__ x1, const double *__restrict__ x2, const double *__restrict__ d1,
+                            const double *__restrict__ d2, double *__restrict__ pts, double *__restrict__ dep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = x1[2 * i], b = x1[2 * i + 1], c = x2[2 * i], d = x2[2 * i + 1];
+    double *p = pts + (size_t)i * PT_STRIDE;
+    p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+    p[4] = 1.0 / sqrt(a * a + b * b + 1.0);
+    p[5] = 1.0 / sqrt(c * c + d * d + 1.0);
+    if (dep) { dep[2 * i] = d1 ? d1[i] : 0.0; dep[2 * i + 1] = d2 ? d2[i] : 0.0; }
+}
+
+__global__ __launch_bounds__(LM_THREADS) void k_refine_unit(int kind, int est_shift, int count, Model *__restrict__ models,
+                                                            const double *__restrict__ pts, const double *__restrict__ dep, int n,
+                                                            double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost) {
+    __shared__ double scratch[4 * MAX_ACC];
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    Model m = models[i];
+    lm_dispatch(kind, est_shift, m, pts, dep, n, nullptr, scale_reproj, ws, o, scratch);
+    double c;
+    const double ssr = sqrt(scale_reproj);
+    if (kind == 0) c = lm_cost<0>(m, pts, dep, n, nullptr, ssr, ws, o, scratch);
+    else if (kind == 1) c = lm_cost<1>(m, pts, dep, n, nullptr, ssr, ws, o, scratch);
+    else c = lm_cost<2>(m, pts, dep, n, nullptr, ssr, ws, o, scratch);
+    if (threadIdx.x == 0) { models[i] = m; if (final_cost) final_cost[i] = c; }
+}
+
+} // namespace mdrp

@@ -1,0 +1,847 @@
+// mdrp_math.h — per-lane fp64 arithmetic of the RePoseD RANSAC hot path: pose algebra, the four minimal solvers,
+// Sampson/cheirality scoring and the per-correspondence residual/Jacobian of the hybrid refinement.
+//
+// Product code (gfx950).  Every function is straight-line register code for ONE lane: one lane = one minimal
+// sample (solvers) or one hypothesis (scoring) — nothing here is a dense contraction, so no MFMA.  Local arrays are
+// only indexed by compile-time constants after unrolling (runtime-indexed arrays would go to scratch).
+// The same header also compiles with a host C++ compiler (MDRP_HD expands to `inline`) for the CPU unit tests of
+// the arithmetic (tests/hostmath); that build is test scaffolding, not a fallback: the library has no CPU path.
+//
+// Reference functions replaced (binary only): p3p @0xecd50, relpose_monodepth_3pt @0x155ca0,
+// relpose_monodepth_3pt_shared_focal @0x18fdf0, relpose_monodepth_3pt_varying_focal @0x19bcd0,
+// compute_sampson_msac_score @0x4f61d0/@0x4f65d0, check_cheirality @0x1dce00, and the Jacobian accumulators
+// behind refine_monodepth_*relpose @0x261030/@0x2592e0/@0x260fa0.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define MDRP_HD __host__ __device__ __forceinline__
+#else
+#define MDRP_HD inline
+#endif
+
+namespace mdrp {
+
+struct Model { // == mdrp_model
+    double q[4];
+    double t[3];
+    double scale, shift1, shift2;
+    double f1, f2;
+};
+
+MDRP_HD void model_identity(Model &m) {
+    m.q[0] = 1.0; m.q[1] = 0.0; m.q[2] = 0.0; m.q[3] = 0.0;
+    m.t[0] = 0.0; m.t[1] = 0.0; m.t[2] = 0.0;
+    m.scale = 1.0; m.shift1 = 0.0; m.shift2 = 0.0; m.f1 = 1.0; m.f2 = 1.0;
+}
+
+// ---------------------------------------------------------------- pose algebra
+MDRP_HD void quat_to_R(const double q[4], double R[9]) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+    R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+MDRP_HD void R_to_quat(const double R[9], double q[4]) {
+    const double tr = R[0] + R[4] + R[8];
+    double w, x, y, z;
+    if (tr > 0) {
+        double t = sqrt(tr + 1.0);
+        w = 0.5 * t; t = 0.5 / t;
+        x = (R[7] - R[5]) * t; y = (R[2] - R[6]) * t; z = (R[3] - R[1]) * t;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {
+        double t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        x = 0.5 * t; t = 0.5 / t;
+        w = (R[7] - R[5]) * t; y = (R[3] + R[1]) * t; z = (R[6] + R[2]) * t;
+    } else if (R[4] >= R[8]) {
+        double t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        y = 0.5 * t; t = 0.5 / t;
+        w = (R[2] - R[6]) * t; z = (R[7] + R[5]) * t; x = (R[1] + R[3]) * t;
+    } else {
+        double t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        z = 0.5 * t; t = 0.5 / t;
+        w = (R[3] - R[1]) * t; x = (R[2] + R[6]) * t; y = (R[5] + R[7]) * t;
+    }
+    const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+    q[0] = w * inv; q[1] = x * inv; q[2] = y * inv; q[3] = z * inv;
+}
+
+// E = [t]x R (row-major)
+MDRP_HD void essential_from_Rt(const double R[9], const double t[3], double E[9]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        E[0 + c] = t[1] * R[6 + c] - t[2] * R[3 + c];
+        E[3 + c] = t[2] * R[0 + c] - t[0] * R[6 + c];
+        E[6 + c] = t[0] * R[3 + c] - t[1] * R[0 + c];
+    }
+}
+
+// F = diag(1,1,f2) E diag(1,1,f1)   (score_model @0x4fac60 / @0x4faf90)
+MDRP_HD void fundamental_from_E(const double E[9], double f1, double f2, double F[9]) {
+    F[0] = E[0]; F[1] = E[1]; F[2] = E[2] * f1;
+    F[3] = E[3]; F[4] = E[4]; F[5] = E[5] * f1;
+    F[6] = E[6] * f2; F[7] = E[7] * f2; F[8] = E[8] * f1 * f2;
+}
+
+MDRP_HD double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+MDRP_HD void cross3(const double *a, const double *b, double *c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// rigid alignment of two congruent triangles: R (X_i - X_0) = Y_i - Y_0, t = Y_0 - R X_0
+MDRP_HD void align3(const double X[9], const double Y[9], double R[9], double t[3]) {
+    double a[3], b[3], c[3], u[3], v[3], w[3], bc[3], ca[3], ab[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { a[i] = X[3 + i] - X[i]; b[i] = X[6 + i] - X[i]; u[i] = Y[3 + i] - Y[i]; v[i] = Y[6 + i] - Y[i]; }
+    cross3(a, b, c); cross3(u, v, w);
+    cross3(b, c, bc); cross3(c, a, ca); cross3(a, b, ab);
+    const double idet = 1.0 / dot3(a, bc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = (u[i] * bc[j] + v[i] * ca[j] + w[i] * ab[j]) * idet;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = Y[i] - (R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2]);
+}
+
+// ---------------------------------------------------------------- univariate polynomials
+// real roots of x^3 + b x^2 + c x + d; Newton-polished; r0 always valid, (r1,r2) valid iff return value is 3
+MDRP_HD int solve_cubic_real(double b, double c, double d, double &r0, double &r1, double &r2) {
+    const double third = 1.0 / 3.0;
+    const double p = c - b * b * third;
+    const double q = 2.0 * b * b * b / 27.0 - b * c * third + d;
+    const double disc = q * q * 0.25 + p * p * p / 27.0;
+    int n;
+    if (disc > 0) {
+        const double sq = sqrt(disc);
+        r0 = cbrt(-0.5 * q + sq) + cbrt(-0.5 * q - sq) - b * third;
+        r1 = r0; r2 = r0;
+        n = 1;
+    } else {
+        const double rr = sqrt(-p * third);
+        double arg = (rr > 0) ? (-0.5 * q) / (rr * rr * rr) : 0.0;
+        arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
+        const double phi = acos(arg) * third;
+        const double tp3 = 2.0943951023931954923; // 2 pi / 3
+        r0 = 2.0 * rr * cos(phi) - b * third;
+        r1 = 2.0 * rr * cos(phi - tp3) - b * third;
+        r2 = 2.0 * rr * cos(phi - 2.0 * tp3) - b * third;
+        n = 3;
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double f0 = ((r0 + b) * r0 + c) * r0 + d, g0 = (3.0 * r0 + 2.0 * b) * r0 + c;
+        const double f1 = ((r1 + b) * r1 + c) * r1 + d, g1 = (3.0 * r1 + 2.0 * b) * r1 + c;
+        const double f2 = ((r2 + b) * r2 + c) * r2 + d, g2 = (3.0 * r2 + 2.0 * b) * r2 + c;
+        if (g0 != 0.0) r0 -= f0 / g0;
+        if (g1 != 0.0) r1 -= f1 / g1;
+        if (g2 != 0.0) r2 -= f2 / g2;
+    }
+    return n;
+}
+
+// real roots of x^4 + b x^3 + c x^2 + d x + e (Ferrari, resolvent cubic), Newton-polished.
+// Returns a 4-bit validity mask for roots[0..3] (pairs {0,1} and {2,3} come from the two quadratic factors).
+MDRP_HD int solve_quartic_real(double b, double c, double d, double e, double roots[4]) {
+    const double b2 = b * b;
+    const double p = c - 0.375 * b2;
+    const double q = d - 0.5 * b * c + 0.125 * b2 * b;
+    const double r = e - 0.25 * b * d + b2 * c * 0.0625 - 3.0 * b2 * b2 / 256.0;
+    double z0, z1, z2;
+    const int nz = solve_cubic_real(2.0 * p, p * p - 4.0 * r, -q * q, z0, z1, z2);
+    double z = z0;
+    if (nz == 3) { z = z1 > z ? z1 : z; z = z2 > z ? z2 : z; }
+    int mask = 0;
+    double y0 = 0, y1 = 0, y2 = 0, y3 = 0;
+    const double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
+    if (z <= 1e-14 * scale) { // biquadratic
+        const double disc = p * p - 4.0 * r;
+        if (disc >= 0) {
+            const double sq = sqrt(disc);
+            const double ya = 0.5 * (-p + sq), yb = 0.5 * (-p - sq);
+            if (ya >= 0) { y0 = sqrt(ya); y1 = -y0; mask |= 3; }
+            if (yb >= 0) { y2 = sqrt(yb); y3 = -y2; mask |= 12; }
+        }
+    } else {
+        const double s = sqrt(z);
+        const double qs = q / s;
+        const double t1 = 0.5 * (p + z - qs), t2 = 0.5 * (p + z + qs);
+        const double disc1 = z - 4.0 * t1, disc2 = z - 4.0 * t2;
+        if (disc1 >= 0) { const double sq = sqrt(disc1); y0 = 0.5 * (-s + sq); y1 = 0.5 * (-s - sq); mask |= 3; }
+        if (disc2 >= 0) { const double sq = sqrt(disc2); y2 = 0.5 * (s + sq); y3 = 0.5 * (s - sq); mask |= 12; }
+    }
+    double x[4] = {y0 - 0.25 * b, y1 - 0.25 * b, y2 - 0.25 * b, y3 - 0.25 * b};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const double f = (((x[k] + b) * x[k] + c) * x[k] + d) * x[k] + e;
+            const double fp = ((4.0 * x[k] + 3.0 * b) * x[k] + 2.0 * c) * x[k] + d;
+            if (fp != 0.0) x[k] -= f / fp;
+        }
+        roots[k] = x[k];
+    }
+    return mask;
+}
+
+MDRP_HD bool solve3x3(const double A[9], const double b[3], double x[3]) {
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    if (!(fabs(det) > 0)) return false;
+    const double id = 1.0 / det;
+    x[0] = (c00 * b[0] + (A[2] * A[7] - A[1] * A[8]) * b[1] + (A[1] * A[5] - A[2] * A[4]) * b[2]) * id;
+    x[1] = (c01 * b[0] + (A[0] * A[8] - A[2] * A[6]) * b[1] + (A[2] * A[3] - A[0] * A[5]) * b[2]) * id;
+    x[2] = (c02 * b[0] + (A[1] * A[6] - A[0] * A[7]) * b[1] + (A[0] * A[4] - A[1] * A[3]) * b[2]) * id;
+    return true;
+}
+
+// ---------------------------------------------------------------- P3P
+// depths l_i > 0 with |l_i x_i - l_j x_j|^2 = a_ij.  Two homogeneous conics in (l0:l1:l2) -> degenerate member of
+// their pencil (cubic) -> real line pair -> intersect each line with a conic of the pencil -> <= 4 points.
+// symmetric 3x3 stored as {00,01,02,11,12,22}
+MDRP_HD void sym_adj(const double C[6], double A[6]) {
+    A[0] = C[3] * C[5] - C[4] * C[4];
+    A[1] = C[2] * C[4] - C[1] * C[5];
+    A[2] = C[1] * C[4] - C[2] * C[3];
+    A[3] = C[0] * C[5] - C[2] * C[2];
+    A[4] = C[1] * C[2] - C[0] * C[4];
+    A[5] = C[0] * C[3] - C[1] * C[1];
+}
+MDRP_HD double sym_det(const double C[6]) {
+    return C[0] * (C[3] * C[5] - C[4] * C[4]) - C[1] * (C[1] * C[5] - C[4] * C[2]) + C[2] * (C[1] * C[4] - C[3] * C[2]);
+}
+MDRP_HD double sym_trprod(const double A[6], const double B[6]) {
+    return A[0] * B[0] + A[3] * B[3] + A[5] * B[5] + 2.0 * (A[1] * B[1] + A[2] * B[2] + A[4] * B[4]);
+}
+MDRP_HD double sym_quad(const double C[6], const double *u, const double *v) {
+    return u[0] * (C[0] * v[0] + C[1] * v[1] + C[2] * v[2]) + u[1] * (C[1] * v[0] + C[3] * v[1] + C[4] * v[2]) +
+           u[2] * (C[2] * v[0] + C[4] * v[1] + C[5] * v[2]);
+}
+
+// quality of a pencil member as a REAL line pair: max diagonal of -adj(C), normalised
+MDRP_HD double linepair_quality(const double D1[6], const double D2[6], double g) {
+    double C[6], A[6], nrm = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { C[i] = D1[i] + g * D2[i]; nrm += C[i] * C[i]; }
+    sym_adj(C, A);
+    double mx = -A[0];
+    mx = (-A[3] > mx) ? -A[3] : mx;
+    mx = (-A[5] > mx) ? -A[5] : mx;
+    return mx / nrm;
+}
+
+// one candidate (tau:sigma) on a line spanned by u,v -> scaled, sign-fixed, polished depths; returns validity
+MDRP_HD bool p3p_finish(double tau, double sig, const double u[3], const double v[3], double m01, double m02, double m12,
+                        double a01, double a02, double a12, double lam[3]) {
+    double l0 = sig * u[0] + tau * v[0], l1 = sig * u[1] + tau * v[1], l2 = sig * u[2] + tau * v[2];
+    double qv, av;
+    if (a12 >= a01 && a12 >= a02) { qv = l1 * l1 + l2 * l2 - 2 * m12 * l1 * l2; av = a12; }
+    else if (a02 >= a01) { qv = l0 * l0 + l2 * l2 - 2 * m02 * l0 * l2; av = a02; }
+    else { qv = l0 * l0 + l1 * l1 - 2 * m01 * l0 * l1; av = a01; }
+    if (!(qv > 0)) return false;
+    double sc = sqrt(av / qv);
+    if (l0 < 0) sc = -sc;
+    l0 *= sc; l1 *= sc; l2 *= sc;
+    if (!(l0 > 0 && l1 > 0 && l2 > 0)) return false;
+    const double tol = 1e-15 * (a01 + a02 + a12);
+    for (int it = 0; it < 5; ++it) {
+        const double r0 = l0 * l0 + l1 * l1 - 2 * m01 * l0 * l1 - a01;
+        const double r1 = l0 * l0 + l2 * l2 - 2 * m02 * l0 * l2 - a02;
+        const double r2 = l1 * l1 + l2 * l2 - 2 * m12 * l1 * l2 - a12;
+        if (fabs(r0) + fabs(r1) + fabs(r2) < tol) break;
+        const double J[9] = {2 * (l0 - m01 * l1), 2 * (l1 - m01 * l0), 0.0,
+                             2 * (l0 - m02 * l2), 0.0, 2 * (l2 - m02 * l0),
+                             0.0, 2 * (l1 - m12 * l2), 2 * (l2 - m12 * l1)};
+        const double res[3] = {r0, r1, r2};
+        double dx[3];
+        if (!solve3x3(J, res, dx)) break;
+        l0 -= dx[0]; l1 -= dx[1]; l2 -= dx[2];
+    }
+    if (!(l0 > 0 && l1 > 0 && l2 > 0)) return false;
+    lam[0] = l0; lam[1] = l1; lam[2] = l2;
+    return true;
+}
+
+// returns number of depth triples written to L (<= 4)
+MDRP_HD int p3p_depths(double m01, double m02, double m12, double a01, double a02, double a12, double L[4][3]) {
+    const double D1[6] = {a12, -a12 * m01, 0.0, a12 - a01, a01 * m12, -a01};
+    const double D2[6] = {a12, 0.0, -a12 * m02, -a02, a02 * m12, a12 - a02};
+    double A1[6], A2[6];
+    sym_adj(D1, A1); sym_adj(D2, A2);
+    const double c3 = sym_det(D2), c2 = sym_trprod(A2, D1), c1 = sym_trprod(A1, D2), c0 = sym_det(D1);
+    if (!(fabs(c3) > 1e-300)) return 0;
+    const double ic3 = 1.0 / c3;
+    double g0, g1, g2;
+    const int nr = solve_cubic_real(c2 * ic3, c1 * ic3, c0 * ic3, g0, g1, g2);
+    double g = g0, best = linepair_quality(D1, D2, g0);
+    if (nr == 3) {
+        const double q1 = linepair_quality(D1, D2, g1), q2 = linepair_quality(D1, D2, g2);
+        if (q1 > best) { best = q1; g = g1; }
+        if (q2 > best) { best = q2; g = g2; }
+    }
+    if (!(best > 0)) return 0;
+    double C[6], B[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) C[i] = D1[i] + g * D2[i];
+    sym_adj(C, B);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) B[i] = -B[i];
+    double p0, p1, p2; // p = l x m, B = p p'
+    if (B[0] >= B[3] && B[0] >= B[5]) { const double s = sqrt(B[0]), is = 1.0 / s; p0 = s; p1 = B[1] * is; p2 = B[2] * is; }
+    else if (B[3] >= B[5]) { const double s = sqrt(B[3]), is = 1.0 / s; p0 = B[1] * is; p1 = s; p2 = B[4] * is; }
+    else { const double s = sqrt(B[5]), is = 1.0 / s; p0 = B[2] * is; p1 = B[4] * is; p2 = s; }
+    // M = C + [p]x = 2 m l' : rows ~ l, columns ~ m
+    const double M[9] = {C[0], C[1] - p2, C[2] + p1, C[1] + p2, C[3], C[4] - p0, C[2] - p1, C[4] + p0, C[5]};
+    double la[3], lb[3];
+    {
+        const double r0 = M[0] * M[0] + M[1] * M[1] + M[2] * M[2], r1 = M[3] * M[3] + M[4] * M[4] + M[5] * M[5],
+                     r2 = M[6] * M[6] + M[7] * M[7] + M[8] * M[8];
+        if (r0 >= r1 && r0 >= r2) { la[0] = M[0]; la[1] = M[1]; la[2] = M[2]; }
+        else if (r1 >= r2) { la[0] = M[3]; la[1] = M[4]; la[2] = M[5]; }
+        else { la[0] = M[6]; la[1] = M[7]; la[2] = M[8]; }
+        const double k0 = M[0] * M[0] + M[3] * M[3] + M[6] * M[6], k1 = M[1] * M[1] + M[4] * M[4] + M[7] * M[7],
+                     k2 = M[2] * M[2] + M[5] * M[5] + M[8] * M[8];
+        if (k0 >= k1 && k0 >= k2) { lb[0] = M[0]; lb[1] = M[3]; lb[2] = M[6]; }
+        else if (k1 >= k2) { lb[0] = M[1]; lb[1] = M[4]; lb[2] = M[7]; }
+        else { lb[0] = M[2]; lb[1] = M[5]; lb[2] = M[8]; }
+    }
+    const bool useD2 = fabs(g) < 1.0; // the pencil member that does NOT vanish on the lines
+    double Dq[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) Dq[i] = useD2 ? D2[i] : D1[i];
+    int n = 0;
+#pragma unroll
+    for (int li = 0; li < 2; ++li) {
+        const double l0 = li ? lb[0] : la[0], l1 = li ? lb[1] : la[1], l2 = li ? lb[2] : la[2];
+        // two points spanning the line: u = l x e_a, v = l x e_b, (a,b) = the two axes other than argmax|l|
+        double u[3], v[3];
+        const double f0 = fabs(l0), f1 = fabs(l1), f2 = fabs(l2);
+        if (f0 >= f1 && f0 >= f2) { // k=0: a=1,b=2 : l x e1 = (-l2,0,l0), l x e2 = (l1,-l0,0)
+            u[0] = -l2; u[1] = 0; u[2] = l0; v[0] = l1; v[1] = -l0; v[2] = 0;
+        } else if (f1 >= f2) {       // k=1: a=2,b=0 : l x e2 = (l1,-l0,0), l x e0 = (0,l2,-l1)
+            u[0] = l1; u[1] = -l0; u[2] = 0; v[0] = 0; v[1] = l2; v[2] = -l1;
+        } else {                     // k=2: a=0,b=1 : l x e0 = (0,l2,-l1), l x e1 = (-l2,0,l0)
+            u[0] = 0; u[1] = l2; u[2] = -l1; v[0] = -l2; v[1] = 0; v[2] = l0;
+        }
+        const double qa = sym_quad(Dq, v, v), qb = sym_quad(Dq, u, v), qc = sym_quad(Dq, u, u);
+        const double disc = qb * qb - qa * qc;
+        if (disc >= 0) {
+            const double sq = sqrt(disc);
+            const double qq = -(qb + (qb >= 0 ? sq : -sq));
+            double lam[3];
+            if (n < 4 && p3p_finish(qq, qa, u, v, m01, m02, m12, a01, a02, a12, lam)) { L[n][0] = lam[0]; L[n][1] = lam[1]; L[n][2] = lam[2]; ++n; }
+            if (n < 4 && p3p_finish(qc, qq, u, v, m01, m02, m12, a01, a02, a12, lam)) { L[n][0] = lam[0]; L[n][1] = lam[1]; L[n][2] = lam[2]; ++n; }
+        }
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- minimal solvers (inputs: 3 correspondences)
+// x1,x2: normalised image points (x,y) per correspondence, homogeneous z = 1 implied.
+struct Sample3 {
+    double x1[3][2], x2[3][2], d1[3], d2[3];
+};
+
+// a-6': P3P on X_k = d1_k (x1_k,1) and unit bearings of image 2; scale from the first correspondence (x component)
+MDRP_HD int solver_calib_p3p(const Sample3 &s, Model out[4]) {
+    double X[9], xb[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double inv = 1.0 / sqrt(s.x2[i][0] * s.x2[i][0] + s.x2[i][1] * s.x2[i][1] + 1.0);
+        X[3 * i] = s.d1[i] * s.x1[i][0]; X[3 * i + 1] = s.d1[i] * s.x1[i][1]; X[3 * i + 2] = s.d1[i];
+        xb[3 * i] = s.x2[i][0] * inv; xb[3 * i + 1] = s.x2[i][1] * inv; xb[3 * i + 2] = inv;
+    }
+    double d01[3], d02[3], d12[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d01[c] = X[c] - X[3 + c]; d02[c] = X[c] - X[6 + c]; d12[c] = X[3 + c] - X[6 + c]; }
+    double L[4][3];
+    const int n = p3p_depths(dot3(xb, xb + 3), dot3(xb, xb + 6), dot3(xb + 3, xb + 6), dot3(d01, d01), dot3(d02, d02),
+                             dot3(d12, d12), L);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            double Y[9], R[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Y[3 * i + c] = L[k][i] * xb[3 * i + c];
+            model_identity(out[k]);
+            align3(X, Y, R, out[k].t);
+            R_to_quat(R, out[k].q);
+            double Rq[9];
+            quat_to_R(out[k].q, Rq);
+            const double px = Rq[0] * X[0] + Rq[1] * X[1] + Rq[2] * X[2] + out[k].t[0];
+            out[k].scale = px / (s.d2[0] * s.x2[0][0]);
+        }
+    }
+    return n;
+}
+
+// a-4: scale + two shifts.  |(d1_i+u) x1_i - (d1_j+u) x1_j|^2 = s^2 |(d2_i+v) x2_i - (d2_j+v) x2_j|^2 for the 3
+// pairs: linear in (a,b,c) = (s^2, s^2 v, s^2 v^2), quadratic in u; a c = b^2 -> quartic in u.
+MDRP_HD int solver_calib_shift(const Sample3 &s, Model out[4]) {
+    double A1[3], B1[3], C1[3], M[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = (k == 2) ? 1 : 0, j = (k == 0) ? 1 : 2;
+        double p[3], q[3];
+        p[0] = s.d1[i] * s.x1[i][0] - s.d1[j] * s.x1[j][0]; p[1] = s.d1[i] * s.x1[i][1] - s.d1[j] * s.x1[j][1]; p[2] = s.d1[i] - s.d1[j];
+        q[0] = s.x1[i][0] - s.x1[j][0]; q[1] = s.x1[i][1] - s.x1[j][1]; q[2] = 0.0;
+        A1[k] = dot3(p, p); B1[k] = dot3(p, q); C1[k] = dot3(q, q);
+        p[0] = s.d2[i] * s.x2[i][0] - s.d2[j] * s.x2[j][0]; p[1] = s.d2[i] * s.x2[i][1] - s.d2[j] * s.x2[j][1]; p[2] = s.d2[i] - s.d2[j];
+        q[0] = s.x2[i][0] - s.x2[j][0]; q[1] = s.x2[i][1] - s.x2[j][1]; q[2] = 0.0;
+        M[3 * k] = dot3(p, p); M[3 * k + 1] = 2.0 * dot3(p, q); M[3 * k + 2] = dot3(q, q);
+    }
+    double g0[3], g1[3], g2[3];
+    const double B2[3] = {2 * B1[0], 2 * B1[1], 2 * B1[2]};
+    if (!solve3x3(M, A1, g0) || !solve3x3(M, B2, g1) || !solve3x3(M, C1, g2)) return 0;
+    const double k4 = g2[0] * g2[2] - g2[1] * g2[1];
+    const double k3 = g1[0] * g2[2] + g2[0] * g1[2] - 2.0 * g1[1] * g2[1];
+    const double k2 = g0[0] * g2[2] + g1[0] * g1[2] + g2[0] * g0[2] - g1[1] * g1[1] - 2.0 * g0[1] * g2[1];
+    const double k1 = g0[0] * g1[2] + g1[0] * g0[2] - 2.0 * g0[1] * g1[1];
+    const double k0 = g0[0] * g0[2] - g0[1] * g0[1];
+    if (!(fabs(k4) > 0)) return 0;
+    const double ik4 = 1.0 / k4;
+    double us[4];
+    const int mask = solve_quartic_real(k3 * ik4, k2 * ik4, k1 * ik4, k0 * ik4, us);
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!((mask >> r) & 1)) continue;
+        double u = us[r];
+        const double a = g0[0] + u * (g1[0] + u * g2[0]);
+        const double b = g0[1] + u * (g1[1] + u * g2[1]);
+        if (!(a > 0)) continue;
+        double sc = sqrt(a), v = b / a;
+        for (int it = 0; it < 5; ++it) { // Newton polish of (s,u,v) on the three distance equations
+            double J[9], res[3], dx[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double lhs = A1[k] + u * (2.0 * B1[k] + u * C1[k]);
+                const double rhs = M[3 * k] + v * (M[3 * k + 1] + v * M[3 * k + 2]);
+                res[k] = lhs - sc * sc * rhs;
+                J[3 * k] = -2.0 * sc * rhs;
+                J[3 * k + 1] = 2.0 * B1[k] + 2.0 * u * C1[k];
+                J[3 * k + 2] = -sc * sc * (M[3 * k + 1] + 2.0 * v * M[3 * k + 2]);
+            }
+            if (!solve3x3(J, res, dx)) break;
+            sc -= dx[0]; u -= dx[1]; v -= dx[2];
+            if (fabs(dx[0]) + fabs(dx[1]) + fabs(dx[2]) < 1e-15 * (fabs(sc) + fabs(u) + fabs(v))) break;
+        }
+        if (!(sc > 0)) continue;
+        bool pos = true;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pos = pos && (s.d1[i] + u > 0) && (s.d2[i] + v > 0);
+        if (!pos) continue;
+        double X[9], Y[9], R[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double e1 = s.d1[i] + u, e2 = sc * (s.d2[i] + v);
+            X[3 * i] = e1 * s.x1[i][0]; X[3 * i + 1] = e1 * s.x1[i][1]; X[3 * i + 2] = e1;
+            Y[3 * i] = e2 * s.x2[i][0]; Y[3 * i + 1] = e2 * s.x2[i][1]; Y[3 * i + 2] = e2;
+        }
+        Model m;
+        model_identity(m);
+        align3(X, Y, R, m.t);
+        R_to_quat(R, m.q);
+        m.scale = sc; m.shift1 = u; m.shift2 = v;
+        // n is a compile-time-unknown index: write through a small switch to keep `out` in registers
+        if (n == 0) out[0] = m; else if (n == 1) out[1] = m; else if (n == 2) out[2] = m; else out[3] = m;
+        ++n;
+    }
+    return n;
+}
+
+// a-6: varying focal, linear in (1/f1^2, s^2/f2^2, s^2)
+MDRP_HD int solver_varying(const Sample3 &s, Model out[4]) {
+    double A[9], rhs[3], sol[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = (k == 2) ? 1 : 0, j = (k == 0) ? 1 : 2;
+        const double ax = s.d1[i] * s.x1[i][0] - s.d1[j] * s.x1[j][0], ay = s.d1[i] * s.x1[i][1] - s.d1[j] * s.x1[j][1];
+        const double bx = s.d2[i] * s.x2[i][0] - s.d2[j] * s.x2[j][0], by = s.d2[i] * s.x2[i][1] - s.d2[j] * s.x2[j][1];
+        const double dz1 = s.d1[i] - s.d1[j], dz2 = s.d2[i] - s.d2[j];
+        A[3 * k] = ax * ax + ay * ay;
+        A[3 * k + 1] = -(bx * bx + by * by);
+        A[3 * k + 2] = -dz2 * dz2;
+        rhs[k] = -dz1 * dz1;
+    }
+    if (!solve3x3(A, rhs, sol)) return 0;
+    if (!(sol[0] > 0 && sol[1] > 0 && sol[2] > 0)) return 0;
+    const double f1 = 1.0 / sqrt(sol[0]), sc = sqrt(sol[2]), f2 = sqrt(sol[2] / sol[1]);
+    double X[9], Y[9], R[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        X[3 * i] = s.d1[i] * s.x1[i][0] / f1; X[3 * i + 1] = s.d1[i] * s.x1[i][1] / f1; X[3 * i + 2] = s.d1[i];
+        Y[3 * i] = sc * s.d2[i] * s.x2[i][0] / f2; Y[3 * i + 1] = sc * s.d2[i] * s.x2[i][1] / f2; Y[3 * i + 2] = sc * s.d2[i];
+    }
+    model_identity(out[0]);
+    align3(X, Y, R, out[0].t);
+    R_to_quat(R, out[0].q);
+    out[0].scale = sc; out[0].f1 = f1; out[0].f2 = f2;
+    return 1;
+}
+
+// a-5: shared focal.  Unknowns w = 1/f^2, sigma = s^2, rho = depth of point 2 in image 2 over s (d2[2] unused).
+//   N(w) = sigma D(w) ; L02(w) = sigma (a0 - 2 rho c0 + rho^2 e) ; L12(w) = sigma (a1 - 2 rho c1 + rho^2 e)
+// -> quintic in w with zero constant term (w = 0 is f = inf) -> quartic.  Kept: w, sigma, rho > 0.
+// Linear polynomials are stored as {c0, c1}; products are expanded by hand (degrees <= 5).
+MDRP_HD int solver_shared(const Sample3 &s, Model out[4]) {
+    double P1[3], Q1[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int i = (k == 2) ? 1 : 0, j = (k == 0) ? 1 : 2;
+        const double ax = s.d1[i] * s.x1[i][0] - s.d1[j] * s.x1[j][0], ay = s.d1[i] * s.x1[i][1] - s.d1[j] * s.x1[j][1];
+        P1[k] = ax * ax + ay * ay;
+        Q1[k] = (s.d1[i] - s.d1[j]) * (s.d1[i] - s.d1[j]);
+    }
+    const double bx = s.d2[0] * s.x2[0][0] - s.d2[1] * s.x2[1][0], by = s.d2[0] * s.x2[0][1] - s.d2[1] * s.x2[1][1];
+    const double Pp = bx * bx + by * by, Qp = (s.d2[0] - s.d2[1]) * (s.d2[0] - s.d2[1]);
+    const double r0 = s.x2[0][0] * s.x2[0][0] + s.x2[0][1] * s.x2[0][1], r1 = s.x2[1][0] * s.x2[1][0] + s.x2[1][1] * s.x2[1][1],
+                 r2 = s.x2[2][0] * s.x2[2][0] + s.x2[2][1] * s.x2[2][1];
+    const double m02 = s.x2[0][0] * s.x2[2][0] + s.x2[0][1] * s.x2[2][1], m12 = s.x2[1][0] * s.x2[2][0] + s.x2[1][1] * s.x2[2][1];
+    // linear polys (c0 + c1 w)
+    const double N0 = Q1[0], N1 = P1[0], D0 = Qp, D1 = Pp;
+    const double a00 = s.d2[0] * s.d2[0], a01 = a00 * r0, a10 = s.d2[1] * s.d2[1], a11 = a10 * r1;
+    const double c00 = s.d2[0], c01 = s.d2[0] * m02, c10 = s.d2[1], c11 = s.d2[1] * m12;
+    const double e0 = 1.0, e1 = r2;
+    const double L020 = Q1[1], L021 = P1[1], L120 = Q1[2], L121 = P1[2];
+    const double dc0 = c00 - c10, dc1 = c01 - c11;
+    const double da0 = a00 - a10, da1 = a01 - a11;
+    const double dL0 = L020 - L120, dL1 = L021 - L121;
+    // U = N*(a0-a1) - (L02-L12)*D   (degree 2)
+    const double U0 = N0 * da0 - dL0 * D0;
+    const double U1 = N0 * da1 + N1 * da0 - dL0 * D1 - dL1 * D0;
+    const double U2 = N1 * da1 - dL1 * D1;
+    // G = L02*D - N*a0 (degree 2)
+    const double G0 = L020 * D0 - N0 * a00;
+    const double G1 = L020 * D1 + L021 * D0 - N0 * a01 - N1 * a00;
+    const double G2 = L021 * D1 - N1 * a01;
+    // H = N*dc (degree 2)
+    const double H0 = N0 * dc0, H1 = N0 * dc1 + N1 * dc0, H2 = N1 * dc1;
+    // T1 = 4 * (H*dc) * G : (H*dc) degree 3
+    const double K0 = H0 * dc0, K1 = H0 * dc1 + H1 * dc0, K2 = H1 * dc1 + H2 * dc0, K3 = H2 * dc1;
+    // T2 = 4 * c0 * H * U : (c0*H) degree 3
+    const double W0 = c00 * H0, W1 = c00 * H1 + c01 * H0, W2 = c00 * H2 + c01 * H1, W3 = c01 * H2;
+    // U^2 degree 4
+    const double V0 = U0 * U0, V1 = 2 * U0 * U1, V2 = 2 * U0 * U2 + U1 * U1, V3 = 2 * U1 * U2, V4 = U2 * U2;
+    // q5 = 4 K G + 4 W U - e V   (coefficients 1..5; coefficient 0 vanishes identically)
+    const double q1 = 4 * (K0 * G1 + K1 * G0) + 4 * (W0 * U1 + W1 * U0) - (e0 * V1 + e1 * V0);
+    const double q2 = 4 * (K0 * G2 + K1 * G1 + K2 * G0) + 4 * (W0 * U2 + W1 * U1 + W2 * U0) - (e0 * V2 + e1 * V1);
+    const double q3 = 4 * (K1 * G2 + K2 * G1 + K3 * G0) + 4 * (W1 * U2 + W2 * U1 + W3 * U0) - (e0 * V3 + e1 * V2);
+    const double q4 = 4 * (K2 * G2 + K3 * G1) + 4 * (W2 * U2 + W3 * U1) - (e0 * V4 + e1 * V3);
+    const double q5 = 4 * (K3 * G2) + 4 * (W3 * U2) - (e1 * V4);
+    if (!(fabs(q5) > 0)) return 0;
+    const double iq = 1.0 / q5;
+    double ws[4];
+    const int mask = solve_quartic_real(q4 * iq, q3 * iq, q2 * iq, q1 * iq, ws);
+    int n = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (!((mask >> r) & 1)) continue;
+        double w = ws[r];
+        if (!(w > 0)) continue;
+        double Nw = N0 + N1 * w, Dw = D0 + D1 * w;
+        double sig = Nw / Dw;
+        if (!(sig > 0)) continue;
+        double rho = (U0 + w * (U1 + w * U2)) / (2.0 * Nw * (dc0 + dc1 * w));
+        for (int it = 0; it < 4; ++it) { // Newton polish of (w, sigma, rho)
+            const double ga0 = a00 + a01 * w, ga1 = a10 + a11 * w, gc0 = c00 + c01 * w, gc1 = c10 + c11 * w, ge = e0 + e1 * w;
+            const double h0 = ga0 - 2 * rho * gc0 + rho * rho * ge, h1 = ga1 - 2 * rho * gc1 + rho * rho * ge;
+            const double dh0 = a01 - 2 * rho * c01 + rho * rho * e1, dh1 = a11 - 2 * rho * c11 + rho * rho * e1;
+            Nw = N0 + N1 * w; Dw = D0 + D1 * w;
+            const double res[3] = {Nw - sig * Dw, (L020 + L021 * w) - sig * h0, (L120 + L121 * w) - sig * h1};
+            const double J[9] = {N1 - sig * D1, -Dw, 0.0,
+                                 L021 - sig * dh0, -h0, -sig * (-2 * gc0 + 2 * rho * ge),
+                                 L121 - sig * dh1, -h1, -sig * (-2 * gc1 + 2 * rho * ge)};
+            double dx[3];
+            if (!solve3x3(J, res, dx)) break;
+            w -= dx[0]; sig -= dx[1]; rho -= dx[2];
+            if (fabs(dx[0]) + fabs(dx[1]) + fabs(dx[2]) < 1e-15 * (fabs(w) + fabs(sig) + fabs(rho))) break;
+        }
+        if (!(w > 0 && sig > 0 && rho > 0)) continue;
+        const double f = 1.0 / sqrt(w), sc = sqrt(sig), lam2 = rho * sc;
+        const double invf = 1.0 / f;
+        double X[9], Y[9], R[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double dy = (i < 2) ? sc * s.d2[i] : lam2;
+            X[3 * i] = s.d1[i] * s.x1[i][0] * invf; X[3 * i + 1] = s.d1[i] * s.x1[i][1] * invf; X[3 * i + 2] = s.d1[i];
+            Y[3 * i] = dy * s.x2[i][0] * invf; Y[3 * i + 1] = dy * s.x2[i][1] * invf; Y[3 * i + 2] = dy;
+        }
+        Model m;
+        model_identity(m);
+        align3(X, Y, R, m.t);
+        R_to_quat(R, m.q);
+        m.scale = sc; m.f1 = f; m.f2 = f;
+        if (n == 0) out[0] = m; else if (n == 1) out[1] = m; else if (n == 2) out[2] = m; else out[3] = m;
+        ++n;
+    }
+    return n;
+}
+
+enum { SOLVER_P3P = 0, SOLVER_SHIFT = 1, SOLVER_SHARED = 2, SOLVER_VARYING = 3 };
+
+MDRP_HD int run_solver(int solver, const Sample3 &s, Model out[4]) {
+    switch (solver) {
+    case SOLVER_P3P: return solver_calib_p3p(s, out);
+    case SOLVER_SHIFT: return solver_calib_shift(s, out);
+    case SOLVER_SHARED: return solver_shared(s, out);
+    default: return solver_varying(s, out);
+    }
+}
+
+// ---------------------------------------------------------------- robust losses (a-8)
+MDRP_HD double loss_value(int type, double thr, double r2) {
+    const double t2 = thr * thr;
+    switch (type) {
+    case 1: case 5: return r2 < t2 ? r2 : t2;
+    case 2: { const double r = sqrt(r2); return r <= thr ? r2 : thr * (2.0 * r - thr); }
+    case 3: return t2 * log1p(r2 / t2);
+    case 4: return t2 * log1p((r2 < t2 ? r2 : t2) / t2);
+    default: return r2;
+    }
+}
+MDRP_HD double loss_weight(int type, double thr, double r2) {
+    const double t2 = thr * thr;
+    const double dmin = 2.2250738585072014e-308;
+    switch (type) {
+    case 1: case 5: return r2 < t2 ? 1.0 : 0.0;
+    case 2: { const double r = sqrt(r2); return r <= thr ? 1.0 : thr / r; }
+    case 3: { const double w = 1.0 / (1.0 + r2 / t2); return w > dmin ? w : dmin; }
+    case 4: { if (!(r2 < t2)) return 0.0; const double w = 1.0 / (1.0 + r2 / t2); return w > dmin ? w : dmin; }
+    default: return 1.0;
+    }
+}
+
+// ---------------------------------------------------------------- refinement: per-correspondence residuals
+// State of one hypothesis during LM, expanded once per cost/accumulate pass.
+struct LmState {
+    double R[9], t[3], s, u, v, f1, f2;
+    double E[9], F[9];
+};
+
+MDRP_HD void lm_state_from_model(const Model &m, bool focal, LmState &st) {
+    quat_to_R(m.q, st.R);
+    st.t[0] = m.t[0]; st.t[1] = m.t[1]; st.t[2] = m.t[2];
+    st.s = m.scale; st.u = m.shift1; st.v = m.shift2;
+    st.f1 = focal ? m.f1 : 1.0; st.f2 = focal ? m.f2 : 1.0;
+    essential_from_Rt(st.R, st.t, st.E);
+    fundamental_from_E(st.E, st.f1, st.f2, st.F);
+}
+
+constexpr int LM_NPAR = 11; // rot(3) t(3) s u v f1 f2
+
+// residuals r[0..4] = {sampson, fwd.x, fwd.y, bwd.x, bwd.y} (reprojection ones times sqrt(sr)); zf / zb = depth of
+// the forward / backward transferred point (terms with negative depth are skipped by the callers).
+// WITH_J: Jacobian rows J[5][LM_NPAR] with R <- R exp([w]x), t <- t + dt, s <- s + ds.
+template <bool WITH_J>
+MDRP_HD void point_residuals(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
+                             double d2, double r[5], double &zf, double &zb, double J[5][LM_NPAR]) {
+    const double *R = st.R, *t = st.t, *F = st.F;
+    const double Fh1_0 = F[0] * x1x + F[1] * x1y + F[2], Fh1_1 = F[3] * x1x + F[4] * x1y + F[5], Fh1_2 = F[6] * x1x + F[7] * x1y + F[8];
+    const double Ft2_0 = F[0] * x2x + F[3] * x2y + F[6], Ft2_1 = F[1] * x2x + F[4] * x2y + F[7];
+    const double C = x2x * Fh1_0 + x2y * Fh1_1 + Fh1_2;
+    const double den = Fh1_0 * Fh1_0 + Fh1_1 * Fh1_1 + Ft2_0 * Ft2_0 + Ft2_1 * Ft2_1;
+    const double isd = 1.0 / sqrt(den);
+    r[0] = C * isd;
+    const double if1 = 1.0 / st.f1, if2 = 1.0 / st.f2;
+    const double b1x = x1x * if1, b1y = x1y * if1, b2x = x2x * if2, b2y = x2y * if2;
+    const double dd1 = d1 + st.u, dd2 = d2 + st.v;
+    const double X1[3] = {dd1 * b1x, dd1 * b1y, dd1};
+    const double Z0 = R[0] * X1[0] + R[1] * X1[1] + R[2] * X1[2] + t[0];
+    const double Z1 = R[3] * X1[0] + R[4] * X1[1] + R[5] * X1[2] + t[1];
+    const double Z2 = R[6] * X1[0] + R[7] * X1[1] + R[8] * X1[2] + t[2];
+    const double iz = 1.0 / Z2;
+    r[1] = sqrt_sr * (st.f2 * Z0 * iz - x2x);
+    r[2] = sqrt_sr * (st.f2 * Z1 * iz - x2y);
+    zf = Z2;
+    const double sd = st.s * dd2;
+    const double Y[3] = {sd * b2x - t[0], sd * b2y - t[1], sd - t[2]};
+    const double W0 = R[0] * Y[0] + R[3] * Y[1] + R[6] * Y[2];
+    const double W1 = R[1] * Y[0] + R[4] * Y[1] + R[7] * Y[2];
+    const double W2 = R[2] * Y[0] + R[5] * Y[1] + R[8] * Y[2];
+    const double iw = 1.0 / W2;
+    r[3] = sqrt_sr * (st.f1 * W0 * iw - x1x);
+    r[4] = sqrt_sr * (st.f1 * W1 * iw - x1y);
+    zb = W2;
+    if (!WITH_J) return;
+
+    // ---- Sampson: G = d r0 / d F, then chain to E, rotation (post), translation, focals
+    const double h1[3] = {x1x, x1y, 1.0}, h2[3] = {x2x, x2y, 1.0};
+    const double Fh1[3] = {Fh1_0, Fh1_1, Fh1_2}, Ft2[3] = {Ft2_0, Ft2_1, 0.0};
+    const double k = C * isd * isd * isd;
+    double GE[9]; // d r0 / d E_ij
+    double G[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double g = h2[i] * h1[j] * isd;
+            if (i < 2) g -= k * Fh1[i] * h1[j];
+            if (j < 2) g -= k * Ft2[j] * h2[i];
+            G[3 * i + j] = g;
+            GE[3 * i + j] = g * (i == 2 ? st.f2 : 1.0) * (j == 2 ? st.f1 : 1.0);
+        }
+    const double *E = st.E;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int b = (a + 1) % 3, c = (a + 2) % 3;
+        // dE/dw_a = E [e_a]x : column b = +E[:,c], column c = -E[:,b], column a = 0
+        double acc = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) acc += GE[3 * i + b] * E[3 * i + c] - GE[3 * i + c] * E[3 * i + b];
+        J[0][a] = acc;
+        // dE/dt_a = [e_a]x R : row b = -R row c, row c = +R row b
+        double acc2 = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc2 += -GE[3 * b + j] * R[3 * c + j] + GE[3 * c + j] * R[3 * b + j];
+        J[0][3 + a] = acc2;
+    }
+    J[0][6] = 0; J[0][7] = 0; J[0][8] = 0;
+    J[0][9] = G[2] * E[2] + G[5] * E[5] + G[8] * E[8] * st.f2;
+    J[0][10] = G[6] * E[6] + G[7] * E[7] + G[8] * E[8] * st.f1;
+
+    // ---- forward reprojection: Z = R X1 + t
+    {
+        const double px0 = sqrt_sr * st.f2 * iz, pz0 = -sqrt_sr * st.f2 * Z0 * iz * iz, pz1 = -sqrt_sr * st.f2 * Z1 * iz * iz;
+        // dZ/dw_a = R (e_a x X1)
+        const double cr[3][3] = {{0.0, -X1[2], X1[1]}, {X1[2], 0.0, -X1[0]}, {-X1[1], X1[0], 0.0}}; // e_a x X1
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double v0 = R[0] * cr[a][0] + R[1] * cr[a][1] + R[2] * cr[a][2];
+            const double v1 = R[3] * cr[a][0] + R[4] * cr[a][1] + R[5] * cr[a][2];
+            const double v2 = R[6] * cr[a][0] + R[7] * cr[a][1] + R[8] * cr[a][2];
+            J[1][a] = px0 * v0 + pz0 * v2;
+            J[2][a] = px0 * v1 + pz1 * v2;
+        }
+        J[1][3] = px0; J[1][4] = 0.0; J[1][5] = pz0;
+        J[2][3] = 0.0; J[2][4] = px0; J[2][5] = pz1;
+        J[1][6] = 0.0; J[2][6] = 0.0;
+        { // shift1: dZ = R b1
+            const double v0 = R[0] * b1x + R[1] * b1y + R[2], v1 = R[3] * b1x + R[4] * b1y + R[5], v2 = R[6] * b1x + R[7] * b1y + R[8];
+            J[1][7] = px0 * v0 + pz0 * v2;
+            J[2][7] = px0 * v1 + pz1 * v2;
+        }
+        J[1][8] = 0.0; J[2][8] = 0.0;
+        { // f1: dX1 = -dd1 (b1x, b1y, 0) / f1
+            const double ex = -dd1 * b1x * if1, ey = -dd1 * b1y * if1;
+            const double v0 = R[0] * ex + R[1] * ey, v1 = R[3] * ex + R[4] * ey, v2 = R[6] * ex + R[7] * ey;
+            J[1][9] = px0 * v0 + pz0 * v2;
+            J[2][9] = px0 * v1 + pz1 * v2;
+        }
+        J[1][10] = sqrt_sr * Z0 * iz;
+        J[2][10] = sqrt_sr * Z1 * iz;
+    }
+    // ---- backward reprojection: W = R'(X2 - t)
+    {
+        const double px0 = sqrt_sr * st.f1 * iw, pz0 = -sqrt_sr * st.f1 * W0 * iw * iw, pz1 = -sqrt_sr * st.f1 * W1 * iw * iw;
+        // dW/dw_a = W x e_a
+        const double wc[3][3] = {{0.0, W2, -W1}, {-W2, 0.0, W0}, {W1, -W0, 0.0}};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            J[3][a] = px0 * wc[a][0] + pz0 * wc[a][2];
+            J[4][a] = px0 * wc[a][1] + pz1 * wc[a][2];
+            // dW/dt_a = -R' e_a = -(row a of R)
+            J[3][3 + a] = -(px0 * R[3 * a + 0] + pz0 * R[3 * a + 2]);
+            J[4][3 + a] = -(px0 * R[3 * a + 1] + pz1 * R[3 * a + 2]);
+        }
+        { // scale: dW = R' (dd2 b2)
+            const double y0 = dd2 * b2x, y1 = dd2 * b2y, y2 = dd2;
+            const double v0 = R[0] * y0 + R[3] * y1 + R[6] * y2, v1 = R[1] * y0 + R[4] * y1 + R[7] * y2, v2 = R[2] * y0 + R[5] * y1 + R[8] * y2;
+            J[3][6] = px0 * v0 + pz0 * v2;
+            J[4][6] = px0 * v1 + pz1 * v2;
+        }
+        J[3][7] = 0.0; J[4][7] = 0.0;
+        { // shift2: dW = R' (s b2)
+            const double y0 = st.s * b2x, y1 = st.s * b2y, y2 = st.s;
+            const double v0 = R[0] * y0 + R[3] * y1 + R[6] * y2, v1 = R[1] * y0 + R[4] * y1 + R[7] * y2, v2 = R[2] * y0 + R[5] * y1 + R[8] * y2;
+            J[3][8] = px0 * v0 + pz0 * v2;
+            J[4][8] = px0 * v1 + pz1 * v2;
+        }
+        J[3][9] = sqrt_sr * W0 * iw;
+        J[4][9] = sqrt_sr * W1 * iw;
+        { // f2: dX2 = -s dd2 (b2x, b2y, 0)/f2
+            const double ex = -sd * b2x * if2, ey = -sd * b2y * if2;
+            const double v0 = R[0] * ex + R[3] * ey, v1 = R[1] * ex + R[4] * ey, v2 = R[2] * ex + R[5] * ey;
+            J[3][10] = px0 * v0 + pz0 * v2;
+            J[4][10] = px0 * v1 + pz1 * v2;
+        }
+    }
+}
+
+// parameter update of the refinement (lm step): R <- R exp([w]x), additive elsewhere; shifts are zeroed when they are
+// not estimated (black-box behaviour of the reference's step()).  delta is in FULL 11-vector layout.
+MDRP_HD void lm_apply_step(const Model &m, const double d[LM_NPAR], bool focal, bool est_shift, Model &o) {
+    const double th2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2], th = sqrt(th2);
+    double re, im;
+    if (th > 1e-6) { re = cos(0.5 * th); im = sin(0.5 * th) / th; }
+    else { re = 1.0 - th2 / 8.0; im = 0.5 - th2 / 48.0; const double nq = 1.0 / sqrt(re * re + im * im * th2); re *= nq; im *= nq; }
+    const double b0 = re, b1 = im * d[0], b2 = im * d[1], b3 = im * d[2];
+    const double a0 = m.q[0], a1 = m.q[1], a2 = m.q[2], a3 = m.q[3];
+    o.q[0] = a0 * b0 - a1 * b1 - a2 * b2 - a3 * b3;
+    o.q[1] = a0 * b1 + a1 * b0 + a2 * b3 - a3 * b2;
+    o.q[2] = a0 * b2 - a1 * b3 + a2 * b0 + a3 * b1;
+    o.q[3] = a0 * b3 + a1 * b2 - a2 * b1 + a3 * b0;
+    o.t[0] = m.t[0] + d[3]; o.t[1] = m.t[1] + d[4]; o.t[2] = m.t[2] + d[5];
+    o.scale = m.scale + d[6];
+    o.shift1 = est_shift ? m.shift1 + d[7] : 0.0;
+    o.shift2 = est_shift ? m.shift2 + d[8] : 0.0;
+    o.f1 = focal ? m.f1 + d[9] : m.f1;
+    o.f2 = focal ? m.f2 + d[10] : m.f2;
+}
+
+// Cholesky solve of the (lower-stored, row-major n x n) damped normal equations; n <= 9
+template <int N>
+MDRP_HD void chol_solve(const double *A, const double *b, double *x) {
+    double L[N * N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k];
+            if (i == j) L[i * N + i] = sqrt(s);
+            else L[i * N + j] = s / L[j * N + j];
+        }
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
+        y[i] = s / L[i * N + i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
+        x[i] = s / L[i * N + i];
+    }
+}
+
+// ---------------------------------------------------------------- sampler (a-3)
+MDRP_HD int32_t splitmix_int(uint64_t &state) {
+    state += 0x9e3779b97f4a7c15ULL;
+    uint64_t z = state;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+    return (int32_t)(z ^ (z >> 31));
+}
+MDRP_HD void draw_sample3(uint64_t n, uint64_t &state, uint32_t &i0, uint32_t &i1, uint32_t &i2) {
+    i0 = (uint32_t)((uint64_t)(int64_t)splitmix_int(state) % n);
+    do { i1 = (uint32_t)((uint64_t)(int64_t)splitmix_int(state) % n); } while (i1 == i0);
+    do { i2 = (uint32_t)((uint64_t)(int64_t)splitmix_int(state) % n); } while (i2 == i0 || i2 == i1);
+}
+
+} // namespace mdrp

@@ -1,0 +1,305 @@
+"""Drop-in for the monodepth part of the reference's `poselib` module, backed by the HIP kernels.
+
+    import mdrp_amd.poselib as poselib
+    geometry, info = poselib.estimate_monodepth_relative_pose(x1, x2, d1, d2, cam1, cam2, ransac_opt, bundle_opt)
+
+Signatures, option dictionaries, result classes and the `info` dictionary follow the reference binding
+(wheel poselib/_core.pyi:446-501, 134-204; callers /root/reference/make_pair.py:111, make_video.py:284,
+README.md:86-96).  Each single-pair call is a batch of one; `*_batch` variants take B pairs at once, which is how
+the GPU is meant to be fed (the reference parallelises over pairs with a process pool, eval.py:355-359).
+The fork names used by the paper scripts (eval.py:153, eval_shared_f.py:177, eval_varying_f.py:168) are provided as
+adapters at the bottom.
+"""
+import numpy as np
+
+from . import _capi
+
+__version__ = "2.0.5+mdrp_amd"
+
+CAMERA_MODELS = {"SIMPLE_PINHOLE": 0, "PINHOLE": 1}
+CAMERA_MODEL_NAMES = {v: k for k, v in CAMERA_MODELS.items()}
+
+
+def _quat_to_R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+class CameraPose:
+    """q = (w,x,y,z), x_cam = R X + t  (_core.pyi:134-156)"""
+
+    def __init__(self, q=None, t=None):
+        self.q = np.array([1.0, 0.0, 0.0, 0.0]) if q is None else np.asarray(q, dtype=np.float64).reshape(4)
+        self.t = np.zeros(3) if t is None else np.asarray(t, dtype=np.float64).reshape(3)
+
+    @property
+    def R(self):
+        return _quat_to_R(self.q)
+
+    @property
+    def Rt(self):
+        return np.hstack([self.R, self.t.reshape(3, 1)])
+
+    def center(self):
+        return -self.R.T @ self.t
+
+    def __repr__(self):
+        return f"[q: {self.q}, t: {self.t}]"
+
+
+class Camera:
+    """COLMAP-style pinhole camera (_core.pyi:76-132).  Only the models the reference callers use."""
+
+    def __init__(self, model="SIMPLE_PINHOLE", params=None, width=-1, height=-1):
+        if isinstance(model, str):
+            if model not in CAMERA_MODELS:
+                raise NotImplementedError(f"camera model {model!r}: only SIMPLE_PINHOLE and PINHOLE are on the monodepth path")
+            model = CAMERA_MODELS[model]
+        self.model_id = int(model)
+        self.params = [1.0, 0.0, 0.0] if params is None else [float(p) for p in params]
+        self.width, self.height = int(width), int(height)
+
+    @classmethod
+    def from_any(cls, c):
+        if isinstance(c, Camera):
+            return c
+        if isinstance(c, dict):
+            return cls(c["model"], c["params"], c.get("width", -1), c.get("height", -1))
+        raise TypeError("camera must be a Camera or a dict {'model','width','height','params'}")
+
+    def model_name(self):
+        return CAMERA_MODEL_NAMES[self.model_id]
+
+    def focal_x(self):
+        return self.params[0]
+
+    def focal_y(self):
+        return self.params[1] if self.model_id == 1 else self.params[0]
+
+    def focal(self):
+        return 0.5 * (self.focal_x() + self.focal_y())
+
+    def principal_point(self):
+        return np.array(self.params[2:4] if self.model_id == 1 else self.params[1:3])
+
+    def unproject(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return (x - self.principal_point()) / np.array([self.focal_x(), self.focal_y()])
+
+    def project(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return x * np.array([self.focal_x(), self.focal_y()]) + self.principal_point()
+
+    def _record(self):
+        r = np.zeros((), dtype=_capi.CAMERA_DTYPE)
+        r["model_id"] = self.model_id
+        p = np.zeros(4)
+        p[: len(self.params)] = self.params
+        r["params"] = p
+        return r
+
+    def __repr__(self):
+        return f"Camera({self.model_name()}, params={self.params}, {self.width}x{self.height})"
+
+
+class MonoDepthTwoViewGeometry:
+    """R (d1+shift1) K1^-1 x1 + t = scale (d2+shift2) K2^-1 x2  (_core.pyi:178-204)"""
+
+    def __init__(self, pose=None, scale=1.0, shift1=0.0, shift2=0.0):
+        self.pose = pose if pose is not None else CameraPose()
+        self.scale, self.shift1, self.shift2 = float(scale), float(shift1), float(shift2)
+
+    def __repr__(self):
+        return f"[pose: {self.pose}, scale: {self.scale}, shift1: {self.shift1}, shift2: {self.shift2}]"
+
+
+class MonoDepthImagePair:
+    """(_core.pyi:171-176); `.pose` is kept for the older wheel's naming used by eval_shared_f.py:84-96"""
+
+    def __init__(self, geometry=None, camera1=None, camera2=None):
+        self.geometry = geometry if geometry is not None else MonoDepthTwoViewGeometry()
+        self.camera1 = camera1 if camera1 is not None else Camera()
+        self.camera2 = camera2 if camera2 is not None else Camera()
+
+    @property
+    def pose(self):
+        return self.geometry.pose
+
+    def __repr__(self):
+        return f"[geometry: {self.geometry}, camera1: {self.camera1}, camera2: {self.camera2}]"
+
+
+def _geometry_from_model(m):
+    return MonoDepthTwoViewGeometry(CameraPose(m["q"].copy(), m["t"].copy()), m["scale"], m["shift1"], m["shift2"])
+
+
+def _pair_from_model(m):
+    return MonoDepthImagePair(_geometry_from_model(m), Camera("SIMPLE_PINHOLE", [float(m["f1"]), 0.0, 0.0]),
+                              Camera("SIMPLE_PINHOLE", [float(m["f2"]), 0.0, 0.0]))
+
+
+def _info(res, mask_row, n):
+    return {"refinements": int(res["refinements"]), "iterations": int(res["iterations"]), "num_inliers": int(res["num_inliers"]),
+            "inlier_ratio": float(res["inlier_ratio"]), "model_score": float(res["model_score"]),
+            "inliers": [bool(v) for v in mask_row[:n]]}
+
+
+def _as_points(p):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    if p.ndim != 2 or p.shape[1] != 2:
+        raise ValueError("points must have shape (N, 2)")
+    return p
+
+
+def _check_initial(initial, ransac_opt):
+    if initial is not None and (ransac_opt or {}).get("score_initial_model", False):
+        raise NotImplementedError("score_initial_model / initial pose is not on the accelerated path")
+
+
+# ------------------------------------------------------------------------------------------------ batch API
+def _stack(points1, points2, depth1, depth2):
+    """list of ragged pairs or already-stacked arrays -> padded (B,N,2),(B,N,2),(B,N),(B,N), n_per_pair"""
+    if isinstance(points1, np.ndarray) and points1.ndim == 3:
+        B, N = points1.shape[:2]
+        return (np.ascontiguousarray(points1, np.float64), np.ascontiguousarray(points2, np.float64),
+                np.ascontiguousarray(depth1, np.float64), np.ascontiguousarray(depth2, np.float64), np.full(B, N, np.int32))
+    B = len(points1)
+    ns = np.array([len(p) for p in points1], dtype=np.int32)
+    N = int(ns.max()) if B else 0
+    x1 = np.zeros((B, N, 2)); x2 = np.zeros((B, N, 2)); d1 = np.ones((B, N)); d2 = np.ones((B, N))
+    for i in range(B):
+        n = ns[i]
+        x1[i, :n] = _as_points(points1[i]); x2[i, :n] = _as_points(points2[i])
+        d1[i, :n] = np.asarray(depth1[i], np.float64).reshape(-1); d2[i, :n] = np.asarray(depth2[i], np.float64).reshape(-1)
+    return x1, x2, d1, d2, ns
+
+
+def estimate_monodepth_relative_pose_batch(points2D_1, points2D_2, depth_1, depth_2, cameras1, cameras2, ransac_opt=None,
+                                           bundle_opt=None, device=0):
+    """B calibrated pairs at once.  cameras1/2: one Camera|dict for all pairs, or a list of B.  Returns
+    (list[MonoDepthTwoViewGeometry], list[info dict])."""
+    x1, x2, d1, d2, ns = _stack(points2D_1, points2D_2, depth_1, depth_2)
+    B = len(ns)
+
+    def cams(c):
+        lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
+        return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
+
+    h = _capi.default_handle(device)
+    res, mask = h.estimate_batch(_capi.CALIB, x1, x2, d1, d2, _capi.ransac_opt_from_dict(ransac_opt),
+                                 _capi.bundle_opt_from_dict(bundle_opt), ns, cams(cameras1), cams(cameras2))
+    return [_geometry_from_model(r["model"]) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(B)]
+
+
+def _focal_batch(kind, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device):
+    x1, x2, d1, d2, ns = _stack(points2D_1, points2D_2, depth_1, depth_2)
+    h = _capi.default_handle(device)
+    res, mask = h.estimate_batch(kind, x1, x2, d1, d2, _capi.ransac_opt_from_dict(ransac_opt),
+                                 _capi.bundle_opt_from_dict(bundle_opt), ns)
+    return [_pair_from_model(r["model"]) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(len(ns))]
+
+
+def estimate_monodepth_shared_focal_relative_pose_batch(points2D_1, points2D_2, depth_1, depth_2, ransac_opt=None,
+                                                        bundle_opt=None, device=0):
+    return _focal_batch(_capi.SHARED_FOCAL, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device)
+
+
+def estimate_monodepth_varying_focal_relative_pose_batch(points2D_1, points2D_2, depth_1, depth_2, ransac_opt=None,
+                                                         bundle_opt=None, device=0):
+    return _focal_batch(_capi.VARYING_FOCAL, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device)
+
+
+# ------------------------------------------------------------------------------------------------ reference signatures
+def estimate_monodepth_relative_pose(points2D_1, points2D_2, depth_1, depth_2, camera1, camera2, ransac_opt={},
+                                     bundle_opt={}, initial_pose=None):
+    """Pose estimation using depth estimates with non-linear refinement (_core.pyi:446-475)."""
+    _check_initial(initial_pose, ransac_opt)
+    g, i = estimate_monodepth_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], [depth_1], [depth_2],
+                                                  camera1, camera2, ransac_opt, bundle_opt)
+    return g[0], i[0]
+
+
+def estimate_monodepth_shared_focal_relative_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt={}, bundle_opt={},
+                                                  initial_image_pair=None):
+    """Unknown equal focal lengths; points principal-point-centred (_core.pyi:477-488, README.md:88-90)."""
+    _check_initial(initial_image_pair, ransac_opt)
+    p, i = estimate_monodepth_shared_focal_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], [depth_1],
+                                                               [depth_2], ransac_opt, bundle_opt)
+    return p[0], i[0]
+
+
+def estimate_monodepth_varying_focal_relative_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt={}, bundle_opt={},
+                                                   initial_image_pair=None):
+    """Two unknown focal lengths (_core.pyi:490-501, README.md:94-96).  `monodepth_estimate_shift` is ignored here
+    exactly like in the reference."""
+    _check_initial(initial_image_pair, ransac_opt)
+    p, i = estimate_monodepth_varying_focal_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], [depth_1],
+                                                                [depth_2], ransac_opt, bundle_opt)
+    return p[0], i[0]
+
+
+# ------------------------------------------------------------------------------------------------ minimal solvers
+def _solver(solver, x1, x2, d1, d2, wrap):
+    x1 = np.asarray(x1, dtype=np.float64).reshape(3, 3)
+    x2 = np.asarray(x2, dtype=np.float64).reshape(3, 3)
+    out, n = _capi.default_handle().solver_batch(solver, x1[None], x2[None], np.asarray(d1, np.float64)[None], np.asarray(d2, np.float64)[None])
+    return [wrap(out[0, k]) for k in range(int(n[0]))]
+
+
+def monodepth_pose_3pt(x1, x2, d1, d2):
+    """relpose_monodepth_3pt: scale + two shifts, <= 4 solutions (_core.pyi:614-619); x = homogeneous points with z = 1"""
+    return _solver(_capi.SOLVER_SHIFT, x1, x2, d1, d2, _geometry_from_model)
+
+
+def shared_focal_monodepth_pose_3pt(x1, x2, d1, d2):
+    """relpose_monodepth_3pt_shared_focal (_core.pyi:871-876)"""
+    return _solver(_capi.SOLVER_SHARED, x1, x2, d1, d2, _pair_from_model)
+
+
+def varying_focal_monodepth_pose_4pt(x1, x2, d1, d2):
+    """relpose_monodepth_3pt_varying_focal — the reference's Python name says 4pt (_core.pyi:914-919)"""
+    return _solver(_capi.SOLVER_VARYING, x1, x2, d1, d2, _pair_from_model)
+
+
+# ------------------------------------------------------------------------------------------------ fork-name adapters
+_FORK_ONLY_FLAGS = ("use_reldepth", "use_madpose", "use_4p4d", "use_fundamental", "optimize_symmetric", "graduated_steps",
+                    "no_normalization", "use_reproj")
+
+
+def _map_fork_options(ransac_opt):
+    """eval*.py build option dicts for kocurvik/PoseLib-mdrp@iccv-eval (eval.py:105-123).  Flags with a PR-152
+    equivalent are mapped; fork-only solver/optimiser variants have no pinned behaviour here -> NotImplementedError."""
+    ro = dict(ransac_opt or {})
+    for k in _FORK_ONLY_FLAGS:
+        if ro.get(k):
+            raise NotImplementedError(f"ransac option {k!r} selects a fork-only variant (parity unpinned, SURVEY.md §8b)")
+    if ro.get("use_ours") and ro.get("solver_shift"):
+        ro["monodepth_estimate_shift"] = True
+    if ro.get("use_p3p"):
+        ro["monodepth_estimate_shift"] = False
+    if "weight_sampson" in ro:
+        ro["monodepth_weight_sampson"] = ro["weight_sampson"]
+    return ro
+
+
+def estimate_relative_pose_w_mono_depth(kp1, kp2, d, camera1, camera2, ransac_opt={}, bundle_opt={}):
+    """eval.py:153 — d is (N,2) with the two depth columns; returns (pose-like with .R/.t, info)"""
+    d = np.asarray(d, dtype=np.float64)
+    g, info = estimate_monodepth_relative_pose(kp1, kp2, d[:, 0], d[:, 1], camera1, camera2, _map_fork_options(ransac_opt), bundle_opt)
+    pose = g.pose
+    pose.scale, pose.shift1, pose.shift2 = g.scale, g.shift1, g.shift2
+    return pose, info
+
+
+def estimate_shared_focal_monodepth_relative_pose(kp1, kp2, d, ransac_opt={}, bundle_opt={}):
+    """eval_shared_f.py:177"""
+    d = np.asarray(d, dtype=np.float64)
+    return estimate_monodepth_shared_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt), bundle_opt)
+
+
+def estimate_varying_focal_monodepth_relative_pose(kp1, kp2, d, ransac_opt={}, bundle_opt={}):
+    """eval_varying_f.py:168"""
+    d = np.asarray(d, dtype=np.float64)
+    return estimate_monodepth_varying_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt), bundle_opt)

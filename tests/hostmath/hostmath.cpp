@@ -1,0 +1,42 @@
+// Host build of mdrp_amd/csrc/mdrp_math.h for CPU unit tests of the per-lane arithmetic (no GPU in the build
+// container).  Test scaffolding only: the shipped library has no CPU path.
+#include "../../mdrp_amd/csrc/mdrp_math.h"
+#include <cstring>
+using namespace mdrp;
+
+extern "C" {
+int hm_solver(int solver, const double *x1h, const double *x2h, const double *d1, const double *d2, double *out /*4*12*/) {
+    Sample3 s;
+    for (int i = 0; i < 3; ++i) {
+        s.x1[i][0] = x1h[3 * i]; s.x1[i][1] = x1h[3 * i + 1];
+        s.x2[i][0] = x2h[3 * i]; s.x2[i][1] = x2h[3 * i + 1];
+        s.d1[i] = d1[i]; s.d2[i] = d2[i];
+    }
+    Model m[4];
+    int n = run_solver(solver, s, m);
+    std::memcpy(out, m, sizeof(Model) * (n > 0 ? n : 0));
+    return n;
+}
+void hm_point(int focal, const double *model12, double scale_reproj, const double *x1, const double *x2, double d1, double d2,
+              double *r7, double *J55) {
+    Model m;
+    std::memcpy(&m, model12, sizeof m);
+    LmState st;
+    lm_state_from_model(m, focal != 0, st);
+    double J[5][LM_NPAR];
+    point_residuals<true>(st, sqrt(scale_reproj), x1[0], x1[1], x2[0], x2[1], d1, d2, r7, r7[5], r7[6], J);
+    std::memcpy(J55, J, sizeof J);
+}
+void hm_step(int focal, int est_shift, const double *model12, const double *delta11, double *out12) {
+    Model m, o;
+    std::memcpy(&m, model12, sizeof m);
+    lm_apply_step(m, delta11, focal != 0, est_shift != 0, o);
+    std::memcpy(out12, &o, sizeof o);
+}
+void hm_chol9(const double *A, const double *b, double *x) { chol_solve<9>(A, b, x); }
+void hm_draw(uint64_t n, uint64_t seed, int count, uint32_t *out) {
+    uint64_t st = seed;
+    for (int i = 0; i < count; ++i) draw_sample3(n, st, out[3 * i], out[3 * i + 1], out[3 * i + 2]);
+}
+double hm_loss(int type, double thr, double r2, int weight) { return weight ? loss_weight(type, thr, r2) : loss_value(type, thr, r2); }
+}

@@ -1,0 +1,39 @@
+"""The C-ABI library builds for gfx950 and exports every symbol include/mdrp.h declares (no compute calls: no GPU here)."""
+import ctypes as C
+import os
+import re
+
+from mdrp_amd import _capi, build as b
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    b.build()
+    lib = C.CDLL(_capi.LIB_PATH)
+    hdr = open(os.path.join(ROOT, "include", "mdrp.h")).read()
+    declared = sorted(set(re.findall(r"\b(mdrp_[a-z_]+)\s*\(", hdr)))
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_capi.EXPORTS) == declared
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_capi.Model) == 96 and C.sizeof(_capi.Camera) == 40 and C.sizeof(_capi.Result) == 136
+    assert C.sizeof(_capi.RansacOpt) == 64 and C.sizeof(_capi.BundleOpt) == 64
+
+
+def test_no_cpu_fallback_in_product():
+    """the product package never touches the oracle"""
+    for fn in os.listdir(os.path.join(ROOT, "mdrp_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "mdrp_amd", fn)).read()
+            assert "oracle" not in src.replace("no CPU fallback", ""), fn
+
+
+def test_option_dicts_follow_reference_defaults():
+    ro = _capi.ransac_opt_from_dict({"lo_iterations": 25, "weight_sampson": 1.0})  # unknown keys ignored (make_pair.py:31-33)
+    assert (ro.max_iterations, ro.min_iterations, ro.max_reproj_error, ro.max_epipolar_error, ro.seed) == (100000, 1000, 12.0, 1.0, 0)
+    bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    assert (bo.max_iterations, bo.loss_type, bo.loss_scale, bo.gradient_tol) == (100, 4, 1.0, 1e-10)

@@ -1,0 +1,111 @@
+"""Per-lane arithmetic of the product (mdrp_amd/csrc/mdrp_math.h, host build) against the CPU oracle.
+Checks the solvers, residual/Jacobian rows, the LM step and the sampler without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyorc as po
+from helpers import match_solution_sets
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "hostmath", "libhostmath.so")
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def hm():
+    src = os.path.join(HERE, "hostmath", "hostmath.cpp")
+    hdr = os.path.join(HERE, "..", "mdrp_amd", "csrc", "mdrp_math.h")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", src, "-o", SO])
+    lib = C.CDLL(SO)
+    lib.hm_loss.restype = C.c_double
+    return lib
+
+
+def _hm_solver(hm, solver, x1, x2, d1, d2):
+    out = np.zeros((4, 12))
+    n = hm.hm_solver(C.c_int(solver), P(po.f64(x1)), P(po.f64(x2)), P(po.f64(d1)), P(po.f64(d2)), P(out))
+    return out[:n]
+
+
+@pytest.mark.parametrize("kind", ["p3p", "calib_shift", "shared", "varying"])
+def test_solvers_equal_oracle(hm, golden, kind):
+    g = golden("solvers")
+    src = "calib_shift" if kind == "p3p" else kind  # the P3P path consumes the same (x1,x2,d1,d2) samples
+    solver = {"p3p": 0, "calib_shift": 1, "shared": 2, "varying": 3}[kind]
+    ofn = {"p3p": po.solver_calib_p3p, "calib_shift": po.solver_calib_shift, "shared": po.solver_shared,
+           "varying": po.solver_varying}[kind]
+    n = len(g[f"{src}_n"])
+    nsol = 0
+    for i in range(n):
+        a = (g[f"{src}_x1"][i], g[f"{src}_x2"][i], g[f"{src}_d1"][i], g[f"{src}_d2"][i])
+        mine, ref = _hm_solver(hm, solver, *a), ofn(*a)
+        assert match_solution_sets(list(ref), list(mine), 1e-9), (kind, i, ref, mine)
+        nsol += len(mine)
+    assert nsol > 0.3 * n
+
+
+def test_sampler_equal_oracle(hm):
+    for n, seed in ((7, 0), (200, 3), (2000, 0), (5000, 9)):
+        out = np.zeros((500, 3), dtype=np.uint32)
+        hm.hm_draw(C.c_uint64(n), C.c_uint64(seed), 500, out.ctypes.data_as(C.c_void_p))
+        assert (out.astype(np.int64) == po.draw_samples(seed, n, 500)).all()
+
+
+def test_residuals_and_jacobian_equal_oracle(hm):
+    rng = np.random.default_rng(0)
+    L = po.lib()
+    for trial in range(40):
+        focal = trial % 2
+        m = po.new_model()
+        q = rng.normal(size=4)
+        m[:4] = q / np.linalg.norm(q)
+        m[4:7] = rng.normal(0, 0.5, 3)
+        m[7] = rng.uniform(0.3, 3)
+        m[8], m[9] = rng.uniform(-0.3, 0.3, 2)
+        if focal:
+            m[10], m[11] = rng.uniform(0.5, 2, 2)
+        x1, x2 = rng.uniform(-0.8, 0.8, 2), rng.uniform(-0.8, 0.8, 2)
+        d1, d2 = rng.uniform(1, 6, 2)
+        r, J = np.zeros(7), np.zeros(55)
+        hm.hm_point(C.c_int(focal), P(m), C.c_double(0.37), P(x1), P(x2), C.c_double(d1), C.c_double(d2), P(r), P(J))
+        ro, Jo = np.zeros(7), np.zeros(55)
+        L.orc_debug_point(C.c_int(2 if focal else 0), P(m), C.c_double(0.37), P(x1), P(x2), C.c_double(d1), C.c_double(d2), P(ro), P(Jo))
+        assert np.allclose(r, ro, rtol=1e-12, atol=1e-14)
+        assert np.allclose(J, Jo, rtol=1e-10, atol=1e-12), np.abs(J - Jo).max()
+
+
+def test_lm_step_and_losses_equal_oracle(hm):
+    rng = np.random.default_rng(1)
+    L = po.lib()
+    for trial in range(20):
+        m = po.new_model()
+        q = rng.normal(size=4)
+        m[:4] = q / np.linalg.norm(q)
+        m[4:10] = rng.normal(0, 0.5, 6)
+        m[10:] = rng.uniform(0.5, 2, 2)
+        d = rng.normal(0, 0.05 if trial % 2 else 1e-8, 11)
+        out, ref = np.zeros(12), np.zeros(12)
+        hm.hm_step(1, 1, P(m), P(d), P(out))
+        L.orc_debug_step(C.c_int(2), P(m), P(d), P(ref))
+        assert np.allclose(out, ref, rtol=1e-13, atol=1e-15)
+    # Cholesky
+    A = rng.normal(size=(9, 9)); A = A @ A.T + 9 * np.eye(9); b = rng.normal(size=9); x = np.zeros(9)
+    hm.hm_chol9(P(np.ascontiguousarray(A)), P(b), P(x))
+    assert np.allclose(A @ x, b, rtol=1e-10)
+    # losses against their closed forms
+    thr = 0.7
+    for r2 in (0.01, 0.3, 0.49, 0.5, 2.0):
+        t2 = thr * thr
+        assert hm.hm_loss(1, C.c_double(thr), C.c_double(r2), 0) == pytest.approx(min(r2, t2))
+        assert hm.hm_loss(3, C.c_double(thr), C.c_double(r2), 0) == pytest.approx(t2 * np.log1p(r2 / t2))
+        assert hm.hm_loss(4, C.c_double(thr), C.c_double(r2), 0) == pytest.approx(t2 * np.log1p(min(r2, t2) / t2))
+        assert hm.hm_loss(4, C.c_double(thr), C.c_double(r2), 1) == pytest.approx(1 / (1 + r2 / t2) if r2 < t2 else 0.0)
