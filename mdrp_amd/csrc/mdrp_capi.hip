@@ -129,7 +129,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->slot_score.ensure(sizeof(double) * slots))) return rc;
     if ((rc = h->slot_inl.ensure(sizeof(int32_t) * slots))) return rc;
     if ((rc = h->tags.ensure(sizeof(uint32_t) * slots))) return rc;
-    if ((rc = h->model_count.ensure(sizeof(int32_t) * batch))) return rc;
+    if ((rc = h->model_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
     if ((rc = h->work_pair.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
@@ -174,9 +174,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     while (true) {
         const int len = (int)std::min<uint64_t>(next_len, (uint64_t)chunk_cap);
         rp.chunk_len = len; rp.chunk_start = it0;
-        HIPCHK(hipMemsetAsync(h->model_count.p, 0, sizeof(int32_t) * batch, s));
+        HIPCHK(hipMemsetAsync(h->model_count.p, 0, sizeof(int32_t) * 2 * batch, s));
         HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
-        hipLaunchKernelGGL(k_samples, dim3((n_tables + 63) / 64), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
+        hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
                            h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
         hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
                            h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(),
@@ -410,7 +410,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * std::max(n, 1))) || (rc = h->st.ensure(sizeof(PairState))) ||
         (rc = h->models.ensure(sizeof(Model) * slots)) || (rc = h->slot_score.ensure(sizeof(double) * slots)) ||
         (rc = h->slot_inl.ensure(sizeof(int32_t) * slots)) || (rc = h->tags.ensure(sizeof(uint32_t) * slots)) ||
-        (rc = h->model_count.ensure(sizeof(int32_t))))
+        (rc = h->model_count.ensure(2 * sizeof(int32_t))))
         return rc;
     const double *x1d = x1, *x2d = x2;
     const Model *md = reinterpret_cast<const Model *>(models);
@@ -428,7 +428,8 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     std::vector<uint32_t> tags(num_models);
     for (int i = 0; i < num_models; ++i) tags[i] = (uint32_t)i;
     HIPCHK(hipMemcpyAsync(h->tags.p, tags.data(), sizeof(uint32_t) * num_models, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->model_count.p, &num_models, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    const int32_t counts2[2] = {num_models, 0};
+    HIPCHK(hipMemcpyAsync(h->model_count.p, counts2, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
     PairState ps;
     std::memset(&ps, 0, sizeof ps);
     ps.n = n; ps.active = 1; ps.sq_thr = sq_threshold; ps.eps = std::sqrt(sq_threshold);

@@ -24,8 +24,21 @@
 namespace mdrp {
 
 constexpr int PT_STRIDE = 6;       // doubles per correspondence record
-constexpr int TILE_PTS = 2048;     // correspondences per LDS tile (96 KiB)
-constexpr int SCORE_THREADS = 512; // 8 waves: 2 per SIMD share one tile
+#ifndef MDRP_TILE_PTS
+#define MDRP_TILE_PTS 512
+#endif
+#ifndef MDRP_SCORE_MINWAVES
+#define MDRP_SCORE_MINWAVES 4
+#endif
+constexpr int TILE_PTS = MDRP_TILE_PTS; // correspondences per LDS tile (48 B each)
+#ifndef MDRP_P1_UNROLL
+#define MDRP_P1_UNROLL 4
+#endif
+constexpr int CLS_PTS = 64;        // records used to pre-classify hypotheses as dense / sparse
+#ifndef MDRP_SCORE_THREADS
+#define MDRP_SCORE_THREADS 256
+#endif
+constexpr int SCORE_THREADS = MDRP_SCORE_THREADS; // waves of one workgroup share one LDS tile
 constexpr int LM_THREADS = 256;
 constexpr int MAX_NP = 9;
 constexpr int MAX_ACC = MAX_NP * (MAX_NP + 1) / 2 + MAX_NP; // 54
@@ -178,22 +191,79 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ samples
-// One lane per distinct N: the sample sequence is a pure function of (seed, N) (RandomSampler @0x4f8970).
-__global__ void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state, int chunk_len,
-                          uint32_t *__restrict__ samples /*[n_tables][chunk_len][3]*/) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// One wavefront per distinct N.  The sample sequence is a pure function of (seed, N) (RandomSampler @0x4f8970): splitmix64
+// is counter based (state after k raw draws = state + k*GAMMA), and a sample consumes 3 raw draws plus one per rejected
+// duplicate (probability ~3/N).  Lane l speculates that its sample starts 3*l draws after the wave's state; lanes up to
+// and including the first one that saw a rejection are correct, the wave commits those and continues from that lane's
+// end state.  ~N/3 samples per rejection -> a 10k-sample table takes ~170 wave steps instead of 10k serial ones.
+__global__ __launch_bounds__(64) void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
+                                                int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][3]*/) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     if (t >= n_tables) return;
-    uint64_t s = table_state[t];
     const uint64_t n = (uint64_t)table_n[t];
+    if (n < 3) return;
+    const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
+    uint64_t state = table_state[t];
     uint32_t *out = samples + (size_t)t * chunk_len * 3;
-    if (n >= 3) {
-        for (int i = 0; i < chunk_len; ++i) {
-            uint32_t a, b, c;
-            draw_sample3(n, s, a, b, c);
-            out[3 * i] = a; out[3 * i + 1] = b; out[3 * i + 2] = c;
+    int done = 0;
+    while (done < chunk_len) {
+        uint64_t s = state + (uint64_t)(3 * lane) * GAMMA;
+        const uint64_t s0 = s;
+        uint32_t a, b, c;
+        draw_sample3(n, s, a, b, c);
+        const bool rejected = (s - s0) != 3 * GAMMA;
+        const unsigned long long ball = __ballot(rejected);
+        const int first = ball ? (__ffsll((long long)ball) - 1) : 63;
+        const int nvalid = min(first + 1, chunk_len - done);
+        if (lane < nvalid) {
+            out[3 * (done + lane)] = a; out[3 * (done + lane) + 1] = b; out[3 * (done + lane) + 2] = c;
         }
+        state = __shfl(s, nvalid - 1, 64);
+        done += nvalid;
     }
-    table_state[t] = s;
+    if (lane == 0) table_state[t] = state;
+}
+
+// ------------------------------------------------------------------------------------------------ Sampson terms
+struct SampsonTerms { double C2, den; };
+
+// d = a*b + c as the three-address VOP3 v_fma_f64.  hipcc (ROCm 7.2) otherwise selects the two-address
+// v_fmac_f64 here and has to copy the loop-invariant addend (an entry of E) with v_mov_b64 before every use:
+// 5 extra fp64-rate moves per Sampson evaluation (+25 % VALU work in the hot loop).
+__device__ __forceinline__ double fma3(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDRP_NO_ASM_FMA)
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#else
+    return fma(a, b, c);
+#endif
+}
+
+__device__ __forceinline__ SampsonTerms sampson_terms(const double E[9], double a, double b, double c, double d) {
+    const double e0 = fma(E[0], a, fma3(E[1], b, E[2]));
+    const double e1 = fma(E[3], a, fma3(E[4], b, E[5]));
+    const double e2 = fma(E[6], a, fma3(E[7], b, E[8]));
+    const double g0 = fma(E[0], c, fma3(E[3], d, E[6]));
+    const double g1 = fma(E[1], c, fma3(E[4], d, E[7]));
+    const double C = fma(c, e0, fma(d, e1, e2));
+    SampsonTerms r;
+    r.den = fma(e0, e0, fma(e1, e1, fma(g0, g0, g1 * g1)));
+    r.C2 = C * C;
+    return r;
+}
+
+// number of phase-1 candidates among the first `npts` records (global memory, wave-uniform addresses)
+__device__ __forceinline__ int candidate_count(const double *__restrict__ recs, int npts, const double E[9], double thr) {
+    const double thr_hi = thr * (1.0 + 1e-12);
+    int c = 0;
+    for (int p = 0; p < npts; ++p) {
+        const double2 *P = reinterpret_cast<const double2 *>(recs + (size_t)p * PT_STRIDE);
+        const double2 p01 = P[0], p23 = P[1];
+        const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
+        c += (s.C2 < thr_hi * s.den) ? 1 : 0;
+    }
+    return c;
 }
 
 // ------------------------------------------------------------------------------------------------ solve
@@ -224,25 +294,55 @@ __global__ __launch_bounds__(256) void k_solve(RunParams rp, const PairState *__
         // a NaN hypothesis can never become a record (its score is N*thr, count 0) except as the very first model;
         // drop it (the reference's own P3P emits NaN poses for ~2% of garbage samples)
     }
-    // wave-aggregated append
-    const int lane = threadIdx.x & 63;
-    int pre = n;
+    // classify each model by its candidate density on the first records of the pair (see k_score): dense
+    // hypotheses are appended from the back of the tag list, sparse ones from the front
+    const int ncls = min(ps.n, CLS_PTS);
+    const int dense_min = max(4, ncls / 8);
+    const double *recs = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    int dense_mask = 0, n_dense = 0;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
-    const int total = __shfl(pre, 63, 64);
-    int basepos = 0;
-    if (lane == 63 && total > 0) basepos = atomicAdd(&model_count[pair], total);
-    basepos = __shfl(basepos, 63, 64);
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            double R[9], Em[9], E[9];
+            quat_to_R(out[k].q, R);
+            essential_from_Rt(R, out[k].t, Em);
+            if (rp.kind == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) E[i] = Em[i];
+            } else fundamental_from_E(Em, out[k].f1, out[k].f2, E);
+#ifndef MDRP_NO_CLASSIFY
+            if (candidate_count(recs, ncls, E, ps.sq_thr) >= dense_min) { dense_mask |= 1 << k; ++n_dense; }
+#endif
+        }
+    }
+    const int n_sparse = n - n_dense;
+    // wave-aggregated append: one atomic per wave and list
+    const int lane = threadIdx.x & 63;
+    int pre_s = n_sparse, pre_d = n_dense;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int vs = __shfl_up(pre_s, o, 64), vd = __shfl_up(pre_d, o, 64);
+        if (lane >= o) { pre_s += vs; pre_d += vd; }
+    }
+    const int tot_s = __shfl(pre_s, 63, 64), tot_d = __shfl(pre_d, 63, 64);
+    int base_s = 0, base_d = 0;
+    if (lane == 63) {
+        if (tot_s > 0) base_s = atomicAdd(&model_count[2 * pair], tot_s);
+        if (tot_d > 0) base_d = atomicAdd(&model_count[2 * pair + 1], tot_d);
+    }
+    base_s = __shfl(base_s, 63, 64);
+    base_d = __shfl(base_d, 63, 64);
     if (!live) return;
     const size_t slot0 = ((size_t)pair * rp.chunk_len + it) * 4;
-    int pos = basepos + pre - n;
+    int pos_s = base_s + pre_s - n_sparse, pos_d = base_d + pre_d - n_dense;
     const size_t tag_base = (size_t)pair * rp.chunk_len * 4;
+    const int cap = rp.chunk_len * 4;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < n) {
             models[slot0 + k] = out[k];
-            tags[tag_base + pos] = (uint32_t)(it * 4 + k);
-            ++pos;
+            if ((dense_mask >> k) & 1) { tags[tag_base + (cap - 1 - pos_d)] = (uint32_t)(it * 4 + k); ++pos_d; }
+            else { tags[tag_base + pos_s] = (uint32_t)(it * 4 + k); ++pos_s; }
         } else {
             slot_inl[slot0 + k] = -1;
         }
@@ -251,78 +351,138 @@ __global__ __launch_bounds__(256) void k_solve(RunParams rp, const PairState *__
 
 // ------------------------------------------------------------------------------------------------ score (HOT)
 // One lane per hypothesis; the pair's correspondences are staged through LDS in tiles and read as wave-wide
-// broadcasts (every lane reads the same record), so a tile is fetched from HBM/L2 once per workgroup and each
-// (model x correspondence) evaluation costs ~20 fp64 VALU ops + 3 broadcast ds_read_b128.
-// Algorithmic bytes: 32 B per evaluation (x1, x2 as four fp64 — what the CPU loop reads).
+// broadcasts (every lane reads the same record), so a tile is fetched from HBM/L2 once per workgroup.
+// Algorithmic bytes: 32 B per (model x correspondence) evaluation (x1, x2 as four fp64 — what the CPU loop reads,
+// SURVEY.md §8d).
+//
+// Each 32-correspondence group runs in two phases so that the common case stays branch-free:
+//   phase 1  Sampson numerator/denominator for all 32 records, four independent chains in flight, no division:
+//            C^2 < thr * den marks a CANDIDATE bit in a per-lane mask                       (~19 fp64 ops / eval)
+//   phase 2  every lane pops ITS OWN candidate bits (per-lane LDS addresses) and runs the exact quotient test,
+//            check_cheirality and the accumulation.  Its trip count is the largest candidate count of any lane
+//            in the wave, not the number of records that are a candidate for SOME lane — with 64 unrelated
+//            hypotheses that union is ~half of all records.
+// k_solve pre-classifies hypotheses by their candidate density on the first records, so that wavefronts hold
+// either "dense" (good) or "sparse" (garbage) hypotheses and phase 2 stays short for the sparse majority.
+// exact inlier test + accumulation for one record (compute_sampson_msac_score @0x4f61d0 body, check_cheirality @0x1dce00)
 template <bool POSE>
-__device__ __forceinline__ void score_tile(const double *__restrict__ tile, int npts, const double E[9], const double R[9],
-                                           const double t[3], double thr, double &score, int &cnt) {
+__device__ __forceinline__ void score_point(const double *__restrict__ rec, const double E[9], const double R[9], const double t[3],
+                                            double thr, double &score, int &cnt) {
+    const double2 *P = reinterpret_cast<const double2 *>(rec);
+    const double2 p01 = P[0], p23 = P[1];
+    const double a = p01.x, b = p01.y, c = p23.x, d = p23.y;
+    const SampsonTerms s = sampson_terms(E, a, b, c, d);
+    const double r2 = s.C2 / s.den;
+    if (r2 < thr) {
+        bool ok = true;
+        if (POSE) { // unit bearings via the precomputed inverse norms, min depth 0.01
+            const double2 p45 = P[2];
+            const double u0 = fma(R[0], a, fma(R[1], b, R[2]));
+            const double u1 = fma(R[3], a, fma(R[4], b, R[5]));
+            const double u2 = fma(R[6], a, fma(R[7], b, R[8]));
+            const double uh = fma(u0, c, fma(u1, d, u2));
+            const double ut = fma(u0, t[0], fma(u1, t[1], u2 * t[2]));
+            const double ht = fma(c, t[0], fma(d, t[1], t[2]));
+            const double A = -uh * p45.x * p45.y;
+            const double b1 = -ut * p45.x, b2 = ht * p45.y;
+            const double l1 = fma(-A, b2, b1), l2 = fma(-A, b1, b2);
+            const double md = 0.01 * fma(-A, A, 1.0);
+            ok = (l1 > md) && (l2 > md);
+        }
+        if (ok) { score += r2; ++cnt; }
+    }
+}
+
+// `recs` may be an LDS tile (broadcast ds_reads) or the pair's records in global memory (wave-uniform addresses ->
+// scalar loads into SGPRs, which v_fma_f64 takes directly as an operand).  The pose (R,t) is only needed by phase 2,
+// so it is rebuilt from the model's quaternion when a group has candidates instead of living in 24 VGPRs.
+template <bool POSE>
+__device__ __forceinline__ void score_tile(const double *__restrict__ recs, int npts, const double E[9], const Model *__restrict__ mp,
+                                           double thr, double &score, int &cnt) {
     const double thr_hi = thr * (1.0 + 1e-12);
-#pragma unroll 2
-    for (int p = 0; p < npts; ++p) {
-        const double2 *P = reinterpret_cast<const double2 *>(tile + p * PT_STRIDE);
-        const double2 p01 = P[0], p23 = P[1];
-        const double a = p01.x, b = p01.y, c = p23.x, d = p23.y;
-        const double e0 = fma(E[0], a, fma(E[1], b, E[2]));
-        const double e1 = fma(E[3], a, fma(E[4], b, E[5]));
-        const double e2 = fma(E[6], a, fma(E[7], b, E[8]));
-        const double g0 = fma(E[0], c, fma(E[3], d, E[6]));
-        const double g1 = fma(E[1], c, fma(E[4], d, E[7]));
-        const double C = fma(c, e0, fma(d, e1, e2));
-        const double den = fma(e0, e0, fma(e1, e1, fma(g0, g0, g1 * g1)));
-        const double C2 = C * C;
-        if (C2 < thr_hi * den) { // candidate inlier; exact test on the quotient like the reference
-            const double r2 = C2 / den;
-            if (r2 < thr) {
-                bool ok = true;
-                if (POSE) { // check_cheirality on unit bearings, min depth 0.01 (@0x1dce00)
-                    const double2 p45 = P[2];
-                    const double u0 = fma(R[0], a, fma(R[1], b, R[2]));
-                    const double u1 = fma(R[3], a, fma(R[4], b, R[5]));
-                    const double u2 = fma(R[6], a, fma(R[7], b, R[8]));
-                    const double uh = fma(u0, c, fma(u1, d, u2));
-                    const double ut = fma(u0, t[0], fma(u1, t[1], u2 * t[2]));
-                    const double ht = fma(c, t[0], fma(d, t[1], t[2]));
-                    const double A = -uh * p45.x * p45.y;
-                    const double b1 = -ut * p45.x, b2 = ht * p45.y;
-                    const double l1 = fma(-A, b2, b1), l2 = fma(-A, b1, b2);
-                    const double md = 0.01 * fma(-A, A, 1.0);
-                    ok = (l1 > md) && (l2 > md);
+    for (int p0 = 0; p0 < npts; p0 += 32) {
+        const int g = min(32, npts - p0);
+        const double *base = recs + (size_t)p0 * PT_STRIDE;
+        uint32_t mask = 0;
+        if (g == 32) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < 32; j0 += MDRP_P1_UNROLL) {
+#pragma unroll
+                for (int jj = 0; jj < MDRP_P1_UNROLL; ++jj) {
+                    const int j = j0 + jj;
+                    const double2 *P = reinterpret_cast<const double2 *>(base + j * PT_STRIDE);
+                    const double2 p01 = P[0], p23 = P[1];
+                    const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
+                    mask |= (s.C2 < thr_hi * s.den) ? (1u << j) : 0u;
                 }
-                if (ok) { score += r2; ++cnt; }
+            }
+        } else {
+            for (int j = 0; j < g; ++j) {
+                const double2 *P = reinterpret_cast<const double2 *>(base + j * PT_STRIDE);
+                const double2 p01 = P[0], p23 = P[1];
+                const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
+                mask |= (s.C2 < thr_hi * s.den) ? (1u << j) : 0u;
+            }
+        }
+#ifdef MDRP_NO_PHASE2
+        cnt += __popc(mask); mask = 0; // timing experiment only
+#endif
+        if (mask) {
+            double R[9], t[3];
+            if (POSE) {
+                double q[4];
+                q[0] = mp->q[0]; q[1] = mp->q[1]; q[2] = mp->q[2]; q[3] = mp->q[3];
+                t[0] = mp->t[0]; t[1] = mp->t[1]; t[2] = mp->t[2];
+                quat_to_R(q, R);
+            }
+            while (mask) { // per-lane candidates, ascending record order (same accumulation order as the CPU loop)
+                const int j = __ffs(mask) - 1;
+                mask &= mask - 1;
+                score_point<POSE>(base + j * PT_STRIDE, E, R, t, thr, score, cnt);
             }
         }
     }
 }
 
 template <bool POSE>
-__global__ __launch_bounds__(SCORE_THREADS) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+__global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags,
                                                          const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
                                                          int32_t *__restrict__ slot_inl) {
     extern __shared__ double tile[]; // TILE_PTS * PT_STRIDE doubles
     const int pair = blockIdx.y;
-    const int count = model_count[pair];
-    const int base = blockIdx.x * SCORE_THREADS;
-    if (base >= count) return;
+    // tag list of the pair: sparse hypotheses grow from the front, dense ones from the back (k_solve)
+    const int cnt_sparse = model_count[2 * pair], cnt_dense = model_count[2 * pair + 1];
+    const int blk_sparse = (cnt_sparse + SCORE_THREADS - 1) / SCORE_THREADS;
+    const int blk_dense = (cnt_dense + SCORE_THREADS - 1) / SCORE_THREADS;
+    const int blk = blockIdx.x;
+    if (blk >= blk_sparse + blk_dense) return;
     const PairState &ps = st[pair];
     const int n = ps.n;
     const double thr = ps.sq_thr;
     const int tid = threadIdx.x;
-    const bool live = base + tid < count;
     const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+    const int cap = rp.chunk_len * 4;
+    bool live;
     uint32_t slot = 0;
-    double E[9], R[9], t[3];
+    if (blk < blk_sparse) {
+        const int i = blk * SCORE_THREADS + tid;
+        live = i < cnt_sparse;
+        if (live) slot = tags[slot_base + i];
+    } else {
+        const int i = (blk - blk_sparse) * SCORE_THREADS + tid;
+        live = i < cnt_dense;
+        if (live) slot = tags[slot_base + (cap - 1 - i)];
+    }
+    double E[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { E[i] = 0; R[i] = 0; }
-    t[0] = t[1] = t[2] = 0;
+    for (int i = 0; i < 9; ++i) E[i] = 0;
+    const Model *mp = models + slot_base + slot;
     if (live) {
-        slot = tags[slot_base + base + tid];
-        const Model m = models[slot_base + slot];
+        const Model m = *mp;
+        double R[9], Em[9];
         quat_to_R(m.q, R);
-        t[0] = m.t[0]; t[1] = m.t[1]; t[2] = m.t[2];
-        double Em[9];
-        essential_from_Rt(R, t, Em);
+        essential_from_Rt(R, m.t, Em);
         if (POSE) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) E[i] = Em[i];
@@ -333,6 +493,9 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(RunParams rp, const Pai
     double score = 0;
     int cnt = 0;
     const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+#ifdef MDRP_SCORE_SCALAR
+    score_tile<POSE>(gp, n, E, mp, thr, score, cnt);
+#else
     for (int t0 = 0; t0 < n; t0 += TILE_PTS) {
         const int npts = min(TILE_PTS, n - t0);
         __syncthreads();
@@ -343,8 +506,9 @@ __global__ __launch_bounds__(SCORE_THREADS) void k_score(RunParams rp, const Pai
             for (int i = tid; i < nvec; i += SCORE_THREADS) dst[i] = src[i];
         }
         __syncthreads();
-        score_tile<POSE>(tile, npts, E, R, t, thr, score, cnt);
+        score_tile<POSE>(tile, npts, E, mp, thr, score, cnt);
     }
+#endif
     if (live) {
         slot_score[slot_base + slot] = score + thr * (double)(n - cnt);
         slot_inl[slot_base + slot] = cnt;
@@ -362,7 +526,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     const int pair = blockIdx.x, lane = threadIdx.x;
     PairState &ps = st[pair];
     if (!ps.active) { if (lane == 0) ps.n_triggers = 0; return; }
-    if (lane == 0) atomicAdd(evals, (unsigned long long)model_count[pair] * (unsigned long long)ps.n);
+    if (lane == 0) atomicAdd(evals, (unsigned long long)(model_count[2 * pair] + model_count[2 * pair + 1]) * (unsigned long long)ps.n);
     long long run_cnt = (long long)ps.best_min_cnt;
     double run_score = ps.best_min_score;
     int ntrig = 0;
@@ -595,8 +759,8 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
     for (int i = threadIdx.x; i < n; i += LM_THREADS) {
         double s1 = 0;
         int c1 = 0;
-        if (kind == 0) score_tile<true>(pts + (size_t)i * PT_STRIDE, 1, E, R, m.t, thr, s1, c1);
-        else score_tile<false>(pts + (size_t)i * PT_STRIDE, 1, E, R, m.t, thr, s1, c1);
+        if (kind == 0) score_point<true>(pts + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
+        else score_point<false>(pts + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
         score += s1; cnt += c1;
         if (mask_out) mask_out[i] = (uint8_t)c1;
     }

@@ -40,3 +40,29 @@ void hm_draw(uint64_t n, uint64_t seed, int count, uint32_t *out) {
 }
 double hm_loss(int type, double thr, double r2, int weight) { return weight ? loss_weight(type, thr, r2) : loss_value(type, thr, r2); }
 }
+
+// host emulation of k_samples' wave-speculative table generation (64 "lanes" per step) for the CPU test
+extern "C" void hm_draw_wave(uint64_t n, uint64_t seed, int count, uint32_t *out, uint64_t *state_out) {
+    const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
+    uint64_t state = seed;
+    int done = 0;
+    while (done < count) {
+        uint64_t s_end[64];
+        uint32_t smp[64][3];
+        int first = 63;
+        bool found = false;
+        for (int lane = 0; lane < 64; ++lane) {
+            uint64_t s = state + (uint64_t)(3 * lane) * GAMMA;
+            const uint64_t s0 = s;
+            draw_sample3(n, s, smp[lane][0], smp[lane][1], smp[lane][2]);
+            s_end[lane] = s;
+            if (!found && (s - s0) != 3 * GAMMA) { first = lane; found = true; }
+        }
+        int nvalid = first + 1 < count - done ? first + 1 : count - done;
+        for (int lane = 0; lane < nvalid; ++lane)
+            for (int k = 0; k < 3; ++k) out[3 * (done + lane) + k] = smp[lane][k];
+        state = s_end[nvalid - 1];
+        done += nvalid;
+    }
+    *state_out = state;
+}

@@ -60,6 +60,20 @@ def test_sampler_equal_oracle(hm):
         assert (out.astype(np.int64) == po.draw_samples(seed, n, 500)).all()
 
 
+def test_wave_speculative_sampler_equals_sequential(hm):
+    """k_samples' speculation scheme (host emulation) reproduces the sequential sampler incl. the end state, also for
+    tiny N where nearly every wave step sees a rejection, and continues correctly across chunks"""
+    for n, seed, count in ((3, 0, 300), (7, 1, 1000), (200, 0, 3000), (2000, 0, 10000), (5000, 4, 10000)):
+        out = np.zeros((count, 3), dtype=np.uint32)
+        st = C.c_uint64(0)
+        hm.hm_draw_wave(C.c_uint64(n), C.c_uint64(seed), count, out.ctypes.data_as(C.c_void_p), C.byref(st))
+        ref = po.draw_samples(seed, n, count + 50)
+        assert (out.astype(np.int64) == ref[:count]).all(), n
+        out2 = np.zeros((50, 3), dtype=np.uint32)
+        hm.hm_draw_wave(C.c_uint64(n), st, 50, out2.ctypes.data_as(C.c_void_p), C.byref(st))
+        assert (out2.astype(np.int64) == ref[count:]).all(), n
+
+
 def test_residuals_and_jacobian_equal_oracle(hm):
     rng = np.random.default_rng(0)
     L = po.lib()
