@@ -102,15 +102,14 @@ def main():
     bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
     stream = torch.cuda.current_stream()
     h = _capi.Handle(local_rank, stream.cuda_stream)
-    gathered = [torch.empty((B, _capi.RESULT_DTYPE.itemsize), dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
+    from mdrp_amd import dist as mdist
 
     def step():
         h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, n, ro, bo, None,
                                 cams if kind == 0 else None, cams if kind == 0 else None, mask.data_ptr())
         res = h.fetch_results(B)
         if world > 1:  # final gather of the pose records over RCCL/xGMI: 136 B per pair
-            mine = torch.from_numpy(res.view(np.uint8).reshape(B, -1)).to(dev)
-            dist.all_gather(gathered, mine)
+            mdist.gather_results(res, B * world, None, dev)
         return res
 
     def barrier():
