@@ -59,6 +59,23 @@ def cpu_baseline(workload, pairs):
             "sample": f"{pairs} pairs of {workload} (same generator, indices 0..{pairs - 1}), {dt:.1f} s wall, 1 thread"}
 
 
+def pmc_traffic(workload, batch):
+    """HBM bytes per k_score launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, per the gfx950
+    correction in MI355X_MICROARCH.md) when they were taken on this workload and batch; else None."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("workload") == workload and d.get("pairs_per_gpu") == batch:
+            for k, v in d.get("kernels", {}).items():
+                if "k_score" in k:
+                    best = (v["hbm_bytes_corrected"], os.path.basename(f))
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,7 +170,9 @@ def main():
                        "outlier_fraction": of, "estimator": ["calibrated", "shared_focal", "varying_focal"][kind],
                        "monodepth_estimate_shift": es, "parallelism": f"pairs sharded x{world}, all_gather of results"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_score", "evals_per_launch": sweep_evals / max(sweep_launches, 1),
+                         "traffic": (pmc_traffic(args.workload, B) or (None, None))[0], "traffic_unit": "bytes per launch (PMC)",
+                         "traffic_source": (pmc_traffic(args.workload, B) or (None, None))[1], "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "kernel": "k_score", "evals_per_launch": sweep_evals / max(sweep_launches, 1),
                          "avg_launch_ms": 1e3 * avg_launch_s, "sweep_share_of_step": (sweep_ms / 1e3) / dt},
             "quality": {"median_rotation_error_deg_first64": R_err,
                         "mean_inlier_ratio": float(np.mean(res["num_inliers"] / n))},
