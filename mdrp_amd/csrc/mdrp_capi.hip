@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -74,6 +75,15 @@ struct mdrp_handle {
 };
 
 namespace {
+
+// one LM instantiation per kernel: dispatch (kind, estimate_shift) on the host
+#define MDRP_LM_DISPATCH(KERNEL, kind, shift, grid, block, stream, ...)                                              \
+    do {                                                                                                             \
+        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true>), grid, block, 0, stream, __VA_ARGS__);      \
+        else if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0, false>), grid, block, 0, stream, __VA_ARGS__);           \
+        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false>), grid, block, 0, stream, __VA_ARGS__);           \
+        else hipLaunchKernelGGL((KERNEL<2, false>), grid, block, 0, stream, __VA_ARGS__);                            \
+    } while (0)
 
 int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -169,8 +179,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     (void)sum_n;
 
     uint64_t it0 = 0;
-    uint64_t next_len = std::min<uint64_t>(ro->max_iterations, std::max<uint64_t>(ro->min_iterations + 1, 1));
-    if (ro->max_iterations == 0) next_len = 1; // the reference's do-while runs one iteration even then
+    // iterations that certainly run: the reference cannot stop before min_iterations + 1 (or max_iterations)
+    const uint64_t certain = ro->max_iterations == 0 ? 1 : std::min<uint64_t>(ro->max_iterations, ro->min_iterations + 1);
+    // chunk schedule: a short first chunk establishes the records that let k_score bail out of hopeless hypotheses in
+    // the following, 4x larger ones (exact, see Prune in mdrp_kernels.h); later chunks follow dynamic_max_iter
+    uint64_t next_len = certain >= 2048 ? 512 : certain;
+    uint64_t last_len = 0;
     while (true) {
         const int len = (int)std::min<uint64_t>(next_len, (uint64_t)chunk_cap);
         rp.chunk_len = len; rp.chunk_start = it0;
@@ -200,9 +214,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
                            h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0, h->work_pair.as<uint32_t>(),
                            h->work_pos.as<uint32_t>(), h->model_count.as<int32_t>(), reinterpret_cast<unsigned long long *>(cnt + 6));
-        hipLaunchKernelGGL(k_lo, dim3(h->num_cu * 2), dim3(LM_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                           h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0,
-                           h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1);
+        MDRP_LM_DISPATCH(k_lo, kind, est_shift, dim3(h->num_cu * 2), dim3(LM_THREADS), s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                         h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0,
+                         h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1);
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                            h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
         HIPCHK(hipGetLastError());
@@ -210,14 +224,26 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->sweep_evals += (int64_t)h->progress_host->evals;
+        if (getenv("MDRP_DEBUG"))
+            fprintf(stderr, "[mdrp] chunk start %llu len %d: evals %llu active %d max_needed %llu\n", (unsigned long long)it0, len,
+                    h->progress_host->evals, h->progress_host->n_active, h->progress_host->max_needed);
+        if (getenv("MDRP_DEBUG")) {
+            PairState dbg;
+            (void)hipMemcpy(&dbg, h->st.p, sizeof dbg, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mdrp]   pair0: n %d active %d ntrig %d it %llu refinements %llu inl %llu score %g best_min_cnt %llu\n", dbg.n, dbg.active,
+                    dbg.n_triggers, (unsigned long long)dbg.iterations, (unsigned long long)dbg.refinements, (unsigned long long)dbg.num_inliers,
+                    dbg.model_score, (unsigned long long)dbg.best_min_cnt);
+        }
         it0 += (uint64_t)len;
         if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
-        next_len = std::max<uint64_t>(h->progress_host->max_needed, 256);
+        last_len = (uint64_t)len;
+        if (it0 < certain) next_len = std::min<uint64_t>(certain - it0, last_len * 4);
+        else next_len = std::max<uint64_t>(h->progress_host->max_needed, 256);
         next_len = std::min<uint64_t>(next_len, ro->max_iterations - it0);
     }
 
-    hipLaunchKernelGGL(k_final, dim3(batch), dim3(LM_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                       h->dep.as<double>(), mask_dev, results_dev);
+    MDRP_LM_DISPATCH(k_final, kind, est_shift, dim3(batch), dim3(LM_THREADS), s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                     h->dep.as<double>(), mask_dev, results_dev);
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -433,6 +459,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     PairState ps;
     std::memset(&ps, 0, sizeof ps);
     ps.n = n; ps.active = 1; ps.sq_thr = sq_threshold; ps.eps = std::sqrt(sq_threshold);
+    ps.best_min_score = DBL_MAX; // no records: nothing is pruned
     HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, x1d, x2d, (const double *)nullptr,
                        (const double *)nullptr, h->pts.as<double>(), (double *)nullptr);
@@ -484,9 +511,9 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
     o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
-    hipLaunchKernelGGL(k_refine_unit, dim3(count), dim3(LM_THREADS), 0, s, kind, (kind == MDRP_CALIB && estimate_shift) ? 1 : 0, count,
-                       h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
-                       h->unit_a.as<double>());
+    MDRP_LM_DISPATCH(k_refine_unit, kind, (kind == MDRP_CALIB && estimate_shift), dim3(count), dim3(LM_THREADS), s, count,
+                     h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
+                     h->unit_a.as<double>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(models, h->unit_e.p, sizeof(Model) * count, hipMemcpyDeviceToHost, s));
     if (final_cost) HIPCHK(hipMemcpyAsync(final_cost, h->unit_a.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));

@@ -34,6 +34,7 @@ constexpr int TILE_PTS = MDRP_TILE_PTS; // correspondences per LDS tile (48 B ea
 #ifndef MDRP_P1_UNROLL
 #define MDRP_P1_UNROLL 4
 #endif
+constexpr int PRUNE_EVERY = 4;     // bail-out test every PRUNE_EVERY groups of 32 records (power of two)
 constexpr int CLS_PTS = 64;        // records used to pre-classify hypotheses as dense / sparse
 #ifndef MDRP_SCORE_THREADS
 #define MDRP_SCORE_THREADS 256
@@ -396,9 +397,26 @@ __device__ __forceinline__ void score_point(const double *__restrict__ rec, cons
 // `recs` may be an LDS tile (broadcast ds_reads) or the pair's records in global memory (wave-uniform addresses ->
 // scalar loads into SGPRs, which v_fma_f64 takes directly as an operand).  The pose (R,t) is only needed by phase 2,
 // so it is rebuilt from the model's quaternion when a group has candidates instead of living in 24 VGPRs.
+// Bail-out against the pair's records from EARLIER chunks (exact): a hypothesis only matters if it beats a running
+// record of the minimal models (score_models<> @0x22ebc0: more inliers OR better score than any earlier minimal model).
+// Records only improve over a run, so the records at the end of the previous chunk are a valid (weaker) bar for every
+// model of this chunk.  After `processed` records a lane is provably irrelevant when
+//     cnt + (n - processed) <= rec_cnt      (cannot end with more inliers)      and
+//     score + thr (processed - cnt) >= rec_score   (all remaining terms are >= 0: cannot end with a better score).
+// Its slot is then written as "not a record" (count -2); k_scan treats it like an empty slot, so the trajectory is
+// identical to scoring everything.  A wavefront stops computing once all of its lanes are out.
+struct Prune {
+    long long rec_cnt;
+    double rec_score; // already inflated by 1e-12 relative; DBL_MAX disables pruning
+    int n;            // correspondences of the pair
+    int processed;    // records consumed so far (all tiles)
+    bool dead;        // this lane is out
+    bool wave_dead;
+};
+
 template <bool POSE>
 __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int npts, const double E[9], const Model *__restrict__ mp,
-                                           double thr, double &score, int &cnt) {
+                                           double thr, double &score, int &cnt, Prune &pr) {
     const double thr_hi = thr * (1.0 + 1e-12);
     for (int p0 = 0; p0 < npts; p0 += 32) {
         const int g = min(32, npts - p0);
@@ -427,6 +445,7 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
 #ifdef MDRP_NO_PHASE2
         cnt += __popc(mask); mask = 0; // timing experiment only
 #endif
+        if (pr.dead) mask = 0;
         if (mask) {
             double R[9], t[3];
             if (POSE) {
@@ -441,6 +460,14 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
                 score_point<POSE>(base + j * PT_STRIDE, E, R, t, thr, score, cnt);
             }
         }
+        pr.processed += g;
+#ifndef MDRP_NO_PRUNE
+        if (pr.rec_score < DBL_MAX && ((p0 >> 5) & (PRUNE_EVERY - 1)) == PRUNE_EVERY - 1) {
+            pr.dead = pr.dead || (((long long)cnt + (long long)(pr.n - pr.processed) <= pr.rec_cnt) &&
+                                  (score + thr * (double)(pr.processed - cnt) >= pr.rec_score));
+            if (__all(pr.dead)) { pr.wave_dead = true; return; }
+        }
+#endif
     }
 }
 
@@ -455,7 +482,11 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     const int cnt_sparse = model_count[2 * pair], cnt_dense = model_count[2 * pair + 1];
     const int blk_sparse = (cnt_sparse + SCORE_THREADS - 1) / SCORE_THREADS;
     const int blk_dense = (cnt_dense + SCORE_THREADS - 1) / SCORE_THREADS;
-    const int blk = blockIdx.x;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs by linear id (pair * gridDim.x + blockIdx.x).
+    // Only the first blk_sparse + blk_dense logical blocks of a pair carry work; when gridDim.x is a multiple of 8 they
+    // would all land on the same few XCDs for EVERY pair (measured: a 2048-iteration chunk took as long as a
+    // 7440-iteration one).  Rotating the logical index by the pair number spreads them evenly.
+    const int blk = (int)((blockIdx.x + 5u * (unsigned)pair) % gridDim.x);
     if (blk >= blk_sparse + blk_dense) return;
     const PairState &ps = st[pair];
     const int n = ps.n;
@@ -492,9 +523,13 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     }
     double score = 0;
     int cnt = 0;
+    Prune pr;
+    pr.rec_cnt = (long long)ps.best_min_cnt;
+    pr.rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
+    pr.n = n; pr.processed = 0; pr.dead = !live; pr.wave_dead = false;
     const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
 #ifdef MDRP_SCORE_SCALAR
-    score_tile<POSE>(gp, n, E, mp, thr, score, cnt);
+    score_tile<POSE>(gp, n, E, mp, thr, score, cnt, pr);
 #else
     for (int t0 = 0; t0 < n; t0 += TILE_PTS) {
         const int npts = min(TILE_PTS, n - t0);
@@ -506,12 +541,13 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
             for (int i = tid; i < nvec; i += SCORE_THREADS) dst[i] = src[i];
         }
         __syncthreads();
-        score_tile<POSE>(tile, npts, E, mp, thr, score, cnt);
+        if (!pr.wave_dead) score_tile<POSE>(tile, npts, E, mp, thr, score, cnt, pr);
     }
 #endif
     if (live) {
-        slot_score[slot_base + slot] = score + thr * (double)(n - cnt);
-        slot_inl[slot_base + slot] = cnt;
+        const bool pruned = pr.dead;
+        slot_score[slot_base + slot] = pruned ? DBL_MAX : score + thr * (double)(n - cnt);
+        slot_inl[slot_base + slot] = pruned ? -2 : cnt;
     }
 }
 
@@ -616,83 +652,130 @@ struct LmOpt {
     double loss_scale, grad_tol, step_tol, lambda0, lambda_min, lambda_max;
 };
 
+// Work-list LM.  With a truncated loss (every LO refinement, and the recommended TRUNCATED_CAUCHY of the final one) a
+// correspondence whose three terms all have zero IRLS weight contributes nothing to J'J, but inside a wavefront the
+// Jacobian code would still run for all 64 lanes whenever one lane has an inlier.  The cost sweep (which runs anyway for
+// every candidate step) therefore also writes the indices of the contributing correspondences, compacted per wavefront
+// with a ballot, into an LDS list; the accumulate sweep of an accepted step walks that list with every lane busy.
+// Lists are double buffered (current model / candidate).  Each wavefront owns a contiguous segment of the
+// correspondences, so list order — and with it the floating-point summation order — is deterministic.
+constexpr int LM_LIST_CAP = 8192; // correspondences per pair up to which the work list is used (2 x 32 KiB of LDS)
+
+struct LmShared {
+    double scratch[4 * MAX_ACC];
+    uint32_t list[2][LM_LIST_CAP];
+    int count[2][4];
+};
+
 template <int KIND>
 __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                          const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *scratch) {
+                          const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, LmShared &sh, int buf) {
     LmState stt;
     lm_state_from_model(m, KIND != 0, stt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool use_list = n <= LM_LIST_CAP;
+    const int seg = ((n + 255) / 256) * 64; // correspondences per wavefront, multiple of 64
+    const int lo = wave * seg, hi = min(n, lo + seg);
     double cost = 0;
-    for (int i = threadIdx.x; i < n; i += LM_THREADS) {
-        if (mask && !mask[i]) continue;
-        const double *p = pts + (size_t)i * PT_STRIDE;
-        double r[5], zf, zb;
-        point_residuals<false>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, nullptr);
-        cost += ws * loss_value(o.loss, o.loss_scale, r[0] * r[0]);
-        if (!(zf < 0)) cost += loss_value(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2]);
-        if (!(zb < 0)) cost += loss_value(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4]);
+    int cnt = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        bool contrib = false;
+        if (i < hi && (!mask || mask[i])) {
+            const double *p = pts + (size_t)i * PT_STRIDE;
+            double r[5], zf, zb;
+            point_residuals<false, KIND != 0>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, nullptr);
+            const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
+            cost += ws * loss_value(o.loss, o.loss_scale, rs);
+            if (!(zf < 0)) cost += loss_value(o.loss, o.loss_scale, rf);
+            if (!(zb < 0)) cost += loss_value(o.loss, o.loss_scale, rb);
+            contrib = (ws * loss_weight(o.loss, o.loss_scale, rs) != 0.0) || (!(zf < 0) && loss_weight(o.loss, o.loss_scale, rf) != 0.0) ||
+                      (!(zb < 0) && loss_weight(o.loss, o.loss_scale, rb) != 0.0);
+        }
+        if (use_list) {
+            const unsigned long long ball = __ballot(contrib);
+            if (contrib) sh.list[buf][lo + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            cnt += __popcll(ball);
+        }
     }
+    if (use_list && lane == 0) sh.count[buf][wave] = cnt;
     double v[1] = {cost};
-    block_sum<1, LM_THREADS>(v, scratch);
+    block_sum<1, LM_THREADS>(v, sh.scratch);
     return v[0];
 }
 
 template <int KIND, bool SHIFT>
+__device__ __forceinline__ void lm_accumulate_point(const LmState &stt, const double *__restrict__ pts, const double *__restrict__ dep, int i,
+                                                    double sqrt_sr, double ws, const LmOpt &o, double *acc) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    const double *p = pts + (size_t)i * PT_STRIDE;
+    double r[5], zf, zb, J[5][LM_NPAR];
+    point_residuals<true, KIND != 0>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, J);
+    const double wS = ws * loss_weight(o.loss, o.loss_scale, r[0] * r[0]);
+    const double wF = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2]);
+    const double wB = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4]);
+    const double wr[5] = {wS, wF, wF, wB, wB};
+#pragma unroll
+    for (int row = 0; row < 5; ++row) {
+        double Ja[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            Ja[q] = J[row][lm_col<KIND, SHIFT>(q)];
+            if (KIND == 1 && q == 7) Ja[q] += J[row][10]; // shared focal: f1 = f2 = f
+        }
+        const double w = wr[row];
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            const double wa = w * Ja[a];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) acc[idx++] += wa * Ja[b];
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r[row];
+    }
+}
+
+template <int KIND, bool SHIFT>
 __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                              const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, double *scratch) {
+                              const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, LmShared &sh, int buf) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NA = NP * (NP + 1) / 2 + NP;
     LmState stt;
     lm_state_from_model(m, KIND != 0, stt);
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0;
-    for (int i = threadIdx.x; i < n; i += LM_THREADS) {
-        if (mask && !mask[i]) continue;
-        const double *p = pts + (size_t)i * PT_STRIDE;
-        double r[5], zf, zb, J[5][LM_NPAR];
-        point_residuals<true>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, J);
-        const double wS = ws * loss_weight(o.loss, o.loss_scale, r[0] * r[0]);
-        const double wF = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2]);
-        const double wB = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4]);
-        const double wr[5] = {wS, wF, wF, wB, wB};
-#pragma unroll
-        for (int row = 0; row < 5; ++row) {
-            double Ja[NP];
-#pragma unroll
-            for (int q = 0; q < NP; ++q) {
-                Ja[q] = J[row][lm_col<KIND, SHIFT>(q)];
-                if (KIND == 1 && q == 7) Ja[q] += J[row][10]; // shared focal: f1 = f2 = f
-            }
-            const double w = wr[row];
-            int idx = 0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a) {
-                const double wa = w * Ja[a];
-#pragma unroll
-                for (int b = 0; b <= a; ++b) acc[idx++] += wa * Ja[b];
-            }
-#pragma unroll
-            for (int a = 0; a < NP; ++a) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r[row];
-        }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = ((n + 255) / 256) * 64;
+    const int lo = wave * seg;
+    if (n <= LM_LIST_CAP) {
+        const int cnt = sh.count[buf][wave];
+        for (int k = lane; k < cnt; k += 64) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, (int)sh.list[buf][lo + k], sqrt_sr, ws, o, acc);
+    } else {
+        const int hi = min(n, lo + seg);
+        for (int i = lo + lane; i < hi; i += 64)
+            if (!mask || mask[i]) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, i, sqrt_sr, ws, o, acc);
     }
-    block_sum<NA, LM_THREADS>(acc, scratch);
+    block_sum<NA, LM_THREADS>(acc, sh.scratch);
 }
 
 // lm_impl<> loop of the reference (upstream PoseLib convention): executed redundantly and uniformly by every
 // thread of the workgroup; only the two sweeps over the correspondences are distributed.
 template <int KIND, bool SHIFT>
 __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o, double *scratch) {
+                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o, LmShared &sh) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NT = NP * (NP + 1) / 2;
     const double sqrt_sr = sqrt(scale_reproj);
-    double cost = lm_cost<KIND>(m, pts, dep, n, mask, sqrt_sr, ws, o, scratch);
+    int cur = 0; // list buffer that belongs to the current model
+    double cost = lm_cost<KIND>(m, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur);
     double lambda = o.lambda0;
     bool recompute = true;
     double acc[NT + NP];
     double A[NP * NP], g[NP], sol[NP];
     for (int it = 0; it < o.max_it; ++it) {
         if (recompute) {
-            lm_accumulate<KIND, SHIFT>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, scratch);
+            lm_accumulate<KIND, SHIFT>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
             double gn = 0;
             int idx = 0;
 #pragma unroll
@@ -722,9 +805,10 @@ __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double
         if (KIND == 1) full[10] = full[9];
         Model cand;
         lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
-        const double cost_new = lm_cost<KIND>(cand, pts, dep, n, mask, sqrt_sr, ws, o, scratch);
+        const double cost_new = lm_cost<KIND>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur ^ 1);
         if (cost_new < cost) {
             m = cand;
+            cur ^= 1;
             lambda = fmax(o.lambda_min, lambda / 10.0);
             cost = cost_new;
             recompute = true;
@@ -733,15 +817,6 @@ __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double
             recompute = false;
         }
     }
-}
-
-__device__ __forceinline__ void lm_dispatch(int kind, int est_shift, Model &m, const double *pts, const double *dep, int n,
-                                            const uint8_t *mask, double scale_reproj, double ws, const LmOpt &o, double *scratch) {
-    if (kind == 0) {
-        if (est_shift) lm_refine<0, true>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
-        else lm_refine<0, false>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
-    } else if (kind == 1) lm_refine<1, false>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
-    else lm_refine<2, false>(m, pts, dep, n, mask, scale_reproj, ws, o, scratch);
 }
 
 // workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask output
@@ -773,12 +848,13 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 // ------------------------------------------------------------------------------------------------ LO
 // Persistent workgroups pop (pair, trigger) items; each refines the triggering minimal model (refine_model
 // @0x4fa550/@0x4fad60/@0x4fb0a0: 25 it, TRUNCATED) and rescoring it.
+template <int KIND, bool SHIFT>
 __global__ __launch_bounds__(LM_THREADS) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
                                                    Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ work_count,
                                                    const uint32_t *__restrict__ work_pair, const uint32_t *__restrict__ work_pos,
                                                    int32_t *__restrict__ work_head) {
-    __shared__ double scratch[4 * MAX_ACC];
+    __shared__ LmShared sh;
     __shared__ int s_item;
     const int total = *work_count;
     for (;;) {
@@ -798,10 +874,10 @@ __global__ __launch_bounds__(LM_THREADS) void k_lo(RunParams rp, const PairState
         o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
         const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
         const double *dd = dep + (size_t)pair * rp.n_max * 2;
-        lm_dispatch(rp.kind, rp.est_shift, m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, scratch);
+        lm_refine<KIND, SHIFT>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
         double sc;
         int cn;
-        block_score(rp.kind, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+        block_score(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
         if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
     }
 }
@@ -883,10 +959,12 @@ struct ResultDev {
     double inlier_ratio, model_score;
 };
 
+template <int KIND, bool SHIFT>
 __global__ __launch_bounds__(LM_THREADS) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
                                                       ResultDev *__restrict__ results) {
-    __shared__ double scratch[4 * MAX_ACC];
+    __shared__ LmShared sh;
+    double *scratch = sh.scratch;
     const int pair = blockIdx.x;
     PairState &ps = st[pair];
     ResultDev res;
@@ -905,23 +983,23 @@ __global__ __launch_bounds__(LM_THREADS) void k_final(RunParams rp, PairState *_
     LmOpt o;
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
     o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-    lm_dispatch(rp.kind, rp.est_shift, m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, scratch);
+    lm_refine<KIND, SHIFT>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
     res.refinements++;
     double sc;
     int cn;
-    block_score(rp.kind, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+    block_score(KIND, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
     Model best = ps.best;
     if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
     for (int i = ps.n + threadIdx.x; i < rp.n_max; i += LM_THREADS) mask[i] = 0;
-    block_score(rp.kind, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
+    block_score(KIND, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
     __syncthreads();
     if (res.num_inliers > 3) {
         LmOpt f;
         f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
         f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
-        lm_dispatch(rp.kind, rp.est_shift, best, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, f, scratch);
+        lm_refine<KIND, SHIFT>(best, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, f, sh);
     }
-    if (rp.kind != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
+    if (KIND != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
     res.model = best;
     if (threadIdx.x == 0) results[pair] = res;
 }
@@ -958,19 +1036,16 @@ __global__ void k_pack_unit(int n, const double *__restrict__ x1, const double *
     if (dep) { dep[2 * i] = d1 ? d1[i] : 0.0; dep[2 * i + 1] = d2 ? d2[i] : 0.0; }
 }
 
-__global__ __launch_bounds__(LM_THREADS) void k_refine_unit(int kind, int est_shift, int count, Model *__restrict__ models,
+template <int KIND, bool SHIFT>
+__global__ __launch_bounds__(LM_THREADS) void k_refine_unit(int count, Model *__restrict__ models,
                                                             const double *__restrict__ pts, const double *__restrict__ dep, int n,
                                                             double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost) {
-    __shared__ double scratch[4 * MAX_ACC];
+    __shared__ LmShared sh;
     const int i = blockIdx.x;
     if (i >= count) return;
     Model m = models[i];
-    lm_dispatch(kind, est_shift, m, pts, dep, n, nullptr, scale_reproj, ws, o, scratch);
-    double c;
-    const double ssr = sqrt(scale_reproj);
-    if (kind == 0) c = lm_cost<0>(m, pts, dep, n, nullptr, ssr, ws, o, scratch);
-    else if (kind == 1) c = lm_cost<1>(m, pts, dep, n, nullptr, ssr, ws, o, scratch);
-    else c = lm_cost<2>(m, pts, dep, n, nullptr, ssr, ws, o, scratch);
+    lm_refine<KIND, SHIFT>(m, pts, dep, n, nullptr, scale_reproj, ws, o, sh);
+    const double c = lm_cost<KIND>(m, pts, dep, n, nullptr, sqrt(scale_reproj), ws, o, sh, 0);
     if (threadIdx.x == 0) { models[i] = m; if (final_cost) final_cost[i] = c; }
 }
 

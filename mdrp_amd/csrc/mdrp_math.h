@@ -643,9 +643,12 @@ constexpr int LM_NPAR = 11; // rot(3) t(3) s u v f1 f2
 // residuals r[0..4] = {sampson, fwd.x, fwd.y, bwd.x, bwd.y} (reprojection ones times sqrt(sr)); zf / zb = depth of
 // the forward / backward transferred point (terms with negative depth are skipped by the callers).
 // WITH_J: Jacobian rows J[5][LM_NPAR] with R <- R exp([w]x), t <- t + dt, s <- s + ds.
-template <bool WITH_J>
-MDRP_HD void point_residuals(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
+template <bool WITH_J, bool FOCAL = true>
+MDRP_HD void point_residuals(const LmState &st_in, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
                              double d2, double r[5], double &zf, double &zb, double J[5][LM_NPAR]) {
+    // calibrated estimator: f1 = f2 = 1 folds away at compile time (F == E, no focal columns)
+    struct View { const double *R, *t, *E, *F; double s, u, v, f1, f2; };
+    const View st = {st_in.R, st_in.t, st_in.E, FOCAL ? st_in.F : st_in.E, st_in.s, st_in.u, st_in.v, FOCAL ? st_in.f1 : 1.0, FOCAL ? st_in.f2 : 1.0};
     const double *R = st.R, *t = st.t, *F = st.F;
     const double Fh1_0 = F[0] * x1x + F[1] * x1y + F[2], Fh1_1 = F[3] * x1x + F[4] * x1y + F[5], Fh1_2 = F[6] * x1x + F[7] * x1y + F[8];
     const double Ft2_0 = F[0] * x2x + F[3] * x2y + F[6], Ft2_1 = F[1] * x2x + F[4] * x2y + F[7];

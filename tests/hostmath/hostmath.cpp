@@ -24,7 +24,7 @@ void hm_point(int focal, const double *model12, double scale_reproj, const doubl
     LmState st;
     lm_state_from_model(m, focal != 0, st);
     double J[5][LM_NPAR];
-    point_residuals<true>(st, sqrt(scale_reproj), x1[0], x1[1], x2[0], x2[1], d1, d2, r7, r7[5], r7[6], J);
+    point_residuals<true, true>(st, sqrt(scale_reproj), x1[0], x1[1], x2[0], x2[1], d1, d2, r7, r7[5], r7[6], J);
     std::memcpy(J55, J, sizeof J);
 }
 void hm_step(int focal, int est_shift, const double *model12, const double *delta11, double *out12) {
