@@ -76,6 +76,9 @@ struct mdrp_handle {
 
 namespace {
 
+#ifndef MDRP_LO_BLOCKS_PER_CU
+#define MDRP_LO_BLOCKS_PER_CU 2
+#endif
 // one LM instantiation per kernel: dispatch (kind, estimate_shift) on the host
 #define MDRP_LM_DISPATCH(KERNEL, kind, shift, grid, block, stream, ...)                                              \
     do {                                                                                                             \
@@ -214,7 +217,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
                            h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0, h->work_pair.as<uint32_t>(),
                            h->work_pos.as<uint32_t>(), h->model_count.as<int32_t>(), reinterpret_cast<unsigned long long *>(cnt + 6));
-        MDRP_LM_DISPATCH(k_lo, kind, est_shift, dim3(h->num_cu * 2), dim3(LM_THREADS), s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+        MDRP_LM_DISPATCH(k_lo, kind, est_shift, dim3(h->num_cu * MDRP_LO_BLOCKS_PER_CU), dim3(LM_THREADS), s, rp, h->st.as<PairState>(), h->pts.as<double>(),
                          h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0,
                          h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1);
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),

@@ -35,7 +35,13 @@ constexpr int TILE_PTS = MDRP_TILE_PTS; // correspondences per LDS tile (48 B ea
 #define MDRP_P1_UNROLL 4
 #endif
 constexpr int PRUNE_EVERY = 4;     // bail-out test every PRUNE_EVERY groups of 32 records (power of two)
-constexpr int CLS_PTS = 64;        // records used to pre-classify hypotheses as dense / sparse
+#ifndef MDRP_CLS_PTS
+#define MDRP_CLS_PTS 32
+#endif
+#ifndef MDRP_SOLVE_MINWAVES
+#define MDRP_SOLVE_MINWAVES 3
+#endif
+constexpr int CLS_PTS = MDRP_CLS_PTS;        // records used to pre-classify hypotheses as dense / sparse
 #ifndef MDRP_SCORE_THREADS
 #define MDRP_SCORE_THREADS 256
 #endif
@@ -270,7 +276,7 @@ __device__ __forceinline__ int candidate_count(const double *__restrict__ recs, 
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
 // with ONE atomic per wave (wave-aggregated prefix sum).
-__global__ __launch_bounds__(256) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+__global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
                                                const double *__restrict__ pts, const double *__restrict__ dep,
                                                Model *__restrict__ models, int32_t *__restrict__ slot_inl,
                                                uint32_t *__restrict__ tags, int32_t *__restrict__ model_count) {
@@ -659,11 +665,11 @@ struct LmOpt {
 // with a ballot, into an LDS list; the accumulate sweep of an accepted step walks that list with every lane busy.
 // Lists are double buffered (current model / candidate).  Each wavefront owns a contiguous segment of the
 // correspondences, so list order — and with it the floating-point summation order — is deterministic.
-constexpr int LM_LIST_CAP = 8192; // correspondences per pair up to which the work list is used (2 x 32 KiB of LDS)
+constexpr int LM_LIST_CAP = 8192; // correspondences per pair up to which the work list is used (2 x 16 KiB of LDS, u16 indices)
 
 struct LmShared {
     double scratch[4 * MAX_ACC];
-    uint32_t list[2][LM_LIST_CAP];
+    uint16_t list[2][LM_LIST_CAP];
     int count[2][4];
 };
 
@@ -694,7 +700,7 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         }
         if (use_list) {
             const unsigned long long ball = __ballot(contrib);
-            if (contrib) sh.list[buf][lo + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = (uint32_t)i;
+            if (contrib) sh.list[buf][lo + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = (uint16_t)i;
             cnt += __popcll(ball);
         }
     }
@@ -848,8 +854,11 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 // ------------------------------------------------------------------------------------------------ LO
 // Persistent workgroups pop (pair, trigger) items; each refines the triggering minimal model (refine_model
 // @0x4fa550/@0x4fad60/@0x4fb0a0: 25 it, TRUNCATED) and rescoring it.
+#ifndef MDRP_LM_MINWAVES
+#define MDRP_LM_MINWAVES 2
+#endif
 template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(LM_THREADS) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+__global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
                                                    Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ work_count,
                                                    const uint32_t *__restrict__ work_pair, const uint32_t *__restrict__ work_pos,
@@ -960,7 +969,7 @@ struct ResultDev {
 };
 
 template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(LM_THREADS) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
+__global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
                                                       ResultDev *__restrict__ results) {
     __shared__ LmShared sh;

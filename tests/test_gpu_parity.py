@@ -218,6 +218,30 @@ def test_poselib_signatures(po):
     assert len(sols) == 1 and abs(sols[0].camera1.focal() * 500 - p["f1"]) < 1e-6 * p["f1"]
 
 
+def test_full_size_noisy_vs_oracle(handle, capi, po):
+    """BASELINE configs[1] shape — N = 2000, 10k iterations, 50 % outliers, noisy — on 6 pairs against the CPU oracle.
+    At this size the driver runs three chunks with bail-out scoring; the trajectory must still be the sequential one:
+    same iterations / LO count / inliers / mask, model within 1e-6 (rounding-level ties may move at most one pair)."""
+    from mdrp_amd import synth
+    B = 6
+    b = synth.make_batch(500, B, 2000, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ro = {"max_iterations": 10000, "min_iterations": 10000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0}
+    res, mask = handle.estimate_batch(capi.CALIB, b["x1"], b["x2"], b["d1"], b["d2"], capi.ransac_opt_from_dict(ro),
+                                      capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None, cams, cams)
+    same = 0
+    for i in range(B):
+        m, st, mk = po.estimate(po.CALIB, b["x1"][i], b["x2"][i], b["d1"][i], b["d2"][i],
+                                po.ransac_opt(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0, max_reproj_error=16.0),
+                                po.bundle_opt(loss_type=4), po.cam_flat(0, [800.0, 0, 0]), po.cam_flat(0, [800.0, 0, 0]))
+        assert int(res[i]["iterations"]) == st.iterations == 10000
+        assert abs(int(res[i]["num_inliers"]) - st.num_inliers) <= 0.01 * st.num_inliers
+        ok = (int(res[i]["num_inliers"]) == st.num_inliers and int(res[i]["refinements"]) == st.refinements and (mask[i] == mk).all()
+              and model_diff(capi.model_to_array(res[i]["model"]), m) < 1e-6)
+        same += ok
+    assert same >= B - 1, same
+
+
 def test_full_size_properties(handle, capi):
     """BASELINE config 2 shape (N=2000, 10k iterations) on a few pairs: size-independent properties —
     noise-free pairs recover ground truth to 1e-6; every true inlier is flagged; duplicating a pair gives
