@@ -183,6 +183,19 @@ def test_batch_ragged_and_degenerate(handle, capi, po):
         assert (mask[i, :n] == mk).all() and mask[i, n:].sum() == 0
 
 
+def test_all_degenerate_and_empty_batches(handle, capi):
+    """ransac<> early-out (@0x22f087): fewer than 3 correspondences -> zeroed stats, model_score = DBL_MAX, identity model"""
+    ro, bo = capi.ransac_opt_from_dict({}), capi.bundle_opt_from_dict({})
+    x = np.zeros((3, 2, 2)); d = np.ones((3, 2))
+    res, mask = handle.estimate_batch(capi.VARYING_FOCAL, x, x, d, d, ro, bo, np.array([0, 1, 2], np.int32))
+    assert (res["iterations"] == 0).all() and (res["num_inliers"] == 0).all() and (res["model_score"] > 1e300).all()
+    assert np.allclose(res["model"]["q"], [[1, 0, 0, 0]] * 3) and (res["model"]["scale"] == 1).all() and mask.sum() == 0
+    res, mask = handle.estimate_batch(capi.SHARED_FOCAL, np.zeros((2, 0, 2)), np.zeros((2, 0, 2)), np.zeros((2, 0)), np.zeros((2, 0)), ro, bo)
+    assert len(res) == 2 and (res["iterations"] == 0).all()
+    res, mask = handle.estimate_batch(capi.SHARED_FOCAL, np.zeros((0, 5, 2)), np.zeros((0, 5, 2)), np.zeros((0, 5)), np.zeros((0, 5)), ro, bo)
+    assert len(res) == 0
+
+
 def test_dynamic_stopping_chunks(handle, capi, po):
     """default options (max 100000 / min 1000): the chunked driver must stop at the reference's iteration"""
     from mdrp_amd import synth
