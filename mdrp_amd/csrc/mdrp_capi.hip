@@ -62,7 +62,7 @@ struct mdrp_handle {
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
-    DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, work_pos, counters, results, mask;
+    DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, work_pos, counters, results, mask, plan;
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -76,17 +76,29 @@ struct mdrp_handle {
 
 namespace {
 
-#ifndef MDRP_LO_BLOCKS_PER_CU
-#define MDRP_LO_BLOCKS_PER_CU 2
-#endif
 // one LM instantiation per kernel: dispatch (kind, estimate_shift) on the host
-#define MDRP_LM_DISPATCH(KERNEL, kind, shift, grid, block, stream, ...)                                              \
+#define MDRP_LM_DISPATCH_T(KERNEL, T, kind, shift, grid, smem, stream, ...)                                          \
     do {                                                                                                             \
-        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true>), grid, block, 0, stream, __VA_ARGS__);      \
-        else if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0, false>), grid, block, 0, stream, __VA_ARGS__);           \
-        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false>), grid, block, 0, stream, __VA_ARGS__);           \
-        else hipLaunchKernelGGL((KERNEL<2, false>), grid, block, 0, stream, __VA_ARGS__);                            \
+        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true, T>), grid, dim3(T), smem, stream, __VA_ARGS__);  \
+        else if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
+        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((KERNEL<2, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);                        \
     } while (0)
+// threads per LM problem: one wavefront (64) when problems outnumber SIMDs, a 256-thread workgroup otherwise
+#define MDRP_LM_DISPATCH(KERNEL, threads, kind, shift, grid, smem, stream, ...)                                      \
+    do {                                                                                                             \
+        if ((threads) == 64) MDRP_LM_DISPATCH_T(KERNEL, 64, kind, shift, grid, smem, stream, __VA_ARGS__);           \
+        else MDRP_LM_DISPATCH_T(KERNEL, 256, kind, shift, grid, smem, stream, __VA_ARGS__);                          \
+    } while (0)
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// LDS work lists: 2 buffers of u16 indices, stride = n_max rounded to 64 (0 disables the lists)
+int lm_list_stride(int n_max) { return n_max <= LM_LIST_MAX_N ? ((n_max + 63) / 64) * 64 : 0; }
+size_t lm_list_bytes(int n_max) { return (size_t)2 * lm_list_stride(n_max) * sizeof(uint16_t); }
 
 int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -147,7 +159,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
     if ((rc = h->work_pair.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
     if ((rc = h->work_pos.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
-    if ((rc = h->counters.ensure(64))) return rc; // [0] work_count, [1] work_head, [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64)
+    if ((rc = h->counters.ensure(64))) return rc;
+    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4)))) return rc; // two prefix arrays + {dense, total, head} // [0] work_count, [1] work_head, [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64)
 
     HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
@@ -175,6 +188,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                        ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>());
     HIPCHK(hipGetLastError());
 
+    // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
+    const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
+    const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
+    const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
     int64_t sum_n = 0;
@@ -184,9 +201,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     uint64_t it0 = 0;
     // iterations that certainly run: the reference cannot stop before min_iterations + 1 (or max_iterations)
     const uint64_t certain = ro->max_iterations == 0 ? 1 : std::min<uint64_t>(ro->max_iterations, ro->min_iterations + 1);
-    // chunk schedule: a short first chunk establishes the records that let k_score bail out of hopeless hypotheses in
-    // the following, 4x larger ones (exact, see Prune in mdrp_kernels.h); later chunks follow dynamic_max_iter
-    uint64_t next_len = certain >= 2048 ? 512 : certain;
+    // chunk schedule: a short first chunk (512 iterations) establishes the records that let k_score bail out of hopeless
+    // hypotheses in the rest (exact, see Prune in mdrp_kernels.h); more, smaller chunks prune a little more but pay a
+    // launch train + LO tail each (measured: 2 chunks 27.6 ms/step, 3 chunks 29.1); later chunks follow dynamic_max_iter
+    const uint64_t first_chunk = (uint64_t)env_int("MDRP_FIRST_CHUNK", 512), growth = (uint64_t)env_int("MDRP_CHUNK_GROWTH", 32);
+    uint64_t next_len = certain >= 4 * first_chunk ? first_chunk : certain;
     uint64_t last_len = 0;
     while (true) {
         const int len = (int)std::min<uint64_t>(next_len, (uint64_t)chunk_cap);
@@ -202,24 +221,27 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             hipEvent_t e0, e1;
             if ((rc = get_events(h, &e0, &e1))) return rc;
             HIPCHK(hipEventRecord(e0, s));
-            const dim3 grid((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS, batch);
+            int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, h->model_count.as<int32_t>(), plan, totals);
+            const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
+                                                    : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
             if (kind == MDRP_CALIB)
                 hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
                                    h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
-                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
             else
                 hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
                                    h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
-                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
             HIPCHK(hipEventRecord(e1, s));
             h->sweep_launches++;
         }
         hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
                            h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0, h->work_pair.as<uint32_t>(),
                            h->work_pos.as<uint32_t>(), h->model_count.as<int32_t>(), reinterpret_cast<unsigned long long *>(cnt + 6));
-        MDRP_LM_DISPATCH(k_lo, kind, est_shift, dim3(h->num_cu * MDRP_LO_BLOCKS_PER_CU), dim3(LM_THREADS), s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                         h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0,
-                         h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1);
+        MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(h->num_cu * (lo_threads == 64 ? 8 : 2)), lm_list_bytes(n_max), s, rp,
+                         h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
+                         trig_cap, cnt + 0, h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1, lm_list_stride(n_max));
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                            h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
         HIPCHK(hipGetLastError());
@@ -240,13 +262,13 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         it0 += (uint64_t)len;
         if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
         last_len = (uint64_t)len;
-        if (it0 < certain) next_len = std::min<uint64_t>(certain - it0, last_len * 4);
+        if (it0 < certain) next_len = std::min<uint64_t>(certain - it0, last_len * growth);
         else next_len = std::max<uint64_t>(h->progress_host->max_needed, 256);
         next_len = std::min<uint64_t>(next_len, ro->max_iterations - it0);
     }
 
-    MDRP_LM_DISPATCH(k_final, kind, est_shift, dim3(batch), dim3(LM_THREADS), s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                     h->dep.as<double>(), mask_dev, results_dev);
+    MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
+                     h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max));
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -340,7 +362,7 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->work_pos, &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
-                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f};
+                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -470,17 +492,20 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk;
     const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
-    const dim3 grid((num_models + SCORE_THREADS - 1) / SCORE_THREADS, 1);
+    if ((rc = h->plan.ensure(sizeof(int32_t) * 8))) return rc;
+    int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 4;
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, 1, h->model_count.as<int32_t>(), plan, totals);
+    const dim3 grid((unsigned)std::min(h->num_cu * 4, (num_models + SCORE_THREADS - 1) / SCORE_THREADS));
     h->ev_used = 0; h->sweep_launches = 1; h->sweep_evals = (int64_t)num_models * n;
     hipEvent_t e0, e1;
     if ((rc = get_events(h, &e0, &e1))) return rc;
     HIPCHK(hipEventRecord(e0, s));
     if (kind == MDRP_CALIB)
         hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     else
         hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>());
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipGetLastError());
     const hipMemcpyKind back = mem_space == MDRP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -514,9 +539,9 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
     o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
-    MDRP_LM_DISPATCH(k_refine_unit, kind, (kind == MDRP_CALIB && estimate_shift), dim3(count), dim3(LM_THREADS), s, count,
-                     h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
-                     h->unit_a.as<double>());
+    MDRP_LM_DISPATCH(k_refine_unit, (count >= 2048 ? 64 : 256), kind, (kind == MDRP_CALIB && estimate_shift), dim3(count), lm_list_bytes(n), s,
+                     count, h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
+                     h->unit_a.as<double>(), lm_list_stride(n));
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(models, h->unit_e.p, sizeof(Model) * count, hipMemcpyDeviceToHost, s));
     if (final_cost) HIPCHK(hipMemcpyAsync(final_cost, h->unit_a.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));

@@ -112,6 +112,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 template <int NV, int NTHREADS>
 __device__ __forceinline__ void block_sum(double *vals, double *scratch) {
     constexpr int NW = NTHREADS / 64;
+    if (NW == 1) { // single wavefront: butterfly only, no LDS, no barrier
+#pragma unroll
+        for (int i = 0; i < NV; ++i) vals[i] = wave_sum(vals[i]);
+        return;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -477,39 +482,78 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
     }
 }
 
+// Work plan of one sweep launch: the workgroups a pair needs (ceil(count / SCORE_THREADS) per density class).
+// One wavefront, 64 pairs per step.  plan[0..B] = prefix sum of blocks per pair, plan[B+1 .. 2B] = sparse blocks of the pair.
+__global__ __launch_bounds__(64) void k_plan(int batch, const int32_t *__restrict__ model_count, int32_t *__restrict__ plan,
+                                             int32_t *__restrict__ totals /*[0] dense, [1] dense + sparse, [2] queue head*/) {
+    const int lane = threadIdx.x;
+    int run_d = 0, run_s = 0;
+    int32_t *pd = plan, *psp = plan + batch + 1;
+    for (int p0 = 0; p0 < batch; p0 += 64) {
+        const int p = p0 + lane;
+        int bd = 0, bs = 0;
+        if (p < batch) {
+            bs = (model_count[2 * p] + SCORE_THREADS - 1) / SCORE_THREADS;
+            bd = (model_count[2 * p + 1] + SCORE_THREADS - 1) / SCORE_THREADS;
+        }
+        int id = bd, is = bs;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int vd = __shfl_up(id, o, 64), vs = __shfl_up(is, o, 64);
+            if (lane >= o) { id += vd; is += vs; }
+        }
+        // pair-major order: a pair's sparse blocks then its dense blocks, pairs consecutive (dense workgroups, whose
+        // phase 2 reads LDS at per-lane addresses, stay spread out in time instead of saturating every CU's LDS at once)
+        if (p < batch) { pd[p] = run_d + run_s + id + is - bd - bs; psp[p] = bs; }
+        run_d += __shfl(id, 63, 64);
+        run_s += __shfl(is, 63, 64);
+    }
+    if (lane == 0) { pd[batch] = run_d + run_s; psp[batch] = 0; totals[0] = run_d; totals[1] = run_d + run_s; totals[2] = 0; }
+}
+
+// largest p with prefix[p] <= w   (prefix non-decreasing, prefix[0] = 0, w < prefix[batch])
+__device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int batch, int w) {
+    int lo = 0, hi = batch;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= w) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Workgroup w handles item w of the plan (grid = an upper bound, surplus workgroups at the END exit at once).  A static
+// blockIdx -> (pair, block) map with per-pair padding put the live blocks of every pair on the same few XCDs whenever
+// blocks-per-pair shared a factor with 8 (workgroups are dealt round-robin over the 8 XCDs by linear id): a
+// 2048-iteration chunk took as long as a 7440-iteration one.  With the compacted plan consecutive workgroups are
+// consecutive live items, so every XCD gets the same mix.  (A persistent variant pulling items from an atomic queue
+// was 3x slower; a persistent static-stride loop 25 % slower from imbalance.)
 template <bool POSE>
 __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags,
                                                          const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
-                                                         int32_t *__restrict__ slot_inl) {
+                                                         int32_t *__restrict__ slot_inl, const int32_t *__restrict__ plan,
+                                                         int32_t *__restrict__ totals) {
     extern __shared__ double tile[]; // TILE_PTS * PT_STRIDE doubles
-    const int pair = blockIdx.y;
-    // tag list of the pair: sparse hypotheses grow from the front, dense ones from the back (k_solve)
+    const int total = totals[1];
+    const int tid = threadIdx.x;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+    const int pair = plan_find(plan, rp.batch, w);
+    const int blk_sparse = plan[rp.batch + 1 + pair];
+    const int bi = w - plan[pair];
+    const bool dense = bi >= blk_sparse;
+    const int blk = dense ? bi - blk_sparse : bi;
     const int cnt_sparse = model_count[2 * pair], cnt_dense = model_count[2 * pair + 1];
-    const int blk_sparse = (cnt_sparse + SCORE_THREADS - 1) / SCORE_THREADS;
-    const int blk_dense = (cnt_dense + SCORE_THREADS - 1) / SCORE_THREADS;
-    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs by linear id (pair * gridDim.x + blockIdx.x).
-    // Only the first blk_sparse + blk_dense logical blocks of a pair carry work; when gridDim.x is a multiple of 8 they
-    // would all land on the same few XCDs for EVERY pair (measured: a 2048-iteration chunk took as long as a
-    // 7440-iteration one).  Rotating the logical index by the pair number spreads them evenly.
-    const int blk = (int)((blockIdx.x + 5u * (unsigned)pair) % gridDim.x);
-    if (blk >= blk_sparse + blk_dense) return;
     const PairState &ps = st[pair];
     const int n = ps.n;
     const double thr = ps.sq_thr;
-    const int tid = threadIdx.x;
     const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
     const int cap = rp.chunk_len * 4;
     bool live;
     uint32_t slot = 0;
-    if (blk < blk_sparse) {
+    { // tag list of the pair: sparse hypotheses grow from the front, dense ones from the back (k_solve)
         const int i = blk * SCORE_THREADS + tid;
-        live = i < cnt_sparse;
-        if (live) slot = tags[slot_base + i];
-    } else {
-        const int i = (blk - blk_sparse) * SCORE_THREADS + tid;
-        live = i < cnt_dense;
-        if (live) slot = tags[slot_base + (cap - 1 - i)];
+        live = i < (dense ? cnt_dense : cnt_sparse);
+        if (live) slot = tags[slot_base + (dense ? cap - 1 - i : i)];
     }
     double E[9];
 #pragma unroll
@@ -555,6 +599,7 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
         slot_score[slot_base + slot] = pruned ? DBL_MAX : score + thr * (double)(n - cnt);
         slot_inl[slot_base + slot] = pruned ? -2 : cnt;
     }
+    } // item loop
 }
 
 // ------------------------------------------------------------------------------------------------ scan
@@ -665,22 +710,28 @@ struct LmOpt {
 // with a ballot, into an LDS list; the accumulate sweep of an accepted step walks that list with every lane busy.
 // Lists are double buffered (current model / candidate).  Each wavefront owns a contiguous segment of the
 // correspondences, so list order — and with it the floating-point summation order — is deterministic.
-constexpr int LM_LIST_CAP = 8192; // correspondences per pair up to which the work list is used (2 x 16 KiB of LDS, u16 indices)
+// The lists live in dynamic LDS sized by the host: 2 buffers x stride u16 indices (stride = n_max rounded up to 64;
+// 0 = no lists, every correspondence is visited).  T = threads per LM problem: 256 (one workgroup of 4 wavefronts, for
+// latency when few problems are in flight) or 64 (one wavefront per problem: no barriers, the serial Cholesky/step part
+// is paid once instead of four times — for throughput when problems outnumber SIMDs).
+constexpr int LM_LIST_MAX_N = 8192; // u16 indices, <= 32 KiB of dynamic LDS (no opt-in needed)
 
 struct LmShared {
     double scratch[4 * MAX_ACC];
-    uint16_t list[2][LM_LIST_CAP];
     int count[2][4];
+    uint16_t *list;  // dynamic LDS, 2 * stride entries
+    int stride;
 };
 
-template <int KIND>
+template <int KIND, int T>
 __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                           const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, LmShared &sh, int buf) {
     LmState stt;
     lm_state_from_model(m, KIND != 0, stt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool use_list = n <= LM_LIST_CAP;
-    const int seg = ((n + 255) / 256) * 64; // correspondences per wavefront, multiple of 64
+    const bool use_list = sh.stride > 0;
+    uint16_t *list = sh.list + (size_t)buf * sh.stride;
+    const int seg = ((n + T - 1) / T) * 64; // correspondences per wavefront, multiple of 64
     const int lo = wave * seg, hi = min(n, lo + seg);
     double cost = 0;
     int cnt = 0;
@@ -700,13 +751,13 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         }
         if (use_list) {
             const unsigned long long ball = __ballot(contrib);
-            if (contrib) sh.list[buf][lo + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            if (contrib) list[lo + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = (uint16_t)i;
             cnt += __popcll(ball);
         }
     }
     if (use_list && lane == 0) sh.count[buf][wave] = cnt;
     double v[1] = {cost};
-    block_sum<1, LM_THREADS>(v, sh.scratch);
+    block_sum<1, T>(v, sh.scratch);
     return v[0];
 }
 
@@ -742,7 +793,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, const do
     }
 }
 
-template <int KIND, bool SHIFT>
+template <int KIND, bool SHIFT, int T>
 __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                               const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, LmShared &sh, int buf) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
@@ -752,36 +803,37 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int seg = ((n + 255) / 256) * 64;
+    const int seg = ((n + T - 1) / T) * 64;
     const int lo = wave * seg;
-    if (n <= LM_LIST_CAP) {
+    if (sh.stride > 0) {
+        const uint16_t *list = sh.list + (size_t)buf * sh.stride;
         const int cnt = sh.count[buf][wave];
-        for (int k = lane; k < cnt; k += 64) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, (int)sh.list[buf][lo + k], sqrt_sr, ws, o, acc);
+        for (int k = lane; k < cnt; k += 64) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, (int)list[lo + k], sqrt_sr, ws, o, acc);
     } else {
         const int hi = min(n, lo + seg);
         for (int i = lo + lane; i < hi; i += 64)
             if (!mask || mask[i]) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, i, sqrt_sr, ws, o, acc);
     }
-    block_sum<NA, LM_THREADS>(acc, sh.scratch);
+    block_sum<NA, T>(acc, sh.scratch);
 }
 
 // lm_impl<> loop of the reference (upstream PoseLib convention): executed redundantly and uniformly by every
 // thread of the workgroup; only the two sweeps over the correspondences are distributed.
-template <int KIND, bool SHIFT>
+template <int KIND, bool SHIFT, int T>
 __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                           const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o, LmShared &sh) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NT = NP * (NP + 1) / 2;
     const double sqrt_sr = sqrt(scale_reproj);
     int cur = 0; // list buffer that belongs to the current model
-    double cost = lm_cost<KIND>(m, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur);
+    double cost = lm_cost<KIND, T>(m, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur);
     double lambda = o.lambda0;
     bool recompute = true;
     double acc[NT + NP];
     double A[NP * NP], g[NP], sol[NP];
     for (int it = 0; it < o.max_it; ++it) {
         if (recompute) {
-            lm_accumulate<KIND, SHIFT>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
+            lm_accumulate<KIND, SHIFT, T>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
             double gn = 0;
             int idx = 0;
 #pragma unroll
@@ -811,7 +863,7 @@ __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double
         if (KIND == 1) full[10] = full[9];
         Model cand;
         lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
-        const double cost_new = lm_cost<KIND>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur ^ 1);
+        const double cost_new = lm_cost<KIND, T>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur ^ 1);
         if (cost_new < cost) {
             m = cand;
             cur ^= 1;
@@ -826,6 +878,7 @@ __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double
 }
 
 // workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask output
+template <int T>
 __device__ void block_score(int kind, const Model &m, const double *__restrict__ pts, int n, double thr, double *scratch,
                             double &score_out, int &cnt_out, uint8_t *__restrict__ mask_out) {
     double R[9], E[9], Em[9];
@@ -837,7 +890,7 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
     } else fundamental_from_E(Em, m.f1, m.f2, E);
     double score = 0;
     int cnt = 0;
-    for (int i = threadIdx.x; i < n; i += LM_THREADS) {
+    for (int i = threadIdx.x; i < n; i += T) {
         double s1 = 0;
         int c1 = 0;
         if (kind == 0) score_point<true>(pts + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
@@ -846,7 +899,7 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
         if (mask_out) mask_out[i] = (uint8_t)c1;
     }
     double v[2] = {score, (double)cnt};
-    block_sum<2, LM_THREADS>(v, scratch);
+    block_sum<2, T>(v, scratch);
     cnt_out = (int)v[1];
     score_out = v[0] + thr * (double)(n - cnt_out);
 }
@@ -857,14 +910,17 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 #ifndef MDRP_LM_MINWAVES
 #define MDRP_LM_MINWAVES 2
 #endif
-template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+template <int KIND, bool SHIFT, int T>
+__global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
                                                    Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ work_count,
                                                    const uint32_t *__restrict__ work_pair, const uint32_t *__restrict__ work_pos,
-                                                   int32_t *__restrict__ work_head) {
+                                                   int32_t *__restrict__ work_head, int list_stride) {
+    extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
+    __syncthreads();
     const int total = *work_count;
     for (;;) {
         __syncthreads();
@@ -883,10 +939,10 @@ __global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_lo(RunParams r
         o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
         const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
         const double *dd = dep + (size_t)pair * rp.n_max * 2;
-        lm_refine<KIND, SHIFT>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
+        lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
         double sc;
         int cn;
-        block_score(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
+        block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
         if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
     }
 }
@@ -968,11 +1024,14 @@ struct ResultDev {
     double inlier_ratio, model_score;
 };
 
-template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
+template <int KIND, bool SHIFT, int T>
+__global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
-                                                      ResultDev *__restrict__ results) {
+                                                      ResultDev *__restrict__ results, int list_stride) {
+    extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
+    __syncthreads();
     double *scratch = sh.scratch;
     const int pair = blockIdx.x;
     PairState &ps = st[pair];
@@ -982,7 +1041,7 @@ __global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_final(RunParam
     res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
     uint8_t *mask = mask_all + (size_t)pair * rp.n_max;
     if (ps.n < 3) {
-        for (int i = threadIdx.x; i < rp.n_max; i += LM_THREADS) mask[i] = 0;
+        for (int i = threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
         if (threadIdx.x == 0) results[pair] = res;
         return;
     }
@@ -992,21 +1051,21 @@ __global__ __launch_bounds__(LM_THREADS, MDRP_LM_MINWAVES) void k_final(RunParam
     LmOpt o;
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
     o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-    lm_refine<KIND, SHIFT>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
+    lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
     res.refinements++;
     double sc;
     int cn;
-    block_score(KIND, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+    block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
     Model best = ps.best;
     if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
-    for (int i = ps.n + threadIdx.x; i < rp.n_max; i += LM_THREADS) mask[i] = 0;
-    block_score(KIND, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
+    for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
+    block_score<T>(KIND, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
     __syncthreads();
     if (res.num_inliers > 3) {
         LmOpt f;
         f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
         f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
-        lm_refine<KIND, SHIFT>(best, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, f, sh);
+        lm_refine<KIND, SHIFT, T>(best, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, f, sh);
     }
     if (KIND != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
     res.model = best;
@@ -1045,16 +1104,19 @@ __global__ void k_pack_unit(int n, const double *__restrict__ x1, const double *
     if (dep) { dep[2 * i] = d1 ? d1[i] : 0.0; dep[2 * i + 1] = d2 ? d2[i] : 0.0; }
 }
 
-template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(LM_THREADS) void k_refine_unit(int count, Model *__restrict__ models,
+template <int KIND, bool SHIFT, int T>
+__global__ __launch_bounds__(T) void k_refine_unit(int count, Model *__restrict__ models,
                                                             const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                                                            double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost) {
+                                                            double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost, int list_stride) {
+    extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
+    __syncthreads();
     const int i = blockIdx.x;
     if (i >= count) return;
     Model m = models[i];
-    lm_refine<KIND, SHIFT>(m, pts, dep, n, nullptr, scale_reproj, ws, o, sh);
-    const double c = lm_cost<KIND>(m, pts, dep, n, nullptr, sqrt(scale_reproj), ws, o, sh, 0);
+    lm_refine<KIND, SHIFT, T>(m, pts, dep, n, nullptr, scale_reproj, ws, o, sh);
+    const double c = lm_cost<KIND, T>(m, pts, dep, n, nullptr, sqrt(scale_reproj), ws, o, sh, 0);
     if (threadIdx.x == 0) { models[i] = m; if (final_cost) final_cost[i] = c; }
 }
 
