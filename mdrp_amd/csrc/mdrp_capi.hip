@@ -488,6 +488,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, x1d, x2d, (const double *)nullptr,
                        (const double *)nullptr, h->pts.as<double>(), (double *)nullptr);
+    hipLaunchKernelGGL(k_box_unit, dim3(1), dim3(256), 0, s, n, h->pts.as<double>(), h->st.as<PairState>());
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk;

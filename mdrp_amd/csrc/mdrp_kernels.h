@@ -61,6 +61,7 @@ struct PairState {
     double lo_loss_scale;   // loss_scale of the LO refinement (eps; 1.0 for varying focal — reference quirk)
     double final_loss_scale; // user bundle loss_scale, normalised
     double norm;        // un-normalisation factor of the focals (1 for calibrated)
+    double box[4];      // max |x1.x|, |x1.y|, |x2.x|, |x2.y| of the normalised correspondences (k_score's denominator bound)
     uint64_t best_min_cnt;
     double best_min_score;
     uint64_t dyn_max_iter;
@@ -169,10 +170,12 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
         norm = (red[0] + red[1] + red[2] + red[3]) / (1.4142135623730951 * (double)(n > 0 ? n : 1));
         k = 1.0 / norm;
     }
+    double bx[4] = {0, 0, 0, 0};
     for (int i = tid; i < n; i += 256) {
         double a = x1[2 * (base + i)], b = x1[2 * (base + i) + 1], c = x2[2 * (base + i)], d = x2[2 * (base + i) + 1];
         if (rp.kind == 0) { a = (a - cx1) / fx1; b = (b - cy1) / fy1; c = (c - cx2) / fx2; d = (d - cy2) / fy2; }
         else { a /= norm; b /= norm; c /= norm; d /= norm; }
+        bx[0] = fmax(bx[0], fabs(a)); bx[1] = fmax(bx[1], fabs(b)); bx[2] = fmax(bx[2], fabs(c)); bx[3] = fmax(bx[3], fabs(d));
         double *p = pts + (base + i) * PT_STRIDE;
         p[0] = a; p[1] = b; p[2] = c; p[3] = d;
         p[4] = 1.0 / sqrt(a * a + b * b + 1.0);
@@ -180,8 +183,19 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
         dep[2 * (base + i)] = d1[base + i];
         dep[2 * (base + i) + 1] = d2[base + i];
     }
+    __shared__ double redbox[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = bx[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        if ((tid & 63) == 0) redbox[tid >> 6][q] = v;
+    }
+    __syncthreads();
     if (tid == 0) {
         PairState s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.box[q] = fmax(fmax(redbox[0][q], redbox[1][q]), fmax(redbox[2][q], redbox[3][q]));
         s.n = n >= 3 ? n : 0;
         s.table = table_of_pair[pair];
         s.active = n >= 3;
@@ -384,6 +398,7 @@ __device__ __forceinline__ void score_point(const double *__restrict__ rec, cons
     const double2 p01 = P[0], p23 = P[1];
     const double a = p01.x, b = p01.y, c = p23.x, d = p23.y;
     const SampsonTerms s = sampson_terms(E, a, b, c, d);
+    if (!(s.C2 < thr * (1.0 + 1e-12) * s.den)) return; // not even a candidate (phase 1 may hand over a superset)
     const double r2 = s.C2 / s.den;
     if (r2 < thr) {
         bool ok = true;
@@ -425,9 +440,83 @@ struct Prune {
     bool wave_dead;
 };
 
+// Dense hypotheses (all 64 lanes close to the true model): their candidate sets nearly coincide (the true inliers), so
+// the plain per-record branch is coherent across the wavefront and the Sampson terms need not be recomputed in a second
+// phase: one pass, records as wave-wide broadcasts, inlier work under a branch most lanes take together.
 template <bool POSE>
+__device__ __forceinline__ void score_tile_dense(const double *__restrict__ recs, int npts, const double E[9], const Model *__restrict__ mp,
+                                                 double thr, double &score, int &cnt, Prune &pr) {
+    const double thr_hi = thr * (1.0 + 1e-12);
+    double R[9], t[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = 0;
+    if (POSE) {
+        double q[4];
+        q[0] = mp->q[0]; q[1] = mp->q[1]; q[2] = mp->q[2]; q[3] = mp->q[3];
+        t[0] = mp->t[0]; t[1] = mp->t[1]; t[2] = mp->t[2];
+        quat_to_R(q, R);
+    }
+    for (int p0 = 0; p0 < npts; p0 += 32 * PRUNE_EVERY) {
+        const int g = min(32 * PRUNE_EVERY, npts - p0);
+        if (!pr.dead) {
+#pragma unroll 2
+            for (int j = 0; j < g; ++j) {
+                const double2 *P = reinterpret_cast<const double2 *>(recs + (size_t)(p0 + j) * PT_STRIDE);
+                const double2 p01 = P[0], p23 = P[1];
+                const double a = p01.x, b = p01.y, c = p23.x, d = p23.y;
+                const SampsonTerms s = sampson_terms(E, a, b, c, d);
+                if (s.C2 < thr_hi * s.den) {
+                    const double r2 = s.C2 / s.den;
+                    if (r2 < thr) {
+                        bool ok = true;
+                        if (POSE) {
+                            const double2 p45 = P[2];
+                            const double u0 = fma(R[0], a, fma(R[1], b, R[2]));
+                            const double u1 = fma(R[3], a, fma(R[4], b, R[5]));
+                            const double u2 = fma(R[6], a, fma(R[7], b, R[8]));
+                            const double uh = fma(u0, c, fma(u1, d, u2));
+                            const double ut = fma(u0, t[0], fma(u1, t[1], u2 * t[2]));
+                            const double ht = fma(c, t[0], fma(d, t[1], t[2]));
+                            const double A = -uh * p45.x * p45.y;
+                            const double b1 = -ut * p45.x, b2 = ht * p45.y;
+                            const double l1 = fma(-A, b2, b1), l2 = fma(-A, b1, b2);
+                            const double md = 0.01 * fma(-A, A, 1.0);
+                            ok = (l1 > md) && (l2 > md);
+                        }
+                        if (ok) { score += r2; ++cnt; }
+                    }
+                }
+            }
+        }
+        pr.processed += g;
+#ifndef MDRP_NO_PRUNE
+        if (pr.rec_score < DBL_MAX) {
+            pr.dead = pr.dead || (((long long)cnt + (long long)(pr.n - pr.processed) <= pr.rec_cnt) &&
+                                  (score + thr * (double)(pr.processed - cnt) >= pr.rec_score));
+            if (__all(pr.dead)) { pr.wave_dead = true; return; }
+        }
+#endif
+    }
+}
+
+// numerator C = x2' E x1 only (8 FMA); true when C^2 < thr * Dmax, i.e. the record MAY be an inlier.  12 ops instead of 22.
+// (Keeping the exact (E x1) half of the denominator and bounding only the (E' x2) half measured slower: +3 ops per
+// evaluation cost more than the fewer false candidates saved.)
+__device__ __forceinline__ bool sampson_maybe(const double E[9], double a, double b, double c, double d, double thr_hi, double dmax) {
+    const double e0 = fma(E[0], a, fma3(E[1], b, E[2]));
+    const double e1 = fma(E[3], a, fma3(E[4], b, E[5]));
+    const double e2 = fma(E[6], a, fma3(E[7], b, E[8]));
+    const double C = fma(c, e0, fma(d, e1, e2));
+    return C * C < thr_hi * dmax;
+}
+
+// BOUND (sparse hypotheses): phase 1 compares the numerator against thr * Dmax, where Dmax >= den for every record of
+// the pair (per-hypothesis bound over the pair's coordinate box).  C^2 >= thr * Dmax >= thr * den proves an outlier
+// with 12 instead of 22 ops; the few records that survive (a superset of the true candidates, ~1 %) get the exact test
+// in phase 2.  Dense hypotheses keep the exact denominator in phase 1 (the bound would send most records to phase 2).
+template <bool POSE, bool BOUND>
 __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int npts, const double E[9], const Model *__restrict__ mp,
-                                           double thr, double &score, int &cnt, Prune &pr) {
+                                           double thr, double thr_dmax, double &score, int &cnt, Prune &pr) {
     const double thr_hi = thr * (1.0 + 1e-12);
     for (int p0 = 0; p0 < npts; p0 += 32) {
         const int g = min(32, npts - p0);
@@ -441,16 +530,24 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
                     const int j = j0 + jj;
                     const double2 *P = reinterpret_cast<const double2 *>(base + j * PT_STRIDE);
                     const double2 p01 = P[0], p23 = P[1];
-                    const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
-                    mask |= (s.C2 < thr_hi * s.den) ? (1u << j) : 0u;
+                    if (BOUND) {
+                        mask |= sampson_maybe(E, p01.x, p01.y, p23.x, p23.y, thr_hi, thr_dmax) ? (1u << j) : 0u;
+                    } else {
+                        const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
+                        mask |= (s.C2 < thr_hi * s.den) ? (1u << j) : 0u;
+                    }
                 }
             }
         } else {
             for (int j = 0; j < g; ++j) {
                 const double2 *P = reinterpret_cast<const double2 *>(base + j * PT_STRIDE);
                 const double2 p01 = P[0], p23 = P[1];
-                const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
-                mask |= (s.C2 < thr_hi * s.den) ? (1u << j) : 0u;
+                if (BOUND) {
+                    mask |= sampson_maybe(E, p01.x, p01.y, p23.x, p23.y, thr_hi, thr_dmax) ? (1u << j) : 0u;
+                } else {
+                    const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
+                    mask |= (s.C2 < thr_hi * s.den) ? (1u << j) : 0u;
+                }
             }
         }
 #ifdef MDRP_NO_PHASE2
@@ -571,6 +668,14 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
             fundamental_from_E(Em, m.f1, m.f2, E);
         }
     }
+    // Dmax: upper bound of the Sampson denominator over the pair's coordinate box
+    double thr_dmax;
+    {
+        const double ax = ps.box[0], ay = ps.box[1], cx = ps.box[2], cy = ps.box[3];
+        const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
+        const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
+        thr_dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
+    }
     double score = 0;
     int cnt = 0;
     Prune pr;
@@ -579,7 +684,7 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     pr.n = n; pr.processed = 0; pr.dead = !live; pr.wave_dead = false;
     const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
 #ifdef MDRP_SCORE_SCALAR
-    score_tile<POSE>(gp, n, E, mp, thr, score, cnt, pr);
+    score_tile<POSE, false>(gp, n, E, mp, thr, thr_dmax, score, cnt, pr);
 #else
     for (int t0 = 0; t0 < n; t0 += TILE_PTS) {
         const int npts = min(TILE_PTS, n - t0);
@@ -591,7 +696,18 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
             for (int i = tid; i < nvec; i += SCORE_THREADS) dst[i] = src[i];
         }
         __syncthreads();
-        if (!pr.wave_dead) score_tile<POSE>(tile, npts, E, mp, thr, score, cnt, pr);
+        if (!pr.wave_dead) {
+#ifdef MDRP_NO_BOUND
+            score_tile<POSE, false>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
+#else
+#ifdef MDRP_DENSE_TWO_PHASE
+            if (dense) score_tile<POSE, false>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
+#else
+            if (dense) score_tile_dense<POSE>(tile, npts, E, mp, thr, score, cnt, pr);
+#endif
+            else score_tile<POSE, true>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
+#endif
+        }
     }
 #endif
     if (live) {
@@ -1089,6 +1205,28 @@ __global__ void k_solver_unit(int solver, int count, const double *__restrict__ 
     n_out[i] = n;
 #pragma unroll
     for (int k = 0; k < 4; ++k) if (k < n) out[4 * i + k] = m[k];
+}
+
+// coordinate box of ONE pair's records into st[0].box (unit sweep path)
+__global__ __launch_bounds__(256) void k_box_unit(int n, const double *__restrict__ pts, PairState *__restrict__ st) {
+    __shared__ double red[4][4];
+    double bx[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bx[q] = fmax(bx[q], fabs(pts[(size_t)i * PT_STRIDE + q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = bx[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st[0].box[q] = fmax(fmax(red[0][q], red[1][q]), fmax(red[2][q], red[3][q]));
+    }
 }
 
 // pack raw normalised correspondences of ONE pair into pts records (for mdrp_score_models / mdrp_refine_models)
