@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="image pairs per GPU per step")
     ap.add_argument("--workload", default="calib_p3p_n2000_i10k", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-pairs", type=int, default=12, help="pairs timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs timed on the CPU baseline (0 = skip)")
     args = ap.parse_args()
 
     import torch

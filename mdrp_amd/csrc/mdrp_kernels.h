@@ -851,13 +851,30 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     const int lo = wave * seg, hi = min(n, lo + seg);
     double cost = 0;
     int cnt = 0;
+    // software-pipelined by one step: the next 64 records are requested before the current ones are consumed (two
+    // wavefronts per SIMD are not enough to hide an L2 round trip behind ~130 fp64 ops)
+    struct Rec { double a, b, c, d, e1, e2; bool ok; };
+    auto fetch = [&](int base) {
+        Rec r;
+        const int i = base + lane;
+        r.ok = i < hi && (!mask || mask[i]);
+        if (r.ok) {
+            const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
+            const double2 p01 = P[0], p23 = P[1];
+            const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i);
+            r.a = p01.x; r.b = p01.y; r.c = p23.x; r.d = p23.y; r.e1 = dd.x; r.e2 = dd.y;
+        } else { r.a = r.b = r.c = r.d = 0; r.e1 = r.e2 = 1; }
+        return r;
+    };
+    Rec nxt = fetch(lo);
     for (int base = lo; base < hi; base += 64) {
+        const Rec cur = nxt;
+        if (base + 64 < hi) nxt = fetch(base + 64);
         const int i = base + lane;
         bool contrib = false;
-        if (i < hi && (!mask || mask[i])) {
-            const double *p = pts + (size_t)i * PT_STRIDE;
+        if (cur.ok) {
             double r[5], zf, zb;
-            point_residuals<false, KIND != 0>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, nullptr);
+            point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
             const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
             cost += ws * loss_value(o.loss, o.loss_scale, rs);
             if (!(zf < 0)) cost += loss_value(o.loss, o.loss_scale, rf);
@@ -925,6 +942,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
         const uint16_t *list = sh.list + (size_t)buf * sh.stride;
         const int cnt = sh.count[buf][wave];
         for (int k = lane; k < cnt; k += 64) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, (int)list[lo + k], sqrt_sr, ws, o, acc);
+        (void)0;
     } else {
         const int hi = min(n, lo + seg);
         for (int i = lo + lane; i < hi; i += 64)
