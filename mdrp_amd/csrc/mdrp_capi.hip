@@ -157,10 +157,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->model_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
-    if ((rc = h->work_pair.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
-    if ((rc = h->work_pos.ensure(sizeof(uint32_t) * (size_t)batch * trig_cap))) return rc;
+    if ((rc = h->work_pair.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc; // LO plan: trigger prefix over permuted pairs
+    if ((rc = h->work_pos.ensure(sizeof(int32_t) * 16))) return rc;                    // LO plan: first item of each XCD class
     if ((rc = h->counters.ensure(64))) return rc;
-    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4)))) return rc; // two prefix arrays + {dense, total, head} // [0] work_count, [1] work_head, [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64)
+    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8..15] LO queue heads
 
     HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
@@ -237,11 +237,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             h->sweep_launches++;
         }
         hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                           h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, cnt + 0, h->work_pair.as<uint32_t>(),
-                           h->work_pos.as<uint32_t>(), h->model_count.as<int32_t>(), reinterpret_cast<unsigned long long *>(cnt + 6));
+                           h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, h->model_count.as<int32_t>(),
+                           reinterpret_cast<unsigned long long *>(cnt + 6));
+        hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), h->work_pair.as<int32_t>(), h->work_pos.as<int32_t>());
         MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(h->num_cu * (lo_threads == 64 ? 8 : 2)), lm_list_bytes(n_max), s, rp,
                          h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                         trig_cap, cnt + 0, h->work_pair.as<uint32_t>(), h->work_pos.as<uint32_t>(), cnt + 1, lm_list_stride(n_max));
+                         trig_cap, h->work_pair.as<int32_t>(), h->work_pos.as<int32_t>(), cnt + 8, lm_list_stride(n_max));
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                            h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
         HIPCHK(hipGetLastError());

@@ -723,8 +723,7 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
 // wave exclusive prefix (max count, min score) -> per-lane replay against the true running records.
 __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict__ st, const double *__restrict__ slot_score,
                                              const int32_t *__restrict__ slot_inl, Trigger *__restrict__ triggers,
-                                             int trig_cap, int32_t *__restrict__ work_count, uint32_t *__restrict__ work_pair,
-                                             uint32_t *__restrict__ work_pos, const int32_t *__restrict__ model_count,
+                                             int trig_cap, const int32_t *__restrict__ model_count,
                                              unsigned long long *__restrict__ evals) {
     const int pair = blockIdx.x, lane = threadIdx.x;
     PairState &ps = st[pair];
@@ -785,9 +784,6 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
                 Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
                 tr.iter = (uint32_t)it; tr.k_ref = k_ref; tr.k_min = k_min; tr.cnt_min = cnt_min; tr.score_min = score_min;
                 tr.ref_score = DBL_MAX; tr.ref_cnt = 0;
-                const int w = atomicAdd(work_count, 1);
-                work_pair[w] = (uint32_t)pair;
-                work_pos[w] = (uint32_t)pos;
             }
         }
         ntrig += __popcll(ball);
@@ -1044,26 +1040,79 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 #ifndef MDRP_LM_MINWAVES
 #define MDRP_LM_MINWAVES 2
 #endif
+// LO work plan, XCD-affine.  Every LM sweep re-reads its pair's records (64 B per correspondence per sweep) and a pair has
+// ~10 triggers in the first chunk; the records of the ~2000 problems in flight chip-wide (256 MB) do not fit the 8 x 4 MB
+// of L2, but the problems ONE XCD runs concurrently do if they belong to few pairs.  Pairs are therefore assigned to XCDs
+// (pair mod 8) and each XCD works through the triggers of its own pairs, pair after pair; when its queue is empty it
+// steals from the next one.  Placement is a speed matter only (workgroup -> XCD by blockIdx.x mod 8 is an observation,
+// not a contract).  prefix[q] = triggers before permuted pair q (pairs grouped by class), start[x] = first item of class x.
+__device__ __forceinline__ int lo_perm_pair(int q, int batch, int &cls) {
+    int off = 0;
+    for (int x = 0; x < 8; ++x) {
+        const int c = (batch - x + 7) / 8;
+        if (q < off + c) { cls = x; return 8 * (q - off) + x; }
+        off += c;
+    }
+    cls = 7;
+    return batch - 1;
+}
+
+__global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__restrict__ st, int32_t *__restrict__ prefix /*[B+1]*/,
+                                                int32_t *__restrict__ start /*[9]*/) {
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int q0 = 0; q0 < batch; q0 += 64) {
+        const int q = q0 + lane;
+        int cls = 0, c = 0, off_is_start = 0;
+        if (q < batch) {
+            const int p = lo_perm_pair(q, batch, cls);
+            c = st[p].n_triggers;
+            off_is_start = (p < 8); // first pair of its class
+        }
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (q < batch) {
+            prefix[q] = run + inc - c;
+            if (off_is_start) start[cls] = run + inc - c;
+        }
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) {
+        prefix[batch] = run;
+        start[8] = run;
+        for (int x = batch; x < 8; ++x) start[x] = run; // classes without pairs (batch < 8)
+    }
+}
+
 template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
-                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ work_count,
-                                                   const uint32_t *__restrict__ work_pair, const uint32_t *__restrict__ work_pos,
-                                                   int32_t *__restrict__ work_head, int list_stride) {
+                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ prefix,
+                                                   const int32_t *__restrict__ start, int32_t *__restrict__ heads /*[8], zeroed*/,
+                                                   int list_stride) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
     if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
     __syncthreads();
-    const int total = *work_count;
+    const int my_xcd = blockIdx.x & 7;
+    int turn = 0; // queues tried so far: own first, then the neighbours'
     for (;;) {
+        const int xc = (my_xcd + turn) & 7;
+        const int q_lo = start[xc], q_hi = start[xc + 1];
         __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(work_head, 1);
+        if (threadIdx.x == 0) s_item = q_lo + atomicAdd(heads + xc, 1);
         __syncthreads();
         const int w = s_item;
-        if (w >= total) break;
-        const int pos = (int)work_pos[w];
-        const int pair = (int)work_pair[w];
+        if (w >= q_hi) {
+            if (++turn == 8) break;
+            continue;
+        }
+        int cls;
+        const int q = plan_find(prefix, rp.batch, w);
+        const int pair = lo_perm_pair(q, rp.batch, cls);
+        const int pos = w - prefix[q];
         const PairState &ps = st[pair];
         Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
         const size_t slot_base = (size_t)pair * rp.chunk_len * 4;

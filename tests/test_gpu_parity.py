@@ -154,6 +154,49 @@ def test_estimate_vs_reference_golden(handle, capi, golden):
     assert same_traj >= 0.8 * noisy, (same_traj, noisy)
 
 
+@pytest.mark.parametrize("kind,es,rf", [(0, False, None), (0, True, None), (1, False, "shared"), (2, False, "varying")])
+def test_statistical_equivalence_noisy(handle, capi, po, kind, es, rf):
+    """north_star: 'statistically equivalent inlier counts on noisy data'.  48 noisy pairs per estimator (N = 500, 35 %
+    outliers, default dynamic stopping) against the CPU oracle: identical iteration counts, mean inlier count within
+    0.5 %, and the large majority of pairs on exactly the same trajectory (same LO count, inliers and mask)."""
+    from mdrp_amd import synth
+    B, N = 48, 500
+    b = synth.make_batch(2000 + 100 * kind + int(es), B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.35, random_focal=rf,
+                         shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
+    ro = {"max_epipolar_error": 2.0, "max_reproj_error": 16.0, "min_iterations": 300, "monodepth_estimate_shift": es}
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    res, mask = handle.estimate_batch(kind, b["x1"], b["x2"], b["d1"], b["d2"], capi.ransac_opt_from_dict(ro),
+                                      capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None,
+                                      cams if kind == 0 else None, cams if kind == 0 else None)
+    oro = po.ransac_opt(max_epipolar_error=2.0, max_reproj_error=16.0, min_iterations=300, estimate_shift=es)
+    cam = po.cam_flat(0, [800.0, 0, 0])
+    same = 0
+    inl_gpu, inl_cpu = [], []
+    for i in range(B):
+        m, st, mk = po.estimate(kind, b["x1"][i], b["x2"][i], b["d1"][i], b["d2"][i], oro, po.bundle_opt(loss_type=4),
+                                cam if kind == 0 else None, cam if kind == 0 else None)
+        inl_gpu.append(int(res[i]["num_inliers"])); inl_cpu.append(st.num_inliers)
+        same += (int(res[i]["iterations"]) == st.iterations and int(res[i]["refinements"]) == st.refinements
+                 and int(res[i]["num_inliers"]) == st.num_inliers and (mask[i] == mk).all())
+    assert abs(np.mean(inl_gpu) - np.mean(inl_cpu)) <= 0.005 * np.mean(inl_cpu), (np.mean(inl_gpu), np.mean(inl_cpu))
+    assert same >= 0.75 * B, (same, B)
+
+
+def test_estimate_shift_flag_ignored_by_focal_estimators(handle, capi):
+    """BASELINE configs[3] combines varying focal with monodepth_estimate_shift=True; the reference reads that flag only in
+    the calibrated estimator -> identical results with and without it, shifts stay 0"""
+    from mdrp_amd import synth
+    b = synth.make_batch(3000, 4, 400, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5, random_focal="varying")
+    out = []
+    for flag in (False, True):
+        ro = {"max_iterations": 2000, "min_iterations": 2000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0, "monodepth_estimate_shift": flag}
+        res, mask = handle.estimate_batch(capi.VARYING_FOCAL, b["x1"], b["x2"], b["d1"], b["d2"], capi.ransac_opt_from_dict(ro),
+                                          capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}))
+        out.append((res.tobytes(), mask.tobytes()))
+        assert (res["model"]["shift1"] == 0).all() and (res["model"]["shift2"] == 0).all()
+    assert out[0] == out[1]
+
+
 def test_batch_ragged_and_degenerate(handle, capi, po):
     """B pairs with different N (one sample table per N), including N<3 and N=0, equal the oracle pair by pair"""
     from mdrp_amd import synth
