@@ -4,18 +4,20 @@
 // is exactly parallelisable: the sample sequence depends only on (seed, N); LO triggers depend only
 // on the running records of the MINIMAL models; every LO starts from the triggering minimal model.  So per chunk
 // of iterations:
-//   k_samples  one lane per distinct N      splitmix64 sample table for the chunk                       (a-3)
-//   k_solve    one lane per minimal sample  solver -> <=4 models, compacted tag list per pair            (a-4..a-6')
-//   k_score    one lane per hypothesis      Sampson/MSAC (+cheirality) sweep over all N correspondences,
-//                                           correspondences staged through LDS, broadcast reads         (a-7)  HOT
-//   k_scan     one wave per pair            ordered prefix scan of (count,score) records -> LO triggers (a-2)
-//   k_lo       one workgroup per trigger    LM refinement (<=25 it, TRUNCATED) + rescoring              (a-8)
-//   k_walk     one lane per pair            replays the reference's bookkeeping over the triggers,
-//                                           dynamic stopping                                            (a-2)
-//   k_final    one workgroup per pair       final LO, inlier mask, inlier-only LM, result record        (a-1, a-9)
+//   k_samples  one wavefront per distinct N  splitmix64 sample table for the chunk (wave-speculative)        (a-3)
+//   k_solve    one lane per minimal sample   solver -> <=4 models; density class; compacted tag lists       (a-4..a-6')
+//   k_plan     one wavefront                 work items of the sweep (workgroups per pair and class)
+//   k_score    one lane per hypothesis       Sampson/MSAC (+cheirality) sweep over all N correspondences,
+//                                            correspondences staged through LDS, broadcast reads            (a-7)  HOT
+//   k_scan     one wavefront per pair        ordered prefix scan of (count,score) records -> LO triggers     (a-2)
+//   k_lo_plan  one wavefront                 XCD-affine queues of the LO problems
+//   k_lo       one wavefront (or workgroup)  LM refinement (<=25 it, TRUNCATED) + rescoring, per trigger     (a-8)
+//   k_walk     one lane per pair             replays the reference's bookkeeping over the triggers,
+//                                            dynamic stopping                                                (a-2)
+//   k_final    one workgroup per pair        final LO, inlier mask, inlier-only LM, result record            (a-1, a-9)
 // HBM layout (all fp64 unless noted): pts[B][n_max][6] = (x1.x, x1.y, x2.x, x2.y, 1/|(x1,1)|, 1/|(x2,1)|)
 // normalised; dep[B][n_max][2] = (d1, d2); models[B][chunk][4] (96 B each); slot_score/slot_inl[B][chunk][4];
-// tags[B][4*chunk] u32 compact list of live slots.
+// tags[B][4*chunk] u32 compact list of live slots (sparse class from the front, dense class from the back).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -376,20 +378,23 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
 }
 
 // ------------------------------------------------------------------------------------------------ score (HOT)
-// One lane per hypothesis; the pair's correspondences are staged through LDS in tiles and read as wave-wide
-// broadcasts (every lane reads the same record), so a tile is fetched from HBM/L2 once per workgroup.
+// One lane per hypothesis; the pair's correspondences are staged through LDS in 512-record tiles (24 KiB) and read as
+// wave-wide broadcasts (every lane reads the same record), so a tile is fetched from HBM/L2 once per workgroup.
 // Algorithmic bytes: 32 B per (model x correspondence) evaluation (x1, x2 as four fp64 — what the CPU loop reads,
-// SURVEY.md §8d).
-//
-// Each 32-correspondence group runs in two phases so that the common case stays branch-free:
-//   phase 1  Sampson numerator/denominator for all 32 records, four independent chains in flight, no division:
-//            C^2 < thr * den marks a CANDIDATE bit in a per-lane mask                       (~19 fp64 ops / eval)
-//   phase 2  every lane pops ITS OWN candidate bits (per-lane LDS addresses) and runs the exact quotient test,
-//            check_cheirality and the accumulation.  Its trip count is the largest candidate count of any lane
-//            in the wave, not the number of records that are a candidate for SOME lane — with 64 unrelated
-//            hypotheses that union is ~half of all records.
-// k_solve pre-classifies hypotheses by their candidate density on the first records, so that wavefronts hold
-// either "dense" (good) or "sparse" (garbage) hypotheses and phase 2 stays short for the sparse majority.
+// SURVEY.md §8d).  The kernel is fp64-VALU bound (88 % VALU-busy, PMC), so everything below is about issuing fewer
+// fp64 instructions per evaluation without changing a single result:
+//   * k_solve classifies hypotheses by their candidate density on the first 32 records; wavefronts hold either DENSE
+//     (near the true model) or SPARSE (garbage, ~90 %) hypotheses.
+//   * SPARSE, per 32 records:  phase 1 is branch-free and needs only the numerator: C^2 < thr * Dmax, Dmax >= den for every
+//     record of the pair (bound over the pair's coordinate box) -> 12 ops instead of 22; survivors (a superset of the true
+//     candidates, ~1 %) set a bit in a per-lane mask.  phase 2: every lane pops ITS OWN bits (per-lane LDS addresses) and
+//     runs the exact test, quotient, check_cheirality and accumulation; its trip count is the largest candidate count of
+//     any lane, not the size of the union over 64 unrelated hypotheses (which is about half of all records).
+//   * DENSE: candidate sets of the 64 lanes nearly coincide (the true inliers), so the plain per-record branch is coherent:
+//     one pass, no recomputation.
+//   * bail-out against the records of earlier chunks (struct Prune): exact, skips ~30 % of the sparse work at 50 % outliers
+//     and nearly all of it on clean data.
+//   * v_fma_f64 with a loop-invariant addend goes through inline asm (fma3): hipcc picks v_fmac_f64 + v_mov_b64 otherwise.
 // exact inlier test + accumulation for one record (compute_sampson_msac_score @0x4f61d0 body, check_cheirality @0x1dce00)
 template <bool POSE>
 __device__ __forceinline__ void score_point(const double *__restrict__ rec, const double E[9], const double R[9], const double t[3],
@@ -550,9 +555,6 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
                 }
             }
         }
-#ifdef MDRP_NO_PHASE2
-        cnt += __popc(mask); mask = 0; // timing experiment only
-#endif
         if (pr.dead) mask = 0;
         if (mask) {
             double R[9], t[3];
@@ -683,9 +685,6 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     pr.rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
     pr.n = n; pr.processed = 0; pr.dead = !live; pr.wave_dead = false;
     const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
-#ifdef MDRP_SCORE_SCALAR
-    score_tile<POSE, false>(gp, n, E, mp, thr, thr_dmax, score, cnt, pr);
-#else
     for (int t0 = 0; t0 < n; t0 += TILE_PTS) {
         const int npts = min(TILE_PTS, n - t0);
         __syncthreads();
@@ -700,16 +699,11 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
 #ifdef MDRP_NO_BOUND
             score_tile<POSE, false>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
 #else
-#ifdef MDRP_DENSE_TWO_PHASE
-            if (dense) score_tile<POSE, false>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
-#else
             if (dense) score_tile_dense<POSE>(tile, npts, E, mp, thr, score, cnt, pr);
-#endif
             else score_tile<POSE, true>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
 #endif
         }
     }
-#endif
     if (live) {
         const bool pruned = pr.dead;
         slot_score[slot_base + slot] = pruned ? DBL_MAX : score + thr * (double)(n - cnt);
