@@ -239,6 +239,29 @@ def test_all_degenerate_and_empty_batches(handle, capi):
     assert len(res) == 0
 
 
+@pytest.mark.timeout(120)
+def test_garbage_inputs_terminate(handle, capi):
+    """NaN / inf / negative depths, all-identical correspondences and huge coordinates must neither hang nor crash the
+    kernels (the reference callers sanitise depths themselves, eval.py:344-346; the binding must still be safe)"""
+    from mdrp_amd import synth
+    b = synth.make_batch(4000, 5, 300, noise_px=0.5, outlier_frac=0.3)
+    x1, x2, d1, d2 = b["x1"].copy(), b["x2"].copy(), b["d1"].copy(), b["d2"].copy()
+    d1[0, ::7] = np.nan; d2[0, ::5] = np.inf; d1[0, ::11] = -1.0
+    x1[1] = x1[1, :1]; x2[1] = x2[1, :1]; d1[1] = 1.0; d2[1] = 1.0          # one correspondence repeated 300 times
+    x1[2] *= 1e12; x2[2] *= 1e-12                                           # absurd scales
+    d1[3] = 0.0; d2[3] = 0.0                                                # zero depths
+    cams = np.zeros(5, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    for kind in (capi.CALIB, capi.SHARED_FOCAL, capi.VARYING_FOCAL):
+        for es in (False, True):
+            ro = capi.ransac_opt_from_dict({"max_iterations": 600, "min_iterations": 300, "max_epipolar_error": 2.0,
+                                            "max_reproj_error": 16.0, "monodepth_estimate_shift": es})
+            res, mask = handle.estimate_batch(kind, x1, x2, d1, d2, ro, capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None,
+                                              cams if kind == 0 else None, cams if kind == 0 else None)
+            assert (res["iterations"] >= 301).all() and (res["iterations"] <= 600).all()
+            assert (res["num_inliers"] <= 300).all()
+            assert int(res[4]["num_inliers"]) > 150  # the clean pair next to them is unaffected
+
+
 def test_dynamic_stopping_chunks(handle, capi, po):
     """default options (max 100000 / min 1000): the chunked driver must stop at the reference's iteration"""
     from mdrp_amd import synth
