@@ -807,6 +807,7 @@ __device__ __forceinline__ constexpr int lm_col(int p) {
 struct LmOpt {
     int max_it, loss;
     double loss_scale, grad_tol, step_tol, lambda0, lambda_min, lambda_max;
+    double mu = 0.5; // TRUNCATED_LE_ZACH penalty strength of the current LM iteration (lm_refine advances it)
 };
 
 // Work-list LM.  With a truncated loss (every LO refinement, and the recommended TRUNCATED_CAUCHY of the final one) a
@@ -869,8 +870,8 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
             cost += ws * loss_value(o.loss, o.loss_scale, rs);
             if (!(zf < 0)) cost += loss_value(o.loss, o.loss_scale, rf);
             if (!(zb < 0)) cost += loss_value(o.loss, o.loss_scale, rb);
-            contrib = (ws * loss_weight(o.loss, o.loss_scale, rs) != 0.0) || (!(zf < 0) && loss_weight(o.loss, o.loss_scale, rf) != 0.0) ||
-                      (!(zb < 0) && loss_weight(o.loss, o.loss_scale, rb) != 0.0);
+            contrib = (ws * loss_weight(o.loss, o.loss_scale, rs, o.mu) != 0.0) || (!(zf < 0) && loss_weight(o.loss, o.loss_scale, rf, o.mu) != 0.0) ||
+                      (!(zb < 0) && loss_weight(o.loss, o.loss_scale, rb, o.mu) != 0.0);
         }
         if (use_list) {
             const unsigned long long ball = __ballot(contrib);
@@ -891,9 +892,9 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, const do
     const double *p = pts + (size_t)i * PT_STRIDE;
     double r[5], zf, zb, J[5][LM_NPAR];
     point_residuals<true, KIND != 0>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, J);
-    const double wS = ws * loss_weight(o.loss, o.loss_scale, r[0] * r[0]);
-    const double wF = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2]);
-    const double wB = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4]);
+    const double wS = ws * loss_weight(o.loss, o.loss_scale, r[0] * r[0], o.mu);
+    const double wF = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2], o.mu);
+    const double wB = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4], o.mu);
     const double wr[5] = {wS, wF, wF, wB, wB};
 #pragma unroll
     for (int row = 0; row < 5; ++row) {
@@ -945,10 +946,12 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
 // thread of the workgroup; only the two sweeps over the correspondences are distributed.
 template <int KIND, bool SHIFT, int T>
 __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o, LmShared &sh) {
+                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o_in, LmShared &sh) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NT = NP * (NP + 1) / 2;
     const double sqrt_sr = sqrt(scale_reproj);
+    LmOpt o = o_in;
+    o.mu = 0.5;
     int cur = 0; // list buffer that belongs to the current model
     double cost = lm_cost<KIND, T>(m, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur);
     double lambda = o.lambda0;
@@ -998,6 +1001,8 @@ __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double
             lambda = fmin(o.lambda_max, lambda * 10.0);
             recompute = false;
         }
+        o.mu *= 1.5; // the reference's per-iteration callback of TRUNCATED_LE_ZACH; note the work list of the current model
+                     // was built with the previous mu — Le-Zach weights are never zero, so the list holds every record
     }
 }
 

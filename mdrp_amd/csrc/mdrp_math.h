@@ -610,11 +610,22 @@ MDRP_HD double loss_value(int type, double thr, double r2) {
     default: return r2;
     }
 }
-MDRP_HD double loss_weight(int type, double thr, double r2) {
+// mu: penalty strength of TRUNCATED_LE_ZACH (Le & Zach, 3DV 2021): 0.5, multiplied by 1.5 after every LM iteration
+// (the reference's per-iteration callback; pinned against the binary to 1e-15 over 5 iterations)
+MDRP_HD double loss_weight(int type, double thr, double r2, double mu = 0.5) {
     const double t2 = thr * thr;
     const double dmin = 2.2250738585072014e-308;
     switch (type) {
-    case 1: case 5: return r2 < t2 ? 1.0 : 0.0;
+    case 1: return r2 < t2 ? 1.0 : 0.0;
+    case 5: {
+        const double r2h = r2 / t2;
+        if (r2h < 1.0) return 0.5;
+        const double r2m1 = r2h - 1.0;
+        const double rho = (2.0 * r2m1 + sqrt(4.0 * r2m1 * r2m1 * mu * mu + 2.0 * mu * r2m1)) / mu;
+        const double a = (r2h + mu * rho - 0.5 * rho) / (1.0 + mu * rho);
+        const double zbar = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
+        return (1.0 - zbar) / rho;
+    }
     case 2: { const double r = sqrt(r2); return r <= thr ? 1.0 : thr / r; }
     case 3: { const double w = 1.0 / (1.0 + r2 / t2); return w > dmin ? w : dmin; }
     case 4: { if (!(r2 < t2)) return 0.0; const double w = 1.0 / (1.0 + r2 / t2); return w > dmin ? w : dmin; }

@@ -34,6 +34,7 @@ static double loss_value(int type, double thr, double r2) {
     }
     return r2;
 }
+static double lz_mu = 0.5; /* TRUNCATED_LE_ZACH penalty strength: starts at 0.5, x1.5 after every LM iteration */
 static double loss_weight(int type, double thr, double r2) {
     const double t2 = thr * thr;
     switch (type) {
@@ -42,7 +43,15 @@ static double loss_weight(int type, double thr, double r2) {
     case 2: { const double r = sqrt(r2); return r <= thr ? 1.0 : thr / r; }
     case 3: { const double w = 1.0 / (1.0 + r2 / t2); return w > DBL_MIN ? w : DBL_MIN; }
     case 4: { if (!(r2 < t2)) return 0.0; const double w = 1.0 / (1.0 + r2 / t2); return w > DBL_MIN ? w : DBL_MIN; }
-    case 5: return r2 < t2 ? 1.0 : 0.0; /* Le-Zach weight not pinned; cost equals TRUNCATED */
+    case 5: { /* Le & Zach, 3DV 2021 (upstream PoseLib TruncatedLossLeZach::weight) */
+        const double r2h = r2 / t2;
+        if (r2h < 1.0) return 0.5;
+        const double mu = lz_mu, zstar = 1.0, r2m1 = r2h - 1.0;
+        const double rho = (2.0 * r2m1 + sqrt(4.0 * r2m1 * r2m1 * mu * mu + 2.0 * mu * r2m1)) / mu;
+        const double a = (r2h + mu * rho * zstar - 0.5 * rho) / (1.0 + mu * rho);
+        const double zbar = a < 0.0 ? 0.0 : (a > 1.0 ? 1.0 : a);
+        return (zstar - zbar) / rho;
+    }
     }
     return 1.0;
 }
@@ -388,6 +397,7 @@ orc_bundle_stats orc_refine(int kind, const double *x1, const double *x2, const 
     stats.lambda = opt->initial_lambda;
     double JtJ[NPAR * NPAR], Jtr[NPAR], sol[NPAR];
     int recompute = 1;
+    lz_mu = 0.5;
     for (stats.iterations = 0; stats.iterations < opt->max_iterations; ++stats.iterations) {
         if (recompute) {
             lm_accumulate(&pb, m, JtJ, Jtr);
@@ -416,6 +426,7 @@ orc_bundle_stats orc_refine(int kind, const double *x1, const double *x2, const 
             stats.lambda = fmin(opt->max_lambda, stats.lambda * 10.0);
             recompute = 0;
         }
+        lz_mu *= 1.5; /* the reference's per-iteration callback */
     }
     return stats;
 }

@@ -39,6 +39,7 @@ void hm_draw(uint64_t n, uint64_t seed, int count, uint32_t *out) {
     for (int i = 0; i < count; ++i) draw_sample3(n, st, out[3 * i], out[3 * i + 1], out[3 * i + 2]);
 }
 double hm_loss(int type, double thr, double r2, int weight) { return weight ? loss_weight(type, thr, r2) : loss_value(type, thr, r2); }
+double hm_loss_mu(int type, double thr, double r2, double mu) { return loss_weight(type, thr, r2, mu); }
 }
 
 // host emulation of k_samples' wave-speculative table generation (64 "lanes" per step) for the CPU test

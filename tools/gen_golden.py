@@ -139,7 +139,7 @@ def gen_refine():
         m[10] = p["f1"] / sc * 1.02 if kind else 1.0
         m[11] = (p["f2"] / sc * 0.97) if kind == 2 else m[10]
         d.update({f"x1_{i}": x1, f"x2_{i}": x2, f"d1_{i}": p["d1"], f"d2_{i}": p["d2"], f"model_{i}": m})
-        for lt in (0, 1, 2, 3, 4):
+        for lt in (0, 1, 2, 3, 4, 5):
             for its in (0, 1, 25):
                 thr = 2.0 / sc
                 bo = rs.bopt(max_iterations=its, loss_type=lt, loss_scale=thr, gradient_tol=1e-10)
