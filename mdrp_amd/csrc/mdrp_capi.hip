@@ -181,7 +181,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     rp.final_max_it = (int)std::min<uint64_t>(bo->max_iterations, 1u << 30); rp.final_loss = bo->loss_type;
     rp.grad_tol = bo->gradient_tol; rp.step_tol = bo->step_tol; rp.lambda0 = bo->initial_lambda;
     rp.lambda_min = bo->min_lambda; rp.lambda_max = bo->max_lambda;
-    rp.chunk_len = chunk_cap; rp.chunk_start = 0;
+    rp.chunk_len = chunk_cap; rp.chunk_off = 0; rp.slot_stride = chunk_cap * 4; rp.super_len = chunk_cap; rp.chunk_start = 0;
 
     hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, h->nper.as<int32_t>(),
                        h->table_of_pair.as<int32_t>(), h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error,
@@ -201,44 +201,61 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     uint64_t it0 = 0;
     // iterations that certainly run: the reference cannot stop before min_iterations + 1 (or max_iterations)
     const uint64_t certain = ro->max_iterations == 0 ? 1 : std::min<uint64_t>(ro->max_iterations, ro->min_iterations + 1);
-    // chunk schedule: a short first chunk (512 iterations) establishes the records that let k_score bail out of hopeless
-    // hypotheses in the rest (exact, see Prune in mdrp_kernels.h); more, smaller chunks prune a little more but pay a
-    // launch train + LO tail each (measured: 2 chunks 27.6 ms/step, 3 chunks 29.1); later chunks follow dynamic_max_iter
-    const uint64_t first_chunk = (uint64_t)env_int("MDRP_FIRST_CHUNK", 512), growth = (uint64_t)env_int("MDRP_CHUNK_GROWTH", 32);
-    uint64_t next_len = certain >= 4 * first_chunk ? first_chunk : certain;
-    uint64_t last_len = 0;
+    // A SUPER-CHUNK is a range of iterations that shares one LO + walk pass and one host read-back; it is swept in one or
+    // more CHUNKS (solve / score / scan launch trains).  Inside the certain range nothing can stop, so the first
+    // super-chunk is split into a short chunk (512 iterations) that establishes the records and the rest, which k_score
+    // then sweeps with the exact bail-out (see Prune in mdrp_kernels.h); both chunks' triggers go to ONE k_lo launch.
+    // Beyond the certain range a super-chunk is one chunk sized by the largest remaining dynamic_max_iter.
+    const uint64_t first_chunk = (uint64_t)env_int("MDRP_FIRST_CHUNK", 512);
+    uint64_t max_needed = 0;
+    rp.slot_stride = chunk_cap * 4;
     while (true) {
-        const int len = (int)std::min<uint64_t>(next_len, (uint64_t)chunk_cap);
-        rp.chunk_len = len; rp.chunk_start = it0;
-        HIPCHK(hipMemsetAsync(h->model_count.p, 0, sizeof(int32_t) * 2 * batch, s));
-        HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
-        hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
-                           h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
-        hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
-                           h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(),
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>());
-        {
-            hipEvent_t e0, e1;
-            if ((rc = get_events(h, &e0, &e1))) return rc;
-            HIPCHK(hipEventRecord(e0, s));
-            int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, h->model_count.as<int32_t>(), plan, totals);
-            const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
-                                                    : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
-            if (kind == MDRP_CALIB)
-                hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                   h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
-                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
-            else
-                hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                   h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
-                                   h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
-            HIPCHK(hipEventRecord(e1, s));
-            h->sweep_launches++;
+        uint64_t lens[2] = {0, 0};
+        int n_chunks = 1;
+        if (it0 < certain) {
+            const uint64_t span = std::min<uint64_t>(certain - it0, (uint64_t)chunk_cap);
+            if (it0 == 0 && span >= 4 * first_chunk) { lens[0] = first_chunk; lens[1] = span - first_chunk; n_chunks = 2; }
+            else lens[0] = span;
+        } else {
+            lens[0] = std::min<uint64_t>(std::min<uint64_t>(std::max<uint64_t>(max_needed, 256), ro->max_iterations - it0), (uint64_t)chunk_cap);
         }
-        hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                           h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, h->model_count.as<int32_t>(),
-                           reinterpret_cast<unsigned long long *>(cnt + 6));
+        const uint64_t super_len = lens[0] + lens[1];
+        rp.chunk_start = it0; rp.super_len = (int)super_len;
+        HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
+        int off = 0;
+        for (int c = 0; c < n_chunks; ++c) {
+            const int len = (int)lens[c];
+            rp.chunk_len = len; rp.chunk_off = off;
+            HIPCHK(hipMemsetAsync(h->model_count.p, 0, sizeof(int32_t) * 2 * batch, s));
+            hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
+                               h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
+            hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
+                               h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(),
+                               h->tags.as<uint32_t>(), h->model_count.as<int32_t>());
+            {
+                hipEvent_t e0, e1;
+                if ((rc = get_events(h, &e0, &e1))) return rc;
+                HIPCHK(hipEventRecord(e0, s));
+                int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, h->model_count.as<int32_t>(), plan, totals);
+                const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
+                                                        : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
+                if (kind == MDRP_CALIB)
+                    hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                                       h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
+                                       h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                else
+                    hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                                       h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
+                                       h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                HIPCHK(hipEventRecord(e1, s));
+                h->sweep_launches++;
+            }
+            hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
+                               h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, h->model_count.as<int32_t>(),
+                               reinterpret_cast<unsigned long long *>(cnt + 6));
+            off += len;
+        }
         hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), h->work_pair.as<int32_t>(), h->work_pos.as<int32_t>());
         MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(h->num_cu * (lo_threads == 64 ? 8 : 2)), lm_list_bytes(n_max), s, rp,
                          h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
@@ -246,26 +263,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                            h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
         HIPCHK(hipGetLastError());
-        // evaluations of this chunk's sweep: sum over pairs of models * n  (read back with the progress record)
+        // progress record: pairs still iterating, iterations they still need, evaluations swept (sum over pairs of models * n)
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->sweep_evals += (int64_t)h->progress_host->evals;
         if (getenv("MDRP_DEBUG"))
-            fprintf(stderr, "[mdrp] chunk start %llu len %d: evals %llu active %d max_needed %llu\n", (unsigned long long)it0, len,
-                    h->progress_host->evals, h->progress_host->n_active, h->progress_host->max_needed);
-        if (getenv("MDRP_DEBUG")) {
-            PairState dbg;
-            (void)hipMemcpy(&dbg, h->st.p, sizeof dbg, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[mdrp]   pair0: n %d active %d ntrig %d it %llu refinements %llu inl %llu score %g best_min_cnt %llu\n", dbg.n, dbg.active,
-                    dbg.n_triggers, (unsigned long long)dbg.iterations, (unsigned long long)dbg.refinements, (unsigned long long)dbg.num_inliers,
-                    dbg.model_score, (unsigned long long)dbg.best_min_cnt);
-        }
-        it0 += (uint64_t)len;
+            fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu active %d max_needed %llu\n", (unsigned long long)it0,
+                    (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->n_active, h->progress_host->max_needed);
+        it0 += super_len;
         if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
-        last_len = (uint64_t)len;
-        if (it0 < certain) next_len = std::min<uint64_t>(certain - it0, last_len * growth);
-        else next_len = std::max<uint64_t>(h->progress_host->max_needed, 256);
-        next_len = std::min<uint64_t>(next_len, ro->max_iterations - it0);
+        max_needed = h->progress_host->max_needed;
     }
 
     MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
@@ -492,7 +499,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     hipLaunchKernelGGL(k_box_unit, dim3(1), dim3(256), 0, s, n, h->pts.as<double>(), h->st.as<PairState>());
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
-    rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk;
+    rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk; rp.chunk_off = 0; rp.slot_stride = chunk * 4; rp.super_len = chunk;
     const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
     if ((rc = h->plan.ensure(sizeof(int32_t) * 8))) return rc;
     int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 4;

@@ -89,8 +89,11 @@ struct RunParams {
     int solver;         // SOLVER_*
     int est_shift;
     int batch, n_max;
-    int chunk_len;      // iterations in this chunk
-    uint64_t chunk_start;
+    int chunk_len;      // iterations in this chunk (one solve/score/scan launch train)
+    int chunk_off;      // offset of this chunk inside its super-chunk
+    int slot_stride;    // slots per pair in models/slot_*/tags: 4 * (iterations a super-chunk can hold)
+    int super_len;      // iterations of the whole super-chunk (chunks that share one LO + walk pass)
+    uint64_t chunk_start; // absolute iteration number of the super-chunk's first iteration
     uint64_t max_iterations, min_iterations;
     double dyn_mult, log_prob_missing;
     double weight_sampson;
@@ -361,16 +364,16 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     base_s = __shfl(base_s, 63, 64);
     base_d = __shfl(base_d, 63, 64);
     if (!live) return;
-    const size_t slot0 = ((size_t)pair * rp.chunk_len + it) * 4;
+    const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * 4;
     int pos_s = base_s + pre_s - n_sparse, pos_d = base_d + pre_d - n_dense;
-    const size_t tag_base = (size_t)pair * rp.chunk_len * 4;
-    const int cap = rp.chunk_len * 4;
+    const size_t tag_base = (size_t)pair * rp.slot_stride;
+    const int cap = rp.slot_stride;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < n) {
             models[slot0 + k] = out[k];
-            if ((dense_mask >> k) & 1) { tags[tag_base + (cap - 1 - pos_d)] = (uint32_t)(it * 4 + k); ++pos_d; }
-            else { tags[tag_base + pos_s] = (uint32_t)(it * 4 + k); ++pos_s; }
+            if ((dense_mask >> k) & 1) { tags[tag_base + (cap - 1 - pos_d)] = (uint32_t)((rp.chunk_off + it) * 4 + k); ++pos_d; }
+            else { tags[tag_base + pos_s] = (uint32_t)((rp.chunk_off + it) * 4 + k); ++pos_s; }
         } else {
             slot_inl[slot0 + k] = -1;
         }
@@ -645,8 +648,8 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     const PairState &ps = st[pair];
     const int n = ps.n;
     const double thr = ps.sq_thr;
-    const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
-    const int cap = rp.chunk_len * 4;
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    const int cap = rp.slot_stride;
     bool live;
     uint32_t slot = 0;
     { // tag list of the pair: sparse hypotheses grow from the front, dense ones from the back (k_solve)
@@ -725,8 +728,8 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     if (lane == 0) atomicAdd(evals, (unsigned long long)(model_count[2 * pair] + model_count[2 * pair + 1]) * (unsigned long long)ps.n);
     long long run_cnt = (long long)ps.best_min_cnt;
     double run_score = ps.best_min_score;
-    int ntrig = 0;
-    const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+    int ntrig = rp.chunk_off > 0 ? ps.n_triggers : 0; // later chunks of a super-chunk append to its trigger list
+    const size_t slot_base = (size_t)pair * rp.slot_stride + (size_t)rp.chunk_off * 4;
     for (int it0 = 0; it0 < rp.chunk_len; it0 += 64) {
         const int it = it0 + lane;
         const bool live = it < rp.chunk_len;
@@ -776,7 +779,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
             const int pos = ntrig + __popcll(ball & ((1ull << lane) - 1ull));
             if (pos < trig_cap) {
                 Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
-                tr.iter = (uint32_t)it; tr.k_ref = k_ref; tr.k_min = k_min; tr.cnt_min = cnt_min; tr.score_min = score_min;
+                tr.iter = (uint32_t)(rp.chunk_off + it); tr.k_ref = k_ref; tr.k_min = k_min; tr.cnt_min = cnt_min; tr.score_min = score_min;
                 tr.ref_score = DBL_MAX; tr.ref_cnt = 0;
             }
         }
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
         const int pos = w - prefix[q];
         const PairState &ps = st[pair];
         Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
-        const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
+        const size_t slot_base = (size_t)pair * rp.slot_stride;
         Model m = models[slot_base + (size_t)tr.iter * 4 + tr.k_ref];
         LmOpt o;
         o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
@@ -1138,8 +1141,8 @@ __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__
     if (pair >= rp.batch) return;
     PairState &ps = st[pair];
     if (!ps.active) return;
-    const size_t slot_base = (size_t)pair * rp.chunk_len * 4;
-    const uint64_t c0 = rp.chunk_start, c1 = rp.chunk_start + (uint64_t)rp.chunk_len;
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    const uint64_t c0 = rp.chunk_start, c1 = rp.chunk_start + (uint64_t)rp.super_len;
     uint64_t it = c0; // iterations completed so far
     bool stopped = false;
     // stop test applied after each completed iteration: it >= max -> stop; it > min && it > dyn -> stop
