@@ -59,10 +59,14 @@ struct mdrp_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
+    hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
+    hipEvent_t ev_scan = nullptr, ev_lo = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
     DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, work_pos, counters, results, mask, plan;
+    DevBuf tags2, model_count2, samples2; // second chunk of a two-chunk super-chunk (its solver runs beside the first chunk's sweep)
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -155,12 +159,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->slot_inl.ensure(sizeof(int32_t) * slots))) return rc;
     if ((rc = h->tags.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->model_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
+    if ((rc = h->model_count2.ensure(sizeof(int32_t) * 2 * batch))) return rc;
+    if ((rc = h->tags2.ensure(sizeof(uint32_t) * slots))) return rc;
+    if ((rc = h->samples2.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
-    if ((rc = h->work_pair.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc; // LO plan: trigger prefix over permuted pairs
-    if ((rc = h->work_pos.ensure(sizeof(int32_t) * 16))) return rc;                    // LO plan: first item of each XCD class
+    if ((rc = h->work_pair.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc; // LO plan of chunk 0: prefix | begin | end | total
+    if ((rc = h->work_pos.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc;  // LO plan of chunk 1
     if ((rc = h->counters.ensure(64))) return rc;
-    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8..15] LO queue heads
+    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
 
     HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
@@ -189,6 +196,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     HIPCHK(hipGetLastError());
 
     // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
+    const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0;
+    const int lo_overlap_waves = env_int("MDRP_LO_OVERLAP_WAVES", 8); // LO wavefronts per CU while it shares the chip
     const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
@@ -222,44 +231,80 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         const uint64_t super_len = lens[0] + lens[1];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
         HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
+        // Two-stream schedule of a two-chunk super-chunk (the benchmark shape):
+        //   main:  samples0 solve0 | plan0 score0 scan0 loplan0 | (wait solve1) plan1 score1 scan1 loplan1 | (wait lo0) lo1 walk
+        //   aux :                    (wait solve0) samples1 solve1 | (wait scan0) lo0
+        // solve1 (latency-bound: gathers, divergent roots) hides behind score0, and lo0 (dependent fp64 latency at 2 waves/SIMD,
+        // ~1 ms per problem on one wavefront) behind score1 (VALU-bound, short workgroups that fill whatever lo0 leaves idle).
+        // Each chunk has its own tag list / model counters; slots, triggers and plans of the two chunks are disjoint.
+        const bool two = n_chunks == 2 && lo_overlap;
+        hipStream_t aux = h->aux_stream;
         int off = 0;
+        bool lo_pending = false;
         for (int c = 0; c < n_chunks; ++c) {
             const int len = (int)lens[c];
             rp.chunk_len = len; rp.chunk_off = off;
-            HIPCHK(hipMemsetAsync(h->model_count.p, 0, sizeof(int32_t) * 2 * batch, s));
-            hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
-                               h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
-            hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
-                               h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(),
-                               h->tags.as<uint32_t>(), h->model_count.as<int32_t>());
+            uint32_t *tags_c = (c == 0 ? h->tags : h->tags2).as<uint32_t>();
+            int32_t *mcount_c = (c == 0 ? h->model_count : h->model_count2).as<int32_t>();
+            if (!(two && c == 1)) { // in two-stream mode chunk 1's sampler + solver were issued on the aux stream during chunk 0
+                HIPCHK(hipMemsetAsync(mcount_c, 0, sizeof(int32_t) * 2 * batch, s));
+                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
+                                   h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
+                hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
+                                   h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tags_c, mcount_c);
+            }
+            if (two && c == 0) HIPCHK(hipEventRecord(h->ev_solve0, s));
+            if (two && c == 0) {
+                // issue chunk 1's sampler + solver now so that it runs beside chunk 0's sweep
+                RunParams rp1 = rp;
+                rp1.chunk_len = (int)lens[1]; rp1.chunk_off = len;
+                HIPCHK(hipStreamWaitEvent(aux, h->ev_solve0, 0));
+                HIPCHK(hipMemsetAsync(h->model_count2.p, 0, sizeof(int32_t) * 2 * batch, aux));
+                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, aux, n_tables, h->table_n.as<int32_t>(),
+                                   h->table_state.as<uint64_t>(), rp1.chunk_len, h->samples2.as<uint32_t>());
+                hipLaunchKernelGGL(k_solve, dim3((rp1.chunk_len + 255) / 256, batch), dim3(256), 0, aux, rp1, h->st.as<PairState>(),
+                                   h->samples2.as<uint32_t>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(),
+                                   h->slot_inl.as<int32_t>(), h->tags2.as<uint32_t>(), h->model_count2.as<int32_t>());
+                HIPCHK(hipEventRecord(h->ev_solve1, aux));
+            }
+            if (two && c == 1) HIPCHK(hipStreamWaitEvent(s, h->ev_solve1, 0));
             {
                 hipEvent_t e0, e1;
                 if ((rc = get_events(h, &e0, &e1))) return rc;
                 HIPCHK(hipEventRecord(e0, s));
                 int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, h->model_count.as<int32_t>(), plan, totals);
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, mcount_c, plan, totals);
                 const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
                                                         : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
                 if (kind == MDRP_CALIB)
                     hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
-                                       h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                       h->models.as<Model>(), tags_c, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 else
                     hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(),
-                                       h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                       h->models.as<Model>(), tags_c, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 HIPCHK(hipEventRecord(e1, s));
                 h->sweep_launches++;
             }
             hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                               h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, h->model_count.as<int32_t>(),
+                               h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
                                reinterpret_cast<unsigned long long *>(cnt + 6));
+            // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
+            int32_t *lo_plan = c == 0 ? h->work_pair.as<int32_t>() : h->work_pos.as<int32_t>();
+            const int32_t *prev_plan = c == 0 ? nullptr : h->work_pair.as<int32_t>();
+            hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
+            const bool overlap = two && c == 0;
+            hipStream_t ls = overlap ? h->aux_stream2 : s;
+            if (overlap) { HIPCHK(hipEventRecord(h->ev_scan, s)); HIPCHK(hipStreamWaitEvent(ls, h->ev_scan, 0)); }
+            // overlapped: one wavefront per SIMD only (a 256-VGPR LO wavefront takes half a SIMD's register file; two of
+            // them would lock the sweep out until they retire)
+            const int lo_blocks = h->num_cu * (lo_threads == 64 ? (overlap ? lo_overlap_waves : 8) : (overlap ? 1 : 2));
+            MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), ls, rp,
+                             h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
+                             trig_cap, lo_plan, cnt + 8 + c, lm_list_stride(n_max));
+            if (overlap) { HIPCHK(hipEventRecord(h->ev_lo, ls)); lo_pending = true; }
             off += len;
         }
-        hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), h->work_pair.as<int32_t>(), h->work_pos.as<int32_t>());
-        MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(h->num_cu * (lo_threads == 64 ? 8 : 2)), lm_list_bytes(n_max), s, rp,
-                         h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                         trig_cap, h->work_pair.as<int32_t>(), h->work_pos.as<int32_t>(), cnt + 8, lm_list_stride(n_max));
+        if (lo_pending) { HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); lo_pending = false; }
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                            h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
         HIPCHK(hipGetLastError());
@@ -356,6 +401,17 @@ int mdrp_create(int device, void *stream, mdrp_handle **out) {
     HIPCHK(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
+    {   // high priority: the few long LO wavefronts should be placed first, the sweep fills the remaining slots
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const int prio = env_int("MDRP_AUX_PRIO", 1) ? prio_hi : prio_lo;
+        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
+        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio));
+    }
+    HIPCHK(hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_solve0, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_solve1, hipEventDisableTiming));
     const int tile_bytes = (int)(sizeof(double) * TILE_PTS * PT_STRIDE);
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
@@ -370,10 +426,16 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->work_pos, &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
-                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan};
+                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
+    if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+    if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
+    if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
+    if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
+    if (h->ev_solve0) (void)hipEventDestroy(h->ev_solve0);
+    if (h->ev_solve1) (void)hipEventDestroy(h->ev_solve1);
     if (h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }

@@ -56,7 +56,7 @@ struct PairState {
     int32_t n;          // correspondences (0 if the pair is degenerate: n < 3)
     int32_t table;      // sample table id (one per distinct n)
     int32_t active;     // still iterating
-    int32_t n_triggers; // triggers found in the current chunk
+    int32_t n_triggers; // triggers found in the current super-chunk
     double eps;         // normalised max_epipolar_error
     double sq_thr;      // eps^2
     double scale_reproj;
@@ -80,7 +80,7 @@ struct Trigger {
     double score_min;
     double ref_score; // filled by k_lo
     int32_t ref_cnt;
-    int32_t pad_;
+    int32_t cnt_ref; // inlier count of the minimal model k_ref (LO cost estimate: heavy problems are scheduled first)
     Model refined;
 };
 
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
         long long bc = max(run_cnt, ec);
         double bs = fmin(run_score, es);
         // replay this iteration's models in order against the true running records
-        int k_ref = -1, k_min = -1, cnt_min = 0;
+        int k_ref = -1, k_min = -1, cnt_min = 0, cnt_ref = 0;
         double score_min = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
                 if (more || better) {
                     if (more) bc = c[k];
                     if (better) { bs = s[k]; k_min = k; score_min = s[k]; cnt_min = c[k]; }
-                    k_ref = k;
+                    k_ref = k; cnt_ref = c[k];
                 }
             }
         }
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
             if (pos < trig_cap) {
                 Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
                 tr.iter = (uint32_t)(rp.chunk_off + it); tr.k_ref = k_ref; tr.k_min = k_min; tr.cnt_min = cnt_min; tr.score_min = score_min;
-                tr.ref_score = DBL_MAX; tr.ref_cnt = 0;
+                tr.ref_score = DBL_MAX; tr.ref_cnt = 0; tr.cnt_ref = cnt_ref;
             }
         }
         ntrig += __popcll(ball);
@@ -1042,79 +1042,54 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 #ifndef MDRP_LM_MINWAVES
 #define MDRP_LM_MINWAVES 2
 #endif
-// LO work plan, XCD-affine.  Every LM sweep re-reads its pair's records (64 B per correspondence per sweep) and a pair has
-// ~10 triggers in the first chunk; the records of the ~2000 problems in flight chip-wide (256 MB) do not fit the 8 x 4 MB
-// of L2, but the problems ONE XCD runs concurrently do if they belong to few pairs.  Pairs are therefore assigned to XCDs
-// (pair mod 8) and each XCD works through the triggers of its own pairs, pair after pair; when its queue is empty it
-// steals from the next one.  Placement is a speed matter only (workgroup -> XCD by blockIdx.x mod 8 is an observation,
-// not a contract).  prefix[q] = triggers before permuted pair q (pairs grouped by class), start[x] = first item of class x.
-__device__ __forceinline__ int lo_perm_pair(int q, int batch, int &cls) {
-    int off = 0;
-    for (int x = 0; x < 8; ++x) {
-        const int c = (batch - x + 7) / 8;
-        if (q < off + c) { cls = x; return 8 * (q - off) + x; }
-        off += c;
-    }
-    cls = 7;
-    return batch - 1;
-}
-
-__global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__restrict__ st, int32_t *__restrict__ prefix /*[B+1]*/,
-                                                int32_t *__restrict__ start /*[9]*/) {
+// LO work plan of one chunk: the triggers the chunk's scan appended to each pair's list, as a prefix sum over the pairs.
+// The plan is frozen when it is built (begin/end per pair), so k_lo of this chunk can run on a second stream while the
+// next chunk's scan keeps appending triggers — the LO of the first, short chunk (most of a run's LO work: records fall
+// fast at the start) hides behind the second chunk's sweep instead of leaving the chip to the tail of a launch whose
+// single problems take ~1 ms on one wavefront.
+// (Measured and dropped: longest-first ordering by inlier count — no change; XCD-affine queues, pair p on XCD p mod 8 —
+// 2.8x less HBM fetch, same time: LO is bound by dependent fp64 latency at 2 waves/SIMD, not by bandwidth or order.)
+// plan layout: prefix[B+1] | begin[B] | end[B] | total
+__global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ prev_plan /*or null*/,
+                                                int32_t *__restrict__ plan) {
     const int lane = threadIdx.x;
+    int32_t *prefix = plan, *begin = plan + batch + 1, *end = begin + batch;
+    const int32_t *prev_end = prev_plan ? prev_plan + 2 * (size_t)batch + 1 : nullptr;
     int run = 0;
-    for (int q0 = 0; q0 < batch; q0 += 64) {
-        const int q = q0 + lane;
-        int cls = 0, c = 0, off_is_start = 0;
-        if (q < batch) {
-            const int p = lo_perm_pair(q, batch, cls);
-            c = st[p].n_triggers;
-            off_is_start = (p < 8); // first pair of its class
-        }
+    for (int p0 = 0; p0 < batch; p0 += 64) {
+        const int p = p0 + lane;
+        int b = 0, e = 0;
+        if (p < batch) { b = prev_end ? prev_end[p] : 0; e = st[p].n_triggers; if (e < b) e = b; }
+        const int c = e - b;
         int inc = c;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-        if (q < batch) {
-            prefix[q] = run + inc - c;
-            if (off_is_start) start[cls] = run + inc - c;
-        }
+        if (p < batch) { prefix[p] = run + inc - c; begin[p] = b; end[p] = e; }
         run += __shfl(inc, 63, 64);
     }
-    if (lane == 0) {
-        prefix[batch] = run;
-        start[8] = run;
-        for (int x = batch; x < 8; ++x) start[x] = run; // classes without pairs (batch < 8)
-    }
+    if (lane == 0) { prefix[batch] = run; plan[3 * (size_t)batch + 1] = run; }
 }
 
 template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
-                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ prefix,
-                                                   const int32_t *__restrict__ start, int32_t *__restrict__ heads /*[8], zeroed*/,
-                                                   int list_stride) {
+                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan,
+                                                   int32_t *__restrict__ head /*zeroed*/, int list_stride) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
     if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
     __syncthreads();
-    const int my_xcd = blockIdx.x & 7;
-    int turn = 0; // queues tried so far: own first, then the neighbours'
+    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
+    const int total = plan[3 * (size_t)rp.batch + 1];
     for (;;) {
-        const int xc = (my_xcd + turn) & 7;
-        const int q_lo = start[xc], q_hi = start[xc + 1];
         __syncthreads();
-        if (threadIdx.x == 0) s_item = q_lo + atomicAdd(heads + xc, 1);
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
         __syncthreads();
         const int w = s_item;
-        if (w >= q_hi) {
-            if (++turn == 8) break;
-            continue;
-        }
-        int cls;
-        const int q = plan_find(prefix, rp.batch, w);
-        const int pair = lo_perm_pair(q, rp.batch, cls);
-        const int pos = w - prefix[q];
+        if (w >= total) break;
+        const int pair = plan_find(prefix, rp.batch, w);
+        const int pos = begin[pair] + (w - prefix[pair]);
         const PairState &ps = st[pair];
         Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
         const size_t slot_base = (size_t)pair * rp.slot_stride;
