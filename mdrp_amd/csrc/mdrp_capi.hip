@@ -66,6 +66,7 @@ struct mdrp_handle {
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
     DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, work_pos, counters, results, mask, plan;
+    DevBuf tags_s, tags2_s; // sparse tag lists ordered by candidate density (k_sort_tags)
     DevBuf tags2, model_count2, samples2; // second chunk of a two-chunk super-chunk (its solver runs beside the first chunk's sweep)
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
@@ -161,13 +162,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->model_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
     if ((rc = h->model_count2.ensure(sizeof(int32_t) * 2 * batch))) return rc;
     if ((rc = h->tags2.ensure(sizeof(uint32_t) * slots))) return rc;
+    if ((rc = h->tags_s.ensure(sizeof(uint32_t) * slots))) return rc;
+    if ((rc = h->tags2_s.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->samples2.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
     if ((rc = h->work_pair.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc; // LO plan of chunk 0: prefix | begin | end | total
     if ((rc = h->work_pos.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc;  // LO plan of chunk 1
     if ((rc = h->counters.ensure(64))) return rc;
-    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
+    if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4 + 16)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
 
     HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
@@ -202,7 +205,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
     int32_t *cnt = h->counters.as<int32_t>();
-    const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
+    const size_t tile_bytes = SCORE_TILE_BYTES;
     int64_t sum_n = 0;
     for (int i = 0; i < batch; ++i) sum_n += n_host[i] >= 3 ? n_host[i] : 0;
     (void)sum_n;
@@ -245,6 +248,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int len = (int)lens[c];
             rp.chunk_len = len; rp.chunk_off = off;
             uint32_t *tags_c = (c == 0 ? h->tags : h->tags2).as<uint32_t>();
+            uint32_t *tags_sc = (c == 0 ? h->tags_s : h->tags2_s).as<uint32_t>();
             int32_t *mcount_c = (c == 0 ? h->model_count : h->model_count2).as<int32_t>();
             if (!(two && c == 1)) { // in two-stream mode chunk 1's sampler + solver were issued on the aux stream during chunk 0
                 HIPCHK(hipMemsetAsync(mcount_c, 0, sizeof(int32_t) * 2 * batch, s));
@@ -252,6 +256,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                    h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
                 hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
                                    h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tags_c, mcount_c);
+                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp.slot_stride, h->st.as<PairState>(), mcount_c, tags_c, tags_sc);
             }
             if (two && c == 0) HIPCHK(hipEventRecord(h->ev_solve0, s));
             if (two && c == 0) {
@@ -265,6 +270,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 hipLaunchKernelGGL(k_solve, dim3((rp1.chunk_len + 255) / 256, batch), dim3(256), 0, aux, rp1, h->st.as<PairState>(),
                                    h->samples2.as<uint32_t>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(),
                                    h->slot_inl.as<int32_t>(), h->tags2.as<uint32_t>(), h->model_count2.as<int32_t>());
+                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, aux, rp1.slot_stride, h->st.as<PairState>(),
+                                   h->model_count2.as<int32_t>(), h->tags2.as<uint32_t>(), h->tags2_s.as<uint32_t>());
                 HIPCHK(hipEventRecord(h->ev_solve1, aux));
             }
             if (two && c == 1) HIPCHK(hipStreamWaitEvent(s, h->ev_solve1, 0));
@@ -278,10 +285,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                                         : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
                 if (kind == MDRP_CALIB)
                     hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), tags_c, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                       h->models.as<Model>(), tags_c, tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 else
                     hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), tags_c, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                       h->models.as<Model>(), tags_c, tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 HIPCHK(hipEventRecord(e1, s));
                 h->sweep_launches++;
             }
@@ -312,6 +319,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->sweep_evals += (int64_t)h->progress_host->evals;
+#ifdef MDRP_EXP_STATS
+        {
+            unsigned long long st8[8];
+            HIPCHK(hipMemcpy(st8, h->plan.as<int32_t>() + 2 * (size_t)batch + 2 + 4, sizeof(st8), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[mdrp] sparse stats: candidates %llu wave-iterations %llu wave-windows %llu live-lane-windows %llu exact-candidates %llu\n",
+                    st8[0], st8[1], st8[2], st8[3], st8[4]);
+            HIPCHK(hipMemset(h->plan.as<int32_t>() + 2 * (size_t)batch + 2 + 4, 0, sizeof(st8)));
+        }
+#endif
         if (getenv("MDRP_DEBUG"))
             fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu active %d max_needed %llu\n", (unsigned long long)it0,
                     (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->n_active, h->progress_host->max_needed);
@@ -412,7 +428,7 @@ int mdrp_create(int device, void *stream, mdrp_handle **out) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_solve0, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_solve1, hipEventDisableTiming));
-    const int tile_bytes = (int)(sizeof(double) * TILE_PTS * PT_STRIDE);
+    const int tile_bytes = (int)SCORE_TILE_BYTES;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     *out = h;
@@ -426,7 +442,7 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->work_pos, &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
-                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2};
+                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -562,7 +578,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk; rp.chunk_off = 0; rp.slot_stride = chunk * 4; rp.super_len = chunk;
-    const size_t tile_bytes = sizeof(double) * TILE_PTS * PT_STRIDE;
+    const size_t tile_bytes = SCORE_TILE_BYTES;
     if ((rc = h->plan.ensure(sizeof(int32_t) * 8))) return rc;
     int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 4;
     hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, 1, h->model_count.as<int32_t>(), plan, totals);
@@ -573,10 +589,10 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     HIPCHK(hipEventRecord(e0, s));
     if (kind == MDRP_CALIB)
         hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                           h->tags.as<uint32_t>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     else
         hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                           h->tags.as<uint32_t>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipGetLastError());
     const hipMemcpyKind back = mem_space == MDRP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

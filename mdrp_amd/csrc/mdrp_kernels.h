@@ -33,6 +33,13 @@ constexpr int PT_STRIDE = 6;       // doubles per correspondence record
 #define MDRP_SCORE_MINWAVES 4
 #endif
 constexpr int TILE_PTS = MDRP_TILE_PTS; // correspondences per LDS tile (48 B each)
+constexpr size_t SCORE_TILE_BYTES = (size_t)TILE_PTS * (PT_STRIDE * sizeof(double) + 4 * sizeof(float)); // + fp32 coordinates
+#ifndef MDRP_P2_WORDS
+#define MDRP_P2_WORDS 1 // 64-record candidate masks per phase-2 window of the fp32-filtered sweep
+#endif
+#ifndef MDRP_P1F_UNROLL
+#define MDRP_P1F_UNROLL 8
+#endif
 #ifndef MDRP_P1_UNROLL
 #define MDRP_P1_UNROLL 4
 #endif
@@ -297,6 +304,47 @@ __device__ __forceinline__ int candidate_count(const double *__restrict__ recs, 
     return c;
 }
 
+// Conservative fp32 phase-1 filter of the sweep for one hypothesis (see score_tile_f32): fp32 copy of E and the
+// threshold tb such that  |fl32(x2' E x1)| > tb  proves  C^2 >= thr * den  for every record inside the pair's box.
+__device__ __forceinline__ void bound_setup(const double E[9], const PairState &ps, double thr, float Ef[9], float &tb, double &thr_dmax) {
+    // Dmax: upper bound of the Sampson denominator over the pair's coordinate box
+    const double ax = ps.box[0], ay = ps.box[1], cx = ps.box[2], cy = ps.box[3];
+    const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
+    const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
+    thr_dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
+    const double e2 = fabs(E[6]) * ax + fabs(E[7]) * ay + fabs(E[8]);
+    const double M = e0 * cx + e1 * cy + e2;
+    const double T = sqrt(thr * (1.0 + 1e-12) * thr_dmax);
+    tb = (M < 1e30) ? (float)((T + 2e-6 * M) * (1.0 + 1e-6)) + 1e-30f : __builtin_inff(); // !(M < 1e30) also catches NaN
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ef[i] = (float)E[i];
+}
+
+// fp32 record layout of the phase-1 filter: two records per 32 B, component-major (a0 a1 b0 b1)(c0 c1 d0 d1)
+__device__ __forceinline__ void store_rec32(float4 *__restrict__ recs32, int i, double a, double b, double c, double d) {
+    float *q = reinterpret_cast<float *>(recs32) + (i >> 1) * 8 + (i & 1);
+    q[0] = (float)a; q[2] = (float)b; q[4] = (float)c; q[6] = (float)d;
+}
+
+constexpr int PROBE_PTS = 64; // records of the density probe (k_solve)
+// phase-1 candidates among the first g <= 64 records: the sort key of k_sort_tags
+__device__ __forceinline__ int probe_count(const float4 *__restrict__ recs32, int g, const float Ef[9], float tb) {
+    int c = 0;
+    for (int j = 0; j < g; j += 2) {
+        const float4 ab = recs32[j], cd = recs32[j + 1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float a = h ? ab.y : ab.x, b = h ? ab.w : ab.z, cc = h ? cd.y : cd.x, d = h ? cd.w : cd.z;
+            const float e0 = fmaf(Ef[0], a, fmaf(Ef[1], b, Ef[2]));
+            const float e1 = fmaf(Ef[3], a, fmaf(Ef[4], b, Ef[5]));
+            const float e2 = fmaf(Ef[6], a, fmaf(Ef[7], b, Ef[8]));
+            const float C = fmaf(cc, e0, fmaf(d, e1, e2));
+            c += (!(fabsf(C) > tb) && j + h < g) ? 1 : 0;
+        }
+    }
+    return c;
+}
+
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
 // with ONE atomic per wave (wave-aggregated prefix sum).
@@ -309,6 +357,13 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     const PairState &ps = st[pair];
     if (!ps.active) return;
     const bool live = it < rp.chunk_len;
+    __shared__ float4 s_probe[PROBE_PTS]; // fp32 copy of the pair's first records (density probe)
+    const int nprobe = min(ps.n, PROBE_PTS);
+    if ((int)threadIdx.x < nprobe) {
+        const double *p = pts + ((size_t)pair * rp.n_max + threadIdx.x) * PT_STRIDE;
+        store_rec32(s_probe, threadIdx.x, p[0], p[1], p[2], p[3]);
+    }
+    __syncthreads();
     int n = 0;
     Model out[4];
     if (live) {
@@ -331,6 +386,7 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     const int dense_min = max(4, ncls / 8);
     const double *recs = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     int dense_mask = 0, n_dense = 0;
+    uint32_t keys = 0; // 8 bits per model: phase-1 candidates among the probe records
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < n) {
@@ -343,6 +399,14 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
             } else fundamental_from_E(Em, out[k].f1, out[k].f2, E);
 #ifndef MDRP_NO_CLASSIFY
             if (candidate_count(recs, ncls, E, ps.sq_thr) >= dense_min) { dense_mask |= 1 << k; ++n_dense; }
+#endif
+#ifndef MDRP_NO_SORT
+            if (!((dense_mask >> k) & 1)) {
+                float Ef[9], tb;
+                double dm;
+                bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
+                keys |= (uint32_t)probe_count(s_probe, nprobe, Ef, tb) << (8 * k);
+            }
 #endif
         }
     }
@@ -373,7 +437,7 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
         if (k < n) {
             models[slot0 + k] = out[k];
             if ((dense_mask >> k) & 1) { tags[tag_base + (cap - 1 - pos_d)] = (uint32_t)((rp.chunk_off + it) * 4 + k); ++pos_d; }
-            else { tags[tag_base + pos_s] = (uint32_t)((rp.chunk_off + it) * 4 + k); ++pos_s; }
+            else { tags[tag_base + pos_s] = (uint32_t)((rp.chunk_off + it) * 4 + k) | (((keys >> (8 * k)) & 0xFFu) << 24); ++pos_s; }
         } else {
             slot_inl[slot0 + k] = -1;
         }
@@ -584,6 +648,156 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
     }
 }
 
+// Sparse hypotheses, phase 1 in fp32.  The phase-1 test only has to be CONSERVATIVE (keep a superset of the records the
+// exact fp64 test accepts), so it runs at the fp32 VALU rate (2x fp64) on an fp32 copy of the coordinates:
+//   exact:  C^2 < thr_hi * den   =>   |C| < T := sqrt(thr_hi * Dmax)
+//   fp32:   |C32 - C| <= 7u * M,  u = 2^-24,  M = sum of |E_ij| |x2_i|max |x1_j|max   (13 input + 8 FMA roundings, depth 7)
+//   keep the record unless |C32| > tb,  tb >= T + 2e-6 * M  (5x margin on 7u = 4.2e-7); NaN keeps; tb = inf keeps all.
+// Survivors (~1-2 % of the records) are re-tested and scored exactly in fp64 by phase 2, so results are bit-identical.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef MDRP_EXP_STATS
+__device__ unsigned long long *g_stats; // experiment counters (set by k_score from its totals pointer)
+#endif
+template <bool POSE>
+__device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, const float4 *__restrict__ recs32, int npts,
+                                               const double E[9], const float Ef[9], float tb, const Model *__restrict__ mp,
+                                               double thr, double &score, int &cnt, Prune &pr) {
+    // recs32: two records per 32 B, component-major: (a0 a1 b0 b1)(c0 c1 d0 d1) -> v_pk_fma_f32 without shuffles.
+    // Phase 1 fills the candidate masks of a whole window (P2_WORDS x 64 records) before phase 2 runs: phase 2 is a
+    // per-lane loop, the wavefront pays the MAXIMUM candidate count over its lanes, and max / mean falls with the
+    // window length (0.5 candidates per lane per 32 records: max ~3 per 32, ~6 per 128).
+    constexpr int K = MDRP_P2_WORDS, WIN = 64 * K;
+    static_assert(TILE_PTS % WIN == 0, "window must divide the tile");
+    f32x2 Ev[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ev[i] = (f32x2)(Ef[i]);
+    for (int p0 = 0; p0 < npts; p0 += WIN) {
+        const int g = min(WIN, npts - p0);
+        const double *base = recs + (size_t)p0 * PT_STRIDE;
+        uint64_t m[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            uint32_t half[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int q0 = 64 * k + 32 * h;
+                if (q0 < g) { // wave-uniform
+                    const float4 *b32 = recs32 + p0 + q0;
+                    uint32_t mask = 0;
+#pragma unroll 1
+                    for (int j0 = 0; j0 < 32; j0 += MDRP_P1F_UNROLL) {
+#pragma unroll
+                        for (int jj = 0; jj < MDRP_P1F_UNROLL; jj += 2) {
+                            const int j = j0 + jj;
+                            const float4 ab = b32[j], cd = b32[j + 1];
+                            const f32x2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, c = {cd.x, cd.y}, d = {cd.z, cd.w};
+                            const f32x2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
+                            const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
+                            const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
+                            const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
+                            mask |= !(fabsf(C.x) > tb) ? (1u << j) : 0u;
+                            mask |= !(fabsf(C.y) > tb) ? (2u << j) : 0u;
+                        }
+                    }
+                    const int valid = g - q0; // records past the end of the tile hold stale LDS
+                    if (valid < 32) mask &= (1u << valid) - 1u;
+                    half[h] = mask;
+                }
+            }
+            m[k] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
+        }
+#ifdef MDRP_EXP_NOP2
+#pragma unroll
+        for (int k = 0; k < K; ++k) { asm volatile("" ::"v"(m[k])); m[k] = 0; }
+#endif
+        uint64_t any = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) { if (pr.dead) m[k] = 0; any |= m[k]; }
+#ifdef MDRP_EXP_STATS
+        {
+            int pc = 0;
+#pragma unroll
+            for (int k = 0; k < K; ++k) pc += __popcll(m[k]);
+            int mx = pc, sm = pc, lv = pr.dead ? 0 : 1;
+            for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); sm += __shfl_xor(sm, o, 64); lv += __shfl_xor(lv, o, 64); }
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&g_stats[0], (unsigned long long)sm); atomicAdd(&g_stats[1], (unsigned long long)mx);
+                atomicAdd(&g_stats[2], 1ull); atomicAdd(&g_stats[3], (unsigned long long)lv);
+            }
+        }
+#endif
+        if (any) {
+            double R[9], t[3];
+            if (POSE) {
+                double q[4];
+                q[0] = mp->q[0]; q[1] = mp->q[1]; q[2] = mp->q[2]; q[3] = mp->q[3];
+                t[0] = mp->t[0]; t[1] = mp->t[1]; t[2] = mp->t[2];
+                quat_to_R(q, R);
+            }
+            while (any) { // per-lane candidates, ascending record order (same accumulation order as the CPU loop)
+                uint64_t cur = m[0];
+                int off = 0;
+#pragma unroll
+                for (int k = 1; k < K; ++k) {
+                    const bool take = cur == 0;
+                    cur = take ? m[k] : cur;
+                    off = take ? 64 * k : off;
+                }
+                const int j = off + __ffsll((unsigned long long)cur) - 1;
+                const uint64_t nxt = cur & (cur - 1);
+                any = 0;
+#pragma unroll
+                for (int k = 0; k < K; ++k) { m[k] = (off == 64 * k) ? nxt : m[k]; any |= m[k]; }
+                score_point<POSE>(base + j * PT_STRIDE, E, R, t, thr, score, cnt);
+            }
+        }
+        pr.processed += g;
+#ifndef MDRP_NO_PRUNE
+        if (pr.rec_score < DBL_MAX) {
+            pr.dead = pr.dead || (((long long)cnt + (long long)(pr.n - pr.processed) <= pr.rec_cnt) &&
+                                  (score + thr * (double)(pr.processed - cnt) >= pr.rec_score));
+            if (__all(pr.dead)) { pr.wave_dead = true; return; }
+        }
+#endif
+    }
+}
+
+// Sparse hypotheses of a pair, ordered by their phase-1 candidate density (key in the top byte of the tag, k_solve).
+// Phase 2 of the sweep costs a wavefront the MAXIMUM candidate count over its lanes and densities differ by 10x between
+// hypotheses (measured unsorted: maximum 14 per 64 records, mean 3), so the sweep wants workgroups of similar
+// hypotheses.  Whole workgroups, not wavefronts: the four wavefronts of a workgroup meet at the tile barriers, and one
+// slow wavefront parks the other three in their SIMD slots (sorting inside the workgroup made the sweep 3x slower).
+// One workgroup per pair, counting sort over 65 keys; which lane scores a hypothesis does not change its result.
+__global__ __launch_bounds__(256) void k_sort_tags(int slot_stride, const PairState *__restrict__ st, const int32_t *__restrict__ model_count,
+                                                   const uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    if (!st[pair].active) return;
+    __shared__ int s_hist[PROBE_PTS + 1], s_pos[PROBE_PTS + 1];
+    const int cnt = model_count[2 * pair];
+    const uint32_t *src = tags + (size_t)pair * slot_stride;
+    uint32_t *dst = tags_sorted + (size_t)pair * slot_stride;
+    if (tid <= PROBE_PTS) s_hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 256) atomicAdd(&s_hist[min(src[i] >> 24, (uint32_t)PROBE_PTS)], 1);
+    __syncthreads();
+    if (tid < 64) {
+        const int v = s_hist[tid];
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (tid >= o) incl += u;
+        }
+        s_pos[tid] = incl - v;
+        if (tid == 63) s_pos[64] = incl;
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 256) {
+        const uint32_t t = src[i];
+        dst[atomicAdd(&s_pos[min(t >> 24, (uint32_t)PROBE_PTS)], 1)] = t & 0xFFFFFFu;
+    }
+}
+
 // Work plan of one sweep launch: the workgroups a pair needs (ceil(count / SCORE_THREADS) per density class).
 // One wavefront, 64 pairs per step.  plan[0..B] = prefix sum of blocks per pair, plan[B+1 .. 2B] = sparse blocks of the pair.
 __global__ __launch_bounds__(64) void k_plan(int batch, const int32_t *__restrict__ model_count, int32_t *__restrict__ plan,
@@ -632,10 +846,15 @@ __device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int
 template <bool POSE>
 __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags,
+                                                         const uint32_t *__restrict__ tags_sparse,
                                                          const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
                                                          int32_t *__restrict__ slot_inl, const int32_t *__restrict__ plan,
                                                          int32_t *__restrict__ totals) {
-    extern __shared__ double tile[]; // TILE_PTS * PT_STRIDE doubles
+    extern __shared__ double tile[]; // TILE_PTS * PT_STRIDE doubles, then TILE_PTS float4 (fp32 coordinates)
+    float4 *tile32 = reinterpret_cast<float4 *>(tile + TILE_PTS * PT_STRIDE);
+#ifdef MDRP_EXP_STATS
+    g_stats = reinterpret_cast<unsigned long long *>(totals + 4);
+#endif
     const int total = totals[1];
     const int tid = threadIdx.x;
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -644,6 +863,12 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     const int bi = w - plan[pair];
     const bool dense = bi >= blk_sparse;
     const int blk = dense ? bi - blk_sparse : bi;
+#ifdef MDRP_SKIP_DENSE  // timing experiments only (results are wrong)
+    if (dense) continue;
+#endif
+#ifdef MDRP_SKIP_SPARSE
+    if (!dense) continue;
+#endif
     const int cnt_sparse = model_count[2 * pair], cnt_dense = model_count[2 * pair + 1];
     const PairState &ps = st[pair];
     const int n = ps.n;
@@ -655,12 +880,13 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     { // tag list of the pair: sparse hypotheses grow from the front, dense ones from the back (k_solve)
         const int i = blk * SCORE_THREADS + tid;
         live = i < (dense ? cnt_dense : cnt_sparse);
-        if (live) slot = tags[slot_base + (dense ? cap - 1 - i : i)];
+        if (live) slot = dense ? tags[slot_base + cap - 1 - i] : (tags_sparse[slot_base + i] & 0xFFFFFFu);
     }
-    double E[9];
+    double E[9], thr_dmax;
+    float tb, Ef[9];
+    const Model *mp = models + slot_base + slot;
 #pragma unroll
     for (int i = 0; i < 9; ++i) E[i] = 0;
-    const Model *mp = models + slot_base + slot;
     if (live) {
         const Model m = *mp;
         double R[9], Em[9];
@@ -673,14 +899,7 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
             fundamental_from_E(Em, m.f1, m.f2, E);
         }
     }
-    // Dmax: upper bound of the Sampson denominator over the pair's coordinate box
-    double thr_dmax;
-    {
-        const double ax = ps.box[0], ay = ps.box[1], cx = ps.box[2], cy = ps.box[3];
-        const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
-        const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
-        thr_dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
-    }
+    bound_setup(E, ps, thr, Ef, tb, thr_dmax);
     double score = 0;
     int cnt = 0;
     Prune pr;
@@ -696,6 +915,14 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
             double2 *dst = reinterpret_cast<double2 *>(tile);
             const int nvec = npts * (PT_STRIDE / 2);
             for (int i = tid; i < nvec; i += SCORE_THREADS) dst[i] = src[i];
+#ifndef MDRP_NO_F32
+            if (!dense) { // fp32 copy of the coordinates for the sparse phase-1 filter (the reads hit L1/L2)
+                for (int i = tid; i < npts; i += SCORE_THREADS) {
+                    const double2 a = src[i * (PT_STRIDE / 2)], c = src[i * (PT_STRIDE / 2) + 1];
+                    store_rec32(tile32, i, a.x, a.y, c.x, c.y);
+                }
+            }
+#endif
         }
         __syncthreads();
         if (!pr.wave_dead) {
@@ -703,7 +930,11 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
             score_tile<POSE, false>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
 #else
             if (dense) score_tile_dense<POSE>(tile, npts, E, mp, thr, score, cnt, pr);
+#ifdef MDRP_NO_F32
             else score_tile<POSE, true>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
+#else
+            else score_tile_f32<POSE>(tile, tile32, npts, E, Ef, tb, mp, thr, score, cnt, pr);
+#endif
 #endif
         }
     }
