@@ -44,13 +44,12 @@ constexpr size_t SCORE_TILE_BYTES = (size_t)TILE_PTS * (PT_STRIDE * sizeof(doubl
 #define MDRP_P1_UNROLL 4
 #endif
 constexpr int PRUNE_EVERY = 4;     // bail-out test every PRUNE_EVERY groups of 32 records (power of two)
-#ifndef MDRP_CLS_PTS
-#define MDRP_CLS_PTS 32
+#ifndef MDRP_DENSE_KEY
+#define MDRP_DENSE_KEY 40 // of 64 probe records
 #endif
 #ifndef MDRP_SOLVE_MINWAVES
 #define MDRP_SOLVE_MINWAVES 3
 #endif
-constexpr int CLS_PTS = MDRP_CLS_PTS;        // records used to pre-classify hypotheses as dense / sparse
 #ifndef MDRP_SCORE_THREADS
 #define MDRP_SCORE_THREADS 256
 #endif
@@ -291,19 +290,6 @@ __device__ __forceinline__ SampsonTerms sampson_terms(const double E[9], double 
     return r;
 }
 
-// number of phase-1 candidates among the first `npts` records (global memory, wave-uniform addresses)
-__device__ __forceinline__ int candidate_count(const double *__restrict__ recs, int npts, const double E[9], double thr) {
-    const double thr_hi = thr * (1.0 + 1e-12);
-    int c = 0;
-    for (int p = 0; p < npts; ++p) {
-        const double2 *P = reinterpret_cast<const double2 *>(recs + (size_t)p * PT_STRIDE);
-        const double2 p01 = P[0], p23 = P[1];
-        const SampsonTerms s = sampson_terms(E, p01.x, p01.y, p23.x, p23.y);
-        c += (s.C2 < thr_hi * s.den) ? 1 : 0;
-    }
-    return c;
-}
-
 // Conservative fp32 phase-1 filter of the sweep for one hypothesis (see score_tile_f32): fp32 copy of E and the
 // threshold tb such that  |fl32(x2' E x1)| > tb  proves  C^2 >= thr * den  for every record inside the pair's box.
 __device__ __forceinline__ void bound_setup(const double E[9], const PairState &ps, double thr, float Ef[9], float &tb, double &thr_dmax) {
@@ -380,11 +366,10 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
         // a NaN hypothesis can never become a record (its score is N*thr, count 0) except as the very first model;
         // drop it (the reference's own P3P emits NaN poses for ~2% of garbage samples)
     }
-    // classify each model by its candidate density on the first records of the pair (see k_score): dense
-    // hypotheses are appended from the back of the tag list, sparse ones from the front
-    const int ncls = min(ps.n, CLS_PTS);
-    const int dense_min = max(4, ncls / 8);
-    const double *recs = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    // Candidate density of each model on the pair's first records (fp32 phase-1 filter of the sweep): the sort key of
+    // k_sort_tags.  Models that keep more than DENSE_KEY of 64 probe records go to the single-pass "dense" sweep
+    // (appended from the back of the tag list), everything else to the two-phase sweep (front).
+    const int dense_min = (MDRP_DENSE_KEY * nprobe + PROBE_PTS - 1) / PROBE_PTS;
     int dense_mask = 0, n_dense = 0;
     uint32_t keys = 0; // 8 bits per model: phase-1 candidates among the probe records
 #pragma unroll
@@ -397,16 +382,13 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
 #pragma unroll
                 for (int i = 0; i < 9; ++i) E[i] = Em[i];
             } else fundamental_from_E(Em, out[k].f1, out[k].f2, E);
+            float Ef[9], tb;
+            double dm;
+            bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
+            const int key = probe_count(s_probe, nprobe, Ef, tb);
+            keys |= (uint32_t)key << (8 * k);
 #ifndef MDRP_NO_CLASSIFY
-            if (candidate_count(recs, ncls, E, ps.sq_thr) >= dense_min) { dense_mask |= 1 << k; ++n_dense; }
-#endif
-#ifndef MDRP_NO_SORT
-            if (!((dense_mask >> k) & 1)) {
-                float Ef[9], tb;
-                double dm;
-                bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
-                keys |= (uint32_t)probe_count(s_probe, nprobe, Ef, tb) << (8 * k);
-            }
+            if (key >= dense_min && nprobe >= 8) { dense_mask |= 1 << k; ++n_dense; }
 #endif
         }
     }
