@@ -1,3 +1,4 @@
+#include <stdio.h>
 /* orc_ransac.c — LO-RANSAC driver and the three estimate_* wrappers.  TEST INFRASTRUCTURE (see mdrp_oracle.h).
  *
  * Restates (reference binary):
@@ -54,8 +55,9 @@ static void refine_model(const estimator *e, orc_model *m) {
     b.max_iterations = 25; b.loss_type = 1;
     b.loss_scale = e->kind == ORC_VARYING ? 1.0 : e->opt->max_epipolar_error;
     b.gradient_tol = 1e-10; b.step_tol = 1e-8; b.initial_lambda = 1e-3; b.min_lambda = 1e-10; b.max_lambda = 1e10;
-    orc_refine(e->kind, e->x1, e->x2, e->d1, e->d2, e->n, m, e->scale_reproj, e->opt->weight_sampson, &b,
-               e->kind == ORC_CALIB && e->opt->estimate_shift, NULL);
+    const orc_bundle_stats st = orc_refine(e->kind, e->x1, e->x2, e->d1, e->d2, e->n, m, e->scale_reproj, e->opt->weight_sampson, &b,
+                                           e->kind == ORC_CALIB && e->opt->estimate_shift, NULL);
+    if (getenv("ORC_TRACE_LM")) fprintf(stderr, "[orc] LO  LM iterations %llu invalid %llu\n", (unsigned long long)st.iterations, (unsigned long long)st.invalid_steps);
 }
 
 orc_ransac_stats orc_ransac(int kind, const double *x1, const double *x2, const double *d1, const double *d2, int n,
@@ -184,7 +186,8 @@ orc_ransac_stats orc_estimate(int kind, const double *x1, const double *x2, cons
         const double sr = ro.max_reproj_error > 0.0
                               ? (ro.max_epipolar_error * ro.max_epipolar_error) / (ro.max_reproj_error * ro.max_reproj_error)
                               : 0.0;
-        orc_refine(kind, i1, i2, e1, e2, ni, best, sr, ro.weight_sampson, &bo, kind == ORC_CALIB && ro.estimate_shift, NULL);
+        const orc_bundle_stats fst = orc_refine(kind, i1, i2, e1, e2, ni, best, sr, ro.weight_sampson, &bo, kind == ORC_CALIB && ro.estimate_shift, NULL);
+        if (getenv("ORC_TRACE_LM")) fprintf(stderr, "[orc] final LM iterations %llu invalid %llu (n = %d)\n", (unsigned long long)fst.iterations, (unsigned long long)fst.invalid_steps, ni);
         free(i1); free(i2); free(e1); free(e2);
     }
     if (kind != ORC_CALIB) { best->f1 *= norm; best->f2 *= norm; }
