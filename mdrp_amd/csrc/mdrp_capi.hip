@@ -61,13 +61,14 @@ struct mdrp_handle {
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
     hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
-    hipEvent_t ev_scan = nullptr, ev_lo = nullptr, ev_solve0 = nullptr, ev_solve1 = nullptr;
+    static constexpr int NC_MAX = 8; // chunks of a super-chunk
+    hipEvent_t ev_lo = nullptr, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
-    DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, work_pos, counters, results, mask, plan;
+    DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, counters, results, mask, plan;
     DevBuf tags_s, tags2_s; // sparse tag lists ordered by candidate density (k_sort_tags)
-    DevBuf tags2, model_count2, samples2; // second chunk of a two-chunk super-chunk (its solver runs beside the first chunk's sweep)
+    DevBuf tags2, model_count2, samples2; // odd chunks of a super-chunk (chunk c + 1 is solved beside the sweep of chunk c)
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -167,8 +168,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->samples2.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
-    if ((rc = h->work_pair.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc; // LO plan of chunk 0: prefix | begin | end | total
-    if ((rc = h->work_pos.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc;  // LO plan of chunk 1
+    if ((rc = h->work_pair.ensure(sizeof(int32_t) * mdrp_handle::NC_MAX * (3 * (size_t)batch + 2)))) return rc; // LO plan per chunk: prefix | begin | end | total
     if ((rc = h->counters.ensure(64))) return rc;
     if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4 + 16)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
 
@@ -218,63 +218,91 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // super-chunk is split into a short chunk (512 iterations) that establishes the records and the rest, which k_score
     // then sweeps with the exact bail-out (see Prune in mdrp_kernels.h); both chunks' triggers go to ONE k_lo launch.
     // Beyond the certain range a super-chunk is one chunk sized by the largest remaining dynamic_max_iter.
-    const uint64_t first_chunk = (uint64_t)env_int("MDRP_FIRST_CHUNK", 512);
+    // leading chunk lengths of the first super-chunk; the last chunk takes the rest.  Measured on the benchmark shape:
+    // "512" 53.9k pairs/s, "512,1536" 52.7k, "512,2560" 49.8k (a 256-VGPR LO wavefront per SIMD leaves little room for a
+    // third concurrent kernel, and the sort of the next chunk crawls beside it)
+    std::vector<uint64_t> lead;
+    {
+        const char *e = getenv("MDRP_CHUNKS");
+        std::string spec = e ? e : "512";
+        size_t pos = 0;
+        while (pos < spec.size() && (int)lead.size() < mdrp_handle::NC_MAX - 1) {
+            const size_t q = spec.find(',', pos);
+            const long v = atol(spec.substr(pos, q == std::string::npos ? std::string::npos : q - pos).c_str());
+            if (v > 0) lead.push_back((uint64_t)v);
+            if (q == std::string::npos) break;
+            pos = q + 1;
+        }
+    }
     uint64_t max_needed = 0;
     rp.slot_stride = chunk_cap * 4;
+    const size_t lo_plan_ints = 3 * (size_t)batch + 2;
     while (true) {
-        uint64_t lens[2] = {0, 0};
+        uint64_t lens[mdrp_handle::NC_MAX] = {0};
         int n_chunks = 1;
         if (it0 < certain) {
             const uint64_t span = std::min<uint64_t>(certain - it0, (uint64_t)chunk_cap);
-            if (it0 == 0 && span >= 4 * first_chunk) { lens[0] = first_chunk; lens[1] = span - first_chunk; n_chunks = 2; }
-            else lens[0] = span;
+            uint64_t used = 0;
+            n_chunks = 0;
+            if (it0 == 0)
+                for (uint64_t l : lead) { // a leading chunk only while at least as much again remains behind it
+                    if (used + 2 * l > span) break;
+                    lens[n_chunks++] = l; used += l;
+                }
+            lens[n_chunks++] = span - used;
         } else {
             lens[0] = std::min<uint64_t>(std::min<uint64_t>(std::max<uint64_t>(max_needed, 256), ro->max_iterations - it0), (uint64_t)chunk_cap);
         }
-        const uint64_t super_len = lens[0] + lens[1];
+        uint64_t super_len = 0;
+        for (int c = 0; c < n_chunks; ++c) super_len += lens[c];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
         HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
-        // Two-stream schedule of a two-chunk super-chunk (the benchmark shape):
-        //   main:  samples0 solve0 | plan0 score0 scan0 loplan0 | (wait solve1) plan1 score1 scan1 loplan1 | (wait lo0) lo1 walk
-        //   aux :                    (wait solve0) samples1 solve1 | (wait scan0) lo0
-        // solve1 (latency-bound: gathers, divergent roots) hides behind score0, and lo0 (dependent fp64 latency at 2 waves/SIMD,
-        // ~1 ms per problem on one wavefront) behind score1 (VALU-bound, short workgroups that fill whatever lo0 leaves idle).
-        // Each chunk has its own tag list / model counters; slots, triggers and plans of the two chunks are disjoint.
-        const bool two = n_chunks == 2 && lo_overlap;
-        hipStream_t aux = h->aux_stream;
-        int off = 0;
-        bool lo_pending = false;
+        // Three-stream pipeline over the chunks of a super-chunk (the benchmark shape: 512 | 9488 iterations):
+        //   main:  solve 0 | score 0, scan 0 | score 1, scan 1 | ... | walk
+        //   aux :            solve 1         | solve 2 ...
+        //   aux2:                              lo 0             | lo 1 ...
+        // The solver (gathers, divergent roots) and the LO refinements (dependent fp64 latency at 2 waves/SIMD) leave most
+        // issue slots idle; the sweep (VALU-bound, short workgroups) fills them.  Chunk c + 1 is solved while chunk c is
+        // swept, and chunk c's triggers are refined while chunk c + 1 is swept.  Chunks alternate between two sets of tag
+        // lists / model counters / sample tables; slots, triggers and LO plans of different chunks are disjoint.
+        const bool piped = n_chunks > 1 && lo_overlap;
+        hipStream_t aux = piped ? h->aux_stream : s, aux2 = piped ? h->aux_stream2 : s;
+        int offs[mdrp_handle::NC_MAX] = {0};
+        for (int c = 1; c < n_chunks; ++c) offs[c] = offs[c - 1] + (int)lens[c - 1];
+        auto issue_solve = [&](int c, hipStream_t st_) -> int {
+            RunParams r = rp;
+            r.chunk_len = (int)lens[c]; r.chunk_off = offs[c];
+            const bool odd = c & 1;
+            uint32_t *tg = (odd ? h->tags2 : h->tags).as<uint32_t>(), *tgs = (odd ? h->tags2_s : h->tags_s).as<uint32_t>();
+            uint32_t *smp = (odd ? h->samples2 : h->samples).as<uint32_t>();
+            int32_t *mc = (odd ? h->model_count2 : h->model_count).as<int32_t>();
+            HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
+            hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(),
+                               h->table_state.as<uint64_t>(), r.chunk_len, smp);
+            hipLaunchKernelGGL(k_solve, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp,
+                               h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+            hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, st_, r, h->st.as<PairState>(), h->pts.as<double>(),
+                               h->models.as<Model>(), mc, tg, tgs);
+            return MDRP_OK;
+        };
+        if ((rc = issue_solve(0, s))) return rc;
+        if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
         for (int c = 0; c < n_chunks; ++c) {
             const int len = (int)lens[c];
-            rp.chunk_len = len; rp.chunk_off = off;
-            uint32_t *tags_c = (c == 0 ? h->tags : h->tags2).as<uint32_t>();
-            uint32_t *tags_sc = (c == 0 ? h->tags_s : h->tags2_s).as<uint32_t>();
-            int32_t *mcount_c = (c == 0 ? h->model_count : h->model_count2).as<int32_t>();
-            if (!(two && c == 1)) { // in two-stream mode chunk 1's sampler + solver were issued on the aux stream during chunk 0
-                HIPCHK(hipMemsetAsync(mcount_c, 0, sizeof(int32_t) * 2 * batch, s));
-                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, s, n_tables, h->table_n.as<int32_t>(),
-                                   h->table_state.as<uint64_t>(), len, h->samples.as<uint32_t>());
-                hipLaunchKernelGGL(k_solve, dim3((len + 255) / 256, batch), dim3(256), 0, s, rp, h->st.as<PairState>(), h->samples.as<uint32_t>(),
-                                   h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tags_c, mcount_c);
-                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp.slot_stride, h->st.as<PairState>(), mcount_c, tags_c, tags_sc);
+            rp.chunk_len = len; rp.chunk_off = offs[c];
+            const bool odd = c & 1;
+            uint32_t *tags_sc = (odd ? h->tags2_s : h->tags_s).as<uint32_t>();
+            int32_t *mcount_c = (odd ? h->model_count2 : h->model_count).as<int32_t>();
+            if (c + 1 < n_chunks) {
+                if (piped) {
+                    // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
+                    HIPCHK(hipStreamWaitEvent(aux, c == 0 ? h->ev_solved[0] : h->ev_scanned[c - 1], 0));
+                    if ((rc = issue_solve(c + 1, aux))) return rc;
+                    HIPCHK(hipEventRecord(h->ev_solved[c + 1], aux));
+                }
             }
-            if (two && c == 0) HIPCHK(hipEventRecord(h->ev_solve0, s));
-            if (two && c == 0) {
-                // issue chunk 1's sampler + solver now so that it runs beside chunk 0's sweep
-                RunParams rp1 = rp;
-                rp1.chunk_len = (int)lens[1]; rp1.chunk_off = len;
-                HIPCHK(hipStreamWaitEvent(aux, h->ev_solve0, 0));
-                HIPCHK(hipMemsetAsync(h->model_count2.p, 0, sizeof(int32_t) * 2 * batch, aux));
-                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, aux, n_tables, h->table_n.as<int32_t>(),
-                                   h->table_state.as<uint64_t>(), rp1.chunk_len, h->samples2.as<uint32_t>());
-                hipLaunchKernelGGL(k_solve, dim3((rp1.chunk_len + 255) / 256, batch), dim3(256), 0, aux, rp1, h->st.as<PairState>(),
-                                   h->samples2.as<uint32_t>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(),
-                                   h->slot_inl.as<int32_t>(), h->tags2.as<uint32_t>(), h->model_count2.as<int32_t>());
-                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, aux, rp1.slot_stride, h->st.as<PairState>(),
-                                   h->model_count2.as<int32_t>(), h->tags2.as<uint32_t>(), h->tags2_s.as<uint32_t>());
-                HIPCHK(hipEventRecord(h->ev_solve1, aux));
-            }
-            if (two && c == 1) HIPCHK(hipStreamWaitEvent(s, h->ev_solve1, 0));
+            if (piped && c > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
+            if (!piped && c > 0 && (rc = issue_solve(c, s))) return rc;
             {
                 hipEvent_t e0, e1;
                 if ((rc = get_events(h, &e0, &e1))) return rc;
@@ -285,10 +313,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                                         : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
                 if (kind == MDRP_CALIB)
                     hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), tags_c, tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                       h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 else
                     hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), tags_c, tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                       h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 HIPCHK(hipEventRecord(e1, s));
                 h->sweep_launches++;
             }
@@ -296,22 +324,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
                                reinterpret_cast<unsigned long long *>(cnt + 6));
             // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
-            int32_t *lo_plan = c == 0 ? h->work_pair.as<int32_t>() : h->work_pos.as<int32_t>();
-            const int32_t *prev_plan = c == 0 ? nullptr : h->work_pair.as<int32_t>();
+            int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
+            const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
             hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
-            const bool overlap = two && c == 0;
-            hipStream_t ls = overlap ? h->aux_stream2 : s;
-            if (overlap) { HIPCHK(hipEventRecord(h->ev_scan, s)); HIPCHK(hipStreamWaitEvent(ls, h->ev_scan, 0)); }
-            // overlapped: one wavefront per SIMD only (a 256-VGPR LO wavefront takes half a SIMD's register file; two of
-            // them would lock the sweep out until they retire)
-            const int lo_blocks = h->num_cu * (lo_threads == 64 ? (overlap ? lo_overlap_waves : 8) : (overlap ? 1 : 2));
-            MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), ls, rp,
+            if (piped) { HIPCHK(hipEventRecord(h->ev_scanned[c], s)); HIPCHK(hipStreamWaitEvent(aux2, h->ev_scanned[c], 0)); }
+            const int lo_blocks = h->num_cu * (lo_threads == 64 ? lo_overlap_waves : 2);
+            MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
                              h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
                              trig_cap, lo_plan, cnt + 8 + c, lm_list_stride(n_max));
-            if (overlap) { HIPCHK(hipEventRecord(h->ev_lo, ls)); lo_pending = true; }
-            off += len;
         }
-        if (lo_pending) { HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); lo_pending = false; }
+        if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                            h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
         HIPCHK(hipGetLastError());
@@ -424,10 +446,11 @@ int mdrp_create(int device, void *stream, mdrp_handle **out) {
         HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
         HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio));
     }
-    HIPCHK(hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_solve0, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_solve1, hipEventDisableTiming));
+    for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&h->ev_solved[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_scanned[i], hipEventDisableTiming));
+    }
     const int tile_bytes = (int)SCORE_TILE_BYTES;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
@@ -441,17 +464,18 @@ void mdrp_destroy(mdrp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
-                      &h->work_pos, &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
+                      &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
-    if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
-    if (h->ev_solve0) (void)hipEventDestroy(h->ev_solve0);
-    if (h->ev_solve1) (void)hipEventDestroy(h->ev_solve1);
+    for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
+        if (h->ev_solved[i]) (void)hipEventDestroy(h->ev_solved[i]);
+        if (h->ev_scanned[i]) (void)hipEventDestroy(h->ev_scanned[i]);
+    }
     if (h->owns_stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -589,10 +613,10 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     HIPCHK(hipEventRecord(e0, s));
     if (kind == MDRP_CALIB)
         hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     else
         hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipGetLastError());
     const hipMemcpyKind back = mem_space == MDRP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

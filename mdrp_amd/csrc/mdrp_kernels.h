@@ -48,7 +48,7 @@ constexpr int PRUNE_EVERY = 4;     // bail-out test every PRUNE_EVERY groups of 
 #define MDRP_DENSE_KEY 40 // of 64 probe records
 #endif
 #ifndef MDRP_SOLVE_MINWAVES
-#define MDRP_SOLVE_MINWAVES 3
+#define MDRP_SOLVE_MINWAVES 2
 #endif
 #ifndef MDRP_SCORE_THREADS
 #define MDRP_SCORE_THREADS 256
@@ -333,7 +333,7 @@ __device__ __forceinline__ int probe_count(const float4 *__restrict__ recs32, in
 
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
-// with ONE atomic per wave (wave-aggregated prefix sum).
+// with ONE atomic per wave (wave-aggregated prefix sum); model_count[2 * pair] counts them.
 __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
                                                const double *__restrict__ pts, const double *__restrict__ dep,
                                                Model *__restrict__ models, int32_t *__restrict__ slot_inl,
@@ -343,13 +343,6 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     const PairState &ps = st[pair];
     if (!ps.active) return;
     const bool live = it < rp.chunk_len;
-    __shared__ float4 s_probe[PROBE_PTS]; // fp32 copy of the pair's first records (density probe)
-    const int nprobe = min(ps.n, PROBE_PTS);
-    if ((int)threadIdx.x < nprobe) {
-        const double *p = pts + ((size_t)pair * rp.n_max + threadIdx.x) * PT_STRIDE;
-        store_rec32(s_probe, threadIdx.x, p[0], p[1], p[2], p[3]);
-    }
-    __syncthreads();
     int n = 0;
     Model out[4];
     if (live) {
@@ -366,60 +359,28 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
         // a NaN hypothesis can never become a record (its score is N*thr, count 0) except as the very first model;
         // drop it (the reference's own P3P emits NaN poses for ~2% of garbage samples)
     }
-    // Candidate density of each model on the pair's first records (fp32 phase-1 filter of the sweep): the sort key of
-    // k_sort_tags.  Models that keep more than DENSE_KEY of 64 probe records go to the single-pass "dense" sweep
-    // (appended from the back of the tag list), everything else to the two-phase sweep (front).
-    const int dense_min = (MDRP_DENSE_KEY * nprobe + PROBE_PTS - 1) / PROBE_PTS;
-    int dense_mask = 0, n_dense = 0;
-    uint32_t keys = 0; // 8 bits per model: phase-1 candidates among the probe records
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (k < n) {
-            double R[9], Em[9], E[9];
-            quat_to_R(out[k].q, R);
-            essential_from_Rt(R, out[k].t, Em);
-            if (rp.kind == 0) {
-#pragma unroll
-                for (int i = 0; i < 9; ++i) E[i] = Em[i];
-            } else fundamental_from_E(Em, out[k].f1, out[k].f2, E);
-            float Ef[9], tb;
-            double dm;
-            bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
-            const int key = probe_count(s_probe, nprobe, Ef, tb);
-            keys |= (uint32_t)key << (8 * k);
-#ifndef MDRP_NO_CLASSIFY
-            if (key >= dense_min && nprobe >= 8) { dense_mask |= 1 << k; ++n_dense; }
-#endif
-        }
-    }
-    const int n_sparse = n - n_dense;
-    // wave-aggregated append: one atomic per wave and list
+    // wave-aggregated append to the pair's tag list: one atomic per wave (k_sort_tags orders and classifies the list)
     const int lane = threadIdx.x & 63;
-    int pre_s = n_sparse, pre_d = n_dense;
+    int pre = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        const int vs = __shfl_up(pre_s, o, 64), vd = __shfl_up(pre_d, o, 64);
-        if (lane >= o) { pre_s += vs; pre_d += vd; }
+        const int v = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += v;
     }
-    const int tot_s = __shfl(pre_s, 63, 64), tot_d = __shfl(pre_d, 63, 64);
-    int base_s = 0, base_d = 0;
-    if (lane == 63) {
-        if (tot_s > 0) base_s = atomicAdd(&model_count[2 * pair], tot_s);
-        if (tot_d > 0) base_d = atomicAdd(&model_count[2 * pair + 1], tot_d);
-    }
-    base_s = __shfl(base_s, 63, 64);
-    base_d = __shfl(base_d, 63, 64);
+    const int tot = __shfl(pre, 63, 64);
+    int base = 0;
+    if (lane == 63 && tot > 0) base = atomicAdd(&model_count[2 * pair], tot);
+    base = __shfl(base, 63, 64);
     if (!live) return;
     const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * 4;
-    int pos_s = base_s + pre_s - n_sparse, pos_d = base_d + pre_d - n_dense;
+    int pos = base + pre - n;
     const size_t tag_base = (size_t)pair * rp.slot_stride;
-    const int cap = rp.slot_stride;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < n) {
             models[slot0 + k] = out[k];
-            if ((dense_mask >> k) & 1) { tags[tag_base + (cap - 1 - pos_d)] = (uint32_t)((rp.chunk_off + it) * 4 + k); ++pos_d; }
-            else { tags[tag_base + pos_s] = (uint32_t)((rp.chunk_off + it) * 4 + k) | (((keys >> (8 * k)) & 0xFFu) << 24); ++pos_s; }
+            tags[tag_base + pos] = (uint32_t)((rp.chunk_off + it) * 4 + k);
+            ++pos;
         } else {
             slot_inl[slot0 + k] = -1;
         }
@@ -744,26 +705,61 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
     }
 }
 
-// Sparse hypotheses of a pair, ordered by their phase-1 candidate density (key in the top byte of the tag, k_solve).
-// Phase 2 of the sweep costs a wavefront the MAXIMUM candidate count over its lanes and densities differ by 10x between
-// hypotheses (measured unsorted: maximum 14 per 64 records, mean 3), so the sweep wants workgroups of similar
-// hypotheses.  Whole workgroups, not wavefronts: the four wavefronts of a workgroup meet at the tile barriers, and one
-// slow wavefront parks the other three in their SIMD slots (sorting inside the workgroup made the sweep 3x slower).
-// One workgroup per pair, counting sort over 65 keys; which lane scores a hypothesis does not change its result.
-__global__ __launch_bounds__(256) void k_sort_tags(int slot_stride, const PairState *__restrict__ st, const int32_t *__restrict__ model_count,
-                                                   const uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
+// The pair's hypotheses, classified and ordered by their phase-1 candidate density.  One workgroup per pair, one lane
+// per model: key = records among the pair's first 64 that survive the fp32 phase-1 filter of the sweep (probe_count).
+//   key >= DENSE_KEY/64 of the probe  -> "dense" list (single-pass sweep), written from the BACK of tags_sorted;
+//   everything else                   -> counting sort by key into the front of tags_sorted (two-phase sweep).
+// Phase 2 of the sweep costs a wavefront the MAXIMUM candidate count over its lanes, and densities differ by 10x
+// between hypotheses (measured unsorted: maximum 14 per 64 records, mean 3; sorted 8.5), so the sweep wants workgroups
+// of similar hypotheses.  Whole workgroups, not wavefronts: the four wavefronts of a workgroup meet at the tile
+// barriers, and one slow wavefront parks the other three in their SIMD slots (sorting inside the workgroup made the
+// sweep 3x slower).  Which lane scores a hypothesis does not change its result.
+// In: model_count[2p] = models of the pair (k_solve).  Out: model_count[2p] = sparse, [2p+1] = dense.
+__global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                   const Model *__restrict__ models, int32_t *__restrict__ model_count,
+                                                   uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
     const int pair = blockIdx.x, tid = threadIdx.x;
-    if (!st[pair].active) return;
+    const PairState &ps = st[pair];
+    if (!ps.active) return;
     __shared__ int s_hist[PROBE_PTS + 1], s_pos[PROBE_PTS + 1];
-    const int cnt = model_count[2 * pair];
-    const uint32_t *src = tags + (size_t)pair * slot_stride;
-    uint32_t *dst = tags_sorted + (size_t)pair * slot_stride;
+    __shared__ int s_dense;
+    __shared__ float4 s_probe[PROBE_PTS]; // fp32 copy of the pair's first records
+    const int nprobe = min(ps.n, PROBE_PTS);
+    if (tid < nprobe) {
+        const double *p = pts + ((size_t)pair * rp.n_max + tid) * PT_STRIDE;
+        store_rec32(s_probe, tid, p[0], p[1], p[2], p[3]);
+    }
     if (tid <= PROBE_PTS) s_hist[tid] = 0;
+    if (tid == 0) s_dense = 0;
     __syncthreads();
-    for (int i = tid; i < cnt; i += 256) atomicAdd(&s_hist[min(src[i] >> 24, (uint32_t)PROBE_PTS)], 1);
+    const int cnt = model_count[2 * pair];
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    uint32_t *src = tags + slot_base, *dst = tags_sorted + slot_base;
+#ifdef MDRP_NO_CLASSIFY
+    const int dense_min = PROBE_PTS + 1;
+#else
+    const int dense_min = nprobe >= 8 ? (MDRP_DENSE_KEY * nprobe + PROBE_PTS - 1) / PROBE_PTS : PROBE_PTS + 1;
+#endif
+    for (int i = tid; i < cnt; i += 256) {
+        const uint32_t slot = src[i];
+        const Model m = models[slot_base + slot];
+        double R[9], Em[9], E[9];
+        quat_to_R(m.q, R);
+        essential_from_Rt(R, m.t, Em);
+        if (rp.kind == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) E[q] = Em[q];
+        } else fundamental_from_E(Em, m.f1, m.f2, E);
+        float Ef[9], tb;
+        double dm;
+        bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
+        const int key = probe_count(s_probe, nprobe, Ef, tb);
+        src[i] = slot | ((uint32_t)key << 24);
+        atomicAdd(&s_hist[key], 1);
+    }
     __syncthreads();
-    if (tid < 64) {
-        const int v = s_hist[tid];
+    if (tid < 64) { // exclusive prefix over the sparse keys
+        const int v = tid < dense_min ? s_hist[tid] : 0;
         int incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -774,10 +770,15 @@ __global__ __launch_bounds__(256) void k_sort_tags(int slot_stride, const PairSt
         if (tid == 63) s_pos[64] = incl;
     }
     __syncthreads();
+    const int cap = rp.slot_stride;
     for (int i = tid; i < cnt; i += 256) {
         const uint32_t t = src[i];
-        dst[atomicAdd(&s_pos[min(t >> 24, (uint32_t)PROBE_PTS)], 1)] = t & 0xFFFFFFu;
+        const int key = (int)(t >> 24);
+        if (key >= dense_min) dst[cap - 1 - atomicAdd(&s_dense, 1)] = t & 0xFFFFFFu;
+        else dst[atomicAdd(&s_pos[key], 1)] = t & 0xFFFFFFu;
     }
+    __syncthreads();
+    if (tid == 0) { model_count[2 * pair] = cnt - s_dense; model_count[2 * pair + 1] = s_dense; }
 }
 
 // Work plan of one sweep launch: the workgroups a pair needs (ceil(count / SCORE_THREADS) per density class).
@@ -828,7 +829,6 @@ __device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int
 template <bool POSE>
 __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags,
-                                                         const uint32_t *__restrict__ tags_sparse,
                                                          const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
                                                          int32_t *__restrict__ slot_inl, const int32_t *__restrict__ plan,
                                                          int32_t *__restrict__ totals) {
@@ -859,10 +859,10 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     const int cap = rp.slot_stride;
     bool live;
     uint32_t slot = 0;
-    { // tag list of the pair: sparse hypotheses grow from the front, dense ones from the back (k_solve)
+    { // sorted tag list of the pair: sparse hypotheses from the front, dense ones from the back (k_sort_tags)
         const int i = blk * SCORE_THREADS + tid;
         live = i < (dense ? cnt_dense : cnt_sparse);
-        if (live) slot = dense ? tags[slot_base + cap - 1 - i] : (tags_sparse[slot_base + i] & 0xFFFFFFu);
+        if (live) slot = tags[slot_base + (dense ? cap - 1 - i : i)];
     }
     double E[9], thr_dmax;
     float tb, Ef[9];
