@@ -892,19 +892,14 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     for (int t0 = 0; t0 < n; t0 += TILE_PTS) {
         const int npts = min(TILE_PTS, n - t0);
         __syncthreads();
-        { // cooperative, coalesced 16-B loads of the tile
+        { // cooperative load of the tile: one 48-B record per thread and trip (a wavefront covers 3 KiB contiguous)
             const double2 *src = reinterpret_cast<const double2 *>(gp + (size_t)t0 * PT_STRIDE);
             double2 *dst = reinterpret_cast<double2 *>(tile);
-            const int nvec = npts * (PT_STRIDE / 2);
-            for (int i = tid; i < nvec; i += SCORE_THREADS) dst[i] = src[i];
-#ifndef MDRP_NO_F32
-            if (!dense) { // fp32 copy of the coordinates for the sparse phase-1 filter (the reads hit L1/L2)
-                for (int i = tid; i < npts; i += SCORE_THREADS) {
-                    const double2 a = src[i * (PT_STRIDE / 2)], c = src[i * (PT_STRIDE / 2) + 1];
-                    store_rec32(tile32, i, a.x, a.y, c.x, c.y);
-                }
+            for (int i = tid; i < npts; i += SCORE_THREADS) {
+                const double2 p0 = src[3 * i], p1 = src[3 * i + 1], p2 = src[3 * i + 2];
+                dst[3 * i] = p0; dst[3 * i + 1] = p1; dst[3 * i + 2] = p2;
+                if (!dense) store_rec32(tile32, i, p0.x, p0.y, p1.x, p1.y); // fp32 coordinates for the phase-1 filter
             }
-#endif
         }
         __syncthreads();
         if (!pr.wave_dead) {
