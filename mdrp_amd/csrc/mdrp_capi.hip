@@ -83,6 +83,10 @@ struct mdrp_handle {
 namespace {
 
 // one LM instantiation per kernel: dispatch (kind, estimate_shift) on the host
+#ifdef MDRP_FAST_BUILD // experiments: only the calibrated, no-shift LM is instantiated (16 s instead of 60 s)
+#define MDRP_LM_DISPATCH_T(KERNEL, T, kind, shift, grid, smem, stream, ...) \
+    hipLaunchKernelGGL((KERNEL<0, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__)
+#else
 #define MDRP_LM_DISPATCH_T(KERNEL, T, kind, shift, grid, smem, stream, ...)                                          \
     do {                                                                                                             \
         if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true, T>), grid, dim3(T), smem, stream, __VA_ARGS__);  \
@@ -90,6 +94,7 @@ namespace {
         else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<2, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);                        \
     } while (0)
+#endif
 // threads per LM problem: one wavefront (64) when problems outnumber SIMDs, a 256-thread workgroup otherwise
 #define MDRP_LM_DISPATCH(KERNEL, threads, kind, shift, grid, smem, stream, ...)                                      \
     do {                                                                                                             \

@@ -1034,6 +1034,27 @@ struct LmOpt {
 // is paid once instead of four times — for throughput when problems outnumber SIMDs).
 constexpr int LM_LIST_MAX_N = 8192; // u16 indices, <= 32 KiB of dynamic LDS (no opt-in needed)
 
+// The LM state is the same in every lane of the workgroup (one problem per workgroup): pin it to scalar registers.
+// The compiler cannot prove uniformity of values that went through vector arithmetic; readfirstlane states it, and the
+// 25-34 doubles move from VGPRs to SGPRs, where VOP3 fp64 instructions read them directly.
+__device__ __forceinline__ double uniform_f64(double x) {
+#ifdef MDRP_NO_SGPR_STATE
+    return x;
+#else
+    const unsigned long long b = __double_as_longlong(x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+#endif
+}
+__device__ __forceinline__ void lm_state_uniform(LmState &st) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { st.R[i] = uniform_f64(st.R[i]); st.E[i] = uniform_f64(st.E[i]); st.F[i] = uniform_f64(st.F[i]); }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) st.t[i] = uniform_f64(st.t[i]);
+    st.s = uniform_f64(st.s); st.u = uniform_f64(st.u); st.v = uniform_f64(st.v);
+    st.f1 = uniform_f64(st.f1); st.f2 = uniform_f64(st.f2);
+}
+
 struct LmShared {
     double scratch[4 * MAX_ACC];
     int count[2][4];
@@ -1046,6 +1067,7 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
                           const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, LmShared &sh, int buf) {
     LmState stt;
     lm_state_from_model(m, KIND != 0, stt);
+    lm_state_uniform(stt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool use_list = sh.stride > 0;
     uint16_t *list = sh.list + (size_t)buf * sh.stride;
@@ -1096,35 +1118,61 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     return v[0];
 }
 
+// JtJ (lower triangle, row-major) and Jtr of one weighted residual row
+template <int KIND, bool SHIFT>
+__device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jrow, double r, double w, double *acc) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    double Ja[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        Ja[q] = Jrow[lm_col<KIND, SHIFT>(q)];
+        if (KIND == 1 && q == 7) Ja[q] += Jrow[10]; // shared focal: f1 = f2 = f
+    }
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+        const double wa = w * Ja[a];
+#pragma unroll
+        for (int b = 0; b <= a; ++b) acc[idx++] += wa * Ja[b];
+    }
+#pragma unroll
+    for (int a = 0; a < NP; ++a) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r;
+}
+
+// One correspondence of the accumulate sweep, term by term: each term's Jacobian rows are folded into the accumulators
+// before the next term is computed (the scheduler is fenced in between), so at most two rows are live beside the
+// NP (NP + 3) / 2 accumulators.
 template <int KIND, bool SHIFT>
 __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, const double *__restrict__ pts, const double *__restrict__ dep, int i,
                                                     double sqrt_sr, double ws, const LmOpt &o, double *acc) {
-    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
-    const double *p = pts + (size_t)i * PT_STRIDE;
-    double r[5], zf, zb, J[5][LM_NPAR];
-    point_residuals<true, KIND != 0>(stt, sqrt_sr, p[0], p[1], p[2], p[3], dep[2 * i], dep[2 * i + 1], r, zf, zb, J);
-    const double wS = ws * loss_weight(o.loss, o.loss_scale, r[0] * r[0], o.mu);
-    const double wF = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[1] * r[1] + r[2] * r[2], o.mu);
-    const double wB = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r[3] * r[3] + r[4] * r[4], o.mu);
-    const double wr[5] = {wS, wF, wF, wB, wB};
-#pragma unroll
-    for (int row = 0; row < 5; ++row) {
-        double Ja[NP];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            Ja[q] = J[row][lm_col<KIND, SHIFT>(q)];
-            if (KIND == 1 && q == 7) Ja[q] += J[row][10]; // shared focal: f1 = f2 = f
-        }
-        const double w = wr[row];
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < NP; ++a) {
-            const double wa = w * Ja[a];
-#pragma unroll
-            for (int b = 0; b <= a; ++b) acc[idx++] += wa * Ja[b];
-        }
-#pragma unroll
-        for (int a = 0; a < NP; ++a) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r[row];
+    const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
+    const double2 p01 = P[0], p23 = P[1];
+    const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i);
+    {
+        double r0, J0[LM_NPAR];
+        lm_sampson_term<true, KIND != 0>(stt, p01.x, p01.y, p23.x, p23.y, r0, J0);
+        const double w = ws * loss_weight(o.loss, o.loss_scale, r0 * r0, o.mu);
+        lm_accumulate_row<KIND, SHIFT>(J0, r0, w, acc);
+    }
+#ifndef MDRP_LM_NO_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    {
+        double r1, r2, zf, J1[LM_NPAR], J2[LM_NPAR];
+        lm_forward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.x, r1, r2, zf, J1, J2);
+        const double w = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r1 * r1 + r2 * r2, o.mu);
+        lm_accumulate_row<KIND, SHIFT>(J1, r1, w, acc);
+        lm_accumulate_row<KIND, SHIFT>(J2, r2, w, acc);
+    }
+#ifndef MDRP_LM_NO_FENCE
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    {
+        double r3, r4, zb, J3[LM_NPAR], J4[LM_NPAR];
+        lm_backward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.y, r3, r4, zb, J3, J4);
+        const double w = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r3 * r3 + r4 * r4, o.mu);
+        lm_accumulate_row<KIND, SHIFT>(J3, r3, w, acc);
+        lm_accumulate_row<KIND, SHIFT>(J4, r4, w, acc);
     }
 }
 
@@ -1135,6 +1183,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
     constexpr int NA = NP * (NP + 1) / 2 + NP;
     LmState stt;
     lm_state_from_model(m, KIND != 0, stt);
+    lm_state_uniform(stt);
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

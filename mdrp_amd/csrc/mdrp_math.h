@@ -653,43 +653,22 @@ constexpr int LM_NPAR = 11; // rot(3) t(3) s u v f1 f2
 
 // residuals r[0..4] = {sampson, fwd.x, fwd.y, bwd.x, bwd.y} (reprojection ones times sqrt(sr)); zf / zb = depth of
 // the forward / backward transferred point (terms with negative depth are skipped by the callers).
-// WITH_J: Jacobian rows J[5][LM_NPAR] with R <- R exp([w]x), t <- t + dt, s <- s + ds.
-template <bool WITH_J, bool FOCAL = true>
-MDRP_HD void point_residuals(const LmState &st_in, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
-                             double d2, double r[5], double &zf, double &zb, double J[5][LM_NPAR]) {
-    // calibrated estimator: f1 = f2 = 1 folds away at compile time (F == E, no focal columns)
-    struct View { const double *R, *t, *E, *F; double s, u, v, f1, f2; };
-    const View st = {st_in.R, st_in.t, st_in.E, FOCAL ? st_in.F : st_in.E, st_in.s, st_in.u, st_in.v, FOCAL ? st_in.f1 : 1.0, FOCAL ? st_in.f2 : 1.0};
-    const double *R = st.R, *t = st.t, *F = st.F;
+// WITH_J: Jacobian rows J[LM_NPAR] with R <- R exp([w]x), t <- t + dt, s <- s + ds.
+// The three terms are separate functions so that the GPU accumulate sweep can consume each term's rows before it
+// computes the next term (register pressure); point_residuals() below strings them together.
+// Calibrated estimator (FOCAL = false): f1 = f2 = 1 folds away at compile time (F == E, no focal columns).
+template <bool WITH_J, bool FOCAL>
+MDRP_HD void lm_sampson_term(const LmState &st, double x1x, double x1y, double x2x, double x2y, double &r0, double *J0) {
+    const double *R = st.R, *F = FOCAL ? st.F : st.E, *E = st.E;
+    const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
     const double Fh1_0 = F[0] * x1x + F[1] * x1y + F[2], Fh1_1 = F[3] * x1x + F[4] * x1y + F[5], Fh1_2 = F[6] * x1x + F[7] * x1y + F[8];
     const double Ft2_0 = F[0] * x2x + F[3] * x2y + F[6], Ft2_1 = F[1] * x2x + F[4] * x2y + F[7];
     const double C = x2x * Fh1_0 + x2y * Fh1_1 + Fh1_2;
     const double den = Fh1_0 * Fh1_0 + Fh1_1 * Fh1_1 + Ft2_0 * Ft2_0 + Ft2_1 * Ft2_1;
     const double isd = 1.0 / sqrt(den);
-    r[0] = C * isd;
-    const double if1 = 1.0 / st.f1, if2 = 1.0 / st.f2;
-    const double b1x = x1x * if1, b1y = x1y * if1, b2x = x2x * if2, b2y = x2y * if2;
-    const double dd1 = d1 + st.u, dd2 = d2 + st.v;
-    const double X1[3] = {dd1 * b1x, dd1 * b1y, dd1};
-    const double Z0 = R[0] * X1[0] + R[1] * X1[1] + R[2] * X1[2] + t[0];
-    const double Z1 = R[3] * X1[0] + R[4] * X1[1] + R[5] * X1[2] + t[1];
-    const double Z2 = R[6] * X1[0] + R[7] * X1[1] + R[8] * X1[2] + t[2];
-    const double iz = 1.0 / Z2;
-    r[1] = sqrt_sr * (st.f2 * Z0 * iz - x2x);
-    r[2] = sqrt_sr * (st.f2 * Z1 * iz - x2y);
-    zf = Z2;
-    const double sd = st.s * dd2;
-    const double Y[3] = {sd * b2x - t[0], sd * b2y - t[1], sd - t[2]};
-    const double W0 = R[0] * Y[0] + R[3] * Y[1] + R[6] * Y[2];
-    const double W1 = R[1] * Y[0] + R[4] * Y[1] + R[7] * Y[2];
-    const double W2 = R[2] * Y[0] + R[5] * Y[1] + R[8] * Y[2];
-    const double iw = 1.0 / W2;
-    r[3] = sqrt_sr * (st.f1 * W0 * iw - x1x);
-    r[4] = sqrt_sr * (st.f1 * W1 * iw - x1y);
-    zb = W2;
+    r0 = C * isd;
     if (!WITH_J) return;
-
-    // ---- Sampson: G = d r0 / d F, then chain to E, rotation (post), translation, focals
+    // G = d r0 / d F, then chain to E, rotation (post), translation, focals
     const double h1[3] = {x1x, x1y, 1.0}, h2[3] = {x2x, x2y, 1.0};
     const double Fh1[3] = {Fh1_0, Fh1_1, Fh1_2}, Ft2[3] = {Ft2_0, Ft2_1, 0.0};
     const double k = C * isd * isd * isd;
@@ -703,9 +682,8 @@ MDRP_HD void point_residuals(const LmState &st_in, double sqrt_sr, double x1x, d
             if (i < 2) g -= k * Fh1[i] * h1[j];
             if (j < 2) g -= k * Ft2[j] * h2[i];
             G[3 * i + j] = g;
-            GE[3 * i + j] = g * (i == 2 ? st.f2 : 1.0) * (j == 2 ? st.f1 : 1.0);
+            GE[3 * i + j] = g * (i == 2 ? f2 : 1.0) * (j == 2 ? f1 : 1.0);
         }
-    const double *E = st.E;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         const int b = (a + 1) % 3, c = (a + 2) % 3;
@@ -713,83 +691,125 @@ MDRP_HD void point_residuals(const LmState &st_in, double sqrt_sr, double x1x, d
         double acc = 0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) acc += GE[3 * i + b] * E[3 * i + c] - GE[3 * i + c] * E[3 * i + b];
-        J[0][a] = acc;
+        J0[a] = acc;
         // dE/dt_a = [e_a]x R : row b = -R row c, row c = +R row b
         double acc2 = 0;
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc2 += -GE[3 * b + j] * R[3 * c + j] + GE[3 * c + j] * R[3 * b + j];
-        J[0][3 + a] = acc2;
+        J0[3 + a] = acc2;
     }
-    J[0][6] = 0; J[0][7] = 0; J[0][8] = 0;
-    J[0][9] = G[2] * E[2] + G[5] * E[5] + G[8] * E[8] * st.f2;
-    J[0][10] = G[6] * E[6] + G[7] * E[7] + G[8] * E[8] * st.f1;
+    J0[6] = 0; J0[7] = 0; J0[8] = 0;
+    J0[9] = G[2] * E[2] + G[5] * E[5] + G[8] * E[8] * f2;
+    J0[10] = G[6] * E[6] + G[7] * E[7] + G[8] * E[8] * f1;
+}
 
-    // ---- forward reprojection: Z = R X1 + t
-    {
-        const double px0 = sqrt_sr * st.f2 * iz, pz0 = -sqrt_sr * st.f2 * Z0 * iz * iz, pz1 = -sqrt_sr * st.f2 * Z1 * iz * iz;
-        // dZ/dw_a = R (e_a x X1)
-        const double cr[3][3] = {{0.0, -X1[2], X1[1]}, {X1[2], 0.0, -X1[0]}, {-X1[1], X1[0], 0.0}}; // e_a x X1
+// forward reprojection: Z = R X1 + t, X1 = (d1 + u) (x1 / f1, 1);  r = sqrt_sr (f2 Z.xy / Z.z - x2)
+template <bool WITH_J, bool FOCAL>
+MDRP_HD void lm_forward_term(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
+                             double &r1, double &r2, double &zf, double *J1, double *J2) {
+    const double *R = st.R, *t = st.t;
+    const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
+    const double if1 = 1.0 / f1;
+    const double b1x = x1x * if1, b1y = x1y * if1;
+    const double dd1 = d1 + st.u;
+    const double X1[3] = {dd1 * b1x, dd1 * b1y, dd1};
+    const double Z0 = R[0] * X1[0] + R[1] * X1[1] + R[2] * X1[2] + t[0];
+    const double Z1 = R[3] * X1[0] + R[4] * X1[1] + R[5] * X1[2] + t[1];
+    const double Z2 = R[6] * X1[0] + R[7] * X1[1] + R[8] * X1[2] + t[2];
+    const double iz = 1.0 / Z2;
+    r1 = sqrt_sr * (f2 * Z0 * iz - x2x);
+    r2 = sqrt_sr * (f2 * Z1 * iz - x2y);
+    zf = Z2;
+    if (!WITH_J) return;
+    const double px0 = sqrt_sr * f2 * iz, pz0 = -sqrt_sr * f2 * Z0 * iz * iz, pz1 = -sqrt_sr * f2 * Z1 * iz * iz;
+    // dZ/dw_a = R (e_a x X1)
+    const double cr[3][3] = {{0.0, -X1[2], X1[1]}, {X1[2], 0.0, -X1[0]}, {-X1[1], X1[0], 0.0}}; // e_a x X1
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double v0 = R[0] * cr[a][0] + R[1] * cr[a][1] + R[2] * cr[a][2];
-            const double v1 = R[3] * cr[a][0] + R[4] * cr[a][1] + R[5] * cr[a][2];
-            const double v2 = R[6] * cr[a][0] + R[7] * cr[a][1] + R[8] * cr[a][2];
-            J[1][a] = px0 * v0 + pz0 * v2;
-            J[2][a] = px0 * v1 + pz1 * v2;
-        }
-        J[1][3] = px0; J[1][4] = 0.0; J[1][5] = pz0;
-        J[2][3] = 0.0; J[2][4] = px0; J[2][5] = pz1;
-        J[1][6] = 0.0; J[2][6] = 0.0;
-        { // shift1: dZ = R b1
-            const double v0 = R[0] * b1x + R[1] * b1y + R[2], v1 = R[3] * b1x + R[4] * b1y + R[5], v2 = R[6] * b1x + R[7] * b1y + R[8];
-            J[1][7] = px0 * v0 + pz0 * v2;
-            J[2][7] = px0 * v1 + pz1 * v2;
-        }
-        J[1][8] = 0.0; J[2][8] = 0.0;
-        { // f1: dX1 = -dd1 (b1x, b1y, 0) / f1
-            const double ex = -dd1 * b1x * if1, ey = -dd1 * b1y * if1;
-            const double v0 = R[0] * ex + R[1] * ey, v1 = R[3] * ex + R[4] * ey, v2 = R[6] * ex + R[7] * ey;
-            J[1][9] = px0 * v0 + pz0 * v2;
-            J[2][9] = px0 * v1 + pz1 * v2;
-        }
-        J[1][10] = sqrt_sr * Z0 * iz;
-        J[2][10] = sqrt_sr * Z1 * iz;
+    for (int a = 0; a < 3; ++a) {
+        const double v0 = R[0] * cr[a][0] + R[1] * cr[a][1] + R[2] * cr[a][2];
+        const double v1 = R[3] * cr[a][0] + R[4] * cr[a][1] + R[5] * cr[a][2];
+        const double v2 = R[6] * cr[a][0] + R[7] * cr[a][1] + R[8] * cr[a][2];
+        J1[a] = px0 * v0 + pz0 * v2;
+        J2[a] = px0 * v1 + pz1 * v2;
     }
-    // ---- backward reprojection: W = R'(X2 - t)
-    {
-        const double px0 = sqrt_sr * st.f1 * iw, pz0 = -sqrt_sr * st.f1 * W0 * iw * iw, pz1 = -sqrt_sr * st.f1 * W1 * iw * iw;
-        // dW/dw_a = W x e_a
-        const double wc[3][3] = {{0.0, W2, -W1}, {-W2, 0.0, W0}, {W1, -W0, 0.0}};
+    J1[3] = px0; J1[4] = 0.0; J1[5] = pz0;
+    J2[3] = 0.0; J2[4] = px0; J2[5] = pz1;
+    J1[6] = 0.0; J2[6] = 0.0;
+    { // shift1: dZ = R b1
+        const double v0 = R[0] * b1x + R[1] * b1y + R[2], v1 = R[3] * b1x + R[4] * b1y + R[5], v2 = R[6] * b1x + R[7] * b1y + R[8];
+        J1[7] = px0 * v0 + pz0 * v2;
+        J2[7] = px0 * v1 + pz1 * v2;
+    }
+    J1[8] = 0.0; J2[8] = 0.0;
+    { // f1: dX1 = -dd1 (b1x, b1y, 0) / f1
+        const double ex = -dd1 * b1x * if1, ey = -dd1 * b1y * if1;
+        const double v0 = R[0] * ex + R[1] * ey, v1 = R[3] * ex + R[4] * ey, v2 = R[6] * ex + R[7] * ey;
+        J1[9] = px0 * v0 + pz0 * v2;
+        J2[9] = px0 * v1 + pz1 * v2;
+    }
+    J1[10] = sqrt_sr * Z0 * iz;
+    J2[10] = sqrt_sr * Z1 * iz;
+}
+
+// backward reprojection: W = R'(X2 - t), X2 = s (d2 + v) (x2 / f2, 1);  r = sqrt_sr (f1 W.xy / W.z - x1)
+template <bool WITH_J, bool FOCAL>
+MDRP_HD void lm_backward_term(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d2,
+                              double &r3, double &r4, double &zb, double *J3, double *J4) {
+    const double *R = st.R, *t = st.t;
+    const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
+    const double if2 = 1.0 / f2;
+    const double b2x = x2x * if2, b2y = x2y * if2;
+    const double dd2 = d2 + st.v;
+    const double sd = st.s * dd2;
+    const double Y[3] = {sd * b2x - t[0], sd * b2y - t[1], sd - t[2]};
+    const double W0 = R[0] * Y[0] + R[3] * Y[1] + R[6] * Y[2];
+    const double W1 = R[1] * Y[0] + R[4] * Y[1] + R[7] * Y[2];
+    const double W2 = R[2] * Y[0] + R[5] * Y[1] + R[8] * Y[2];
+    const double iw = 1.0 / W2;
+    r3 = sqrt_sr * (f1 * W0 * iw - x1x);
+    r4 = sqrt_sr * (f1 * W1 * iw - x1y);
+    zb = W2;
+    if (!WITH_J) return;
+    const double px0 = sqrt_sr * f1 * iw, pz0 = -sqrt_sr * f1 * W0 * iw * iw, pz1 = -sqrt_sr * f1 * W1 * iw * iw;
+    // dW/dw_a = W x e_a
+    const double wc[3][3] = {{0.0, W2, -W1}, {-W2, 0.0, W0}, {W1, -W0, 0.0}};
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            J[3][a] = px0 * wc[a][0] + pz0 * wc[a][2];
-            J[4][a] = px0 * wc[a][1] + pz1 * wc[a][2];
-            // dW/dt_a = -R' e_a = -(row a of R)
-            J[3][3 + a] = -(px0 * R[3 * a + 0] + pz0 * R[3 * a + 2]);
-            J[4][3 + a] = -(px0 * R[3 * a + 1] + pz1 * R[3 * a + 2]);
-        }
-        { // scale: dW = R' (dd2 b2)
-            const double y0 = dd2 * b2x, y1 = dd2 * b2y, y2 = dd2;
-            const double v0 = R[0] * y0 + R[3] * y1 + R[6] * y2, v1 = R[1] * y0 + R[4] * y1 + R[7] * y2, v2 = R[2] * y0 + R[5] * y1 + R[8] * y2;
-            J[3][6] = px0 * v0 + pz0 * v2;
-            J[4][6] = px0 * v1 + pz1 * v2;
-        }
-        J[3][7] = 0.0; J[4][7] = 0.0;
-        { // shift2: dW = R' (s b2)
-            const double y0 = st.s * b2x, y1 = st.s * b2y, y2 = st.s;
-            const double v0 = R[0] * y0 + R[3] * y1 + R[6] * y2, v1 = R[1] * y0 + R[4] * y1 + R[7] * y2, v2 = R[2] * y0 + R[5] * y1 + R[8] * y2;
-            J[3][8] = px0 * v0 + pz0 * v2;
-            J[4][8] = px0 * v1 + pz1 * v2;
-        }
-        J[3][9] = sqrt_sr * W0 * iw;
-        J[4][9] = sqrt_sr * W1 * iw;
-        { // f2: dX2 = -s dd2 (b2x, b2y, 0)/f2
-            const double ex = -sd * b2x * if2, ey = -sd * b2y * if2;
-            const double v0 = R[0] * ex + R[3] * ey, v1 = R[1] * ex + R[4] * ey, v2 = R[2] * ex + R[5] * ey;
-            J[3][10] = px0 * v0 + pz0 * v2;
-            J[4][10] = px0 * v1 + pz1 * v2;
-        }
+    for (int a = 0; a < 3; ++a) {
+        J3[a] = px0 * wc[a][0] + pz0 * wc[a][2];
+        J4[a] = px0 * wc[a][1] + pz1 * wc[a][2];
+        // dW/dt_a = -R' e_a = -(row a of R)
+        J3[3 + a] = -(px0 * R[3 * a + 0] + pz0 * R[3 * a + 2]);
+        J4[3 + a] = -(px0 * R[3 * a + 1] + pz1 * R[3 * a + 2]);
     }
+    { // scale: dW = R' (dd2 b2)
+        const double y0 = dd2 * b2x, y1 = dd2 * b2y, y2 = dd2;
+        const double v0 = R[0] * y0 + R[3] * y1 + R[6] * y2, v1 = R[1] * y0 + R[4] * y1 + R[7] * y2, v2 = R[2] * y0 + R[5] * y1 + R[8] * y2;
+        J3[6] = px0 * v0 + pz0 * v2;
+        J4[6] = px0 * v1 + pz1 * v2;
+    }
+    J3[7] = 0.0; J4[7] = 0.0;
+    { // shift2: dW = R' (s b2)
+        const double y0 = st.s * b2x, y1 = st.s * b2y, y2 = st.s;
+        const double v0 = R[0] * y0 + R[3] * y1 + R[6] * y2, v1 = R[1] * y0 + R[4] * y1 + R[7] * y2, v2 = R[2] * y0 + R[5] * y1 + R[8] * y2;
+        J3[8] = px0 * v0 + pz0 * v2;
+        J4[8] = px0 * v1 + pz1 * v2;
+    }
+    J3[9] = sqrt_sr * W0 * iw;
+    J4[9] = sqrt_sr * W1 * iw;
+    { // f2: dX2 = -s dd2 (b2x, b2y, 0)/f2
+        const double ex = -sd * b2x * if2, ey = -sd * b2y * if2;
+        const double v0 = R[0] * ex + R[3] * ey, v1 = R[1] * ex + R[4] * ey, v2 = R[2] * ex + R[5] * ey;
+        J3[10] = px0 * v0 + pz0 * v2;
+        J4[10] = px0 * v1 + pz1 * v2;
+    }
+}
+
+template <bool WITH_J, bool FOCAL = true>
+MDRP_HD void point_residuals(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
+                             double d2, double r[5], double &zf, double &zb, double J[5][LM_NPAR]) {
+    lm_sampson_term<WITH_J, FOCAL>(st, x1x, x1y, x2x, x2y, r[0], WITH_J ? J[0] : nullptr);
+    lm_forward_term<WITH_J, FOCAL>(st, sqrt_sr, x1x, x1y, x2x, x2y, d1, r[1], r[2], zf, WITH_J ? J[1] : nullptr, WITH_J ? J[2] : nullptr);
+    lm_backward_term<WITH_J, FOCAL>(st, sqrt_sr, x1x, x1y, x2x, x2y, d2, r[3], r[4], zb, WITH_J ? J[3] : nullptr, WITH_J ? J[4] : nullptr);
 }
 
 // parameter update of the refinement (lm step): R <- R exp([w]x), additive elsewhere; shifts are zeroed when they are
