@@ -206,6 +206,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
     const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0;
     const int lo_overlap_waves = env_int("MDRP_LO_OVERLAP_WAVES", 8); // LO wavefronts per CU while it shares the chip
+    const bool lo_after_solve = env_int("MDRP_LO_AFTER_SOLVE", 0) != 0;
     const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
@@ -333,7 +334,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
             hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
             if (piped) { HIPCHK(hipEventRecord(h->ev_scanned[c], s)); HIPCHK(hipStreamWaitEvent(aux2, h->ev_scanned[c], 0)); }
-            const int lo_blocks = h->num_cu * (lo_threads == 64 ? lo_overlap_waves : 2);
+            // LO beside the solver wastes both (two latency-bound kernels share a SIMD); LO beside the sweep does not
+            if (piped && lo_after_solve && c + 1 < n_chunks) HIPCHK(hipStreamWaitEvent(aux2, h->ev_solved[c + 1], 0));
+            const int lo_waves_c = (piped && c + 1 < n_chunks) ? lo_overlap_waves : 8; // the last chunk's LO has the chip to itself
+            const int lo_blocks = h->num_cu * (lo_threads == 64 ? lo_waves_c : 2);
             MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
                              h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
                              trig_cap, lo_plan, cnt + 8 + c, lm_list_stride(n_max));
@@ -448,8 +452,9 @@ int mdrp_create(int device, void *stream, mdrp_handle **out) {
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         const int prio = env_int("MDRP_AUX_PRIO", 1) ? prio_hi : prio_lo;
+        const int prio2 = env_int("MDRP_AUX2_PRIO", 1) ? prio_hi : prio_lo;
         HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
-        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio));
+        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio2));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {

@@ -1143,11 +1143,8 @@ __device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jro
 // before the next term is computed (the scheduler is fenced in between), so at most two rows are live beside the
 // NP (NP + 3) / 2 accumulators.
 template <int KIND, bool SHIFT>
-__device__ __forceinline__ void lm_accumulate_point(const LmState &stt, const double *__restrict__ pts, const double *__restrict__ dep, int i,
+__device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 p01, double2 p23, double2 dd,
                                                     double sqrt_sr, double ws, const LmOpt &o, double *acc) {
-    const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
-    const double2 p01 = P[0], p23 = P[1];
-    const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i);
     {
         double r0, J0[LM_NPAR];
         lm_sampson_term<true, KIND != 0>(stt, p01.x, p01.y, p23.x, p23.y, r0, J0);
@@ -1192,12 +1189,30 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
     if (sh.stride > 0) {
         const uint16_t *list = sh.list + (size_t)buf * sh.stride;
         const int cnt = sh.count[buf][wave];
-        for (int k = lane; k < cnt; k += 64) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, (int)list[lo + k], sqrt_sr, ws, o, acc);
-        (void)0;
+        // software-pipelined by one step like the cost sweep: list entry and record of the next trip are requested
+        // before the current record's ~700 fp64 ops (an unhidden LDS + L2 round trip was ~30 % of the sweep: PMC SQ_WAIT_ANY)
+        double2 n01 = make_double2(0, 0), n23 = n01, ndd = n01;
+        auto fetch = [&](int k) {
+            if (k < cnt) {
+                const size_t i = (size_t)list[lo + k];
+                const double2 *P = reinterpret_cast<const double2 *>(pts + i * PT_STRIDE);
+                n01 = P[0]; n23 = P[1];
+                ndd = *reinterpret_cast<const double2 *>(dep + 2 * i);
+            }
+        };
+        fetch(lane);
+        for (int k = lane; k < cnt; k += 64) {
+            const double2 c01 = n01, c23 = n23, cdd = ndd;
+            fetch(k + 64);
+            lm_accumulate_point<KIND, SHIFT>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
+        }
     } else {
         const int hi = min(n, lo + seg);
         for (int i = lo + lane; i < hi; i += 64)
-            if (!mask || mask[i]) lm_accumulate_point<KIND, SHIFT>(stt, pts, dep, i, sqrt_sr, ws, o, acc);
+            if (!mask || mask[i]) {
+                const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
+                lm_accumulate_point<KIND, SHIFT>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i), sqrt_sr, ws, o, acc);
+            }
     }
     block_sum<NA, T>(acc, sh.scratch);
 }
