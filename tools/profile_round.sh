@@ -19,5 +19,6 @@ for C in FETCH_SIZE WRITE_SIZE; do
   if [ -n "$F" ]; then grep -E "Counter_Name|mdrp::" "$F" > $O/pmc_$C.csv; fi
 done
 python3 $R/tools/pmc_hbm_json.py $O/pmc_FETCH_SIZE.csv $O/pmc_WRITE_SIZE.csv calib_p3p_n2000_i10k 1024 2 > $O/pmc_hbm.json
+cp $O/pmc_hbm.json $R/profiles/${TAG}_pmc_hbm.json   # so that the bench line below cites this round's PMC pass
 cd $R && python3 bench.py > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-220
 head -12 $O/kernel_stats.txt
