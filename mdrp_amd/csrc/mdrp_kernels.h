@@ -5,19 +5,21 @@
 // on the running records of the MINIMAL models; every LO starts from the triggering minimal model.  So per chunk
 // of iterations:
 //   k_samples  one wavefront per distinct N  splitmix64 sample table for the chunk (wave-speculative)        (a-3)
-//   k_solve    one lane per minimal sample   solver -> <=4 models; density class; compacted tag lists       (a-4..a-6')
+//   k_solve    one lane per minimal sample   solver -> <=4 models; compacted tag list                       (a-4..a-6')
+//   k_sort_tags one workgroup per pair       density probe per model -> dense / sparse class, sparse sorted by density
 //   k_plan     one wavefront                 work items of the sweep (workgroups per pair and class)
 //   k_score    one lane per hypothesis       Sampson/MSAC (+cheirality) sweep over all N correspondences,
 //                                            correspondences staged through LDS, broadcast reads            (a-7)  HOT
 //   k_scan     one wavefront per pair        ordered prefix scan of (count,score) records -> LO triggers     (a-2)
-//   k_lo_plan  one wavefront                 XCD-affine queues of the LO problems
+//   k_lo_plan  one wavefront                 this chunk's trigger range per pair, frozen (later scans only append)
 //   k_lo       one wavefront (or workgroup)  LM refinement (<=25 it, TRUNCATED) + rescoring, per trigger     (a-8)
 //   k_walk     one lane per pair             replays the reference's bookkeeping over the triggers,
 //                                            dynamic stopping                                                (a-2)
 //   k_final    one workgroup per pair        final LO, inlier mask, inlier-only LM, result record            (a-1, a-9)
 // HBM layout (all fp64 unless noted): pts[B][n_max][6] = (x1.x, x1.y, x2.x, x2.y, 1/|(x1,1)|, 1/|(x2,1)|)
 // normalised; dep[B][n_max][2] = (d1, d2); models[B][chunk][4] (96 B each); slot_score/slot_inl[B][chunk][4];
-// tags[B][4*chunk] u32 compact list of live slots (sparse class from the front, dense class from the back).
+// tags[B][4*chunk] u32 compact list of live slots (k_solve); tags_sorted = the same, sparse class ordered by candidate
+// density from the front, dense class from the back (k_sort_tags).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
@@ -391,15 +393,15 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
 // One lane per hypothesis; the pair's correspondences are staged through LDS in 512-record tiles (24 KiB) and read as
 // wave-wide broadcasts (every lane reads the same record), so a tile is fetched from HBM/L2 once per workgroup.
 // Algorithmic bytes: 32 B per (model x correspondence) evaluation (x1, x2 as four fp64 — what the CPU loop reads,
-// SURVEY.md §8d).  The kernel is fp64-VALU bound (88 % VALU-busy, PMC), so everything below is about issuing fewer
-// fp64 instructions per evaluation without changing a single result:
-//   * k_solve classifies hypotheses by their candidate density on the first 32 records; wavefronts hold either DENSE
-//     (near the true model) or SPARSE (garbage, ~90 %) hypotheses.
-//   * SPARSE, per 32 records:  phase 1 is branch-free and needs only the numerator: C^2 < thr * Dmax, Dmax >= den for every
-//     record of the pair (bound over the pair's coordinate box) -> 12 ops instead of 22; survivors (a superset of the true
-//     candidates, ~1 %) set a bit in a per-lane mask.  phase 2: every lane pops ITS OWN bits (per-lane LDS addresses) and
-//     runs the exact test, quotient, check_cheirality and accumulation; its trip count is the largest candidate count of
-//     any lane, not the size of the union over 64 unrelated hypotheses (which is about half of all records).
+// SURVEY.md §8d).  The kernel is VALU-issue bound (88 % VALU-busy, PMC), so everything below is about issuing fewer
+// (and cheaper) instructions per evaluation without changing a single result:
+//   * k_sort_tags classifies hypotheses by their candidate density on the pair's first 64 records and sorts the SPARSE
+//     ones (garbage, > 90 %) by it; DENSE ones (> 40 of 64 probe records survive phase 1) take the coherent single pass.
+//   * SPARSE, per 64 records:  phase 1 is branch-free, needs only the numerator C = x2' E x1 and runs in packed fp32 on an
+//     fp32 copy of the tile (score_tile_f32: conservative threshold, two records per v_pk_fma_f32); survivors (a superset
+//     of the true candidates, ~5 %) set a bit in a per-lane mask.  phase 2: every lane pops ITS OWN bits (per-lane LDS
+//     addresses) and runs the exact fp64 test, quotient, check_cheirality and accumulation in record order; its trip count
+//     is the largest candidate count of any lane of the wavefront — hence the sort: similar hypotheses share a workgroup.
 //   * DENSE: candidate sets of the 64 lanes nearly coincide (the true inliers), so the plain per-record branch is coherent:
 //     one pass, no recomputation.
 //   * bail-out against the records of earlier chunks (struct Prune): exact, skips ~30 % of the sparse work at 50 % outliers
