@@ -292,20 +292,9 @@ __device__ __forceinline__ SampsonTerms sampson_terms(const double E[9], double 
     return r;
 }
 
-// Conservative fp32 phase-1 filter of the sweep for one hypothesis (see score_tile_f32): fp32 copy of E and the
-// threshold tb such that  |fl32(x2' E x1)| > tb  proves  C^2 >= thr * den  for every record inside the pair's box.
+// Conservative fp32 phase-1 filter of the sweep for one hypothesis: mdrp_math.h filter_setup / filter_keeps
 __device__ __forceinline__ void bound_setup(const double E[9], const PairState &ps, double thr, float Ef[9], float &tb, double &thr_dmax) {
-    // Dmax: upper bound of the Sampson denominator over the pair's coordinate box
-    const double ax = ps.box[0], ay = ps.box[1], cx = ps.box[2], cy = ps.box[3];
-    const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
-    const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
-    thr_dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
-    const double e2 = fabs(E[6]) * ax + fabs(E[7]) * ay + fabs(E[8]);
-    const double M = e0 * cx + e1 * cy + e2;
-    const double T = sqrt(thr * (1.0 + 1e-12) * thr_dmax);
-    tb = (M < 1e30) ? (float)((T + 2e-6 * M) * (1.0 + 1e-6)) + 1e-30f : __builtin_inff(); // !(M < 1e30) also catches NaN
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Ef[i] = (float)E[i];
+    filter_setup(E, ps.box, thr, Ef, tb, thr_dmax);
 }
 
 // fp32 record layout of the phase-1 filter: two records per 32 B, component-major (a0 a1 b0 b1)(c0 c1 d0 d1)
@@ -320,15 +309,8 @@ __device__ __forceinline__ int probe_count(const float4 *__restrict__ recs32, in
     int c = 0;
     for (int j = 0; j < g; j += 2) {
         const float4 ab = recs32[j], cd = recs32[j + 1];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const float a = h ? ab.y : ab.x, b = h ? ab.w : ab.z, cc = h ? cd.y : cd.x, d = h ? cd.w : cd.z;
-            const float e0 = fmaf(Ef[0], a, fmaf(Ef[1], b, Ef[2]));
-            const float e1 = fmaf(Ef[3], a, fmaf(Ef[4], b, Ef[5]));
-            const float e2 = fmaf(Ef[6], a, fmaf(Ef[7], b, Ef[8]));
-            const float C = fmaf(cc, e0, fmaf(d, e1, e2));
-            c += (!(fabsf(C) > tb) && j + h < g) ? 1 : 0;
-        }
+        c += (filter_keeps(Ef, tb, ab.x, ab.z, cd.x, cd.z) && j < g) ? 1 : 0;
+        c += (filter_keeps(Ef, tb, ab.y, ab.w, cd.y, cd.w) && j + 1 < g) ? 1 : 0;
     }
     return c;
 }

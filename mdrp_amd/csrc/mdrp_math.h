@@ -633,6 +633,37 @@ MDRP_HD double loss_weight(int type, double thr, double r2, double mu = 0.5) {
     }
 }
 
+// ---------------------------------------------------------------- conservative fp32 pre-filter of the scoring sweep
+// Exact inlier test of compute_sampson_msac_score: C^2 < thr * den, C = x2' E x1, den = |(E x1)_xy|^2 + |(E' x2)_xy|^2.
+// With Dmax >= den for every record inside the pair's coordinate box (|x1| <= (ax, ay), |x2| <= (cx, cy)):
+//     inlier  =>  |C| < T := sqrt(thr * Dmax).
+// In fp32 (E and the coordinates rounded once, 8 FMAs, depth 7):  |C32 - C| <= 7u * M,  u = 2^-24,
+// M = sum |E_ij| |x2_i|max |x1_j|max.  filter_keeps() drops a record only if |C32| > tb with
+// tb = (T + 2e-6 M)(1 + 1e-6) + 1e-30 (5x margin on 7u = 4.2e-7; the absolute term covers flushed denormals).
+// NaN keeps; M >= 1e30 or non-finite (fp32 overflow possible) -> tb = inf, keeps everything.
+// thr_dmax = Dmax * (1 + 1e-9) is returned for the fp64 variant of the same bound.
+MDRP_HD void filter_setup(const double E[9], const double box[4], double thr, float Ef[9], float &tb, double &thr_dmax) {
+    const double ax = box[0], ay = box[1], cx = box[2], cy = box[3];
+    const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
+    const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
+    thr_dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
+    const double e2 = fabs(E[6]) * ax + fabs(E[7]) * ay + fabs(E[8]);
+    const double M = e0 * cx + e1 * cy + e2;
+    const double T = sqrt(thr * (1.0 + 1e-12) * thr_dmax);
+    tb = (M < 1e30) ? (float)((T + 2e-6 * M) * (1.0 + 1e-6)) + 1e-30f : __builtin_inff(); // !(M < 1e30) also catches NaN
+    for (int i = 0; i < 9; ++i) Ef[i] = (float)E[i];
+}
+
+// phase 1 for one record (a, b) = x1, (c, d) = x2, all already rounded to fp32; the sweep runs the same arithmetic two
+// records at a time (v_pk_fma_f32)
+MDRP_HD bool filter_keeps(const float Ef[9], float tb, float a, float b, float c, float d) {
+    const float e0 = fmaf(Ef[0], a, fmaf(Ef[1], b, Ef[2]));
+    const float e1 = fmaf(Ef[3], a, fmaf(Ef[4], b, Ef[5]));
+    const float e2 = fmaf(Ef[6], a, fmaf(Ef[7], b, Ef[8]));
+    const float C = fmaf(c, e0, fmaf(d, e1, e2));
+    return !(fabsf(C) > tb);
+}
+
 // ---------------------------------------------------------------- refinement: per-correspondence residuals
 // State of one hypothesis during LM, expanded once per cost/accumulate pass.
 struct LmState {

@@ -67,3 +67,30 @@ extern "C" void hm_draw_wave(uint64_t n, uint64_t seed, int count, uint32_t *out
     }
     *state_out = state;
 }
+
+// conservative fp32 pre-filter of the sweep: returns the number of records the EXACT fp64 test accepts but the filter
+// drops (must be 0); *kept = records the filter keeps, *exact = records the exact test accepts
+extern "C" long hm_filter_check(const double *E, const double *x1, const double *x2, long n, double thr, long *kept, long *exact) {
+    double box[4] = {0, 0, 0, 0};
+    for (long i = 0; i < n; ++i) {
+        box[0] = fmax(box[0], fabs(x1[2 * i])); box[1] = fmax(box[1], fabs(x1[2 * i + 1]));
+        box[2] = fmax(box[2], fabs(x2[2 * i])); box[3] = fmax(box[3], fabs(x2[2 * i + 1]));
+    }
+    float Ef[9], tb;
+    double dm;
+    filter_setup(E, box, thr, Ef, tb, dm);
+    long missed = 0, k = 0, ex = 0;
+    for (long i = 0; i < n; ++i) {
+        const double a = x1[2 * i], b = x1[2 * i + 1], c = x2[2 * i], d = x2[2 * i + 1];
+        const bool keep = filter_keeps(Ef, tb, (float)a, (float)b, (float)c, (float)d);
+        const long double e0 = (long double)E[0] * a + (long double)E[1] * b + E[2], e1 = (long double)E[3] * a + (long double)E[4] * b + E[5],
+                          e2 = (long double)E[6] * a + (long double)E[7] * b + E[8];
+        const long double g0 = (long double)E[0] * c + (long double)E[3] * d + E[6], g1 = (long double)E[1] * c + (long double)E[4] * d + E[7];
+        const long double Cv = c * e0 + d * e1 + e2, den = e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1;
+        const bool inl = Cv * Cv < (long double)thr * (1.0L + 1e-12L) * den;
+        k += keep; ex += inl;
+        if (inl && !keep) ++missed;
+    }
+    *kept = k; *exact = ex;
+    return missed;
+}

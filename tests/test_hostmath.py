@@ -123,3 +123,56 @@ def test_lm_step_and_losses_equal_oracle(hm):
         assert hm.hm_loss(3, C.c_double(thr), C.c_double(r2), 0) == pytest.approx(t2 * np.log1p(r2 / t2))
         assert hm.hm_loss(4, C.c_double(thr), C.c_double(r2), 0) == pytest.approx(t2 * np.log1p(min(r2, t2) / t2))
         assert hm.hm_loss(4, C.c_double(thr), C.c_double(r2), 1) == pytest.approx(1 / (1 + r2 / t2) if r2 < t2 else 0.0)
+
+
+def _rand_E(rng, kind):
+    from mdrp_amd import synth
+    R = synth.rodrigues(rng.normal(0, 0.6, 3))
+    t = rng.normal(0, 1.0, 3) * 10.0 ** rng.uniform(-4, 1)
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    if kind:  # fundamental matrix of a focal estimator: diag(1,1,f2) E diag(1,1,f1), normalised focals around 1
+        f1, f2 = 10.0 ** rng.uniform(-1, 1, 2)
+        E = np.diag([1, 1, f2]) @ E @ np.diag([1, 1, f1])
+    return np.ascontiguousarray(E.reshape(9))
+
+
+def test_fp32_prefilter_is_conservative(hm):
+    """mdrp_math.h filter_setup / filter_keeps (phase 1 of the scoring sweep, run in fp32 on the GPU) must keep every record
+    the exact fp64 test `C^2 < thr * den` accepts: random and near-degenerate hypotheses, coordinate scales 1e-3 .. 1e3,
+    inliers planted exactly on the epipolar lines, thresholds from 1e-8 to 1e-2."""
+    hm.hm_filter_check.restype = C.c_long
+    rng = np.random.default_rng(11)
+    n = 4000
+    total_kept = total_exact = 0
+    for trial in range(300):
+        kind = trial % 2
+        E = _rand_E(rng, kind)
+        scale = 10.0 ** rng.uniform(-3, 3) if trial % 3 == 0 else 1.0
+        x1 = rng.uniform(-1, 1, (n, 2)) * np.array([0.8, 0.6]) * scale
+        x2 = rng.uniform(-1, 1, (n, 2)) * np.array([0.8, 0.6]) * scale
+        # plant near-inliers: move x2 onto (or within a few thresholds of) its epipolar line l = E (x1, 1)
+        thr = 10.0 ** rng.uniform(-8, -2) * scale * scale
+        Em = E.reshape(3, 3)
+        l = (Em @ np.c_[x1, np.ones(n)].T).T
+        nl = np.hypot(l[:, 0], l[:, 1]) + 1e-300
+        dist = (l[:, 0] * x2[:, 0] + l[:, 1] * x2[:, 1] + l[:, 2]) / nl
+        k = n // 2
+        off = rng.uniform(-3, 3, k) * np.sqrt(thr)
+        x2[:k, 0] -= (dist[:k] - off) * l[:k, 0] / nl[:k]
+        x2[:k, 1] -= (dist[:k] - off) * l[:k, 1] / nl[:k]
+        if trial % 7 == 0:  # box corners
+            x1[-8:] = np.abs(x1).max(0) * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1]] * 2)
+        kept, exact = C.c_long(), C.c_long()
+        missed = hm.hm_filter_check(P(E), P(np.ascontiguousarray(x1)), P(np.ascontiguousarray(x2)), C.c_long(n), C.c_double(thr),
+                                    C.byref(kept), C.byref(exact))
+        assert missed == 0, (trial, kind, scale, thr)
+        assert kept.value >= exact.value
+        total_kept += kept.value; total_exact += exact.value
+    assert total_exact > 10000  # the planted inliers are really inliers
+    # degenerate inputs keep everything: E = 0, NaN, fp32-overflowing magnitudes
+    x1 = rng.uniform(-1, 1, (64, 2)); x2 = rng.uniform(-1, 1, (64, 2))
+    for E in (np.zeros(9), np.full(9, np.nan), _rand_E(rng, 0) * 1e35):
+        kept, exact = C.c_long(), C.c_long()
+        assert hm.hm_filter_check(P(np.ascontiguousarray(E)), P(x1), P(x2), C.c_long(64), C.c_double(1e-5), C.byref(kept), C.byref(exact)) == 0
+        assert kept.value == 64
