@@ -633,10 +633,6 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
             }
             m[k] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
         }
-#ifdef MDRP_EXP_NOP2
-#pragma unroll
-        for (int k = 0; k < K; ++k) { asm volatile("" ::"v"(m[k])); m[k] = 0; }
-#endif
         uint64_t any = 0;
 #pragma unroll
         for (int k = 0; k < K; ++k) { if (pr.dead) m[k] = 0; any |= m[k]; }
@@ -829,12 +825,6 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     const int bi = w - plan[pair];
     const bool dense = bi >= blk_sparse;
     const int blk = dense ? bi - blk_sparse : bi;
-#ifdef MDRP_SKIP_DENSE  // timing experiments only (results are wrong)
-    if (dense) continue;
-#endif
-#ifdef MDRP_SKIP_SPARSE
-    if (!dense) continue;
-#endif
     const int cnt_sparse = model_count[2 * pair], cnt_dense = model_count[2 * pair + 1];
     const PairState &ps = st[pair];
     const int n = ps.n;
