@@ -1114,8 +1114,7 @@ __device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jro
 }
 
 // One correspondence of the accumulate sweep, term by term: each term's Jacobian rows are folded into the accumulators
-// before the next term is computed (the scheduler is fenced in between), so at most two rows are live beside the
-// NP (NP + 3) / 2 accumulators.
+// before the next term is computed, so at most two rows need to be live beside the NP (NP + 3) / 2 accumulators.
 template <int KIND, bool SHIFT>
 __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 p01, double2 p23, double2 dd,
                                                     double sqrt_sr, double ws, const LmOpt &o, double *acc) {
@@ -1125,7 +1124,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         const double w = ws * loss_weight(o.loss, o.loss_scale, r0 * r0, o.mu);
         lm_accumulate_row<KIND, SHIFT>(J0, r0, w, acc);
     }
-#ifndef MDRP_LM_NO_FENCE
+#ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
 #endif
     {
@@ -1135,7 +1134,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         lm_accumulate_row<KIND, SHIFT>(J1, r1, w, acc);
         lm_accumulate_row<KIND, SHIFT>(J2, r2, w, acc);
     }
-#ifndef MDRP_LM_NO_FENCE
+#ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
 #endif
     {
