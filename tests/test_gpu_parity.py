@@ -339,3 +339,42 @@ def test_full_size_properties(handle, capi):
         assert np.abs(res[i]["model"]["t"] - gt["t"]).max() < 1e-6 and abs(res[i]["model"]["scale"] - gt["scale"]) < 1e-6 * gt["scale"]
         assert int(res[i]["iterations"]) == 10000 and int(res[i]["num_inliers"]) == 2000 and mask[i].all()
     assert res[3].tobytes() == res[0].tobytes() and (mask[3] == mask[0]).all()
+
+
+@pytest.mark.gpu
+def test_schedule_does_not_change_results(handle, capi, monkeypatch):
+    """The chunk split, the three-stream pipeline and the LO grid are scheduling only: every setting must reproduce the
+    same records bit for bit (single chunk on one stream is the plain sequential schedule)."""
+    from mdrp_amd import synth
+    B, N = 12, 700
+    b = synth.make_batch(4000, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4)
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE)
+    cams["params"][:, 0] = 800.0
+    ro = capi.ransac_opt_from_dict({"max_iterations": 4000, "min_iterations": 4000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+    bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+
+    def run():
+        res, mask = handle.estimate_batch(0, b["x1"], b["x2"], b["d1"], b["d2"], ro, bo, None, cams, cams)
+        return res.copy(), mask.copy()
+
+    monkeypatch.setenv("MDRP_CHUNKS", "0")          # no leading chunk: one chunk, no bail-out bar, no overlap
+    monkeypatch.setenv("MDRP_LO_OVERLAP", "0")
+    ref, ref_mask = run()
+    assert int(ref["iterations"].min()) == 4000 and int(ref["num_inliers"].min()) > 300
+    for env in ({"MDRP_CHUNKS": "512"}, {"MDRP_CHUNKS": "256,1024"}, {"MDRP_CHUNKS": "512", "MDRP_LO_OVERLAP": "0"},
+                {"MDRP_CHUNKS": "128,256,512", "MDRP_LO_OVERLAP_WAVES": "4", "MDRP_LO_AFTER_SOLVE": "1"},
+                {"MDRP_CHUNKS": "512", "MDRP_LO_THREADS": "256", "MDRP_FINAL_THREADS": "64"}):
+        for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_THREADS", "MDRP_FINAL_THREADS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        res, mask = run()
+        for f in ("refinements", "iterations", "num_inliers"):
+            assert np.array_equal(res[f], ref[f]), (env, f)
+        assert np.array_equal(mask, ref_mask), env
+        # thread-count variants reduce in a different order: models agree to rounding, not bitwise
+        tol = 1e-9 if "MDRP_LO_THREADS" in env else 0.0
+        def flat(m):
+            return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
+        assert np.allclose(flat(res["model"]), flat(ref["model"]), rtol=tol, atol=tol), env
+        assert np.allclose(res["model_score"], ref["model_score"], rtol=max(tol, 0.0), atol=0.0), env
