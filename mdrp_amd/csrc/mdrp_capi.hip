@@ -209,6 +209,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const bool lo_after_solve = env_int("MDRP_LO_AFTER_SOLVE", 0) != 0;
     const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
+    const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = SCORE_TILE_BYTES;
@@ -337,8 +338,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             // LO beside the solver wastes both (two latency-bound kernels share a SIMD); LO beside the sweep does not
             if (piped && lo_after_solve && c + 1 < n_chunks) HIPCHK(hipStreamWaitEvent(aux2, h->ev_solved[c + 1], 0));
             const int lo_waves_c = (piped && c + 1 < n_chunks) ? lo_overlap_waves : 8; // the last chunk's LO has the chip to itself
-            const int lo_blocks = h->num_cu * (lo_threads == 64 ? lo_waves_c : 2);
-            MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
+            const int lo_threads_c = (c + 1 == n_chunks) ? lo_threads_last : lo_threads;
+            const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
+            MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
                              h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
                              trig_cap, lo_plan, cnt + 8 + c, lm_list_stride(n_max));
         }
