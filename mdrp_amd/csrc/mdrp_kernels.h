@@ -1092,25 +1092,32 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     return v[0];
 }
 
-// JtJ (lower triangle, row-major) and Jtr of one weighted residual row
-template <int KIND, bool SHIFT>
+// JtJ (lower triangle, row-major) and Jtr of one weighted residual row.  ZMASK: columns of the full 11-wide row that are
+// structurally zero for this term (no shift / scale / cross-translation dependence); their products are skipped — the
+// compiler cannot drop `acc += w * 0.0 * x` on its own under IEEE rules (18-22 % of the normal-equation FMAs).
+template <int KIND, bool SHIFT, unsigned ZMASK>
 __device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jrow, double r, double w, double *acc) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     double Ja[NP];
+    bool nz[NP];
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        Ja[q] = Jrow[lm_col<KIND, SHIFT>(q)];
-        if (KIND == 1 && q == 7) Ja[q] += Jrow[10]; // shared focal: f1 = f2 = f
+        const int col = lm_col<KIND, SHIFT>(q);
+        Ja[q] = Jrow[col];
+        nz[q] = !((ZMASK >> col) & 1u);
+        if (KIND == 1 && q == 7) { Ja[q] += Jrow[10]; nz[q] = nz[q] || !((ZMASK >> 10) & 1u); } // shared focal: f1 = f2 = f
     }
     int idx = 0;
 #pragma unroll
     for (int a = 0; a < NP; ++a) {
         const double wa = w * Ja[a];
 #pragma unroll
-        for (int b = 0; b <= a; ++b) acc[idx++] += wa * Ja[b];
+        for (int b = 0; b <= a; ++b, ++idx)
+            if (nz[a] && nz[b]) acc[idx] += wa * Ja[b];
     }
 #pragma unroll
-    for (int a = 0; a < NP; ++a) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r;
+    for (int a = 0; a < NP; ++a)
+        if (nz[a]) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r;
 }
 
 // One correspondence of the accumulate sweep, term by term: each term's Jacobian rows are folded into the accumulators
@@ -1122,7 +1129,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         double r0, J0[LM_NPAR];
         lm_sampson_term<true, KIND != 0>(stt, p01.x, p01.y, p23.x, p23.y, r0, J0);
         const double w = ws * loss_weight(o.loss, o.loss_scale, r0 * r0, o.mu);
-        lm_accumulate_row<KIND, SHIFT>(J0, r0, w, acc);
+        lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); // no scale / shift dependence
     }
 #ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
@@ -1131,8 +1138,8 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         double r1, r2, zf, J1[LM_NPAR], J2[LM_NPAR];
         lm_forward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.x, r1, r2, zf, J1, J2);
         const double w = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r1 * r1 + r2 * r2, o.mu);
-        lm_accumulate_row<KIND, SHIFT>(J1, r1, w, acc);
-        lm_accumulate_row<KIND, SHIFT>(J2, r2, w, acc);
+        lm_accumulate_row<KIND, SHIFT, 0x150u>(J1, r1, w, acc); // t.y, scale, shift2
+        lm_accumulate_row<KIND, SHIFT, 0x148u>(J2, r2, w, acc); // t.x, scale, shift2
     }
 #ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
@@ -1141,8 +1148,8 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         double r3, r4, zb, J3[LM_NPAR], J4[LM_NPAR];
         lm_backward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.y, r3, r4, zb, J3, J4);
         const double w = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r3 * r3 + r4 * r4, o.mu);
-        lm_accumulate_row<KIND, SHIFT>(J3, r3, w, acc);
-        lm_accumulate_row<KIND, SHIFT>(J4, r4, w, acc);
+        lm_accumulate_row<KIND, SHIFT, 0x080u>(J3, r3, w, acc); // shift1
+        lm_accumulate_row<KIND, SHIFT, 0x080u>(J4, r4, w, acc); // shift1
     }
 }
 
