@@ -158,7 +158,8 @@ def test_estimate_vs_reference_golden(handle, capi, golden):
 def test_statistical_equivalence_noisy(handle, capi, po, kind, es, rf):
     """north_star: 'statistically equivalent inlier counts on noisy data'.  48 noisy pairs per estimator (N = 500, 35 %
     outliers, default dynamic stopping) against the CPU oracle: identical iteration counts, mean inlier count within
-    0.5 %, and the large majority of pairs on exactly the same trajectory (same LO count, inliers and mask)."""
+    0.5 %, and (nearly) all pairs on exactly the same trajectory (same LO count, inliers and mask; tools/stress_parity.py
+    measured 1920 of 1920, the slack is for rounding-level ties)."""
     from mdrp_amd import synth
     B, N = 48, 500
     b = synth.make_batch(2000 + 100 * kind + int(es), B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.35, random_focal=rf,
@@ -179,7 +180,7 @@ def test_statistical_equivalence_noisy(handle, capi, po, kind, es, rf):
         same += (int(res[i]["iterations"]) == st.iterations and int(res[i]["refinements"]) == st.refinements
                  and int(res[i]["num_inliers"]) == st.num_inliers and (mask[i] == mk).all())
     assert abs(np.mean(inl_gpu) - np.mean(inl_cpu)) <= 0.005 * np.mean(inl_cpu), (np.mean(inl_gpu), np.mean(inl_cpu))
-    assert same >= 0.75 * B, (same, B)
+    assert same >= 0.9 * B, (same, B)
 
 
 def test_estimate_shift_flag_ignored_by_focal_estimators(handle, capi):
