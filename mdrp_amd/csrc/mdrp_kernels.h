@@ -622,10 +622,24 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
                             const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
                             const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
                             const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
+#ifdef MDRP_NO_ASM_MASK
                             mask |= !(fabsf(C.x) > tb) ? (1u << j) : 0u;
                             mask |= !(fabsf(C.y) > tb) ? (2u << j) : 0u;
+#else
+                            // mask = 2 * mask + keep: compare into VCC, add-with-carry shifts it in (2 instructions per
+                            // record instead of compare + select + constant move + or); record j lands in bit 31 - j
+                            const float cx = C.x, cy = C.y;
+                            unsigned long long kx, ky, co;
+                            asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(kx) : "v"(cx), "v"(tb));
+                            asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(ky) : "v"(cy), "v"(tb));
+                            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(kx));
+                            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(ky));
+#endif
                         }
                     }
+#ifndef MDRP_NO_ASM_MASK
+                    mask = __brev(mask); // back to record j in bit j
+#endif
                     const int valid = g - q0; // records past the end of the tile hold stale LDS
                     if (valid < 32) mask &= (1u << valid) - 1u;
                     half[h] = mask;
