@@ -286,8 +286,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
             hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(),
                                h->table_state.as<uint64_t>(), r.chunk_len, smp);
-            hipLaunchKernelGGL(k_solve, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp,
-                               h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+#define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
+    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp, \
+                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc)
+            switch (r.solver) {
+            case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
+            case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;
+            case SOLVER_SHARED: MDRP_SOLVE_LAUNCH(SOLVER_SHARED); break;
+            default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
+            }
+#undef MDRP_SOLVE_LAUNCH
             hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, st_, r, h->st.as<PairState>(), h->pts.as<double>(),
                                h->models.as<Model>(), mc, tg, tgs);
             return MDRP_OK;

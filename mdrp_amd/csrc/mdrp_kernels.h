@@ -318,6 +318,7 @@ __device__ __forceinline__ int probe_count(const float4 *__restrict__ recs32, in
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
 // with ONE atomic per wave (wave-aggregated prefix sum); model_count[2 * pair] counts them.
+template <int SOLVER> // one solver per kernel (host dispatch): a runtime switch made every launch carry the registers of the largest
 __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
                                                const double *__restrict__ pts, const double *__restrict__ dep,
                                                Model *__restrict__ models, int32_t *__restrict__ slot_inl,
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
             s.x1[k][0] = p[0]; s.x1[k][1] = p[1]; s.x2[k][0] = p[2]; s.x2[k][1] = p[3];
             s.d1[k] = dep[2 * idx]; s.d2[k] = dep[2 * idx + 1];
         }
-        n = run_solver(rp.solver, s, out);
+        n = run_solver(SOLVER, s, out);
         // a NaN hypothesis can never become a record (its score is N*thr, count 0) except as the very first model;
         // drop it (the reference's own P3P emits NaN poses for ~2% of garbage samples)
     }
