@@ -409,7 +409,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     const int chunk_cap = (int)chunk_cap64;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_pair = (size_t)chunk_cap * 4 * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t)) +
+    const size_t per_pair = (size_t)chunk_cap * 4 * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair));
