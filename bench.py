@@ -206,6 +206,8 @@ def main():
         from mdrp_amd import synth
         from mdrp_amd.poselib import _quat_to_R
         R_err = float(np.median([synth.rotation_error_deg(g["R"], _quat_to_R(r["model"]["q"])) for r, g in zip(res[:64], b["gt"][:64])]))
+        traffic = pmc_traffic(args.workload, B)
+        phys = (traffic[0] / avg_launch_s / 1e9) if (traffic and avg_launch_s > 0) else None
         line = {
             "metric": "image-pairs/sec (2000 corrs, 10k RANSAC iters)", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -214,10 +216,12 @@ def main():
                        "outlier_fraction": of, "estimator": ["calibrated", "shared_focal", "varying_focal"][kind],
                        "monodepth_estimate_shift": es, "parallelism": f"pairs sharded x{world}, all_gather of results"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (pmc_traffic(args.workload, B) or (None, None))[0], "traffic_unit": "bytes per launch (PMC)",
-                         "traffic_source": (pmc_traffic(args.workload, B) or (None, None))[1], "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "traffic": (traffic or (None, None))[0], "traffic_unit": "bytes per launch (PMC)",
+                         "traffic_source": (traffic or (None, None))[1], "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "k_score", "evals_per_launch": sweep_evals / max(sweep_launches, 1),
-                         "avg_launch_ms": 1e3 * avg_launch_s, "sweep_share_of_step": (sweep_ms / 1e3) / dt},
+                         "avg_launch_ms": 1e3 * avg_launch_s, "sweep_share_of_step": (sweep_ms / 1e3) / dt,
+                         # physical HBM-side rate of the sweep: PMC bytes per launch / this run's launch duration
+                         "physical_GBs": phys, "physical_frac": (phys / HBM_PEAK_GBS) if phys else None},
             # SURVEY.md §8(d) asks for both fractions: the physically binding limit of the sweep is VALU issue, not HBM
             "roofline_valu": {"bound": "valu-fp64", "achieved": valu_tf, "frac": valu_tf / FP64_PEAK_TFLOPS,
                               "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (algorithmic: 35 flop per evaluation the CPU loop would do)",
