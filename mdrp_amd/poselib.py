@@ -303,3 +303,19 @@ def estimate_varying_focal_monodepth_relative_pose(kp1, kp2, d, ransac_opt={}, b
     """eval_varying_f.py:168"""
     d = np.asarray(d, dtype=np.float64)
     return estimate_monodepth_varying_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt), bundle_opt)
+
+
+def _not_on_path(name, where):
+    def stub(*args, **kwargs):
+        raise NotImplementedError(f"poselib.{name} ({where}) is a non-monodepth baseline outside the accelerated hot path "
+                                  "(SURVEY.md §8f-4 / DESIGN.md §8); use upstream PoseLib for it")
+    stub.__name__ = name
+    stub.__doc__ = f"{where}: not on the monodepth RANSAC path rebuilt here — raises NotImplementedError."
+    return stub
+
+
+# names the reference scripts also reach for (baseline rows of the paper tables): present so that a swapped import fails
+# with a clear message at the call, not with an AttributeError
+estimate_relative_pose = _not_on_path("estimate_relative_pose", "5-point baseline, eval.py:136")
+estimate_shared_focal_relative_pose = _not_on_path("estimate_shared_focal_relative_pose", "6-point baseline, eval_shared_f.py:161")
+estimate_relative_pose_w_relative_depth = _not_on_path("estimate_relative_pose_w_relative_depth", "fork-only variant, eval.py:140 (commented out upstream)")
