@@ -8,7 +8,7 @@
  * demo/reposed_demo.ipynb cell 4).  Only its compiled binary ships (demo/poselib-2.0.5-cp312-*.whl).
  * Every function here restates the published/observed algorithm of one exported symbol of that
  * binary (ELF addresses as in SURVEY.md §2/§8a) and is PINNED against outputs of that very binary
- * run in the build container (oracle/refshim + tools/gen_golden.py -> tests/golden/ fixtures).
+ * run in the build container (oracle/refshim + tests/tools/gen_golden.py -> tests/golden/ fixtures).
  */
 #ifndef MDRP_ORACLE_H
 #define MDRP_ORACLE_H

@@ -6,7 +6,7 @@
 // it cannot be compiled; it CAN be dlopen()ed.  This file is our own
 // code: it declares ABI-compatible plain structs and calls the exported C++ entry points by their
 // mangled names.  It is used to (1) pin oracle/mdrp_oracle.c function by function and (2) emit the
-// golden vectors committed under tests/golden/ (tools/gen_golden.py).  Neither the wheel nor its
+// golden vectors committed under tests/golden/ (tests/tools/gen_golden.py).  Neither the wheel nor its
 // .so is ever copied into this repository; the built shim lands in oracle/_ref/ (git-ignored) and
 // is useless on the GPU box (the wheel does not travel).
 //

@@ -158,7 +158,7 @@ def test_estimate_vs_reference_golden(handle, capi, golden):
 def test_statistical_equivalence_noisy(handle, capi, po, kind, es, rf):
     """north_star: 'statistically equivalent inlier counts on noisy data'.  48 noisy pairs per estimator (N = 500, 35 %
     outliers, default dynamic stopping) against the CPU oracle: identical iteration counts, mean inlier count within
-    0.5 %, and (nearly) all pairs on exactly the same trajectory (same LO count, inliers and mask; tools/stress_parity.py
+    0.5 %, and (nearly) all pairs on exactly the same trajectory (same LO count, inliers and mask; tests/tools/stress_parity.py
     measured 1920 of 1920, the slack is for rounding-level ties)."""
     from mdrp_amd import synth
     B, N = 48, 500

@@ -1,5 +1,5 @@
 """The CPU oracle (oracle/*.c) against golden vectors produced by the reference's own PoseLib binary
-(tools/gen_golden.py).  No GPU."""
+(tests/tools/gen_golden.py).  No GPU."""
 import numpy as np
 import pytest
 

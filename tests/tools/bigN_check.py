@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0,'/root/repo')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import numpy as np
 from mdrp_amd import _capi as capi, synth
 from oracle import pyorc as po

@@ -5,7 +5,7 @@ Runs only in the build container (needs /root/reference/demo/poselib-2.0.5-*.whl
 first).  The fixtures are data only: inputs and the reference binary's outputs.  Re-running reproduces the
 files bit for bit (all randomness is seeded).
 
-    python3 tools/gen_golden.py
+    python3 tests/tools/gen_golden.py
 """
 import os
 import sys
@@ -14,11 +14,11 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.join(HERE, ".."))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))
 import refshim as rs  # noqa: E402
 from mdrp_amd import synth  # noqa: E402
 
-OUT = os.path.join(HERE, "..", "tests", "golden")
+OUT = os.path.join(HERE, "..", "golden")
 
 
 def rodrigues(w):

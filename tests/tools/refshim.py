@@ -1,14 +1,14 @@
 """ctypes front-end for oracle/_ref/librefshim.so (the reference's own PoseLib binary, dlopen()ed).
 
-THIS CONTAINER ONLY — used by tools/gen_golden.py and by ad-hoc parity probes while developing the
-oracle.  Nothing under tests/ (gpu or not), bench.py or mdrp_amd/ imports this module.
+THIS CONTAINER ONLY — used by tests/tools/gen_golden.py and by ad-hoc parity probes while developing the
+oracle.  No test (gpu or not), bench.py or mdrp_amd/ imports this module.
 """
 import ctypes as C
 import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SHIM = os.path.join(_HERE, "..", "oracle", "_ref", "librefshim.so")
+_SHIM = os.path.join(_HERE, "..", "..", "oracle", "_ref", "librefshim.so")
 _REF_SO = "/tmp/mdrp_ref_whl/poselib/_core.cpython-312-x86_64-linux-gnu.so"
 
 _lib = None

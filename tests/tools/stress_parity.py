@@ -2,14 +2,14 @@
 """Wide GPU-vs-oracle comparison (not part of the test suite): for every estimator, many noisy pairs over a spread of
 sizes, outlier rates, seeds and option sets.  Prints, per configuration, how many pairs land on exactly the oracle's
 trajectory (iterations, refinements, inliers, mask) and the worst model deviation among those.  Run on the GPU box:
-    python tools/stress_parity.py [pairs_per_config]"""
+    python tests/tools/stress_parity.py [pairs_per_config]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from mdrp_amd import _capi as capi, synth  # noqa: E402
 from oracle import pyorc as po  # noqa: E402
 
