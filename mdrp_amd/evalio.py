@@ -1,0 +1,181 @@
+"""Dataset I/O and scoring around the accelerated estimators — the reference's evaluation loop, batched.
+
+The reference's `eval.py` walks an H5 file pair by pair and calls PoseLib once per pair in a process pool
+(`eval.py:307-359`).  Here the same file layout is read (any mapping with the same keys works: `h5py.File`, a dict of
+arrays), all pairs of one experiment go to the GPU in batches, and the same result records / summary numbers come out:
+
+    corr_{a}_{b}   (N, 32) float   cols 0-3 = x1, y1, x2, y2; depth column pairs as in `utils/data.py:22-46`
+    pose_{a}_{b}   (3, 4)          ground-truth [R | t]
+    K_{img}        (3, 3)          intrinsics                                               (eval.py:318-336)
+
+Only the calibrated monodepth experiments that map onto the upstream-PoseLib (PR 152) estimators are runnable; fork-only
+variants raise NotImplementedError (see `mdrp_amd.poselib._map_fork_options`).  h5py is optional: `open_h5` imports it
+lazily.
+"""
+import json
+import time
+
+import numpy as np
+
+# utils/data.py:22-46 — depth estimator id -> the two columns of corr_* holding (depth in image 1, depth in image 2)
+_DEPTH_COLUMNS = {1: (8, 9), 2: (10, 11), 3: (12, 13), 4: (14, 15), 5: (16, 17), 6: (18, 19), 7: (20, 21), 8: (22, 23),
+                  9: (24, 25), 10: (26, 27), 11: (28, 29), 12: (30, 31)}
+DEPTH_NAMES = {1: "real", 2: "midas", 3: "dpt", 4: "zoe", 5: "depth-any-v1", 6: "depth-any-v2", 7: "depth-pro", 8: "metric3d",
+               9: "marigold-e2e", 10: "moge", 11: "marigold", 12: "unidepth"}
+
+
+def depth_indices(depth):
+    """utils/data.py:22-46"""
+    return _DEPTH_COLUMNS[int(depth)]
+
+
+def invalid_depth_mask(d):
+    """utils/data.py:13-19 (`get_valid_depth_mask` — despite its name it marks the INVALID rows: inf, nan or negative)"""
+    d = np.asarray(d)
+    return np.isinf(d[:, 0]) | np.isinf(d[:, 1]) | np.isnan(d[:, 0]) | np.isnan(d[:, 1]) | (d[:, 0] < 0) | (d[:, 1] < 0)
+
+
+def rotation_error_deg(R_gt, R):
+    """utils/data.py:49-61: chordal form, 2 asin(|R_gt - R|_F / (2 sqrt 2))"""
+    s = np.linalg.norm(np.asarray(R_gt, dtype=np.float64) - np.asarray(R, dtype=np.float64)) / (2.0 * np.sqrt(2.0))
+    return float(np.rad2deg(2.0 * np.arcsin(max(min(1.0, s), -1.0))))
+
+
+def translation_error_deg(t_gt, t):
+    """utils/data.py:64-82: angle between the translation DIRECTIONS, sign-agnostic"""
+    t = np.asarray(t, dtype=np.float64).flatten()
+    t_gt = np.asarray(t_gt, dtype=np.float64).flatten()
+    eps = 1e-15
+    t = t / (np.linalg.norm(t) + eps)
+    t_gt = t_gt / (np.linalg.norm(t_gt) + eps)
+    loss_t = np.maximum(eps, 1.0 - np.sum(t * t_gt) ** 2)
+    return float(np.rad2deg(np.arccos(np.sqrt(1.0 - loss_t))))
+
+
+def open_h5(path):
+    try:
+        import h5py
+    except ImportError as e:  # pragma: no cover - h5py is not part of the build image
+        raise ImportError("reading the RePoseD .h5 files needs h5py; any dict-like with the same keys works too") from e
+    return h5py.File(path, "r")
+
+
+def list_pairs(h5, first=None):
+    """eval.py:309-314: image-name pairs from the `corr_{a}_o_{b}` keys"""
+    prelim = [k.split("corr_")[1] for k in h5.keys() if "corr_" in k]
+    pairs = [(p.split("_o_")[0] + "_o", p.split("_o_")[1]) for p in prelim]
+    return pairs[:first] if first is not None else pairs
+
+
+def load_pair(h5, name1, name2, depth=None):
+    """eval.py:318-345: keypoints, depth columns (invalid -> 1.0), ground truth, intrinsics of one pair"""
+    Rt = np.array(h5[f"pose_{name1}_{name2}"], dtype=np.float64)
+    data = np.array(h5[f"corr_{name1}_{name2}"], dtype=np.float64)
+    kp1, kp2 = data[:, :2].copy(), data[:, 2:4].copy()
+    if depth is not None:
+        d = data[:, list(depth_indices(depth))].copy()
+    else:
+        d = np.ones_like(kp1)
+    d[invalid_depth_mask(d)] = 1.0
+    return {"kp1": kp1, "kp2": kp2, "d": d, "R_gt": Rt[:3, :3], "t_gt": Rt[:, 3],
+            "K1": np.array(h5[f"K_{name1}"], dtype=np.float64), "K2": np.array(h5[f"K_{name2}"], dtype=np.float64)}
+
+
+def experiment_options(experiment, iters=None, threshold=1.0, reproj_threshold=16.0):
+    """eval.py:93-127: option dicts of an experiment name (e.g. '3p_ours_shift_scale+10', 'p3p+12')"""
+    lo_iterations = 0 if "nLO" in experiment else 25
+    it = 1000 if iters is None else int(iters)
+    ro = {"max_iterations": it, "min_iterations": it, "max_epipolar_error": threshold, "progressive_sampling": False,
+          "lo_iterations": lo_iterations, "max_reproj_error": reproj_threshold, "all_permutations": True,
+          "use_reldepth": "reldepth" in experiment, "use_p3p": "p3p" in experiment, "use_ours": "ours" in experiment,
+          "use_madpose": "mad_poselib" in experiment, "solver_shift": "shift" in experiment, "solver_scale": "scale" in experiment,
+          "use_reproj": "reproj" in experiment, "optimize_symmetric": "sym_reproj" in experiment,
+          "optimize_hybrid": "hybrid" in experiment, "optimize_shift": "reproj-s" in experiment or "hybrid-s" in experiment,
+          "use_madpose_shift_optim": "noshift" not in experiment, "weight_sampson": 1.0,
+          "graduated_steps": 3 if "GLO" in experiment else 0}
+    bo = {"max_iterations": 0 if lo_iterations == 0 else 100, "verbose": False}
+    if "truncated" in experiment:
+        bo["loss_type"] = "TRUNCATED"
+    if "ctruncated" in experiment:
+        bo["loss_type"] = "TRUNCATED_CAUCHY"
+    return ro, bo
+
+
+def _pinhole(K):
+    return {"model": "PINHOLE", "width": -1, "height": -1, "params": [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]}  # eval.py:129-130
+
+
+def result_record(experiment, info, R, t, R_gt, t_gt):
+    """eval.py:48-67 `get_result_dict`"""
+    out = {"R": np.asarray(R).tolist(), "R_gt": np.asarray(R_gt).tolist(), "t": np.asarray(t).tolist(), "t_gt": np.asarray(t_gt).tolist()}
+    out["R_err"] = rotation_error_deg(R_gt, R)
+    out["t_err"] = translation_error_deg(t_gt, t)
+    info = dict(info)
+    info["inliers"] = []
+    out["info"] = info
+    out["experiment"] = experiment
+    return out
+
+
+def evaluate_calibrated(h5, experiments, iters=None, threshold=1.0, reproj_threshold=16.0, first=None, batch=4096,
+                        estimate_batch=None, device=0):
+    """eval.py:316-359 for the calibrated estimator, batched: every experiment's pairs go to the GPU `batch` at a time.
+    `estimate_batch(kp1s, kp2s, d1s, d2s, cams1, cams2, ransac_opt, bundle_opt)` defaults to the accelerated
+    `poselib.estimate_monodepth_relative_pose_batch` (injectable for tests).  Pairs with fewer than 5 correspondences are
+    skipped as in the reference.  `info['runtime']` is the batch wall time divided by the batch size, in ms."""
+    from . import poselib
+    if estimate_batch is None:
+        def estimate_batch(k1, k2, a, b, c1, c2, ro, bo):
+            return poselib.estimate_monodepth_relative_pose_batch(k1, k2, a, b, c1, c2, ro, bo, device=device)
+    pairs = list_pairs(h5, first)
+    results = []
+    for experiment in experiments:
+        depth = int(experiment.split("+")[1]) if "+" in experiment else None
+        ro, bo = experiment_options(experiment, iters, threshold, reproj_threshold)
+        ro = poselib._map_fork_options(ro)
+        loaded = []
+        for a, b in pairs:
+            p = load_pair(h5, a, b, depth)
+            if len(p["kp1"]) >= 5:
+                loaded.append(p)
+        for s in range(0, len(loaded), batch):
+            chunk = loaded[s:s + batch]
+            t0 = time.perf_counter()
+            geoms, infos = estimate_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [p["d"][:, 0] for p in chunk],
+                                          [p["d"][:, 1] for p in chunk], [_pinhole(p["K1"]) for p in chunk],
+                                          [_pinhole(p["K2"]) for p in chunk], ro, bo)
+            ms = 1000.0 * (time.perf_counter() - t0) / max(len(chunk), 1)
+            for p, g, info in zip(chunk, geoms, infos):
+                info = dict(info)
+                info["runtime"] = ms
+                results.append(result_record(experiment, info, g.pose.R, g.pose.t, p["R_gt"], p["t_gt"]))
+    return results
+
+
+def summarize(experiments, results):
+    """utils/eval_utils.py:41-66 `print_results`, as rows: (experiment, median pose error, pose mAA over 1..10 degrees,
+    mean runtime ms, mean inlier ratio).  NaN errors count as 180 degrees."""
+    rows = []
+    for exp in experiments:
+        rs = [x for x in results if x["experiment"] == exp]
+        if not rs:
+            continue
+        p = np.array([max(r["R_err"], r["t_err"]) for r in rs], dtype=np.float64)
+        p[np.isnan(p)] = 180.0
+        maa = float(np.mean([np.sum(p < t) / len(p) for t in range(1, 11)]))
+        rows.append((exp, float(np.median(p)), maa, float(np.mean([x["info"]["runtime"] for x in rs])),
+                     float(np.mean([x["info"]["inlier_ratio"] for x in rs]))))
+    return rows
+
+
+def format_table(rows):
+    lines = [f"{'solver':32s} {'median pose err':>16s} {'pose mAA':>10s} {'mean time':>10s} {'mean inliers':>13s}"]
+    for r in rows:
+        lines.append(f"{r[0]:32s} {r[1]:16.4f} {r[2]:10.4f} {r[3]:10.4f} {r[4]:13.4f}")
+    return "\n".join(lines)
+
+
+def write_results(path, results):
+    """eval.py:378-379: the `results_new/calibrated-*.json` list of records"""
+    with open(path, "w") as f:
+        json.dump(results, f)

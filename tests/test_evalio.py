@@ -1,0 +1,105 @@
+"""mdrp_amd/evalio.py — the reference's dataset loop (eval.py:307-379) around the batched estimator.
+CPU: helpers against golden vectors produced by the reference's own utils/data.py (tests/tools/gen_golden_evalio.py),
+the H5 layout / option mapping / result records with a stub estimator.  GPU: end to end on a synthetic H5-like dict."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from mdrp_amd import evalio, synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_helpers_match_reference_golden():
+    g = np.load(os.path.join(HERE, "golden", "evalio.npz"))
+    for i in range(len(g["R"])):
+        assert evalio.rotation_error_deg(g["R_gt"][i], g["R"][i]) == pytest.approx(g["R_err"][i], rel=1e-12, abs=1e-12)
+        assert evalio.translation_error_deg(g["t_gt"][i], g["t"][i]) == pytest.approx(g["t_err"][i], rel=1e-12, abs=1e-12)
+    assert np.array_equal(evalio.invalid_depth_mask(g["d"]), g["invalid_mask"])
+    assert [list(evalio.depth_indices(k)) for k in range(1, 13)] == g["depth_columns"].tolist()
+
+
+def fake_h5(n_pairs=6, n=300, depth=10, seed=0):
+    """a dict with the key layout of the RePoseD .h5 files (eval.py:307-336), built from synthetic pairs"""
+    h5 = {}
+    gt = []
+    for i in range(n_pairs):
+        p = synth.make_pair(500 + seed + i, n if i != 2 else 4, noise_px=0.3, depth_noise=0.01, outlier_frac=0.3 if i % 2 else 0.0,
+                            pp=(640.0, 480.0), f1=900.0, f2=700.0)
+        a, b = f"img{i:02d}a_o", f"img{i:02d}b"
+        data = np.zeros((len(p["x1"]), 32))
+        data[:, :2] = p["x1"]; data[:, 2:4] = p["x2"]
+        c1, c2 = evalio.depth_indices(depth)
+        data[:, c1] = p["d1"]; data[:, c2] = p["d2"]
+        if len(data) > 10:
+            data[3, c1] = np.inf; data[5, c2] = np.nan; data[7, c1] = -1.0   # invalid depths -> 1.0 (eval.py:344-346)
+        h5[f"corr_{a}_{b}"] = data
+        h5[f"pose_{a}_{b}"] = np.c_[p["R"], p["t"]]
+        h5[f"K_{a}"] = np.array([[900.0, 0, 640.0], [0, 900.0, 480.0], [0, 0, 1]])
+        h5[f"K_{b}"] = np.array([[700.0, 0, 640.0], [0, 700.0, 480.0], [0, 0, 1]])
+        gt.append(p)
+    return h5, gt
+
+
+def test_layout_options_and_records_with_stub_estimator(tmp_path):
+    h5, gt = fake_h5()
+    pairs = evalio.list_pairs(h5)
+    assert pairs[0] == ("img00a_o", "img00b") and len(pairs) == 6 and len(evalio.list_pairs(h5, first=2)) == 2
+    p = evalio.load_pair(h5, *pairs[0], depth=10)
+    assert p["d"][3, 0] == 1.0 and p["d"][5, 1] == 1.0 and p["d"][7, 0] == 1.0 and p["kp1"].shape == (300, 2)
+    assert np.all(evalio.load_pair(h5, *pairs[0])["d"] == 1.0)
+    ro, bo = evalio.experiment_options("3p_ours_shift_scale_hybrid_ctruncated+10", iters=2000, threshold=1.5, reproj_threshold=12.0)
+    assert ro["max_iterations"] == ro["min_iterations"] == 2000 and ro["max_epipolar_error"] == 1.5 and ro["max_reproj_error"] == 12.0
+    assert ro["use_ours"] and ro["solver_shift"] and ro["solver_scale"] and ro["optimize_hybrid"] and not ro["use_p3p"]
+    assert bo == {"max_iterations": 100, "verbose": False, "loss_type": "TRUNCATED_CAUCHY"}
+    assert evalio.experiment_options("p3p_nLO+1")[1]["max_iterations"] == 0
+
+    seen = {}
+
+    def stub(k1, k2, d1, d2, c1, c2, ro_, bo_):   # returns the ground truth of the pair it was handed
+        from mdrp_amd.poselib import CameraPose, MonoDepthTwoViewGeometry
+        seen["ro"], seen["n"] = ro_, len(k1)
+        out = []
+        for kp in k1:
+            g = next(q for q in gt if len(q["x1"]) == len(kp) and np.allclose(q["x1"], kp))
+            geom = MonoDepthTwoViewGeometry.__new__(MonoDepthTwoViewGeometry)
+            pose = CameraPose.__new__(CameraPose)
+            pose.__dict__.update(_R=g["R"], _t=g["t"])
+            geom.pose, geom.scale, geom.shift1, geom.shift2 = type("P", (), {"R": g["R"], "t": g["t"]})(), 1.0, 0.0, 0.0
+            out.append(geom)
+        infos = [{"refinements": 1, "iterations": 10, "num_inliers": len(kp), "inlier_ratio": 1.0, "model_score": 0.0, "inliers": [True] * len(kp)}
+                 for kp in k1]
+        return out, infos
+
+    exps = ["3p_ours_shift_scale_hybrid+10", "p3p+10"]
+    res = evalio.evaluate_calibrated(h5, exps, iters=500, batch=4, estimate_batch=stub)
+    assert len(res) == 2 * 5                      # the 4-correspondence pair is skipped (eval.py:338-339)
+    assert seen["ro"]["monodepth_estimate_shift"] is False and seen["n"] == 1    # last call: p3p, second batch of 5 pairs
+    r0 = res[0]
+    assert set(r0) == {"R", "R_gt", "t", "t_gt", "R_err", "t_err", "info", "experiment"} and r0["info"]["inliers"] == []
+    assert r0["R_err"] < 1e-6 and r0["t_err"] < 1e-4 and r0["experiment"] == exps[0] and "runtime" in r0["info"]
+    rows = evalio.summarize(exps, res)
+    assert rows[0][0] == exps[0] and rows[0][2] == 1.0 and rows[0][4] == 1.0        # every pose error below 1 degree
+    res[0]["R_err"] = float("nan"); res[1]["t_err"] = 7.5
+    rows = evalio.summarize(exps, res)
+    assert rows[0][2] == pytest.approx((7 * 3 / 5 + 3 * 4 / 5) / 10)                  # nan -> 180 never passes; 7.5 deg passes t = 8, 9, 10
+    assert "pose mAA" in evalio.format_table(rows)
+    out = tmp_path / "calibrated-test.json"
+    evalio.write_results(out, res)
+    back = json.load(open(out))
+    assert len(back) == len(res) and back[2]["experiment"] == exps[0]
+    with pytest.raises(NotImplementedError):
+        evalio.evaluate_calibrated(h5, ["3p_reldepth+10"], estimate_batch=stub)       # fork-only variant
+
+
+@pytest.mark.gpu
+def test_evaluate_calibrated_end_to_end_gpu():
+    h5, gt = fake_h5(n_pairs=8, n=400, seed=40)
+    exps = ["3p_ours_scale_hybrid_ctruncated+10", "3p_ours_shift_scale_hybrid_ctruncated+10"]
+    res = evalio.evaluate_calibrated(h5, exps, iters=1000, threshold=2.0)
+    assert len(res) == 2 * 7
+    rows = evalio.summarize(exps, res)
+    for exp, med, maa, ms, inl in rows:
+        assert med < 0.5 and maa > 0.9 and ms > 0 and 0.5 < inl <= 1.0, rows
