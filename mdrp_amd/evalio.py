@@ -179,3 +179,108 @@ def write_results(path, results):
     """eval.py:378-379: the `results_new/calibrated-*.json` list of records"""
     with open(path, "w") as f:
         json.dump(results, f)
+
+
+# ------------------------------------------------------------------------------------------------ focal loops
+def focal_options(experiment, iters=None, threshold=1.0, reproj_threshold=16.0, varying=False):
+    """eval_shared_f.py:111-152 / eval_varying_f.py:105-146"""
+    lo_iterations = 0 if "nLO" in experiment else 25
+    it = 1000 if iters is None else int(iters)
+    ro = {"max_iterations": it, "min_iterations": it, "max_epipolar_error": threshold, "progressive_sampling": False,
+          "lo_iterations": lo_iterations, "max_reproj_error": reproj_threshold,
+          "use_p3p": "p3p" in experiment, "use_ours": "ours" in experiment, "use_madpose": "mad_poselib" in experiment,
+          "solver_shift": "shift" in experiment, "solver_scale": "scale" in experiment, "use_reproj": "reproj" in experiment,
+          "optimize_shift": "reproj-s" in experiment, "use_madpose_shift_optim": "noshift" not in experiment,
+          "graduated_steps": 3 if "GLO" in experiment else 0}
+    if varying:
+        ro.update({"use_fundamental": "7p" in experiment, "use_4p4d": "4p4d" in experiment, "use_eigen": "eigen" in experiment})
+    else:
+        ro.update({"all_permutations": "perm" in experiment, "use_reldepth": "reldepth" in experiment,
+                   "optimize_hybrid": "hybrid" in experiment, "sym_repro": "sym_reproj" in experiment,
+                   "no_normalization": "NN" in experiment})
+    bo = {"max_iterations": 0 if lo_iterations == 0 else 100, "verbose": False}
+    if "truncated" in experiment:
+        bo["loss_type"] = "TRUNCATED"
+    if "ctruncated" in experiment:
+        bo["loss_type"] = "TRUNCATED_CAUCHY"
+    return ro, bo
+
+
+def load_pair_focal(h5, name1, name2, depth=None, shared=True):
+    """eval_shared_f.py:330-360 / eval_varying_f.py:329-357: principal points removed; for the shared-focal loop the second
+    image is rescaled to the first one's focal length.  Depth columns are passed as stored (no invalid -> 1.0 here)."""
+    Rt = np.array(h5[f"pose_{name1}_{name2}"], dtype=np.float64)
+    K1 = np.array(h5[f"K_{name1}"], dtype=np.float64)
+    K2 = np.array(h5[f"K_{name2}"], dtype=np.float64)
+    data = np.array(h5[f"corr_{name1}_{name2}"], dtype=np.float64)
+    kp1 = data[:, :2] - K1[:2, 2]
+    kp2 = data[:, 2:4] - K2[:2, 2]
+    if shared and (K1[0, 0] + K1[1, 1]) != (K2[0, 0] + K2[1, 1]):
+        r = (K1[0, 0] + K1[1, 1]) / (K2[0, 0] + K2[1, 1])
+        kp2 = kp2 * r
+        K2 = r * K2
+    d = data[:, list(depth_indices(depth))].copy() if depth is not None else np.ones_like(kp1)
+    return {"kp1": kp1, "kp2": kp2, "d": d, "R_gt": Rt[:3, :3], "t_gt": Rt[:, 3], "K1": K1, "K2": K2}
+
+
+def result_record_focal(experiment, info, pair, R_gt, t_gt, f1_gt, f2_gt):
+    """eval_shared_f.py:80-108 `get_result_dict`"""
+    out = result_record(experiment, info, pair.pose.R, pair.pose.t, R_gt, t_gt)
+    out["f1_gt"], out["f1"] = float(f1_gt), float(pair.camera1.focal())
+    out["f2_gt"], out["f2"] = float(f2_gt), float(pair.camera2.focal())
+    out["f1_err"] = abs(out["f1"] - f1_gt) / f1_gt
+    out["f2_err"] = abs(out["f2"] - f2_gt) / f2_gt
+    out["f_err"] = float(np.sqrt(out["f1_err"] * out["f2_err"]))
+    return out
+
+
+def evaluate_focal(h5, experiments, shared=True, iters=None, threshold=1.0, reproj_threshold=16.0, first=None, batch=4096,
+                   estimate_batch=None, device=0):
+    """eval_shared_f.py / eval_varying_f.py main loop for the monodepth focal estimators, batched.  Pairs with fewer than
+    6 (shared) / 7 (varying) correspondences are skipped as in the reference."""
+    from . import poselib
+    if estimate_batch is None:
+        fn = poselib.estimate_monodepth_shared_focal_relative_pose_batch if shared else poselib.estimate_monodepth_varying_focal_relative_pose_batch
+
+        def estimate_batch(k1, k2, a, b, ro, bo):
+            return fn(k1, k2, a, b, ro, bo, device=device)
+    min_n = 6 if shared else 7
+    pairs = list_pairs(h5, first)
+    results = []
+    for experiment in experiments:
+        depth = int(experiment.split("+")[1]) if "+" in experiment else None
+        ro, bo = focal_options(experiment, iters, threshold, reproj_threshold, varying=not shared)
+        ro = poselib._map_fork_options(ro)
+        loaded = [p for p in (load_pair_focal(h5, a, b, depth, shared) for a, b in pairs) if len(p["kp1"]) >= min_n]
+        for s in range(0, len(loaded), batch):
+            chunk = loaded[s:s + batch]
+            t0 = time.perf_counter()
+            out, infos = estimate_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [p["d"][:, 0] for p in chunk],
+                                        [p["d"][:, 1] for p in chunk], ro, bo)
+            ms = 1000.0 * (time.perf_counter() - t0) / max(len(chunk), 1)
+            for p, ip, info in zip(chunk, out, infos):
+                info = dict(info)
+                info["runtime"] = ms
+                f1_gt = (p["K1"][0, 0] + p["K1"][1, 1]) / 2
+                f2_gt = (p["K2"][0, 0] + p["K2"][1, 1]) / 2
+                results.append(result_record_focal(experiment, info, ip, p["R_gt"], p["t_gt"], f1_gt, f2_gt))
+    return results
+
+
+def summarize_focal(experiments, results):
+    """utils/eval_utils.py:8-38 `print_results_focal`: (experiment, median pose error, median focal error, pose mAA over
+    1..10 degrees, focal mAA over 1..10 %, mean runtime ms, mean inlier ratio)"""
+    rows = []
+    for exp in experiments:
+        rs = [x for x in results if x["experiment"] == exp]
+        if not rs:
+            continue
+        p = np.array([max(r["R_err"], r["t_err"]) for r in rs], dtype=np.float64)
+        f = np.array([r["f_err"] for r in rs], dtype=np.float64)
+        p[np.isnan(p)] = 180.0
+        f[np.isnan(f)] = 1.0
+        rows.append((exp, float(np.median(p)), float(np.median(f)),
+                     float(np.mean([np.sum(p < t) / len(p) for t in range(1, 11)])),
+                     float(np.mean([np.sum(f < t / 100) / len(f) for t in range(1, 11)])),
+                     float(np.mean([x["info"]["runtime"] for x in rs])), float(np.mean([x["info"]["inlier_ratio"] for x in rs]))))
+    return rows

@@ -103,3 +103,53 @@ def test_evaluate_calibrated_end_to_end_gpu():
     rows = evalio.summarize(exps, res)
     for exp, med, maa, ms, inl in rows:
         assert med < 0.5 and maa > 0.9 and ms > 0 and 0.5 < inl <= 1.0, rows
+
+
+def fake_h5_focal(n_pairs=6, n=400, depth=12, seed=0, varying=False):
+    h5 = {}
+    for i in range(n_pairs):
+        p = synth.make_pair(800 + seed + i, n if i != 1 else 5, noise_px=0.3, depth_noise=0.01, outlier_frac=0.25,
+                            random_focal="varying" if varying else "shared", pp=(0.0, 0.0))
+        a, b = f"f{i:02d}a_o", f"f{i:02d}b"
+        pp1, pp2 = np.array([512.0, 384.0]), np.array([500.0, 400.0])
+        data = np.zeros((len(p["x1"]), 32))
+        data[:, :2] = p["x1"] + pp1; data[:, 2:4] = p["x2"] + pp2
+        c1, c2 = evalio.depth_indices(depth)
+        data[:, c1] = p["d1"]; data[:, c2] = p["d2"]
+        h5[f"corr_{a}_{b}"] = data
+        h5[f"pose_{a}_{b}"] = np.c_[p["R"], p["t"]]
+        h5[f"K_{a}"] = np.array([[p["f1"], 0, pp1[0]], [0, p["f1"], pp1[1]], [0, 0, 1]])
+        h5[f"K_{b}"] = np.array([[p["f2"], 0, pp2[0]], [0, p["f2"], pp2[1]], [0, 0, 1]])
+    return h5
+
+
+def test_focal_loader_and_summary():
+    h5 = fake_h5_focal()
+    a, b = evalio.list_pairs(h5)[0]
+    p = evalio.load_pair_focal(h5, a, b, depth=12, shared=True)
+    assert abs(p["kp1"]).max() < 1700 and p["kp1"].shape == (400, 2) and np.allclose(p["K1"][0, 0], p["K2"][0, 0])
+    K2 = np.array(h5[f"K_{b}"]); h5[f"K_{b}"] = 2.0 * K2        # different focal: second image rescaled (eval_shared_f.py:351-353)
+    h5[f"K_{b}"][2, 2] = 1.0
+    q = evalio.load_pair_focal(h5, a, b, depth=12, shared=True)
+    raw2 = np.array(h5[f"corr_{a}_{b}"])[:, 2:4] - h5[f"K_{b}"][:2, 2]
+    assert np.allclose(q["kp2"], 0.5 * raw2) and np.allclose(q["K2"][0, 0], q["K1"][0, 0])
+    assert np.allclose(evalio.load_pair_focal(h5, a, b, depth=12, shared=False)["kp2"], raw2)
+    ro, bo = evalio.focal_options("3p_ours_scale_hybrid_ctruncated+12", iters=300, varying=False)
+    assert ro["use_ours"] and ro["optimize_hybrid"] and "use_4p4d" not in ro and bo["loss_type"] == "TRUNCATED_CAUCHY"
+    assert evalio.focal_options("4p4d+1", varying=True)[0]["use_4p4d"]
+    recs = [{"experiment": "e", "R_err": 0.5, "t_err": 2.5, "f_err": 0.035, "info": {"runtime": 1.0, "inlier_ratio": 0.5}},
+            {"experiment": "e", "R_err": float("nan"), "t_err": 0.1, "f_err": float("nan"), "info": {"runtime": 3.0, "inlier_ratio": 0.7}}]
+    (row,) = evalio.summarize_focal(["e"], recs)
+    assert row[1] == pytest.approx((2.5 + 180) / 2) and row[2] == pytest.approx((0.035 + 1.0) / 2)
+    assert row[3] == pytest.approx(8 * 0.5 / 10) and row[4] == pytest.approx(7 * 0.5 / 10) and row[5] == 2.0 and row[6] == pytest.approx(0.6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared", [True, False])
+def test_evaluate_focal_end_to_end_gpu(shared):
+    h5 = fake_h5_focal(n_pairs=8, n=500, seed=20, varying=not shared)
+    exps = ["3p_ours_scale_hybrid_ctruncated+12"]
+    res = evalio.evaluate_focal(h5, exps, shared=shared, iters=1000, threshold=2.0)
+    assert len(res) == 7 and {"f1", "f2", "f_err", "f1_gt"} <= set(res[0])
+    (row,) = evalio.summarize_focal(exps, res)
+    assert row[1] < 1.0 and row[2] < 0.02 and row[3] > 0.85 and row[4] > 0.85, row
