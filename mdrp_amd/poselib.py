@@ -143,7 +143,7 @@ def _pair_from_model(m):
 def _info(res, mask_row, n):
     return {"refinements": int(res["refinements"]), "iterations": int(res["iterations"]), "num_inliers": int(res["num_inliers"]),
             "inlier_ratio": float(res["inlier_ratio"]), "model_score": float(res["model_score"]),
-            "inliers": [bool(v) for v in mask_row[:n]]}
+            "inliers": np.asarray(mask_row[:n]).astype(bool).tolist()}  # list[bool] like the reference, built at C speed
 
 
 def _as_points(p):
