@@ -296,8 +296,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
             }
 #undef MDRP_SOLVE_LAUNCH
-            hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, st_, r, h->st.as<PairState>(), h->pts.as<double>(),
-                               h->models.as<Model>(), mc, tg, tgs);
+            hipLaunchKernelGGL(k_probe, dim3((4 * r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(),
+                               h->pts.as<double>(), h->models.as<Model>(), mc, tg);
+            hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, st_, r, h->st.as<PairState>(), mc, tg, tgs);
             return MDRP_OK;
         };
         if ((rc = issue_solve(0, s))) return rc;

@@ -6,7 +6,8 @@
 // of iterations:
 //   k_samples  one wavefront per distinct N  splitmix64 sample table for the chunk (wave-speculative)        (a-3)
 //   k_solve    one lane per minimal sample   solver -> <=4 models; compacted tag list                       (a-4..a-6')
-//   k_sort_tags one workgroup per pair       density probe per model -> dense / sparse class, sparse sorted by density
+//   k_probe    one lane per model            candidate density on the pair's first 64 records (fp32 filter of the sweep)
+//   k_sort_tags one workgroup per pair       dense / sparse class by density, sparse counting-sorted by it
 //   k_plan     one wavefront                 work items of the sweep (workgroups per pair and class)
 //   k_score    one lane per hypothesis       Sampson/MSAC (+cheirality) sweep over all N correspondences,
 //                                            correspondences staged through LDS, broadcast reads            (a-7)  HOT
@@ -306,11 +307,20 @@ __device__ __forceinline__ void store_rec32(float4 *__restrict__ recs32, int i, 
 constexpr int PROBE_PTS = 64; // records of the density probe (k_solve)
 // phase-1 candidates among the first g <= 64 records: the sort key of k_sort_tags
 __device__ __forceinline__ int probe_count(const float4 *__restrict__ recs32, int g, const float Ef[9], float tb) {
+    typedef float pf2 __attribute__((ext_vector_type(2)));
+    pf2 Ev[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Ev[i] = (pf2)(Ef[i]);
     int c = 0;
-    for (int j = 0; j < g; j += 2) {
+    for (int j = 0; j < g; j += 2) { // two records per packed FMA, the arithmetic of filter_keeps()
         const float4 ab = recs32[j], cd = recs32[j + 1];
-        c += (filter_keeps(Ef, tb, ab.x, ab.z, cd.x, cd.z) && j < g) ? 1 : 0;
-        c += (filter_keeps(Ef, tb, ab.y, ab.w, cd.y, cd.w) && j + 1 < g) ? 1 : 0;
+        const pf2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, cc = {cd.x, cd.y}, d = {cd.z, cd.w};
+        const pf2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
+        const pf2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
+        const pf2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
+        const pf2 C = __builtin_elementwise_fma(cc, e0, __builtin_elementwise_fma(d, e1, e2));
+        c += !(fabsf(C.x) > tb) ? 1 : 0;
+        c += (!(fabsf(C.y) > tb) && j + 1 < g) ? 1 : 0;
     }
     return c;
 }
@@ -700,58 +710,71 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
     }
 }
 
-// The pair's hypotheses, classified and ordered by their phase-1 candidate density.  One workgroup per pair, one lane
-// per model: key = records among the pair's first 64 that survive the fp32 phase-1 filter of the sweep (probe_count).
-//   key >= DENSE_KEY/64 of the probe  -> "dense" list (single-pass sweep), written from the BACK of tags_sorted;
-//   everything else                   -> counting sort by key into the front of tags_sorted (two-phase sweep).
+// The pair's hypotheses, classified and ordered by their phase-1 candidate density, in two kernels.
+//   k_probe      one lane per model (grid: tag index x pair): key = records among the pair's first 64 that survive the
+//                fp32 phase-1 filter of the sweep (probe_count), stored in the top byte of the model's tag;
+//   k_sort_tags  one workgroup per pair: key >= DENSE_KEY/64 of the probe -> "dense" list (single-pass sweep), written
+//                from the BACK of tags_sorted; everything else -> counting sort by key into the front (two-phase sweep).
 // Phase 2 of the sweep costs a wavefront the MAXIMUM candidate count over its lanes, and densities differ by 10x
 // between hypotheses (measured unsorted: maximum 14 per 64 records, mean 3; sorted 8.5), so the sweep wants workgroups
 // of similar hypotheses.  Whole workgroups, not wavefronts: the four wavefronts of a workgroup meet at the tile
 // barriers, and one slow wavefront parks the other three in their SIMD slots (sorting inside the workgroup made the
 // sweep 3x slower).  Which lane scores a hypothesis does not change its result.
-// In: model_count[2p] = models of the pair (k_solve).  Out: model_count[2p] = sparse, [2p+1] = dense.
-__global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
-                                                   const Model *__restrict__ models, int32_t *__restrict__ model_count,
-                                                   uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
-    const int pair = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_probe(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                               const Model *__restrict__ models, const int32_t *__restrict__ model_count,
+                                               uint32_t *__restrict__ tags) {
+    const int pair = blockIdx.y, tid = threadIdx.x;
     const PairState &ps = st[pair];
     if (!ps.active) return;
-    __shared__ int s_hist[PROBE_PTS + 1], s_pos[PROBE_PTS + 1];
-    __shared__ int s_dense;
+    const int cnt = model_count[2 * pair];
+    if ((int)(blockIdx.x * 256) >= cnt) return;
     __shared__ float4 s_probe[PROBE_PTS]; // fp32 copy of the pair's first records
     const int nprobe = min(ps.n, PROBE_PTS);
     if (tid < nprobe) {
         const double *p = pts + ((size_t)pair * rp.n_max + tid) * PT_STRIDE;
         store_rec32(s_probe, tid, p[0], p[1], p[2], p[3]);
     }
+    __syncthreads();
+    const int i = blockIdx.x * 256 + tid;
+    if (i >= cnt) return;
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    const uint32_t slot = tags[slot_base + i];
+    const Model m = models[slot_base + slot];
+    double R[9], Em[9], E[9];
+    quat_to_R(m.q, R);
+    essential_from_Rt(R, m.t, Em);
+    if (rp.kind == 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) E[q] = Em[q];
+    } else fundamental_from_E(Em, m.f1, m.f2, E);
+    float Ef[9], tb;
+    double dm;
+    bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
+    tags[slot_base + i] = slot | ((uint32_t)probe_count(s_probe, nprobe, Ef, tb) << 24);
+}
+
+// In: model_count[2p] = models of the pair (k_solve), keys in the tags (k_probe).  Out: model_count[2p] = sparse, [2p+1] = dense.
+__global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState *__restrict__ st, int32_t *__restrict__ model_count,
+                                                   const uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const PairState &ps = st[pair];
+    if (!ps.active) return;
+    __shared__ int s_hist[PROBE_PTS + 1], s_pos[PROBE_PTS + 1];
+    __shared__ int s_dense;
+    const int nprobe = min(ps.n, PROBE_PTS);
     if (tid <= PROBE_PTS) s_hist[tid] = 0;
     if (tid == 0) s_dense = 0;
     __syncthreads();
     const int cnt = model_count[2 * pair];
     const size_t slot_base = (size_t)pair * rp.slot_stride;
-    uint32_t *src = tags + slot_base, *dst = tags_sorted + slot_base;
+    const uint32_t *src = tags + slot_base;
+    uint32_t *dst = tags_sorted + slot_base;
 #ifdef MDRP_NO_CLASSIFY
     const int dense_min = PROBE_PTS + 1;
 #else
     const int dense_min = nprobe >= 8 ? (MDRP_DENSE_KEY * nprobe + PROBE_PTS - 1) / PROBE_PTS : PROBE_PTS + 1;
 #endif
-    for (int i = tid; i < cnt; i += 256) {
-        const uint32_t slot = src[i];
-        const Model m = models[slot_base + slot];
-        double R[9], Em[9], E[9];
-        quat_to_R(m.q, R);
-        essential_from_Rt(R, m.t, Em);
-        if (rp.kind == 0) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) E[q] = Em[q];
-        } else fundamental_from_E(Em, m.f1, m.f2, E);
-        float Ef[9], tb;
-        double dm;
-        bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
-        const int key = probe_count(s_probe, nprobe, Ef, tb);
-        src[i] = slot | ((uint32_t)key << 24);
-        atomicAdd(&s_hist[key], 1);
-    }
+    for (int i = tid; i < cnt; i += 256) atomicAdd(&s_hist[min(src[i] >> 24, (uint32_t)PROBE_PTS)], 1);
     __syncthreads();
     if (tid < 64) { // exclusive prefix over the sparse keys
         const int v = tid < dense_min ? s_hist[tid] : 0;
@@ -768,7 +791,7 @@ __global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState
     const int cap = rp.slot_stride;
     for (int i = tid; i < cnt; i += 256) {
         const uint32_t t = src[i];
-        const int key = (int)(t >> 24);
+        const int key = (int)min(t >> 24, (uint32_t)PROBE_PTS);
         if (key >= dense_min) dst[cap - 1 - atomicAdd(&s_dense, 1)] = t & 0xFFFFFFu;
         else dst[atomicAdd(&s_pos[key], 1)] = t & 0xFFFFFFu;
     }
