@@ -950,20 +950,32 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     double run_score = ps.best_min_score;
     int ntrig = rp.chunk_off > 0 ? ps.n_triggers : 0; // later chunks of a super-chunk append to its trigger list
     const size_t slot_base = (size_t)pair * rp.slot_stride + (size_t)rp.chunk_off * 4;
+    // one wavefront walks ~150 steps of 64 iterations: the slots of the next step are requested before this step is
+    // examined, and a step in which no lane beats the running records (most of them) skips the prefix and the replay
+    struct Slots { int4 c; double2 s01, s23; };
+    auto fetch = [&](int it0) {
+        Slots r;
+        const int it = it0 + lane;
+        if (it < rp.chunk_len) {
+            r.c = *reinterpret_cast<const int4 *>(slot_inl + slot_base + (size_t)it * 4);
+            const double2 *sp = reinterpret_cast<const double2 *>(slot_score + slot_base + (size_t)it * 4);
+            r.s01 = sp[0]; r.s23 = sp[1]; // empty slots hold stale scores: masked by the count below
+        } else { r.c = make_int4(-1, -1, -1, -1); r.s01 = r.s23 = make_double2(DBL_MAX, DBL_MAX); }
+        return r;
+    };
+    Slots nxt = fetch(0);
     for (int it0 = 0; it0 < rp.chunk_len; it0 += 64) {
         const int it = it0 + lane;
-        const bool live = it < rp.chunk_len;
-        int c[4];
-        double s[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            c[k] = live ? slot_inl[slot_base + (size_t)it * 4 + k] : -1;
-            s[k] = (live && c[k] >= 0) ? slot_score[slot_base + (size_t)it * 4 + k] : DBL_MAX;
-        }
+        const Slots cur = nxt;
+        if (it0 + 64 < rp.chunk_len) nxt = fetch(it0 + 64);
+        const int c[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
+        const double s[4] = {c[0] >= 0 ? cur.s01.x : DBL_MAX, c[1] >= 0 ? cur.s01.y : DBL_MAX, c[2] >= 0 ? cur.s23.x : DBL_MAX,
+                             c[3] >= 0 ? cur.s23.y : DBL_MAX};
         long long lc = -1;
         double ls = DBL_MAX;
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (c[k] >= 0) { lc = max(lc, (long long)c[k]); ls = fmin(ls, s[k]); }
+        if (__all(lc <= run_cnt && !(ls < run_score))) continue; // nothing in these 64 iterations improves a record
         // exclusive prefix over lanes
         long long pc = lc;
         double psn = ls;
