@@ -37,9 +37,6 @@ constexpr int PT_STRIDE = 6;       // doubles per correspondence record
 #endif
 constexpr int TILE_PTS = MDRP_TILE_PTS; // correspondences per LDS tile (48 B each)
 constexpr size_t SCORE_TILE_BYTES = (size_t)TILE_PTS * (PT_STRIDE * sizeof(double) + 4 * sizeof(float)); // + fp32 coordinates
-#ifndef MDRP_P2_WORDS
-#define MDRP_P2_WORDS 1 // 64-record candidate masks per phase-2 window of the fp32-filtered sweep
-#endif
 #ifndef MDRP_P1F_UNROLL
 #define MDRP_P1F_UNROLL 8
 #endif
@@ -601,10 +598,10 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
                                                const double E[9], const float Ef[9], float tb, const Model *__restrict__ mp,
                                                double thr, double &score, int &cnt, Prune &pr) {
     // recs32: two records per 32 B, component-major: (a0 a1 b0 b1)(c0 c1 d0 d1) -> v_pk_fma_f32 without shuffles.
-    // Phase 1 fills the candidate masks of a whole window (P2_WORDS x 64 records) before phase 2 runs: phase 2 is a
-    // per-lane loop, the wavefront pays the MAXIMUM candidate count over its lanes, and max / mean falls with the
-    // window length (0.5 candidates per lane per 32 records: max ~3 per 32, ~6 per 128).
-    constexpr int K = MDRP_P2_WORDS, WIN = 64 * K;
+    // Phase 1 fills the candidate mask of a 64-record window before phase 2 runs: phase 2 is a per-lane loop, the
+    // wavefront pays the MAXIMUM candidate count over its lanes, and max / mean falls with the window length (windows of
+    // 128 / 256 records measured equal / slower: the multi-word bit bookkeeping eats the gain).
+    constexpr int WIN = 64;
     static_assert(TILE_PTS % WIN == 0, "window must divide the tile");
     f32x2 Ev[9];
 #pragma unroll
@@ -612,60 +609,52 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
     for (int p0 = 0; p0 < npts; p0 += WIN) {
         const int g = min(WIN, npts - p0);
         const double *base = recs + (size_t)p0 * PT_STRIDE;
-        uint64_t m[K];
+        uint32_t half[2] = {0, 0};
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            uint32_t half[2] = {0, 0};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int q0 = 64 * k + 32 * h;
-                if (q0 < g) { // wave-uniform
-                    const float4 *b32 = recs32 + p0 + q0;
-                    uint32_t mask = 0;
+        for (int h = 0; h < 2; ++h) {
+            const int q0 = 32 * h;
+            if (q0 < g) { // wave-uniform
+                const float4 *b32 = recs32 + p0 + q0;
+                uint32_t mask = 0;
 #pragma unroll 1
-                    for (int j0 = 0; j0 < 32; j0 += MDRP_P1F_UNROLL) {
+                for (int j0 = 0; j0 < 32; j0 += MDRP_P1F_UNROLL) {
 #pragma unroll
-                        for (int jj = 0; jj < MDRP_P1F_UNROLL; jj += 2) {
-                            const int j = j0 + jj;
-                            const float4 ab = b32[j], cd = b32[j + 1];
-                            const f32x2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, c = {cd.x, cd.y}, d = {cd.z, cd.w};
-                            const f32x2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
-                            const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
-                            const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
-                            const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
+                    for (int jj = 0; jj < MDRP_P1F_UNROLL; jj += 2) {
+                        const int j = j0 + jj;
+                        const float4 ab = b32[j], cd = b32[j + 1];
+                        const f32x2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, c = {cd.x, cd.y}, d = {cd.z, cd.w};
+                        const f32x2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
+                        const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
+                        const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
+                        const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
 #ifdef MDRP_NO_ASM_MASK
-                            mask |= !(fabsf(C.x) > tb) ? (1u << j) : 0u;
-                            mask |= !(fabsf(C.y) > tb) ? (2u << j) : 0u;
+                        mask |= !(fabsf(C.x) > tb) ? (1u << j) : 0u;
+                        mask |= !(fabsf(C.y) > tb) ? (2u << j) : 0u;
 #else
-                            // mask = 2 * mask + keep: compare into VCC, add-with-carry shifts it in (2 instructions per
-                            // record instead of compare + select + constant move + or); record j lands in bit 31 - j
-                            const float cx = C.x, cy = C.y;
-                            unsigned long long kx, ky, co;
-                            asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(kx) : "v"(cx), "v"(tb));
-                            asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(ky) : "v"(cy), "v"(tb));
-                            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(kx));
-                            asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(ky));
+                        // mask = 2 * mask + keep: compare into an SGPR pair, add-with-carry shifts it in (2 instructions per
+                        // record instead of compare + select + constant move + or); record j lands in bit 31 - j
+                        const float cx = C.x, cy = C.y;
+                        unsigned long long kx, ky, co;
+                        asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(kx) : "v"(cx), "v"(tb));
+                        asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(ky) : "v"(cy), "v"(tb));
+                        asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(kx));
+                        asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(ky));
 #endif
-                        }
                     }
-#ifndef MDRP_NO_ASM_MASK
-                    mask = __brev(mask); // back to record j in bit j
-#endif
-                    const int valid = g - q0; // records past the end of the tile hold stale LDS
-                    if (valid < 32) mask &= (1u << valid) - 1u;
-                    half[h] = mask;
                 }
+#ifndef MDRP_NO_ASM_MASK
+                mask = __brev(mask); // back to record j in bit j
+#endif
+                const int valid = g - q0; // records past the end of the tile hold stale LDS
+                if (valid < 32) mask &= (1u << valid) - 1u;
+                half[h] = mask;
             }
-            m[k] = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
         }
-        uint64_t any = 0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) { if (pr.dead) m[k] = 0; any |= m[k]; }
+        uint64_t m = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
+        if (pr.dead) m = 0;
 #ifdef MDRP_EXP_STATS
         {
-            int pc = 0;
-#pragma unroll
-            for (int k = 0; k < K; ++k) pc += __popcll(m[k]);
+            const int pc = __popcll(m);
             int mx = pc, sm = pc, lv = pr.dead ? 0 : 1;
             for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); sm += __shfl_xor(sm, o, 64); lv += __shfl_xor(lv, o, 64); }
             if ((threadIdx.x & 63) == 0) {
@@ -674,7 +663,7 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
             }
         }
 #endif
-        if (any) {
+        if (m) {
             double R[9], t[3];
             if (POSE) {
                 double q[4];
@@ -682,20 +671,9 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
                 t[0] = mp->t[0]; t[1] = mp->t[1]; t[2] = mp->t[2];
                 quat_to_R(q, R);
             }
-            while (any) { // per-lane candidates, ascending record order (same accumulation order as the CPU loop)
-                uint64_t cur = m[0];
-                int off = 0;
-#pragma unroll
-                for (int k = 1; k < K; ++k) {
-                    const bool take = cur == 0;
-                    cur = take ? m[k] : cur;
-                    off = take ? 64 * k : off;
-                }
-                const int j = off + __ffsll((unsigned long long)cur) - 1;
-                const uint64_t nxt = cur & (cur - 1);
-                any = 0;
-#pragma unroll
-                for (int k = 0; k < K; ++k) { m[k] = (off == 64 * k) ? nxt : m[k]; any |= m[k]; }
+            while (m) { // per-lane candidates, ascending record order (same accumulation order as the CPU loop)
+                const int j = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
                 score_point<POSE>(base + j * PT_STRIDE, E, R, t, thr, score, cnt);
             }
         }
