@@ -319,3 +319,43 @@ def _not_on_path(name, where):
 estimate_relative_pose = _not_on_path("estimate_relative_pose", "5-point baseline, eval.py:136")
 estimate_shared_focal_relative_pose = _not_on_path("estimate_shared_focal_relative_pose", "6-point baseline, eval_shared_f.py:161")
 estimate_relative_pose_w_relative_depth = _not_on_path("estimate_relative_pose_w_relative_depth", "fork-only variant, eval.py:140 (commented out upstream)")
+
+
+# ------------------------------------------------------------------------------------------------ device-resident batches
+_torch_handles = {}
+
+
+def estimate_batch_torch(kind, points2D_1, points2D_2, depth_1, depth_2, cameras1=None, cameras2=None, ransac_opt=None,
+                         bundle_opt=None, n_per_pair=None):
+    """Batch that already lives on the GPU (e.g. matcher output): `points2D_*` (B, N, 2) and `depth_*` (B, N) float64 torch
+    tensors on a ROCm device; the work is queued on that device's CURRENT torch stream, nothing crosses PCIe except the
+    136-byte result records.  kind: "calibrated" | "shared_focal" | "varying_focal".  Returns (records: numpy structured
+    array with `model`, `refinements`, `iterations`, `num_inliers`, `inlier_ratio`, `model_score`; inlier mask: (B, N) uint8
+    tensor on the device).  Ragged batches: pad and pass `n_per_pair`."""
+    import torch
+    kinds = {"calibrated": _capi.CALIB, "shared_focal": _capi.SHARED_FOCAL, "varying_focal": _capi.VARYING_FOCAL}
+    k = kinds[kind] if isinstance(kind, str) else int(kind)
+    x1, x2, d1, d2 = (t.contiguous() for t in (points2D_1, points2D_2, depth_1, depth_2))
+    for t in (x1, x2, d1, d2):
+        if not (t.is_cuda and t.dtype == torch.float64):
+            raise ValueError("estimate_batch_torch needs float64 tensors on the GPU")
+    B, N = d1.shape
+    if x1.shape != (B, N, 2) or x2.shape != (B, N, 2) or d2.shape != (B, N):
+        raise ValueError("shapes must be (B, N, 2), (B, N, 2), (B, N), (B, N)")
+    dev = x1.device.index or 0
+    stream = torch.cuda.current_stream(x1.device)
+    key = (dev, stream.cuda_stream)
+    h = _torch_handles.get(key)
+    if h is None:
+        h = _torch_handles[key] = _capi.Handle(dev, stream.cuda_stream)
+    cams1 = cams2 = None
+    if k == _capi.CALIB:
+        def cams(c):
+            lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
+            return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
+        cams1, cams2 = cams(cameras1), cams(cameras2)
+    mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
+    h.estimate_batch_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N,
+                            _capi.ransac_opt_from_dict(ransac_opt), _capi.bundle_opt_from_dict(bundle_opt), n_per_pair, cams1, cams2,
+                            mask.data_ptr())
+    return h.fetch_results(B), mask

@@ -379,3 +379,27 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
             return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
         assert np.allclose(flat(res["model"]), flat(ref["model"]), rtol=tol, atol=tol), env
         assert np.allclose(res["model_score"], ref["model_score"], rtol=max(tol, 0.0), atol=0.0), env
+
+
+@pytest.mark.gpu
+def test_device_resident_batch_matches_host_batch(capi):
+    """poselib.estimate_batch_torch (tensors already on the GPU, current torch stream) == the host-buffer batch API"""
+    import torch
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    b = synth.make_batch(6100, 10, 350, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3)
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+    ro = {"max_iterations": 1500, "min_iterations": 1500, "max_epipolar_error": 2.0, "max_reproj_error": 16.0}
+    bo = {"loss_type": "TRUNCATED_CAUCHY"}
+    geoms, infos = poselib.estimate_monodepth_relative_pose_batch(b["x1"], b["x2"], b["d1"], b["d2"], cam, cam, ro, bo)
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(b[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        res, mask = poselib.estimate_batch_torch("calibrated", *t, cam, cam, ro, bo)
+    assert mask.is_cuda and mask.shape == (10, 350)
+    for i in range(10):
+        assert int(res[i]["num_inliers"]) == infos[i]["num_inliers"] and int(res[i]["refinements"]) == infos[i]["refinements"]
+        assert np.array_equal(mask[i].cpu().numpy().astype(bool), np.array(infos[i]["inliers"]))
+        assert np.allclose(res[i]["model"]["q"], geoms[i].pose.q, atol=0, rtol=0)
+    with pytest.raises(ValueError):
+        poselib.estimate_batch_torch("calibrated", t[0].float(), t[1], t[2], t[3], cam, cam, ro, bo)
