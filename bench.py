@@ -160,8 +160,7 @@ def main():
     ro = _capi.ransac_opt_from_dict({"max_iterations": iters, "min_iterations": iters, "max_epipolar_error": 2.0,
                                      "max_reproj_error": 16.0, "monodepth_estimate_shift": es})
     bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
-    stream = torch.cuda.current_stream()
-    h = _capi.Handle(local_rank, stream.cuda_stream)
+    h = _capi.Handle(local_rank)  # its own stream; the sweep is timed with HIP events recorded on that stream
     from mdrp_amd import dist as mdist
 
     def step():

@@ -10,8 +10,10 @@
  * mdrp_amd/_capi.py is the ctypes binding; INTEGRATION.md shows the stub a PoseLib maintainer would add.
  *
  * Conventions: plain pointers + sizes, caller owns every buffer, the library never frees caller memory,
- * int return codes (0 = ok), no exceptions cross the boundary.  One HIP stream per handle; calls on different
- * handles may run concurrently from different host threads.
+ * int return codes (0 = ok), no exceptions cross the boundary.  One HIP stream per handle.  Threading (the reference
+ * releases the GIL around its estimators, wrapper @0x8ad01, and is re-entrant): calls on DIFFERENT handles run
+ * concurrently from different host threads; calls on the SAME handle are serialised by a lock inside the handle.
+ * Every entry point runs on the handle's device and restores the caller's current HIP device before it returns.
  */
 #ifndef MDRP_H
 #define MDRP_H
@@ -87,11 +89,17 @@ typedef struct {
 
 typedef struct mdrp_handle mdrp_handle;
 
-/* Library/handle management.  device = HIP device ordinal.  stream = a hipStream_t created by the caller (e.g.
- * torch's current stream) or NULL to let the handle create its own. */
+/* Library/handle management.  device = HIP device ordinal.  stream = a hipStream_t created by the caller or NULL to
+ * let the handle create its own (non-blocking) stream. */
 int mdrp_create(int device, void *stream, mdrp_handle **out);
+/* Same, but `stream` is used exactly as given: NULL means the device's legacy default (null) stream — which is what
+ * torch.cuda.current_stream().cuda_stream is (0) unless the caller switched streams.  Work of the handle is then
+ * ordered with everything else queued on that stream (inputs produced by earlier kernels, consumers of the mask). */
+int mdrp_create_on_stream(int device, void *stream, mdrp_handle **out);
 void mdrp_destroy(mdrp_handle *h);
 const char *mdrp_last_error(void);
+/* "mdrp-hip <ver> (gfx950) MDRP_SRC_HASH=<16 hex digits>": the hash covers mdrp_capi.hip, mdrp_kernels.h, mdrp_math.h and
+ * this header as they were when the library was built (mdrp_amd/build.py source_hash()) */
 const char *mdrp_version(void);
 /* block the calling thread until all work queued on the handle's stream is done */
 int mdrp_synchronize(mdrp_handle *h);

@@ -10,14 +10,14 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmdrp_hip.so")
+LIB_PATH = os.environ.get("MDRP_LIB") or os.path.join(_HERE, "libmdrp_hip.so")  # MDRP_LIB: experiment builds (tools/)
 
 CALIB, SHARED_FOCAL, VARYING_FOCAL = 0, 1, 2
 MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
-    "mdrp_create", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
+    "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
     "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_solver_batch", "mdrp_score_models", "mdrp_refine_models",
     "mdrp_last_sweep_stats",
 )
@@ -76,6 +76,7 @@ def load_library():
         lib.mdrp_last_error.restype = C.c_char_p
         lib.mdrp_version.restype = C.c_char_p
         lib.mdrp_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+        lib.mdrp_create_on_stream.argtypes = [C.c_int, vp, C.POINTER(vp)]
         lib.mdrp_destroy.argtypes = [vp]
         lib.mdrp_destroy.restype = None
         lib.mdrp_synchronize.argtypes = [vp]
@@ -128,15 +129,33 @@ def bundle_opt_from_dict(d=None):
                      float(d.get("min_lambda", 1e-10)), float(d.get("max_lambda", 1e10)))
 
 
+def library_version():
+    return load_library().mdrp_version().decode()
+
+
+def library_source_hash():
+    """the source hash the loaded library was built from (mdrp_version(); compare with build.source_hash())"""
+    v = library_version()
+    return v.split("MDRP_SRC_HASH=", 1)[1][:16] if "MDRP_SRC_HASH=" in v else None
+
+
 class Handle:
-    """One handle = one HIP device + one stream + its scratch buffers."""
+    """One handle = one HIP device + one stream + its scratch buffers.  Calls on one handle are serialised inside the
+    library; use one handle per host thread for concurrency (default_handle() does).
+
+    stream=None: the handle creates its own stream.  stream=<int>: a hipStream_t of the caller, used as given —
+    0 is the device's legacy default stream (torch.cuda.current_stream().cuda_stream is 0 on torch's default stream)."""
 
     def __init__(self, device=0, stream=None):
         self._lib = load_library()
         h = C.c_void_p()
-        _check(self._lib, self._lib.mdrp_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h)))
+        if stream is None:
+            _check(self._lib, self._lib.mdrp_create(int(device), None, C.byref(h)))
+        else:
+            _check(self._lib, self._lib.mdrp_create_on_stream(int(device), C.c_void_p(int(stream)) if stream else None, C.byref(h)))
         self._h = h
         self.device = int(device)
+        self.stream = stream
 
     def close(self):
         if getattr(self, "_h", None):
@@ -233,17 +252,20 @@ class Handle:
         return models, cost
 
 
-_default_handles = {}
-_default_lock = threading.Lock()
+_default_tls = threading.local()
 
 
 def default_handle(device=0):
-    with _default_lock:
-        h = _default_handles.get(device)
-        if h is None:
-            h = Handle(device)
-            _default_handles[device] = h
-        return h
+    """The calling THREAD's handle for `device` (created on first use): the drop-in entry points release the GIL inside
+    the C call like the reference does, so two Python threads must not share scratch buffers — each gets its own handle
+    and stream, and their batches run concurrently on the GPU."""
+    handles = getattr(_default_tls, "handles", None)
+    if handles is None:
+        handles = _default_tls.handles = {}
+    h = handles.get(device)
+    if h is None:
+        h = handles[device] = Handle(device)
+    return h
 
 
 def model_to_array(m):

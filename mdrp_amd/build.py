@@ -1,5 +1,11 @@
-"""Compile the HIP library in-tree: hipcc --offload-arch=gfx950 -> mdrp_amd/libmdrp_hip.so (cross-compiles without a GPU)."""
+"""Compile the HIP library in-tree: hipcc --offload-arch=gfx950 -> mdrp_amd/libmdrp_hip.so (cross-compiles without a GPU).
+
+The library embeds a hash of its source files (returned by mdrp_version()); build() rebuilds whenever the hash inside
+the existing .so differs from the tree, so a prebuilt library can never silently be stale.
+"""
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 
@@ -8,6 +14,7 @@ SRC = os.path.join(HERE, "csrc", "mdrp_capi.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "mdrp_kernels.h"), os.path.join(HERE, "csrc", "mdrp_math.h"),
         os.path.join(HERE, "..", "include", "mdrp.h")]
 OUT = os.path.join(HERE, "libmdrp_hip.so")
+_MARK = b"MDRP_SRC_HASH="
 
 
 def hipcc():
@@ -17,19 +24,40 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+def source_hash():
+    """sha256 over the four source files (name + content), first 16 hex digits"""
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash(path=OUT):
+    """the hash embedded in an existing library (read from its bytes: no dlopen, no GPU), or None"""
+    try:
+        with open(path, "rb") as f:
+            m = re.search(_MARK + rb"([0-9a-f]{16})", f.read())
+        return m.group(1).decode() if m else None
+    except OSError:
+        return None
+
+
 def up_to_date():
-    return os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS)
+    return built_hash() == source_hash()
 
 
-def build(force=False, verbose=False):
-    if not force and up_to_date():
-        return OUT
-    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=fast", SRC, "-o", OUT + ".tmp"]
+def build(force=False, verbose=False, defines=(), out=OUT):
+    if not force and not defines and out == OUT and up_to_date():
+        return out
+    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=fast",
+           f'-DMDRP_SRC_HASH="{source_hash()}"', *[f"-D{d}" for d in defines], SRC, "-o", out + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -53,9 +54,25 @@ struct DevBuf {
 
 struct Progress { int32_t n_active; int32_t pad; unsigned long long max_needed; unsigned long long evals; };
 
+// Every entry point runs on the handle's device and puts the caller's current device back on return (the caller is
+// usually torch, which tracks its own current device).
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
 } // namespace
 
 struct mdrp_handle {
+    std::mutex mu; // one call at a time per handle (scratch, events and counters are per handle); different handles run concurrently
     int device = 0;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
@@ -389,7 +406,6 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
                     const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
     if (!h || batch < 0 || n_max < 0 || kind < 0 || kind > 2 || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (kind == MDRP_CALIB && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
     h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->last_batch = batch;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
@@ -414,6 +430,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair));
+    per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
     for (int p0 = 0; p0 < batch; p0 += per_pass) {
         const int nb = std::min(per_pass, batch - p0);
         rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 + (size_t)p0 * n_max, d2 + (size_t)p0 * n_max, nb,
@@ -438,22 +455,41 @@ int finish_timing(mdrp_handle *h) {
 
 } // namespace
 
+// serialise calls on one handle and run them on the handle's device; the caller's current device is restored on return
+#define MDRP_ENTER(h)                                                                      \
+    std::lock_guard<std::mutex> lock_((h)->mu);                                            \
+    DeviceGuard guard_((h)->device);                                                       \
+    if (!guard_.ok) { g_err = "hipSetDevice failed"; return MDRP_ERR_HIP; }
+
+#ifndef MDRP_SRC_HASH
+#define MDRP_SRC_HASH "unknown"
+#endif
+
+static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_handle **out);
+
 extern "C" {
 
 const char *mdrp_last_error(void) { return g_err.c_str(); }
-const char *mdrp_version(void) { return "mdrp-hip 0.1 (gfx950)"; }
+// the build embeds a hash of the source files (mdrp_amd/build.py) so that a stale prebuilt library can be told from the tree
+const char *mdrp_version(void) { return "mdrp-hip 0.2 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
 
-int mdrp_create(int device, void *stream, mdrp_handle **out) {
+int mdrp_create(int device, void *stream, mdrp_handle **out) { return create_handle(device, (hipStream_t)stream, stream == nullptr, out); }
+int mdrp_create_on_stream(int device, void *stream, mdrp_handle **out) { return create_handle(device, (hipStream_t)stream, false, out); }
+
+} // extern "C"
+
+static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_handle **out) {
     if (!out) return MDRP_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
         g_err = "no usable HIP device";
         return MDRP_ERR_NO_DEVICE;
     }
-    HIPCHK(hipSetDevice(device));
+    DeviceGuard guard_(device);
+    if (!guard_.ok) { g_err = "hipSetDevice failed"; return MDRP_ERR_HIP; }
     mdrp_handle *h = new mdrp_handle();
     h->device = device;
-    if (stream) { h->stream = (hipStream_t)stream; h->owns_stream = false; }
+    if (!own_stream) { h->stream = stream; h->owns_stream = false; } // NULL here = the device's legacy default stream
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->owns_stream = true; }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -479,9 +515,11 @@ int mdrp_create(int device, void *stream, mdrp_handle **out) {
     return MDRP_OK;
 }
 
+extern "C" {
+
 void mdrp_destroy(mdrp_handle *h) {
     if (!h) return;
-    (void)hipSetDevice(h->device);
+    DeviceGuard guard_(h->device);
     (void)hipStreamSynchronize(h->stream);
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
@@ -503,6 +541,7 @@ void mdrp_destroy(mdrp_handle *h) {
 
 int mdrp_synchronize(mdrp_handle *h) {
     if (!h) return MDRP_ERR_INVALID;
+    MDRP_ENTER(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     return MDRP_OK;
 }
@@ -510,22 +549,29 @@ int mdrp_synchronize(mdrp_handle *h) {
 int mdrp_estimate_batch_async(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2,
                               int batch, int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1, const mdrp_camera *cam2,
                               const mdrp_ransac_opt *ropt, const mdrp_bundle_opt *bopt, uint8_t *inlier_mask_dev) {
+    if (!h) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    MDRP_ENTER(h);
     return estimate_device(h, kind, x1, x2, d1, d2, batch, n_max, n_per_pair, cam1, cam2, ropt, bopt, inlier_mask_dev);
 }
 
-int mdrp_fetch_results(mdrp_handle *h, mdrp_result *out, int batch) {
-    if (!h || !out || batch < 0 || batch > h->last_batch) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
+static int fetch_results_locked(mdrp_handle *h, mdrp_result *out, int batch) {
+    if (!out || batch < 0 || batch > h->last_batch) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     HIPCHK(hipMemcpyAsync(out, h->results.p, sizeof(ResultDev) * batch, hipMemcpyDeviceToHost, h->stream));
     return finish_timing(h);
+}
+
+int mdrp_fetch_results(mdrp_handle *h, mdrp_result *out, int batch) {
+    if (!h) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    MDRP_ENTER(h);
+    return fetch_results_locked(h, out, batch);
 }
 
 int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x1, const double *x2, const double *d1,
                         const double *d2, int batch, int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1,
                         const mdrp_camera *cam2, const mdrp_ransac_opt *ropt, const mdrp_bundle_opt *bopt, mdrp_result *out,
                         uint8_t *inlier_mask) {
-    if (!h || !out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
-    HIPCHK(hipSetDevice(h->device));
+    if (!h || !out || batch < 0 || n_max < 0) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    MDRP_ENTER(h);
     const size_t np = (size_t)batch * n_max;
     int rc;
     uint8_t *mask_dev = inlier_mask;
@@ -544,11 +590,12 @@ int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x
     if (rc) return rc;
     if (mem_space == MDRP_MEM_HOST && inlier_mask && np > 0)
         HIPCHK(hipMemcpyAsync(inlier_mask, h->mask.p, np, hipMemcpyDeviceToHost, h->stream));
-    return mdrp_fetch_results(h, out, batch);
+    return fetch_results_locked(h, out, batch);
 }
 
 int mdrp_last_sweep_stats(mdrp_handle *h, double *sweep_ms, int64_t *launches, int64_t *evaluations) {
     if (!h) return MDRP_ERR_INVALID;
+    std::lock_guard<std::mutex> lock_(h->mu);
     if (sweep_ms) *sweep_ms = h->sweep_ms;
     if (launches) *launches = h->sweep_launches;
     if (evaluations) *evaluations = h->sweep_evals;
@@ -559,7 +606,7 @@ int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const doubl
                       int count, mdrp_model *out, int32_t *n_out) {
     if (!h || count < 0 || solver < 0 || solver > 3 || !out || !n_out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (count == 0) return MDRP_OK;
-    HIPCHK(hipSetDevice(h->device));
+    MDRP_ENTER(h);
     int rc;
     if ((rc = h->unit_a.ensure(sizeof(double) * 9 * count)) || (rc = h->unit_b.ensure(sizeof(double) * 9 * count)) ||
         (rc = h->unit_c.ensure(sizeof(double) * 3 * count)) || (rc = h->unit_d.ensure(sizeof(double) * 3 * count)) ||
@@ -584,7 +631,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
                       const double *x2, int n, double sq_threshold, double *scores, int32_t *counts) {
     if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 2 || !scores || !counts) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (num_models == 0) return MDRP_OK;
-    HIPCHK(hipSetDevice(h->device));
+    MDRP_ENTER(h);
     hipStream_t s = h->stream;
     const int chunk = (num_models + 3) / 4;
     const size_t slots = (size_t)chunk * 4;
@@ -651,7 +698,7 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
                        const mdrp_bundle_opt *opt, int estimate_shift, double *final_cost) {
     if (!h || count < 0 || n < 0 || kind < 0 || kind > 2 || !opt || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (count == 0) return MDRP_OK;
-    HIPCHK(hipSetDevice(h->device));
+    MDRP_ENTER(h);
     hipStream_t s = h->stream;
     int rc;
     const int nn = std::max(n, 1);

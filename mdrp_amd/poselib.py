@@ -322,16 +322,39 @@ estimate_relative_pose_w_relative_depth = _not_on_path("estimate_relative_pose_w
 
 
 # ------------------------------------------------------------------------------------------------ device-resident batches
-_torch_handles = {}
+_TORCH_HANDLE_CACHE = 4  # handles kept per thread (each owns its scratch buffers); least recently used is closed
+_torch_tls = None
+
+
+def _torch_handle(dev, stream_ptr):
+    """the calling thread's handle bound to (device, stream), LRU-bounded; stream_ptr 0 = the legacy default stream"""
+    global _torch_tls
+    import collections
+    import threading
+    if _torch_tls is None:
+        _torch_tls = threading.local()
+    cache = getattr(_torch_tls, "cache", None)
+    if cache is None:
+        cache = _torch_tls.cache = collections.OrderedDict()
+    key = (dev, stream_ptr)
+    h = cache.pop(key, None)
+    if h is None:
+        h = _capi.Handle(dev, stream_ptr)
+        while len(cache) >= _TORCH_HANDLE_CACHE:
+            cache.popitem(last=False)[1].close()
+    cache[key] = h
+    return h
 
 
 def estimate_batch_torch(kind, points2D_1, points2D_2, depth_1, depth_2, cameras1=None, cameras2=None, ransac_opt=None,
                          bundle_opt=None, n_per_pair=None):
     """Batch that already lives on the GPU (e.g. matcher output): `points2D_*` (B, N, 2) and `depth_*` (B, N) float64 torch
-    tensors on a ROCm device; the work is queued on that device's CURRENT torch stream, nothing crosses PCIe except the
-    136-byte result records.  kind: "calibrated" | "shared_focal" | "varying_focal".  Returns (records: numpy structured
-    array with `model`, `refinements`, `iterations`, `num_inliers`, `inlier_ratio`, `model_score`; inlier mask: (B, N) uint8
-    tensor on the device).  Ragged batches: pad and pass `n_per_pair`."""
+    tensors on a ROCm device; the work is queued on that device's CURRENT torch stream — including torch's default
+    (null) stream — so it is ordered after whatever produced the inputs there and before later consumers of the mask;
+    nothing crosses PCIe except the 136-byte result records.  kind: "calibrated" | "shared_focal" | "varying_focal".
+    Returns (records: numpy structured array with `model`, `refinements`, `iterations`, `num_inliers`, `inlier_ratio`,
+    `model_score`; inlier mask: (B, N) uint8 tensor on the device).  Ragged batches: pad and pass `n_per_pair`
+    (sequence, numpy array or tensor on any device)."""
     import torch
     kinds = {"calibrated": _capi.CALIB, "shared_focal": _capi.SHARED_FOCAL, "varying_focal": _capi.VARYING_FOCAL}
     k = kinds[kind] if isinstance(kind, str) else int(kind)
@@ -339,23 +362,26 @@ def estimate_batch_torch(kind, points2D_1, points2D_2, depth_1, depth_2, cameras
     for t in (x1, x2, d1, d2):
         if not (t.is_cuda and t.dtype == torch.float64):
             raise ValueError("estimate_batch_torch needs float64 tensors on the GPU")
+        if t.device != x1.device:
+            raise ValueError("all tensors must live on the same device")
     B, N = d1.shape
     if x1.shape != (B, N, 2) or x2.shape != (B, N, 2) or d2.shape != (B, N):
         raise ValueError("shapes must be (B, N, 2), (B, N, 2), (B, N), (B, N)")
-    dev = x1.device.index or 0
+    dev = x1.device.index if x1.device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(x1.device)
-    key = (dev, stream.cuda_stream)
-    h = _torch_handles.get(key)
-    if h is None:
-        h = _torch_handles[key] = _capi.Handle(dev, stream.cuda_stream)
+    h = _torch_handle(dev, int(stream.cuda_stream))
+    if n_per_pair is not None and isinstance(n_per_pair, torch.Tensor):
+        n_per_pair = n_per_pair.detach().cpu().numpy()
     cams1 = cams2 = None
     if k == _capi.CALIB:
         def cams(c):
             lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
             return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
         cams1, cams2 = cams(cameras1), cams(cameras2)
-    mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
-    h.estimate_batch_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N,
-                            _capi.ransac_opt_from_dict(ransac_opt), _capi.bundle_opt_from_dict(bundle_opt), n_per_pair, cams1, cams2,
-                            mask.data_ptr())
-    return h.fetch_results(B), mask
+    with torch.cuda.device(x1.device):
+        mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
+        h.estimate_batch_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N,
+                                _capi.ransac_opt_from_dict(ransac_opt), _capi.bundle_opt_from_dict(bundle_opt), n_per_pair, cams1, cams2,
+                                mask.data_ptr())
+        res = h.fetch_results(B)
+    return res, mask

@@ -37,3 +37,12 @@ def test_option_dicts_follow_reference_defaults():
     assert (ro.max_iterations, ro.min_iterations, ro.max_reproj_error, ro.max_epipolar_error, ro.seed) == (100000, 1000, 12.0, 1.0, 0)
     bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
     assert (bo.max_iterations, bo.loss_type, bo.loss_scale, bo.gradient_tol) == (100, 4, 1.0, 1e-10)
+
+
+def test_library_carries_the_hash_of_its_sources():
+    """mdrp_version() names the sources the binary was built from; build() rebuilds on a mismatch (a stale prebuilt
+    library must never be mistaken for the tree)"""
+    b.build()
+    assert b.built_hash() == b.source_hash()
+    assert _capi.library_source_hash() == b.source_hash()
+    assert _capi.library_version().startswith("mdrp-hip")

@@ -1,0 +1,118 @@
+"""Boundary behaviour of the C-ABI / drop-in module on a real MI355X: streams, threads, devices."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CAM = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+RO = {"max_iterations": 1500, "min_iterations": 1500, "max_epipolar_error": 2.0, "max_reproj_error": 16.0}
+BO = {"loss_type": "TRUNCATED_CAUCHY"}
+
+
+def test_default_stream_orders_with_async_producers():
+    """estimate_batch_torch on torch's DEFAULT (null) stream, inputs produced by asynchronous torch kernels queued just
+    before the call (a long dependent chain, so they are certainly still running when the call is made): results must
+    equal the host-buffer path.  cuda_stream == 0 must mean the legacy default stream, not a private stream."""
+    import torch
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    b = synth.make_batch(6200, 16, 600, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3)
+    geoms, infos = poselib.estimate_monodepth_relative_pose_batch(b["x1"], b["x2"], b["d1"], b["d2"], CAM, CAM, RO, BO)
+    dev = torch.device("cuda", 0)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0
+    src = [torch.from_numpy(b[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
+    big = torch.randn(4096, 4096, device=dev)
+    for rep in range(3):
+        t = [torch.full_like(v, float("nan")) for v in src]              # the inputs do not exist yet: poison
+        torch.cuda.synchronize()
+        junk = big
+        for _ in range(40):                                               # ~100 ms of queued work in front of the producers
+            junk = junk @ big
+            junk = junk / junk.abs().max()
+        bump = (junk[0, 0] * 0.0).double()                                # data dependence on the long chain
+        for v, o in zip(src, t):
+            torch.add(v, bump, out=o)                                     # asynchronous producers of the real inputs
+        res, mask = poselib.estimate_batch_torch("calibrated", *t, CAM, CAM, RO, BO)
+        after = mask.sum(dim=1)                                           # consumer on the same stream, no explicit sync
+        for i in range(16):
+            assert int(res[i]["num_inliers"]) == infos[i]["num_inliers"], (rep, i)
+            assert int(res[i]["refinements"]) == infos[i]["refinements"]
+            assert np.array_equal(mask[i].cpu().numpy().astype(bool), np.array(infos[i]["inliers"]))
+        assert np.array_equal(after.cpu().numpy(), np.array([sum(x["inliers"]) for x in infos]))
+
+
+def test_torch_batch_accepts_tensor_n_per_pair_and_keeps_current_device():
+    import torch
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    b = synth.make_batch(6300, 4, 300, noise_px=0.5, outlier_frac=0.2)
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(b[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
+    npp = torch.tensor([300, 250, 3, 0], device=dev, dtype=torch.int32)
+    before = torch.cuda.current_device()
+    res, mask = poselib.estimate_batch_torch("calibrated", *t, CAM, CAM, RO, BO, n_per_pair=npp)
+    assert torch.cuda.current_device() == before
+    assert int(res[3]["iterations"]) == 0 and int(mask[1, 250:].sum()) == 0 and int(res[0]["num_inliers"]) > 150
+
+
+def test_two_threads_two_handles_run_concurrently_and_agree():
+    """The reference releases the GIL around its estimators and is re-entrant.  Here: Python threads
+    calling the drop-in API get one handle each (thread-local default handle) and must produce exactly the results of
+    the same calls made one after the other; threads sharing ONE explicit handle are serialised by the library's lock
+    and must agree as well."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi, synth
+    jobs = []
+    for k in range(4):
+        b = synth.make_batch(6400 + 50 * k, 24, 500 + 100 * k, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4)
+        jobs.append(b)
+    ro = dict(RO, max_iterations=3000, min_iterations=3000)
+
+    def run(b):
+        g, info = poselib.estimate_monodepth_relative_pose_batch(b["x1"], b["x2"], b["d1"], b["d2"], CAM, CAM, ro, BO)
+        return [(tuple(x.pose.q), tuple(x.pose.t), x.scale) for x in g], [(i["num_inliers"], i["refinements"], i["model_score"]) for i in info]
+
+    serial = [run(b) for b in jobs]
+    out = [None] * len(jobs)
+    handles = [None] * len(jobs)
+    errs = []
+
+    def worker(i):
+        try:
+            for _ in range(3):
+                out[i] = run(jobs[i])
+            handles[i] = _capi.default_handle(0)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert out == serial
+    assert len({id(h) for h in handles}) == len(jobs), "threads must not share a default handle"
+
+    # one shared handle, four threads: the library serialises the calls
+    h = _capi.Handle(0)
+    cams = np.zeros(24, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ropt, bopt = _capi.ransac_opt_from_dict(ro), _capi.bundle_opt_from_dict(BO)
+    ref = [h.estimate_batch(0, b["x1"], b["x2"], b["d1"], b["d2"], ropt, bopt, None, cams, cams) for b in jobs]
+    got = [None] * len(jobs)
+
+    def shared(i):
+        try:
+            b = jobs[i]
+            for _ in range(3):
+                got[i] = h.estimate_batch(0, b["x1"], b["x2"], b["d1"], b["d2"], ropt, bopt, None, cams, cams)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=shared, args=(i,)) for i in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for (r0, m0), (r1, m1) in zip(ref, got):
+        assert r0.tobytes() == r1.tobytes() and np.array_equal(m0, m1)
+    h.close()
