@@ -40,3 +40,18 @@ def widen(sol, width=12):
     out = np.ones(width)
     out[: len(sol)] = sol
     return out
+
+
+# ---- enumerated deviations from the reference binary, by fixture index -------------------------------
+# tests/golden/solvers.npz: problems on which the reference binary itself returns NaN models (nothing to compare)
+REFERENCE_NAN_SOLUTIONS = {"p3p": (), "calib_shift": (21,), "shared": (), "varying": ()}
+
+# tests/golden/estimate_full.npz: our LO count minus the reference's.  Found with the per-iteration replay of both
+# sides' minimal models (tests/tools/diag_lo_count.py):
+#   case 1 (calibrated P3P, pair 1): the reference's P3P returns four NaN poses for the sample of iteration 0; a NaN model
+#           scores N * eps^2 < DBL_MAX, so it is the run's first "record" and costs the reference one LO that cannot
+#           change the result; ours returns the empty set.
+#   case 4 (calibrated + shift, pair 1): at iteration 2827 the reference's relpose_monodepth_3pt misses a true root
+#           that ours finds; that model has 993 inliers, sets a record and costs us one LO.
+# Iterations, inliers, score, mask and model are identical in both cases.
+KNOWN_LO_COUNT_DEVIATIONS = {1: -1, 4: +1}

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pyorc as po
-from helpers import match_solution_sets, model_diff, widen
+from helpers import KNOWN_LO_COUNT_DEVIATIONS, REFERENCE_NAN_SOLUTIONS, match_solution_sets, model_diff, widen
 
 
 def test_sampler_known_answers(golden):
@@ -33,9 +33,8 @@ def test_scoring_bit_exact(golden):
 
 @pytest.mark.parametrize("kind", ["p3p", "calib_shift", "shared", "varying"])
 def test_solver_solution_sets(golden, kind):
-    """Solution sets equal the reference's.  Known, documented deviations: the reference
-    returns NaN poses for ~2% of garbage P3P inputs and mis-polishes <1% of calib-shift roots; those
-    problems are excluded by the NaN filter / counted against the 3% budget below."""
+    """Solution sets equal the reference's on every golden problem.  The only exclusion is enumerated in
+    helpers.REFERENCE_NAN_SOLUTIONS: problems on which the reference binary itself returns NaN models."""
     g = golden("solvers")
     n = len(g[f"{kind}_n"])
     agree = checked = 0
@@ -43,6 +42,7 @@ def test_solver_solution_sets(golden, kind):
         nref = int(g[f"{kind}_n"][i])
         ref = g[f"{kind}_sols"][i][:nref]
         if np.isnan(ref).any():
+            assert i in REFERENCE_NAN_SOLUTIONS[kind], (kind, i)
             continue
         if kind == "p3p":
             mine = po.p3p(g["p3p_x"][i], g["p3p_X"][i])
@@ -54,8 +54,8 @@ def test_solver_solution_sets(golden, kind):
             mine = [np.r_[m[:7], np.ones(5)] for m in mine]
         checked += 1
         agree += match_solution_sets(ref, list(mine), 1e-6)
-    assert checked >= 0.9 * n
-    assert agree >= 0.97 * checked, (agree, checked)
+    assert checked == n - len(REFERENCE_NAN_SOLUTIONS[kind])
+    assert agree == checked, (agree, checked)
 
 
 def test_refine_matches_reference(golden):
@@ -99,3 +99,29 @@ def test_estimate_matches_reference(golden):
             # noise-free: scores are ~1e-30 rounding noise, LO count may differ; results must not
             assert st.num_inliers == int(ref_st[2]) and (mask == ref_mask).all()
             assert st.model_score < 1e-20 or abs(st.model_score - ref_st[4]) <= 1e-6 * ref_st[4], (case, st.model_score, ref_st[4])
+
+
+def full_size_cases(g):
+    """(index, kind, estimate_shift, n, reference model, stats, mask) of tests/golden/estimate_full.npz"""
+    for case in g["cases"]:
+        i, kind, es, n = int(case[0]), int(case[1]), int(case[2]), int(case[3])
+        yield i, kind, es, n, g[f"model_{i}"], g[f"stats_{i}"], np.unpackbits(g[f"mask_{i}"])[:n]
+
+
+def test_estimate_full_size_matches_reference(golden):
+    """BASELINE.json's full-size shapes (N = 2000 / 5000, 10^4 iterations, 50 % and 0 % outliers, every estimator incl.
+    varying focal with the shift flag set) captured from the reference binary: the oracle lands on the same
+    trajectory — iterations, LO count, inlier count, score, mask, model.  The LO count differs on exactly the two
+    cases enumerated (with their cause) in helpers.KNOWN_LO_COUNT_DEVIATIONS."""
+    g = golden("estimate_full")
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
+    for i, kind, es, n, ref_m, ref_st, ref_mask in full_size_cases(g):
+        ro = po.ransac_opt(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0, max_reproj_error=16.0, estimate_shift=bool(es))
+        m, st, mask = po.estimate(kind, g[f"x1_{i}"], g[f"x2_{i}"], g[f"d1_{i}"], g[f"d2_{i}"], ro, po.bundle_opt(loss_type=4),
+                                  cam if kind == 0 else None, cam if kind == 0 else None)
+        assert st.iterations == int(ref_st[1]) == 10000
+        assert st.num_inliers == int(ref_st[2]), (i, st.num_inliers, ref_st[2])
+        assert (mask == ref_mask).all(), i
+        assert model_diff(m, ref_m) < 1e-6, (i, model_diff(m, ref_m))
+        assert abs(st.model_score - ref_st[4]) <= 1e-9 * ref_st[4]
+        assert st.refinements == int(ref_st[0]) + KNOWN_LO_COUNT_DEVIATIONS.get(i, 0), (i, st.refinements, ref_st[0])

@@ -190,6 +190,40 @@ def gen_estimate():
     np.savez_compressed(os.path.join(OUT, "estimate.npz"), **d)
 
 
+FULL_CASES = (
+    # name, kind, estimate_shift, n, outlier_frac, random_focal, first synth index, pairs   (BASELINE.json configs[1..3])
+    ("calib_p3p", 0, 0, 2000, 0.5, None, 0, 2),        # bench.py's headline workload, pairs 0 and 1
+    ("calib_p3p_clean", 0, 0, 2000, 0.0, None, 0, 1),  # SURVEY.md 8d C2 also names the outlier-free shape
+    ("calib_shift", 0, 1, 2000, 0.5, None, 0, 2),
+    ("shared", 1, 0, 2000, 0.5, "shared", 0, 2),
+    ("varying_shiftflag", 2, 1, 5000, 0.5, "varying", 0, 2),  # configs[3]: the flag is set and ignored by the reference
+)
+
+
+def gen_estimate_full():
+    """BASELINE.json's full-size shapes through the reference binary: N = 2000 / 5000, max = min = 10^4 iterations
+    (make_video.py:192-194), eps = 2 px, rep = 16 px, TRUNCATED_CAUCHY; inputs exactly as bench.py generates them."""
+    d = {}
+    cases = []
+    for name, kind, es, n, of, rf, first, pairs in FULL_CASES:
+        for j in range(pairs):
+            p = synth.make_pair(first + j, n, noise_px=0.5, depth_noise=0.02, outlier_frac=of, random_focal=rf,
+                                shift1=0.2 if es and kind == 0 else 0.0, shift2=-0.1 if es and kind == 0 else 0.0)
+            kw = dict(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0, max_reproj_error=16.0, seed=0, estimate_shift=bool(es))
+            c1 = c2 = None
+            if kind == 0:
+                c1 = c2 = rs.cam_flat(0, 1600, 1200, [800.0, 0.0, 0.0])
+            m, st, mask = rs.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], rs.ropt(**kw), rs.bopt(loss_type=4), c1, c2)
+            i = len(cases)
+            d.update({f"x1_{i}": p["x1"], f"x2_{i}": p["x2"], f"d1_{i}": p["d1"], f"d2_{i}": p["d2"],
+                      f"model_{i}": np.r_[m, 1.0, 1.0] if kind == 0 else m, f"stats_{i}": st, f"mask_{i}": np.packbits(mask)})
+            cases.append([i, kind, es, n, of, first + j])
+            print(name, j, "stats", st, flush=True)
+    d["cases"] = np.array(cases)
+    d["names"] = np.array([c[0] for c in FULL_CASES for _ in range(c[7])])
+    np.savez_compressed(os.path.join(OUT, "estimate_full.npz"), **d)
+
+
 if __name__ == "__main__":
     if not rs.available():
         sys.exit("reference shim not built: run `make -C oracle ref` in the build container")
@@ -199,5 +233,6 @@ if __name__ == "__main__":
     gen_scoring()
     gen_refine()
     gen_estimate()
+    gen_estimate_full()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
