@@ -136,6 +136,12 @@ int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const doubl
 int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model *models, int num_models,
                       const double *x1, const double *x2, int n, double sq_threshold, double *scores, int32_t *counts);
 
+/* Candidate counts of the MFMA pre-pass alone (k_count): for every model an UPPER bound on its inlier count against the n
+ * normalised correspondences of one pair — the number of correspondences the conservative bf16-split filter cannot prove
+ * to be outliers.  Host memory.  candidates: [num_models]. */
+int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1,
+                          const double *x2, int n, double sq_threshold, int32_t *candidates);
+
 /* Hybrid LM refinement of `count` models, each over the correspondences of ONE pair (refine_monodepth_*relpose
  * @0x261030/@0x2592e0/@0x260fa0).  Host memory.  models in/out. */
 int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,
@@ -145,6 +151,20 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
 /* Timing of the last mdrp_estimate_batch* call on this handle, measured with HIP events on the handle's stream:
  * total milliseconds in the scoring-sweep kernel, number of its launches, and (model x correspondence) evaluations. */
 int mdrp_last_sweep_stats(mdrp_handle *h, double *sweep_ms, int64_t *launches, int64_t *evaluations);
+
+/* The same with the two scoring kernels apart (HIP events on the handle's stream around every launch of each kernel):
+ * k_count — candidate counts of all hypotheses on the matrix cores (v_mfma_f32_16x16x32_bf16) — and k_score — the exact
+ * fp64 sweep of the hypotheses k_count could not retire. */
+typedef struct {
+    double count_ms;           /* total time in k_count */
+    int64_t count_launches;
+    double sweep_ms;           /* total time in k_score */
+    int64_t sweep_launches;
+    int64_t evals_algorithmic; /* (model x correspondence) evaluations the CPU loop does: sum over pairs of models * n */
+    int64_t evals_mfma;        /* evaluations executed by k_count (16 x 16 tiles, padding included) */
+    int64_t evals_fp64;        /* evaluations handed to k_score (survivors * n) */
+} mdrp_stats;
+int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out);
 
 #ifdef __cplusplus
 }

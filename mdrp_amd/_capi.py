@@ -18,8 +18,8 @@ SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
     "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
-    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_solver_batch", "mdrp_score_models", "mdrp_refine_models",
-    "mdrp_last_sweep_stats",
+    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_refine_models",
+    "mdrp_last_sweep_stats", "mdrp_last_stats",
 )
 
 
@@ -42,6 +42,11 @@ class BundleOpt(C.Structure):
 
 class Camera(C.Structure):
     _fields_ = [("model_id", C.c_int32), ("pad_", C.c_int32), ("params", C.c_double * 4)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("count_ms", C.c_double), ("count_launches", C.c_int64), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
+                ("evals_algorithmic", C.c_int64), ("evals_mfma", C.c_int64), ("evals_fp64", C.c_int64)]
 
 
 class Result(C.Structure):
@@ -87,9 +92,11 @@ def load_library():
         lib.mdrp_fetch_results.argtypes = [vp, vp, C.c_int]
         lib.mdrp_solver_batch.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int, vp, vp]
         lib.mdrp_score_models.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp, vp]
+        lib.mdrp_count_candidates.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp]
         lib.mdrp_refine_models.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, dp, dp, C.c_int, C.c_double, C.c_double,
                                            C.POINTER(BundleOpt), C.c_int, vp]
         lib.mdrp_last_sweep_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        lib.mdrp_last_stats.argtypes = [vp, C.POINTER(Stats)]
         _lib = lib
         return lib
 
@@ -211,6 +218,12 @@ class Handle:
         _check(self._lib, self._lib.mdrp_last_sweep_stats(self._h, C.byref(ms), C.byref(launches), C.byref(evals)))
         return ms.value, launches.value, evals.value
 
+    def last_stats(self):
+        """dict: time and launches of k_count (MFMA) and k_score (fp64), and the evaluation counters of the last estimate call"""
+        st = Stats()
+        _check(self._lib, self._lib.mdrp_last_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in Stats._fields_}
+
     # ---- unit-parity entry points
     def solver_batch(self, solver, x1h, x2h, d1, d2):
         x1h = np.ascontiguousarray(x1h, dtype=np.float64).reshape(-1, 3, 3)
@@ -233,6 +246,16 @@ class Handle:
         _check(self._lib, self._lib.mdrp_score_models(self._h, int(kind), MEM_HOST, _ptr(models), len(models), _ptr(x1), _ptr(x2),
                                                       len(x1), float(sq_threshold), _ptr(scores), _ptr(counts)))
         return scores, counts
+
+    def count_candidates(self, kind, models, x1, x2, sq_threshold):
+        """k_count alone: per model an upper bound on its inlier count (MFMA pre-pass)"""
+        models = np.ascontiguousarray(models, dtype=MODEL_DTYPE).reshape(-1)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        cand = np.zeros(len(models), dtype=np.int32)
+        _check(self._lib, self._lib.mdrp_count_candidates(self._h, int(kind), _ptr(models), len(models), _ptr(x1), _ptr(x2), len(x1),
+                                                          float(sq_threshold), _ptr(cand)))
+        return cand
 
     def score_models_device(self, kind, models_ptr, num_models, x1_ptr, x2_ptr, n, sq_threshold, scores_ptr, counts_ptr):
         _check(self._lib, self._lib.mdrp_score_models(self._h, int(kind), MEM_DEVICE, C.c_void_p(models_ptr), int(num_models),

@@ -52,7 +52,16 @@ struct DevBuf {
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
 
-struct Progress { int32_t n_active; int32_t pad; unsigned long long max_needed; unsigned long long evals; };
+// read back once per super-chunk: device counters at int32 index 2.. of the `counters` buffer
+struct Progress {
+    int32_t n_active; int32_t pad;
+    unsigned long long max_needed;
+    unsigned long long evals;       // (model x correspondence) evaluations the CPU loop would do: sum over pairs of models * n
+    unsigned long long evals_mfma;  // evaluations executed by k_count on the matrix cores (padded to 16 x 16 tiles)
+    unsigned long long evals_sweep; // evaluations handed to the fp64 sweep (survivors * n)
+};
+constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
+constexpr size_t COUNTERS_BYTES = 128;
 
 // Every entry point runs on the handle's device and puts the caller's current device back on return (the caller is
 // usually torch, which tracks its own current device).
@@ -84,16 +93,21 @@ struct mdrp_handle {
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
     DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, counters, results, mask, plan;
-    DevBuf tags_s, tags2_s; // sparse tag lists ordered by candidate density (k_sort_tags)
+    DevBuf tags_s, tags2_s; // survivor lists ordered by candidate density (k_sort_tags)
     DevBuf tags2, model_count2, samples2; // odd chunks of a super-chunk (chunk c + 1 is solved beside the sweep of chunk c)
+    DevBuf tags_v, surv_count; // survivors of k_count (unsorted, with density keys) and their number per pair
+    DevBuf rfrag;              // MFMA A fragments of the correspondences (k_prep): [pair][ceil(n_max/16)][64] x 16 B
+    DevBuf cplan;              // work plan of k_count
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
     // sweep timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    std::vector<int> ev_what; // 0 = k_score (fp64 sweep), 1 = k_count (MFMA)
     size_t ev_used = 0;
-    double sweep_ms = 0.0;
-    int64_t sweep_launches = 0, sweep_evals = 0;
+    double sweep_ms = 0.0, count_ms = 0.0;
+    int64_t count_launches = 0;
+    int64_t sweep_launches = 0, sweep_evals = 0, mfma_evals = 0, fp64_evals = 0;
     int last_batch = 0;
 };
 
@@ -128,13 +142,15 @@ int env_int(const char *name, int dflt) {
 int lm_list_stride(int n_max) { return n_max <= LM_LIST_MAX_N ? ((n_max + 63) / 64) * 64 : 0; }
 size_t lm_list_bytes(int n_max) { return (size_t)2 * lm_list_stride(n_max) * sizeof(uint16_t); }
 
-int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b) {
+int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b, int what = 0) {
     if (h->ev_used == h->ev_pool.size()) {
         hipEvent_t x, y;
         HIPCHK(hipEventCreate(&x));
         HIPCHK(hipEventCreate(&y));
         h->ev_pool.emplace_back(x, y);
+        h->ev_what.push_back(0);
     }
+    h->ev_what[h->ev_used] = what;
     *a = h->ev_pool[h->ev_used].first;
     *b = h->ev_pool[h->ev_used].second;
     h->ev_used++;
@@ -188,10 +204,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->tags_s.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->tags2_s.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->samples2.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
+    if ((rc = h->tags_v.ensure(sizeof(uint32_t) * slots))) return rc;
+    if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
+    if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
+    const size_t groups_max = ((size_t)n_max + 15) / 16;
+    if ((rc = h->rfrag.ensure(std::max<size_t>(1024, (size_t)batch * groups_max * 1024)))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
     if ((rc = h->work_pair.ensure(sizeof(int32_t) * mdrp_handle::NC_MAX * (3 * (size_t)batch + 2)))) return rc; // LO plan per chunk: prefix | begin | end | total
-    if ((rc = h->counters.ensure(64))) return rc;
+    if ((rc = h->counters.ensure(COUNTERS_BYTES))) return rc;
     if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4 + 16)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
 
     HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
@@ -217,7 +238,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
 
     hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, h->nper.as<int32_t>(),
                        h->table_of_pair.as<int32_t>(), h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error,
-                       ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>());
+                       ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>(),
+                       h->rfrag.as<uint4>());
     HIPCHK(hipGetLastError());
 
     // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
@@ -280,7 +302,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         uint64_t super_len = 0;
         for (int c = 0; c < n_chunks; ++c) super_len += lens[c];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
-        HIPCHK(hipMemsetAsync(h->counters.p, 0, 64, s));
+        HIPCHK(hipMemsetAsync(h->counters.p, 0, COUNTERS_BYTES, s));
         // Three-stream pipeline over the chunks of a super-chunk (the benchmark shape: 512 | 9488 iterations):
         //   main:  solve 0 | score 0, scan 0 | score 1, scan 1 | ... | walk
         //   aux :            solve 1         | solve 2 ...
@@ -297,7 +319,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             RunParams r = rp;
             r.chunk_len = (int)lens[c]; r.chunk_off = offs[c];
             const bool odd = c & 1;
-            uint32_t *tg = (odd ? h->tags2 : h->tags).as<uint32_t>(), *tgs = (odd ? h->tags2_s : h->tags_s).as<uint32_t>();
+            uint32_t *tg = (odd ? h->tags2 : h->tags).as<uint32_t>();
             uint32_t *smp = (odd ? h->samples2 : h->samples).as<uint32_t>();
             int32_t *mc = (odd ? h->model_count2 : h->model_count).as<int32_t>();
             HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
@@ -313,9 +335,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
             }
 #undef MDRP_SOLVE_LAUNCH
-            hipLaunchKernelGGL(k_probe, dim3((4 * r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(),
-                               h->pts.as<double>(), h->models.as<Model>(), mc, tg);
-            hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, st_, r, h->st.as<PairState>(), mc, tg, tgs);
             return MDRP_OK;
         };
         if ((rc = issue_solve(0, s))) return rc;
@@ -337,11 +356,30 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (piped && c > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
             if (!piped && c > 0 && (rc = issue_solve(c, s))) return rc;
             {
-                hipEvent_t e0, e1;
-                if ((rc = get_events(h, &e0, &e1))) return rc;
-                HIPCHK(hipEventRecord(e0, s));
+                hipEvent_t e0, e1, c0, c1;
+                if ((rc = get_events(h, &e0, &e1, 0)) || (rc = get_events(h, &c0, &c1, 1))) return rc;
+                // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
+                const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
+                HIPCHK(hipMemsetAsync(h->surv_count.p, 0, sizeof(int32_t) * batch, s));
+                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), mcount_c, h->cplan.as<int32_t>());
+                const dim3 cgrid((unsigned)batch * (unsigned)((len * 4 + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
+                unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
+                HIPCHK(hipEventRecord(c0, s));
+                if (kind == MDRP_CALIB)
+                    hipLaunchKernelGGL(k_count<true>, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                                       tags_c, mcount_c, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
+                                       h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
+                else
+                    hipLaunchKernelGGL(k_count<false>, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                                       tags_c, mcount_c, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
+                                       h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
+                HIPCHK(hipEventRecord(c1, s));
+                h->count_launches++;
+                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, h->surv_count.as<int32_t>(),
+                                   h->tags_v.as<uint32_t>(), tags_sc);
                 int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, mcount_c, plan, totals);
+                HIPCHK(hipEventRecord(e0, s));
                 const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
                                                         : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
                 if (kind == MDRP_CALIB)
@@ -355,7 +393,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             }
             hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
                                h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
-                               reinterpret_cast<unsigned long long *>(cnt + 6));
+                               reinterpret_cast<unsigned long long *>(cnt + 10));
             // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
             int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
             const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
@@ -368,7 +406,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
             MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
                              h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                             trig_cap, lo_plan, cnt + 8 + c, lm_list_stride(n_max));
+                             trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max));
         }
         if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
@@ -378,6 +416,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         h->sweep_evals += (int64_t)h->progress_host->evals;
+        h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
+        h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
 #ifdef MDRP_EXP_STATS
         {
             unsigned long long st8[8];
@@ -406,7 +446,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
                     const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
     if (!h || batch < 0 || n_max < 0 || kind < 0 || kind > 2 || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (kind == MDRP_CALIB && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
-    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->last_batch = batch;
+    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
     if (batch == 0) return MDRP_OK;
@@ -443,13 +483,13 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
 
 int finish_timing(mdrp_handle *h) {
     HIPCHK(hipStreamSynchronize(h->stream));
-    double ms = 0;
+    double ms[2] = {0, 0};
     for (size_t i = 0; i < h->ev_used; ++i) {
         float t = 0;
         HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
-        ms += t;
+        ms[h->ev_what[i] & 1] += t;
     }
-    h->sweep_ms = ms;
+    h->sweep_ms = ms[0]; h->count_ms = ms[1];
     return MDRP_OK;
 }
 
@@ -524,7 +564,8 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
-                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s};
+                      &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
+                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -599,6 +640,15 @@ int mdrp_last_sweep_stats(mdrp_handle *h, double *sweep_ms, int64_t *launches, i
     if (sweep_ms) *sweep_ms = h->sweep_ms;
     if (launches) *launches = h->sweep_launches;
     if (evaluations) *evaluations = h->sweep_evals;
+    return MDRP_OK;
+}
+
+int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out) {
+    if (!h || !out) return MDRP_ERR_INVALID;
+    std::lock_guard<std::mutex> lock_(h->mu);
+    out->count_ms = h->count_ms; out->count_launches = h->count_launches;
+    out->sweep_ms = h->sweep_ms; out->sweep_launches = h->sweep_launches;
+    out->evals_algorithmic = h->sweep_evals; out->evals_mfma = h->mfma_evals; out->evals_fp64 = h->fp64_evals;
     return MDRP_OK;
 }
 
@@ -691,6 +741,60 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     HIPCHK(hipMemcpyAsync(scores, h->slot_score.p, sizeof(double) * num_models, back, s));
     HIPCHK(hipMemcpyAsync(counts, h->slot_inl.p, sizeof(int32_t) * num_models, back, s));
     return finish_timing(h);
+}
+
+int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1, const double *x2,
+                          int n, double sq_threshold, int32_t *candidates) {
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 2 || !candidates || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (num_models == 0) return MDRP_OK;
+    MDRP_ENTER(h);
+    hipStream_t s = h->stream;
+    const int nn = std::max(n, 1);
+    const size_t slots = (size_t)num_models;
+    int rc;
+    if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * nn)) || (rc = h->st.ensure(sizeof(PairState))) ||
+        (rc = h->models.ensure(sizeof(Model) * slots)) || (rc = h->slot_inl.ensure(sizeof(int32_t) * slots)) ||
+        (rc = h->tags.ensure(sizeof(uint32_t) * slots)) || (rc = h->tags_v.ensure(sizeof(uint32_t) * slots)) ||
+        (rc = h->model_count.ensure(2 * sizeof(int32_t))) || (rc = h->surv_count.ensure(sizeof(int32_t))) ||
+        (rc = h->cplan.ensure(2 * sizeof(int32_t))) || (rc = h->rfrag.ensure((size_t)((nn + 15) / 16) * 1024)) ||
+        (rc = h->unit_f.ensure(sizeof(int32_t) * slots)) || (rc = h->in_x1.ensure(sizeof(double) * 2 * nn)) ||
+        (rc = h->in_x2.ensure(sizeof(double) * 2 * nn)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->models.p, models, sizeof(Model) * num_models, hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> tags(num_models);
+    for (int i = 0; i < num_models; ++i) tags[i] = (uint32_t)i;
+    HIPCHK(hipMemcpyAsync(h->tags.p, tags.data(), sizeof(uint32_t) * num_models, hipMemcpyHostToDevice, s));
+    const int32_t counts2[2] = {num_models, 0};
+    HIPCHK(hipMemcpyAsync(h->model_count.p, counts2, 2 * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->surv_count.p, 0, sizeof(int32_t), s));
+    PairState ps;
+    std::memset(&ps, 0, sizeof ps);
+    ps.n = n; ps.active = 1; ps.sq_thr = sq_threshold; ps.eps = std::sqrt(sq_threshold);
+    ps.best_min_score = DBL_MAX; // no records: nothing is retired
+    HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, h->in_x1.as<double>(), h->in_x2.as<double>(),
+                       (const double *)nullptr, (const double *)nullptr, h->pts.as<double>(), (double *)nullptr);
+    hipLaunchKernelGGL(k_box_unit, dim3(1), dim3(256), 0, s, n, h->pts.as<double>(), h->st.as<PairState>());
+    hipLaunchKernelGGL(k_frag_unit, dim3((n + 16 + 255) / 256), dim3(256), 0, s, n, h->pts.as<double>(), h->rfrag.as<uint4>());
+    RunParams rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.kind = kind; rp.batch = 1; rp.n_max = nn; rp.slot_stride = num_models;
+    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, 1, h->st.as<PairState>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>());
+    const dim3 grid((unsigned)((num_models + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
+    if (kind == MDRP_CALIB)
+        hipLaunchKernelGGL(k_count<true>, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
+    else
+        hipLaunchKernelGGL(k_count<false>, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(candidates, h->unit_f.p, sizeof(int32_t) * num_models, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MDRP_OK;
 }
 
 int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,

@@ -6,8 +6,10 @@
 // of iterations:
 //   k_samples  one wavefront per distinct N  splitmix64 sample table for the chunk (wave-speculative)        (a-3)
 //   k_solve    one lane per minimal sample   solver -> <=4 models; compacted tag list                       (a-4..a-6')
-//   k_probe    one lane per model            candidate density on the pair's first 64 records (fp32 filter of the sweep)
-//   k_sort_tags one workgroup per pair       dense / sparse class by density, sparse counting-sorted by it
+//   k_count    one wavefront per 128 models  MFMA: candidate COUNT of every model over all correspondences (the Sampson
+//                                            numerator is a [models x 9].[9 x correspondences] product); models that provably
+//                                            cannot break a running record are retired here, the rest go on as survivors
+//   k_sort_tags one workgroup per pair       survivors: dense / sparse class by candidate density, sparse counting-sorted by it
 //   k_plan     one wavefront                 work items of the sweep (workgroups per pair and class)
 //   k_score    one lane per hypothesis       Sampson/MSAC (+cheirality) sweep over all N correspondences,
 //                                            correspondences staged through LDS, broadcast reads            (a-7)  HOT
@@ -146,6 +148,31 @@ __device__ __forceinline__ void block_sum(double *vals, double *scratch) {
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------ MFMA fragments
+// A operand of v_mfma_f32_16x16x32_bf16 for 16 consecutive correspondences ("group"): lane l holds row l & 15 (the
+// correspondence), K slots 8 (l >> 4) .. + 7, as 8 bf16 in one uint4.  K layout (mdrp_math.h, count_setup):
+//   lanes  0..15: mh_0..7    lanes 16..31: ml_0..7    lanes 32..47: mh_0..7    lanes 48..63: 1, 1, 1, 0, 0, 0, 0, 0
+__device__ __forceinline__ uint4 pack_bf16x8(const uint16_t v[8]) {
+    return make_uint4((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16),
+                      (uint32_t)v[4] | ((uint32_t)v[5] << 16), (uint32_t)v[6] | ((uint32_t)v[7] << 16));
+}
+__device__ __forceinline__ void store_record_fragment(uint4 *__restrict__ frag, int i, double a, double b, double c, double d) {
+    double m[8];
+    count_monomials(a, b, c, d, m);
+    uint16_t mh[8], ml[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bf16_split(m[j], mh[j], ml[j]);
+    uint4 *g = frag + (size_t)(i >> 4) * 64 + (i & 15);
+    const uint4 hi = pack_bf16x8(mh);
+    g[0] = hi; g[16] = pack_bf16x8(ml); g[32] = hi;
+    g[48] = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
+}
+__device__ __forceinline__ void clear_record_fragment(uint4 *__restrict__ frag, int i) {
+    uint4 *g = frag + (size_t)(i >> 4) * 64 + (i & 15);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    g[0] = z; g[16] = z; g[32] = z; g[48] = z;
+}
+
 // ------------------------------------------------------------------------------------------------ prep
 // One workgroup per pair: normalise the correspondences into the pts/dep records and set up the pair state.
 // calibrated: Camera::unproject + thresholds * (1/f1 + 1/f2)/2 (estimate_monodepth_relative_pose @0x2242bf-0x224348)
@@ -157,7 +184,8 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
                                               const int32_t *__restrict__ n_per_pair, const int32_t *__restrict__ table_of_pair,
                                               const CamDev *__restrict__ cam1, const CamDev *__restrict__ cam2,
                                               double max_epi, double max_reproj, double bundle_loss_scale,
-                                              double *__restrict__ pts, double *__restrict__ dep, PairState *__restrict__ st) {
+                                              double *__restrict__ pts, double *__restrict__ dep, PairState *__restrict__ st,
+                                              uint4 *__restrict__ rfrag /*[pair][ceil(n_max/16)][64] MFMA A fragments, or null*/) {
     __shared__ double red[4];
     const int pair = blockIdx.x, tid = threadIdx.x;
     const int n = n_per_pair[pair];
@@ -193,6 +221,11 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
         p[5] = 1.0 / sqrt(c * c + d * d + 1.0);
         dep[2 * (base + i)] = d1[base + i];
         dep[2 * (base + i) + 1] = d2[base + i];
+        if (rfrag) store_record_fragment(rfrag + (size_t)pair * ((rp.n_max + 15) / 16) * 64, i, a, b, c, d);
+    }
+    if (rfrag) { // rows past n in the last group: all-zero rows give C = 0, never a definite outlier
+        const int g_end = ((n + 15) / 16) * 16;
+        for (int i = n + tid; i < g_end; i += 256) clear_record_fragment(rfrag + (size_t)pair * ((rp.n_max + 15) / 16) * 64, i);
     }
     __shared__ double redbox[4][4];
 #pragma unroll
@@ -301,26 +334,7 @@ __device__ __forceinline__ void store_rec32(float4 *__restrict__ recs32, int i, 
     q[0] = (float)a; q[2] = (float)b; q[4] = (float)c; q[6] = (float)d;
 }
 
-constexpr int PROBE_PTS = 64; // records of the density probe (k_solve)
-// phase-1 candidates among the first g <= 64 records: the sort key of k_sort_tags
-__device__ __forceinline__ int probe_count(const float4 *__restrict__ recs32, int g, const float Ef[9], float tb) {
-    typedef float pf2 __attribute__((ext_vector_type(2)));
-    pf2 Ev[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) Ev[i] = (pf2)(Ef[i]);
-    int c = 0;
-    for (int j = 0; j < g; j += 2) { // two records per packed FMA, the arithmetic of filter_keeps()
-        const float4 ab = recs32[j], cd = recs32[j + 1];
-        const pf2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, cc = {cd.x, cd.y}, d = {cd.z, cd.w};
-        const pf2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
-        const pf2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
-        const pf2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
-        const pf2 C = __builtin_elementwise_fma(cc, e0, __builtin_elementwise_fma(d, e1, e2));
-        c += !(fabsf(C.x) > tb) ? 1 : 0;
-        c += (!(fabsf(C.y) > tb) && j + 1 < g) ? 1 : 0;
-    }
-    return c;
-}
+constexpr int PROBE_PTS = 64; // scale of the candidate-density key: key = candidates per 64 correspondences (k_count)
 
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
@@ -688,69 +702,231 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
     }
 }
 
-// The pair's hypotheses, classified and ordered by their phase-1 candidate density, in two kernels.
-//   k_probe      one lane per model (grid: tag index x pair): key = records among the pair's first 64 that survive the
-//                fp32 phase-1 filter of the sweep (probe_count), stored in the top byte of the model's tag;
-//   k_sort_tags  one workgroup per pair: key >= DENSE_KEY/64 of the probe -> "dense" list (single-pass sweep), written
-//                from the BACK of tags_sorted; everything else -> counting sort by key into the front (two-phase sweep).
-// Phase 2 of the sweep costs a wavefront the MAXIMUM candidate count over its lanes, and densities differ by 10x
-// between hypotheses (measured unsorted: maximum 14 per 64 records, mean 3; sorted 8.5), so the sweep wants workgroups
-// of similar hypotheses.  Whole workgroups, not wavefronts: the four wavefronts of a workgroup meet at the tile
-// barriers, and one slow wavefront parks the other three in their SIMD slots (sorting inside the workgroup made the
-// sweep 3x slower).  Which lane scores a hypothesis does not change its result.
-__global__ __launch_bounds__(256) void k_probe(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
-                                               const Model *__restrict__ models, const int32_t *__restrict__ model_count,
-                                               uint32_t *__restrict__ tags) {
-    const int pair = blockIdx.y, tid = threadIdx.x;
-    const PairState &ps = st[pair];
-    if (!ps.active) return;
-    const int cnt = model_count[2 * pair];
-    if ((int)(blockIdx.x * 256) >= cnt) return;
-    __shared__ float4 s_probe[PROBE_PTS]; // fp32 copy of the pair's first records
-    const int nprobe = min(ps.n, PROBE_PTS);
-    if (tid < nprobe) {
-        const double *p = pts + ((size_t)pair * rp.n_max + tid) * PT_STRIDE;
-        store_rec32(s_probe, tid, p[0], p[1], p[2], p[3]);
+// largest p with prefix[p] <= w   (prefix non-decreasing, prefix[0] = 0, w < prefix[batch])
+__device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int batch, int w) {
+    int lo = 0, hi = batch;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= w) lo = mid; else hi = mid;
     }
-    __syncthreads();
-    const int i = blockIdx.x * 256 + tid;
-    if (i >= cnt) return;
-    const size_t slot_base = (size_t)pair * rp.slot_stride;
-    const uint32_t slot = tags[slot_base + i];
-    const Model m = models[slot_base + slot];
-    double R[9], Em[9], E[9];
-    quat_to_R(m.q, R);
-    essential_from_Rt(R, m.t, Em);
-    if (rp.kind == 0) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) E[q] = Em[q];
-    } else fundamental_from_E(Em, m.f1, m.f2, E);
-    float Ef[9], tb;
-    double dm;
-    bound_setup(E, ps, ps.sq_thr, Ef, tb, dm);
-    tags[slot_base + i] = slot | ((uint32_t)probe_count(s_probe, nprobe, Ef, tb) << 24);
+    return lo;
 }
 
-// In: model_count[2p] = models of the pair (k_solve), keys in the tags (k_probe).  Out: model_count[2p] = sparse, [2p+1] = dense.
+// ------------------------------------------------------------------------------------------------ count (MFMA)
+// Candidate count of EVERY hypothesis over ALL correspondences of its pair, on the matrix cores, and the retirement of the
+// hypotheses that provably cannot matter.
+//   * A hypothesis matters only if it beats a running record of the minimal models (score_models<> @0x22ebc0: more inliers
+//     OR a better score than every earlier minimal model).  With `cand` >= its true inlier count (conservative filter,
+//     mdrp_math.h count_setup):  count <= cand, and score = sum of r^2 over inliers + thr (N - count) >= thr (N - cand).
+//     So  cand <= rec_cnt  and  thr (N - cand) >= rec_score  prove it irrelevant, where (rec_cnt, rec_score) are the records
+//     at the end of the previous chunk (records only improve, so they are a valid bar for every later model).  Its slot
+//     is marked "no record" (-2) exactly like a hypothesis the sweep's Prune retires; k_scan skips it.  Garbage hypotheses
+//     (> 90 % at 50 % outliers: ~5 % of the correspondences survive the filter) never reach the fp64 sweep at all.
+//   * Survivors are appended to the pair's survivor list with their candidate density (per 64 correspondences) in the top
+//     byte: k_sort_tags classifies and sorts them for k_score, which computes their exact scores.
+//   * In the first chunk of a run there is no record yet: everything survives and this kernel only provides the densities.
+// Work split: a wavefront owns 128 hypotheses = 8 MFMA tiles of 16 (B operand, in registers for the whole sweep) and streams
+// the pair's correspondences as prebuilt A fragments (k_prep; 1 KiB per 16 correspondences, coalesced 16 B per lane, L2
+// resident: every wavefront of the pair reads the same 64 N bytes).  Output tile: lane l holds hypothesis l & 15 against
+// correspondences 4 (l >> 4) .. + 3 of the group, so the four |C| > tb tests of a lane belong to ONE hypothesis and add into
+// one counter per tile.  Per 16 x 16 evaluations: one MFMA (16 cycles) + 4 x (v_cmp + v_addc).
+constexpr int CNT_TILES = 8;                       // MFMA tiles (16 hypotheses) per wavefront
+constexpr int CNT_WAVE_MODELS = 16 * CNT_TILES;    // 128
+constexpr int CNT_THREADS = 256;
+constexpr int CNT_WG_MODELS = CNT_WAVE_MODELS * (CNT_THREADS / 64);
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// plan[0..B] = prefix sum of workgroups per pair (ceil(models / 512)); one wavefront
+__global__ __launch_bounds__(64) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ model_count,
+                                                   int32_t *__restrict__ plan) {
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int p0 = 0; p0 < batch; p0 += 64) {
+        const int p = p0 + lane;
+        const int b = (p < batch && st[p].active) ? (model_count[2 * p] + CNT_WG_MODELS - 1) / CNT_WG_MODELS : 0;
+        int inc = b;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
+        if (p < batch) plan[p] = run + inc - b;
+        run += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) plan[batch] = run;
+}
+
+template <bool POSE>
+__global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const PairState *__restrict__ st, const uint4 *__restrict__ rfrag,
+                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags,
+                                                          const int32_t *__restrict__ model_count, const int32_t *__restrict__ plan,
+                                                          int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_surv,
+                                                          int32_t *__restrict__ surv_count, unsigned long long *__restrict__ stats,
+                                                          int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/) {
+    __shared__ uint4 s_frag[CNT_THREADS / 64][CNT_WAVE_MODELS][4]; // per hypothesis: Eh_0..7 | El_0..7 | E8 parts | tb
+    const int total = plan[rp.batch];
+    const int w = blockIdx.x;
+    if (w >= total) return;
+    const int pair = plan_find(plan, rp.batch, w);
+    const int blk = w - plan[pair];
+    const PairState &ps = st[pair];
+    const int n = ps.n, cnt = model_count[2 * pair];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blk * CNT_WG_MODELS + wave * CNT_WAVE_MODELS; // first hypothesis of this wavefront in the pair's tag list
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    const double thr = ps.sq_thr;
+    // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS)
+    uint32_t slot_r[2] = {0, 0};
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = m0 + 64 * r + lane;
+        uint16_t eh[8], el[8], e8[3];
+        float tb = __builtin_inff();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
+        e8[0] = e8[1] = e8[2] = 0;
+        if (i < cnt) {
+            const uint32_t slot = tags[slot_base + i] & 0xFFFFFFu;
+            slot_r[r] = slot;
+            const Model m = models[slot_base + slot];
+            double R[9], Em[9], E[9];
+            quat_to_R(m.q, R);
+            essential_from_Rt(R, m.t, Em);
+            if (POSE) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) E[q] = Em[q];
+            } else fundamental_from_E(Em, m.f1, m.f2, E);
+            count_setup(E, ps.box, thr, eh, el, e8, tb);
+        }
+        uint4 *dst = s_frag[wave][64 * r + lane];
+        dst[0] = pack_bf16x8(eh);
+        dst[1] = pack_bf16x8(el);
+        dst[2] = make_uint4((uint32_t)e8[0] | ((uint32_t)e8[1] << 16), (uint32_t)e8[2], 0u, 0u);
+        dst[3] = make_uint4(__float_as_uint(tb), 0u, 0u, 0u);
+    }
+    __syncthreads();
+    if (m0 >= cnt) return; // nothing for this wavefront (no barrier below)
+    const int col = lane & 15, ksl = lane >> 4;
+    const int part = ksl < 2 ? 0 : ksl - 1; // lanes 0..31 carry Eh, 32..47 El, 48..63 the constant term
+    bf16x8_t bfrag[CNT_TILES];
+    float tbv[CNT_TILES];
+    uint32_t outl[CNT_TILES];
+#pragma unroll
+    for (int t = 0; t < CNT_TILES; ++t) {
+        const uint4 *src = s_frag[wave][16 * t + col];
+        bfrag[t] = __builtin_bit_cast(bf16x8_t, src[part]);
+        tbv[t] = __uint_as_float(src[3].x);
+        outl[t] = 0;
+    }
+    // ---- sweep: one A fragment per 16 correspondences, two groups in flight
+    const int G = (n + 15) >> 4;
+    const uint4 *A = rfrag + (size_t)pair * ((rp.n_max + 15) >> 4) * 64 + lane;
+    // Hand-ordered group body: the 8 MFMAs first (independent accumulators, back to back on the matrix pipe), then the 8
+    // blocks of four compares + four add-with-carry.  hipcc's own schedule reuses one accumulator quad and one SGPR pair
+    // and pads every dependence with s_nop (MFMA -> VALU read, VALU-written SGPR -> VALU read): 3x slower.  In this order
+    // every accumulator is read >= 7 instructions after its MFMA issued and every compare mask >= 3 instructions after
+    // its v_cmp, so no wait states are needed (hipcc pads nothing around inline asm).
+    auto group = [&](const uint4 &araw) {
+        const bf16x8_t a = __builtin_bit_cast(bf16x8_t, araw);
+        f32x4_t acc[CNT_TILES];
+#pragma unroll
+        for (int t = 0; t < CNT_TILES; ++t)
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[t]) : "v"(a), "v"(bfrag[t]));
+#pragma unroll
+        for (int t = 0; t < CNT_TILES; ++t) {
+            const float c0 = acc[t][0], c1 = acc[t][1], c2 = acc[t][2], c3 = acc[t][3];
+            unsigned long long k0, k1, k2, k3, co;
+            asm volatile("v_cmp_gt_f32_e64 %1, |%6|, %10\n\t"
+                         "v_cmp_gt_f32_e64 %2, |%7|, %10\n\t"
+                         "v_cmp_gt_f32_e64 %3, |%8|, %10\n\t"
+                         "v_cmp_gt_f32_e64 %4, |%9|, %10\n\t"
+                         "v_addc_co_u32_e64 %0, %5, %0, 0, %1\n\t"
+                         "v_addc_co_u32_e64 %0, %5, %0, 0, %2\n\t"
+                         "v_addc_co_u32_e64 %0, %5, %0, 0, %3\n\t"
+                         "v_addc_co_u32_e64 %0, %5, %0, 0, %4"
+                         : "+v"(outl[t]), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(co)
+                         : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(tbv[t])); // NaN never compares greater: not an outlier
+        }
+    };
+    // four fragments in flight: a register is refilled right after its group is done, three groups ahead of its next use.
+    // The refills are unconditional (index clamped to the last group) so that the waits are counted (vmcnt(3)), not vmcnt(0).
+    const int last = G - 1;
+    uint4 a0 = A[0], a1 = A[(size_t)min(1, last) * 64], a2 = A[(size_t)min(2, last) * 64], a3 = A[(size_t)min(3, last) * 64];
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        group(a0); a0 = A[(size_t)min(g + 4, last) * 64];
+        group(a1); a1 = A[(size_t)min(g + 5, last) * 64];
+        group(a2); a2 = A[(size_t)min(g + 6, last) * 64];
+        group(a3); a3 = A[(size_t)min(g + 7, last) * 64];
+    }
+    if (g < G) group(a0);
+    if (g + 1 < G) group(a1);
+    if (g + 2 < G) group(a2);
+    // ---- epilogue: totals per hypothesis, retirement, survivor list
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(&s_frag[wave][0][0]); // wave-private, fragments are in registers now
+#pragma unroll
+    for (int t = 0; t < CNT_TILES; ++t) {
+        uint32_t o = outl[t];
+        o += __shfl_xor(o, 16, 64);
+        o += __shfl_xor(o, 32, 64);
+        if (ksl == 0) s_out[16 * t + col] = o;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const long long rec_cnt = (long long)ps.best_min_cnt;
+    const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = m0 + 64 * r + lane;
+        const bool live = i < cnt;
+        const int cand = live ? n - (int)s_out[64 * r + lane] : 0;
+        if (cand_out && live) cand_out[i] = cand;
+        const bool surv = live && ((long long)cand > rec_cnt || thr * (double)(n - cand) < rec_score);
+        if (live && !surv) slot_inl[slot_base + slot_r[r]] = -2;
+        const unsigned long long ball = __ballot(surv);
+        if (ball) {
+            int base = 0;
+            const int first = __ffsll((long long)ball) - 1;
+            if (lane == first) base = atomicAdd(&surv_count[pair], __popcll(ball));
+            base = __shfl(base, first, 64);
+            if (surv) {
+                const uint32_t key = (uint32_t)min(PROBE_PTS, (int)(((long long)cand * PROBE_PTS + n - 1) / n));
+                tags_surv[slot_base + base + __popcll(ball & ((1ull << lane) - 1ull))] = slot_r[r] | (key << 24);
+            }
+        }
+    }
+    if (stats && lane == 0 && wave == 0 && blk == 0) { // per pair, once: evaluations the CPU loop would do, and those the MFMA sweep does
+        atomicAdd(&stats[0], (unsigned long long)cnt * (unsigned long long)n);
+        atomicAdd(&stats[1], (unsigned long long)(((cnt + 15) / 16) * 16) * (unsigned long long)(G * 16));
+    }
+}
+
+// The survivors of k_count, classified and ordered by their candidate density.  One workgroup per pair: key >= DENSE_KEY of
+// 64 -> "dense" list (single-pass sweep), written from the BACK of tags_sorted; everything else -> counting sort by key into
+// the front (two-phase sweep).  Phase 2 of the sweep costs a wavefront the MAXIMUM candidate count over its lanes, and
+// densities differ by 10x between hypotheses, so the sweep wants workgroups of similar hypotheses.  Whole workgroups, not
+// wavefronts: the four wavefronts of a workgroup meet at the tile barriers, and one slow wavefront parks the other three in
+// their SIMD slots (sorting inside the workgroup made the sweep 3x slower).  Which lane scores a hypothesis does not
+// change its result.
+// In: surv_count[p] survivors with keys in tags (k_count).  Out: model_count[2p] = sparse, [2p+1] = dense (model_count[2p]
+// held the pair's model count until here: k_count has consumed it).
 __global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState *__restrict__ st, int32_t *__restrict__ model_count,
+                                                   const int32_t *__restrict__ surv_count,
                                                    const uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
     const int pair = blockIdx.x, tid = threadIdx.x;
     const PairState &ps = st[pair];
     if (!ps.active) return;
     __shared__ int s_hist[PROBE_PTS + 1], s_pos[PROBE_PTS + 1];
     __shared__ int s_dense;
-    const int nprobe = min(ps.n, PROBE_PTS);
     if (tid <= PROBE_PTS) s_hist[tid] = 0;
     if (tid == 0) s_dense = 0;
     __syncthreads();
-    const int cnt = model_count[2 * pair];
+    const int cnt = surv_count[pair];
     const size_t slot_base = (size_t)pair * rp.slot_stride;
     const uint32_t *src = tags + slot_base;
     uint32_t *dst = tags_sorted + slot_base;
 #ifdef MDRP_NO_CLASSIFY
     const int dense_min = PROBE_PTS + 1;
 #else
-    const int dense_min = nprobe >= 8 ? (MDRP_DENSE_KEY * nprobe + PROBE_PTS - 1) / PROBE_PTS : PROBE_PTS + 1;
+    const int dense_min = ps.n >= 8 ? MDRP_DENSE_KEY : PROBE_PTS + 1;
 #endif
     for (int i = tid; i < cnt; i += 256) atomicAdd(&s_hist[min(src[i] >> 24, (uint32_t)PROBE_PTS)], 1);
     __syncthreads();
@@ -804,16 +980,6 @@ __global__ __launch_bounds__(64) void k_plan(int batch, const int32_t *__restric
         run_s += __shfl(is, 63, 64);
     }
     if (lane == 0) { pd[batch] = run_d + run_s; psp[batch] = 0; totals[0] = run_d; totals[1] = run_d + run_s; totals[2] = 0; }
-}
-
-// largest p with prefix[p] <= w   (prefix non-decreasing, prefix[0] = 0, w < prefix[batch])
-__device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int batch, int w) {
-    int lo = 0, hi = batch;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (prefix[mid] <= w) lo = mid; else hi = mid;
-    }
-    return lo;
 }
 
 // Workgroup w handles item w of the plan (grid = an upper bound, surplus workgroups at the END exit at once).  A static
@@ -923,7 +1089,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     const int pair = blockIdx.x, lane = threadIdx.x;
     PairState &ps = st[pair];
     if (!ps.active) { if (lane == 0) ps.n_triggers = 0; return; }
-    if (lane == 0) atomicAdd(evals, (unsigned long long)(model_count[2 * pair] + model_count[2 * pair + 1]) * (unsigned long long)ps.n);
+    if (lane == 0 && evals) atomicAdd(evals, (unsigned long long)(model_count[2 * pair] + model_count[2 * pair + 1]) * (unsigned long long)ps.n); // survivors handed to the fp64 sweep
     long long run_cnt = (long long)ps.best_min_cnt;
     double run_score = ps.best_min_score;
     int ntrig = rp.chunk_off > 0 ? ps.n_triggers : 0; // later chunks of a super-chunk append to its trigger list
@@ -1551,6 +1717,16 @@ __global__ __launch_bounds__(256) void k_box_unit(int n, const double *__restric
 #pragma unroll
         for (int q = 0; q < 4; ++q) st[0].box[q] = fmax(fmax(red[0][q], red[1][q]), fmax(red[2][q], red[3][q]));
     }
+}
+
+// MFMA A fragments of ONE pair's packed records (unit path of k_count)
+__global__ void k_frag_unit(int n, const double *__restrict__ pts, uint4 *__restrict__ rfrag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g_end = ((n + 15) / 16) * 16;
+    if (i < n) {
+        const double *p = pts + (size_t)i * PT_STRIDE;
+        store_record_fragment(rfrag, i, p[0], p[1], p[2], p[3]);
+    } else if (i < g_end) clear_record_fragment(rfrag, i);
 }
 
 // pack raw normalised correspondences of ONE pair into pts records (for mdrp_score_models / mdrp_refine_models)

@@ -664,6 +664,64 @@ MDRP_HD bool filter_keeps(const float Ef[9], float tb, float a, float b, float c
     return !(fabsf(C) > tb);
 }
 
+// ---------------------------------------------------------------- candidate COUNT on the matrix cores (k_count)
+// The numerator of the Sampson test is bilinear in the correspondence: with x1 = (a, b, 1), x2 = (c, d, 1)
+//     C = x2' E x1 = E0 ac + E1 bc + E2 c + E3 ad + E4 bd + E5 d + E6 a + E7 b + E8,
+// a contraction over 8 monomials + 1: [models x 9] . [9 x correspondences] — this one piece of the path IS a dense
+// matrix product, so it runs on MFMA (v_mfma_f32_16x16x32_bf16).  bf16 keeps 8 significand bits, so every coefficient and
+// every monomial is split into bf16 parts x = xh + xl (+ xl2) and the K = 32 slots of one instruction hold
+//     k  0.. 7: Eh_j * mh_j      k  8..15: Eh_j * ml_j      k 16..23: El_j * mh_j      k 24..26: (E8h, E8l, E8l2) * 1.
+// Error against the exact C (u = 2^-9 per bf16 rounding, two-stage split exact to u^2 = 2^-18):
+//     dropped El_j ml_j and the two split remainders: <= 3.02 * 2^-18 * sum_j |E_j m_j|    = 1.16e-5 * A
+//     fp32 accumulation of 27 exact products inside the MFMA (<= 1 ulp per add assumed):   <= 27 * 2^-23 * A = 3.2e-6 * A
+// with A <= M = sum |E_ij| |x2_i|max |x1_j|max over the pair's coordinate box.  KAPPA carries a 4x margin on the sum
+// (tests/test_hostmath.py emulates the arithmetic; the GPU test measures the real instruction against fp64).
+// A correspondence is counted as a DEFINITE outlier iff |C_mfma| > tb, tb = (T + KAPPA M)(1 + 1e-6), T = sqrt(thr Dmax) as
+// in filter_setup; NaN never compares greater, so broken models keep every correspondence (count = N, nothing pruned).
+constexpr double COUNT_KAPPA = 6e-5;
+
+MDRP_HD uint16_t bf16_bits(float x) { // round to nearest even; NaN stays NaN
+    uint32_t u;
+    __builtin_memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+MDRP_HD float bf16_value(uint16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+// x = h + l (+ l2), each a bf16
+MDRP_HD void bf16_split(double x, uint16_t &h, uint16_t &l) {
+    h = bf16_bits((float)x);
+    l = bf16_bits((float)(x - (double)bf16_value(h)));
+}
+MDRP_HD void bf16_split3(double x, uint16_t &h, uint16_t &l, uint16_t &l2) {
+    bf16_split(x, h, l);
+    l2 = bf16_bits((float)(x - (double)bf16_value(h) - (double)bf16_value(l)));
+}
+
+// the 8 monomials of one correspondence in coefficient order E0..E7
+MDRP_HD void count_monomials(double a, double b, double c, double d, double m[8]) {
+    m[0] = a * c; m[1] = b * c; m[2] = c; m[3] = a * d; m[4] = b * d; m[5] = d; m[6] = a; m[7] = b;
+}
+
+// model side of the contraction: eh[8], el[8], e8[3] (bf16 bit patterns) and the outlier threshold tb
+MDRP_HD void count_setup(const double E[9], const double box[4], double thr, uint16_t eh[8], uint16_t el[8], uint16_t e8[3], float &tb) {
+    const double ax = box[0], ay = box[1], cx = box[2], cy = box[3];
+    const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
+    const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
+    const double dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
+    const double e2 = fabs(E[6]) * ax + fabs(E[7]) * ay + fabs(E[8]);
+    const double M = e0 * cx + e1 * cy + e2;
+    const double T = sqrt(thr * (1.0 + 1e-12) * dmax);
+    tb = (M < 1e30) ? (float)((T + COUNT_KAPPA * M) * (1.0 + 1e-6)) + 1e-30f : __builtin_inff(); // !(M < 1e30) also catches NaN
+    for (int j = 0; j < 8; ++j) bf16_split(E[j], eh[j], el[j]);
+    bf16_split3(E[8], e8[0], e8[1], e8[2]);
+}
+
 // ---------------------------------------------------------------- refinement: per-correspondence residuals
 // State of one hypothesis during LM, expanded once per cost/accumulate pass.
 struct LmState {

@@ -100,6 +100,70 @@ def test_score_sweep_many_models_vs_oracle(handle, capi, po, n):
             assert s[k] == pytest.approx(so, rel=1e-10)
 
 
+# ---------------------------------------------------------------------------------------------- MFMA candidate count
+@pytest.mark.parametrize("n", [3, 15, 16, 17, 2000, 2049, 5000])
+def test_count_candidates_is_conservative(handle, capi, po, n):
+    """k_count (bf16-split MFMA filter) must never undercount: for every model, candidates >= correspondences that pass the
+    exact fp64 Sampson test (a superset of the inliers, cheirality aside), at group-ragged sizes; garbage models must stay
+    sparse (that is what retires them), NaN / inf models must keep everything."""
+    from mdrp_amd import synth
+    rng = np.random.default_rng(1000 + n)
+    p = synth.make_pair(n, n, noise_px=1.0, outlier_frac=0.4 if n > 20 else 0.0)
+    x1, x2 = p["x1"] / 800.0, p["x2"] / 800.0
+    ms = []
+    for k in range(600):
+        m = po.new_model()
+        if k % 3 == 0:
+            R = p["R"] @ synth.rodrigues(rng.normal(0, 0.003 * (k % 7), 3)); t = p["t"] + rng.normal(0, 0.003 * (k % 5), 3)
+        else:
+            R = synth.rodrigues(rng.normal(0, 1.0, 3)); t = rng.normal(size=3) * 10.0 ** rng.integers(-3, 3)
+        q = np.zeros(4); po.lib().orc_rotmat_to_quat(np.ascontiguousarray(R.reshape(-1)).ctypes.data_as(po._dp), q.ctypes.data_as(po._dp))
+        m[:4] = q; m[4:7] = t; m[10] = 1.0 + 0.3 * (k % 5); m[11] = 0.8 + 0.1 * (k % 7)
+        ms.append(m)
+    ms[7][4] = np.nan; ms[8][5] = np.inf; ms[9][:4] = 0.0
+    thr = (2.0 / 800.0) ** 2
+    models = capi.array_to_models(np.stack(ms))
+    h1 = np.c_[x1, np.ones(n)]; h2 = np.c_[x2, np.ones(n)]
+    for kind in (capi.CALIB, capi.VARYING_FOCAL):
+        cand = handle.count_candidates(kind, models, x1, x2, thr)
+        assert cand[7] == n and cand[8] == n
+        sparse = []
+        for k in range(600):
+            if k in (7, 8, 9):
+                continue
+            E = po.essential(ms[k]) if kind == capi.CALIB else po.fundamental(ms[k])
+            Ex1 = h1 @ E.T; Etx2 = h2 @ E
+            C = np.sum(h2 * Ex1, axis=1)
+            den = Ex1[:, 0] ** 2 + Ex1[:, 1] ** 2 + Etx2[:, 0] ** 2 + Etx2[:, 1] ** 2
+            exact = int(np.sum(C * C < thr * den))
+            assert cand[k] >= exact, (n, kind, k, cand[k], exact)
+            assert cand[k] <= n
+            if k % 3:
+                sparse.append(cand[k] / n)
+        if n >= 2000:
+            assert np.median(sparse) < 0.15, np.median(sparse)
+
+
+def test_count_filter_error_bound_on_exact_correspondences(handle, capi, po):
+    """The analytical error bound of the bf16-split contraction, measured on the real instruction: with a ZERO threshold the
+    filter keeps a correspondence only if |C_mfma| <= KAPPA * M.  Noise-free correspondences of the true model have C = 0
+    in exact arithmetic, so every one of them must be kept: 48 pairs x 2000 correspondences x 2 estimators."""
+    from mdrp_amd import synth
+    for i in range(48):
+        rf = "varying" if i % 2 else None
+        p = synth.make_pair(7000 + i, 2000, noise_px=0.0, depth_noise=0.0, random_focal=rf)
+        f1, f2 = (p["f1"], p["f2"]) if rf else (800.0, 800.0)
+        sc = 800.0
+        x1, x2 = p["x1"] / (f1 if not rf else sc), p["x2"] / (f2 if not rf else sc)
+        m = po.new_model()
+        q = np.zeros(4); po.lib().orc_rotmat_to_quat(np.ascontiguousarray(p["R"].reshape(-1)).ctypes.data_as(po._dp), q.ctypes.data_as(po._dp))
+        m[:4] = q; m[4:7] = p["t"] * (1.0 + i)   # the scale of t does not matter to E x = 0
+        if rf:
+            m[10], m[11] = f1 / sc, f2 / sc  # F = diag(1,1,f2') E diag(1,1,f1') with x in pixels / sc
+        cand = handle.count_candidates(capi.VARYING_FOCAL if rf else capi.CALIB, capi.array_to_models(m[None]), x1, x2, 0.0)
+        assert cand[0] == 2000, (i, cand[0])
+
+
 # ---------------------------------------------------------------------------------------------- refinement
 def test_refine_vs_reference_golden(handle, capi, golden):
     g = golden("refine")
