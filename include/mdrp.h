@@ -163,6 +163,7 @@ typedef struct {
     int64_t evals_algorithmic; /* (model x correspondence) evaluations the CPU loop does: sum over pairs of models * n */
     int64_t evals_mfma;        /* evaluations executed by k_count (16 x 16 tiles, padding included) */
     int64_t evals_fp64;        /* evaluations handed to k_score (survivors * n) */
+    int64_t evals_bound;       /* evaluations executed by k_bound in fp32 (k_count's survivors * n) */
 } mdrp_stats;
 int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out);
 

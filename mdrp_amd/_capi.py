@@ -46,7 +46,7 @@ class Camera(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("count_ms", C.c_double), ("count_launches", C.c_int64), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
-                ("evals_algorithmic", C.c_int64), ("evals_mfma", C.c_int64), ("evals_fp64", C.c_int64)]
+                ("evals_algorithmic", C.c_int64), ("evals_mfma", C.c_int64), ("evals_fp64", C.c_int64), ("evals_bound", C.c_int64)]
 
 
 class Result(C.Structure):

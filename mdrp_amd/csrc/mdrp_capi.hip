@@ -59,6 +59,7 @@ struct Progress {
     unsigned long long evals;       // (model x correspondence) evaluations the CPU loop would do: sum over pairs of models * n
     unsigned long long evals_mfma;  // evaluations executed by k_count on the matrix cores (padded to 16 x 16 tiles)
     unsigned long long evals_sweep; // evaluations handed to the fp64 sweep (survivors * n)
+    unsigned long long evals_bound; // evaluations executed by k_bound in fp32 (k_count's survivors * n)
 };
 constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
 constexpr size_t COUNTERS_BYTES = 128;
@@ -97,7 +98,8 @@ struct mdrp_handle {
     DevBuf tags2, model_count2, samples2; // odd chunks of a super-chunk (chunk c + 1 is solved beside the sweep of chunk c)
     DevBuf tags_v, surv_count; // survivors of k_count (unsorted, with density keys) and their number per pair
     DevBuf rfrag;              // MFMA A fragments of the correspondences (k_prep): [pair][ceil(n_max/16)][64] x 16 B
-    DevBuf cplan;              // work plan of k_count
+    DevBuf cplan;              // work plan of k_count / k_bound
+    DevBuf surv2_count;        // survivors of k_bound per pair
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -107,7 +109,7 @@ struct mdrp_handle {
     size_t ev_used = 0;
     double sweep_ms = 0.0, count_ms = 0.0;
     int64_t count_launches = 0;
-    int64_t sweep_launches = 0, sweep_evals = 0, mfma_evals = 0, fp64_evals = 0;
+    int64_t sweep_launches = 0, sweep_evals = 0, mfma_evals = 0, fp64_evals = 0, bound_evals = 0;
     int last_batch = 0;
 };
 
@@ -207,6 +209,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->tags_v.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
     if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
+    if ((rc = h->surv2_count.ensure(sizeof(int32_t) * batch))) return rc;
     const size_t groups_max = ((size_t)n_max + 15) / 16;
     if ((rc = h->rfrag.ensure(std::max<size_t>(1024, (size_t)batch * groups_max * 1024)))) return rc;
     const int trig_cap = chunk_cap;
@@ -245,8 +248,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
     const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0;
     const int lo_overlap_waves = env_int("MDRP_LO_OVERLAP_WAVES", 8); // LO wavefronts per CU while it shares the chip
-    const bool lo_after_solve = env_int("MDRP_LO_AFTER_SOLVE", 0) != 0;
+    const bool lo_after_solve = env_int("MDRP_LO_AFTER_SOLVE", 1) != 0; // LO of chunk c starts when chunk c + 1 is solved (the solver is on the critical path)
     const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
+    const bool use_bound = env_int("MDRP_BOUND", 1) != 0; // fp32 lower-bound stage between k_count and the fp64 sweep
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
@@ -260,17 +264,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // iterations that certainly run: the reference cannot stop before min_iterations + 1 (or max_iterations)
     const uint64_t certain = ro->max_iterations == 0 ? 1 : std::min<uint64_t>(ro->max_iterations, ro->min_iterations + 1);
     // A SUPER-CHUNK is a range of iterations that shares one LO + walk pass and one host read-back; it is swept in one or
-    // more CHUNKS (solve / score / scan launch trains).  Inside the certain range nothing can stop, so the first
-    // super-chunk is split into a short chunk (512 iterations) that establishes the records and the rest, which k_score
-    // then sweeps with the exact bail-out (see Prune in mdrp_kernels.h); both chunks' triggers go to ONE k_lo launch.
+    // more CHUNKS (solve / count / bound / score / scan launch trains).  Inside the certain range nothing can stop, so the
+    // first super-chunk is split into a short chunk (128 iterations) that establishes the records and the rest, whose
+    // hypotheses are retired against those records by k_count (MFMA) and k_bound (fp32) unless they might break one.
     // Beyond the certain range a super-chunk is one chunk sized by the largest remaining dynamic_max_iter.
-    // leading chunk lengths of the first super-chunk; the last chunk takes the rest.  Measured on the benchmark shape:
-    // "512" 53.9k pairs/s, "512,1536" 52.7k, "512,2560" 49.8k (a 256-VGPR LO wavefront per SIMD leaves little room for a
-    // third concurrent kernel, and the sort of the next chunk crawls beside it)
+    // leading chunk lengths of the first super-chunk; the last chunk takes the rest.  The first chunk has no records to
+    // retire anything against, so it is scored exactly in full: keep it short.  Every later chunk goes through k_count /
+    // k_bound against the records of the chunks before it.  Measured on the benchmark shape: "128" 84.5 k pairs/s, "64" 82 k,
+    // "256" 82.5 k, "512" 82 k, "256,768" 79 k (every chunk costs ~10 launches and a solver hand-over)
     std::vector<uint64_t> lead;
     {
         const char *e = getenv("MDRP_CHUNKS");
-        std::string spec = e ? e : "512";
+        std::string spec = e ? e : "128";
         size_t pos = 0;
         while (pos < spec.size() && (int)lead.size() < mdrp_handle::NC_MAX - 1) {
             const size_t q = spec.find(',', pos);
@@ -361,7 +366,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
                 const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
                 HIPCHK(hipMemsetAsync(h->surv_count.p, 0, sizeof(int32_t) * batch, s));
-                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), mcount_c, h->cplan.as<int32_t>());
+                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>());
                 const dim3 cgrid((unsigned)batch * (unsigned)((len * 4 + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                 unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
                 HIPCHK(hipEventRecord(c0, s));
@@ -375,8 +380,27 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                        h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
                 HIPCHK(hipEventRecord(c1, s));
                 h->count_launches++;
-                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, h->surv_count.as<int32_t>(),
-                                   h->tags_v.as<uint32_t>(), tags_sc);
+                const uint32_t *surv_tags = h->tags_v.as<uint32_t>();
+                const int32_t *surv_cnt = h->surv_count.as<int32_t>();
+                if (use_bound && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
+                    // fp32 lower bound of the score for k_count's survivors; its survivors go back into the chunk's tag list
+                    uint32_t *tags_b = (odd ? h->tags2 : h->tags).as<uint32_t>();
+                    HIPCHK(hipMemsetAsync(h->surv2_count.p, 0, sizeof(int32_t) * batch, s));
+                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1,
+                                       BND_THREADS, h->cplan.as<int32_t>());
+                    const dim3 bgrid((unsigned)batch * (unsigned)((len * 4 + BND_THREADS - 1) / BND_THREADS));
+                    unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
+                    if (kind == MDRP_CALIB)
+                        hipLaunchKernelGGL(k_bound<true>, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
+                                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                                           tags_b, h->surv2_count.as<int32_t>(), bstats);
+                    else
+                        hipLaunchKernelGGL(k_bound<false>, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
+                                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                                           tags_b, h->surv2_count.as<int32_t>(), bstats);
+                    surv_tags = tags_b; surv_cnt = h->surv2_count.as<int32_t>();
+                }
+                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, surv_cnt, surv_tags, tags_sc);
                 int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, mcount_c, plan, totals);
                 HIPCHK(hipEventRecord(e0, s));
@@ -418,6 +442,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         h->sweep_evals += (int64_t)h->progress_host->evals;
         h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
         h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
+        h->bound_evals += (int64_t)h->progress_host->evals_bound;
 #ifdef MDRP_EXP_STATS
         {
             unsigned long long st8[8];
@@ -428,8 +453,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         }
 #endif
         if (getenv("MDRP_DEBUG"))
-            fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu active %d max_needed %llu\n", (unsigned long long)it0,
-                    (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->n_active, h->progress_host->max_needed);
+            fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu (mfma %llu, fp32 bound %llu, fp64 sweep %llu = %.2f %%) active %d max_needed %llu\n",
+                    (unsigned long long)it0, (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->evals_mfma,
+                    h->progress_host->evals_bound, h->progress_host->evals_sweep, 100.0 * (double)h->progress_host->evals_sweep / (double)std::max<unsigned long long>(1, h->progress_host->evals),
+                    h->progress_host->n_active, h->progress_host->max_needed);
         it0 += super_len;
         if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
         max_needed = h->progress_host->max_needed;
@@ -446,7 +473,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
                     const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
     if (!h || batch < 0 || n_max < 0 || kind < 0 || kind > 2 || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (kind == MDRP_CALIB && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
-    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch;
+    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
     if (batch == 0) return MDRP_OK;
@@ -565,7 +592,7 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan};
+                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -648,7 +675,7 @@ int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out) {
     std::lock_guard<std::mutex> lock_(h->mu);
     out->count_ms = h->count_ms; out->count_launches = h->count_launches;
     out->sweep_ms = h->sweep_ms; out->sweep_launches = h->sweep_launches;
-    out->evals_algorithmic = h->sweep_evals; out->evals_mfma = h->mfma_evals; out->evals_fp64 = h->fp64_evals;
+    out->evals_algorithmic = h->sweep_evals; out->evals_mfma = h->mfma_evals; out->evals_fp64 = h->fp64_evals; out->evals_bound = h->bound_evals;
     return MDRP_OK;
 }
 
@@ -781,7 +808,7 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.batch = 1; rp.n_max = nn; rp.slot_stride = num_models;
-    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, 1, h->st.as<PairState>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>());
+    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, 1, h->st.as<PairState>(), h->model_count.as<int32_t>(), 2, CNT_WG_MODELS, h->cplan.as<int32_t>());
     const dim3 grid((unsigned)((num_models + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
     if (kind == MDRP_CALIB)
         hipLaunchKernelGGL(k_count<true>, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),

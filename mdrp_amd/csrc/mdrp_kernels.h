@@ -159,10 +159,18 @@ __device__ __forceinline__ uint4 pack_bf16x8(const uint16_t v[8]) {
 __device__ __forceinline__ void store_record_fragment(uint4 *__restrict__ frag, int i, double a, double b, double c, double d) {
     double m[8];
     count_monomials(a, b, c, d, m);
+    uint4 *g = frag + (size_t)(i >> 4) * 64 + (i & 15);
+    double mag = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mag = fmax(mag, fabs(m[j])); // fmax drops NaN: test the sum too
+    if (!(mag < 1e15) || !(m[0] + m[1] + m[3] + m[4] == m[0] + m[1] + m[3] + m[4])) { // non-finite or absurd coordinates: an all-zero row gives
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);                                   // C = 0, "never a definite outlier" (k_count's sign test must not see NaN)
+        g[0] = z; g[16] = z; g[32] = z; g[48] = z;
+        return;
+    }
     uint16_t mh[8], ml[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bf16_split(m[j], mh[j], ml[j]);
-    uint4 *g = frag + (size_t)(i >> 4) * 64 + (i & 15);
     const uint4 hi = pack_bf16x8(mh);
     g[0] = hi; g[16] = pack_bf16x8(ml); g[32] = hi;
     g[48] = make_uint4(0x3F803F80u, 0x00003F80u, 0u, 0u);
@@ -737,14 +745,14 @@ constexpr int CNT_WG_MODELS = CNT_WAVE_MODELS * (CNT_THREADS / 64);
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-// plan[0..B] = prefix sum of workgroups per pair (ceil(models / 512)); one wavefront
-__global__ __launch_bounds__(64) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ model_count,
-                                                   int32_t *__restrict__ plan) {
+// plan[0..B] = prefix sum of workgroups per pair (ceil(counts[stride * pair] / per_wg)); one wavefront
+__global__ __launch_bounds__(64) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
+                                                   int per_wg, int32_t *__restrict__ plan) {
     const int lane = threadIdx.x;
     int run = 0;
     for (int p0 = 0; p0 < batch; p0 += 64) {
         const int p = p0 + lane;
-        const int b = (p < batch && st[p].active) ? (model_count[2 * p] + CNT_WG_MODELS - 1) / CNT_WG_MODELS : 0;
+        const int b = (p < batch && st[p].active) ? (counts[stride * p] + per_wg - 1) / per_wg : 0;
         int inc = b;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
@@ -761,7 +769,11 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
                                                           int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_surv,
                                                           int32_t *__restrict__ surv_count, unsigned long long *__restrict__ stats,
                                                           int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/) {
-    __shared__ uint4 s_frag[CNT_THREADS / 64][CNT_WAVE_MODELS][4]; // per hypothesis: Eh_0..7 | El_0..7 | E8 parts | tb
+    // LDS: first the B fragments of the workgroup's 512 hypotheses (prologue), then the A-fragment tiles of the sweep
+    constexpr int A_TILE_GROUPS = 16;                                   // 16 groups = 256 correspondences = 16 KiB per tile
+    __shared__ uint4 s_lds[2 * A_TILE_GROUPS * 64];                     // 32 KiB: two tiles (double buffer)
+    uint4 (*s_frag)[CNT_WAVE_MODELS][4] = reinterpret_cast<uint4 (*)[CNT_WAVE_MODELS][4]>(s_lds); // [wave][hypothesis][Eh | El | E8 parts | tb]
+    static_assert(sizeof(uint4) * (CNT_THREADS / 64) * CNT_WAVE_MODELS * 4 <= sizeof(uint4) * 2 * A_TILE_GROUPS * 64, "fragment staging fits the tile buffers");
     const int total = plan[rp.batch];
     const int w = blockIdx.x;
     if (w >= total) return;
@@ -779,7 +791,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     for (int r = 0; r < 2; ++r) {
         const int i = m0 + 64 * r + lane;
         uint16_t eh[8], el[8], e8[3];
-        float tb = __builtin_inff();
+        float tb = 1.0f; // here: (tb S)^2 of count_setup_scaled; zero coefficients against 1 keep everything
 #pragma unroll
         for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
         e8[0] = e8[1] = e8[2] = 0;
@@ -794,7 +806,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
 #pragma unroll
                 for (int q = 0; q < 9; ++q) E[q] = Em[q];
             } else fundamental_from_E(Em, m.f1, m.f2, E);
-            count_setup(E, ps.box, thr, eh, el, e8, tb);
+            count_setup_scaled(E, ps.box, thr, eh, el, e8, tb);
         }
         uint4 *dst = s_frag[wave][64 * r + lane];
         dst[0] = pack_bf16x8(eh);
@@ -803,71 +815,112 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
         dst[3] = make_uint4(__float_as_uint(tb), 0u, 0u, 0u);
     }
     __syncthreads();
-    if (m0 >= cnt) return; // nothing for this wavefront (no barrier below)
+    const bool idle = m0 >= cnt; // nothing to count for this wavefront: it still helps to stage the tiles
     const int col = lane & 15, ksl = lane >> 4;
     const int part = ksl < 2 ? 0 : ksl - 1; // lanes 0..31 carry Eh, 32..47 El, 48..63 the constant term
     bf16x8_t bfrag[CNT_TILES];
-    float tbv[CNT_TILES];
-    uint32_t outl[CNT_TILES];
+    f32x2 tbv[CNT_TILES];  // (tb S)^2 in both halves
+    f32x2 cand[CNT_TILES]; // running candidate counts (exact in fp32: <= 2^24)
 #pragma unroll
     for (int t = 0; t < CNT_TILES; ++t) {
         const uint4 *src = s_frag[wave][16 * t + col];
         bfrag[t] = __builtin_bit_cast(bf16x8_t, src[part]);
-        tbv[t] = __uint_as_float(src[3].x);
-        outl[t] = 0;
+        const float tb2 = __uint_as_float(src[3].x);
+        tbv[t] = (f32x2){tb2, tb2};
+        cand[t] = (f32x2){0.f, 0.f};
     }
-    // ---- sweep: one A fragment per 16 correspondences, two groups in flight
-    const int G = (n + 15) >> 4;
-    const uint4 *A = rfrag + (size_t)pair * ((rp.n_max + 15) >> 4) * 64 + lane;
-    // Hand-ordered group body: the 8 MFMAs first (independent accumulators, back to back on the matrix pipe), then the 8
-    // blocks of four compares + four add-with-carry.  hipcc's own schedule reuses one accumulator quad and one SGPR pair
-    // and pads every dependence with s_nop (MFMA -> VALU read, VALU-written SGPR -> VALU read): 3x slower.  In this order
-    // every accumulator is read >= 7 instructions after its MFMA issued and every compare mask >= 3 instructions after
-    // its v_cmp, so no wait states are needed (hipcc pads nothing around inline asm).
-    auto group = [&](const uint4 &araw) {
+    __syncthreads(); // the fragments are in registers: the buffer now holds correspondence tiles
+    // ---- sweep.  The pair's A fragments (64 N bytes, k_prep) are staged through LDS one 16-group tile at a time, double
+    // buffered: read from global memory ONCE per workgroup instead of once per wavefront.
+    // The group body is a hand-ordered software pipeline (inline asm; hipcc's own schedule reuses one accumulator quad
+    // and pads every dependence with s_nop: 3x slower).  Per pair of MFMA tiles:
+    //     8 VALU on the accumulators of group g   |   2 MFMAs of group g + 1 into the same accumulators
+    // so the matrix pipe works on the next group while the vector pipe tests this one, and every accumulator is read >= 24
+    // instructions after its MFMA issued (no wait states needed; hipcc pads nothing around inline asm).
+    // The test (every VALU instruction costs 4 cycles per wavefront here; packed fp32 ones carry two values):
+    //     v_pk_fma_f32 d = -C * C + tb^2, clamp      1 = candidate, 0 = definite outlier (scaled so that nothing falls between)
+    //     v_pk_add_f32 cand += d
+    // = one VALU instruction per evaluation, 16 cycles per MFMA tile against the MFMA's own 16.  C is never NaN: rows of
+    // non-finite correspondences and the coefficients of unjudgeable models are zeroed when the fragments are built.
+    f32x4_t acc[CNT_TILES];
+    auto mfma2 = [&](const uint4 &araw, int t0) {
         const bf16x8_t a = __builtin_bit_cast(bf16x8_t, araw);
-        f32x4_t acc[CNT_TILES];
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %3, 0\n\t"
+                     "v_mfma_f32_16x16x32_bf16 %1, %2, %4, 0"
+                     : "=&v"(acc[t0]), "=&v"(acc[t0 + 1]) : "v"(a), "v"(bfrag[t0]), "v"(bfrag[t0 + 1]));
+    };
+    auto test2 = [&](int t0) {
+        const f32x2 x01 = {acc[t0][0], acc[t0][1]}, x23 = {acc[t0][2], acc[t0][3]};
+        const f32x2 y01 = {acc[t0 + 1][0], acc[t0 + 1][1]}, y23 = {acc[t0 + 1][2], acc[t0 + 1][3]};
+        f32x2 d0, d1, d2, d3;
+        asm volatile("v_pk_fma_f32 %2, %6, %6, %10 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+                     "v_pk_fma_f32 %3, %7, %7, %10 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+                     "v_pk_fma_f32 %4, %8, %8, %11 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+                     "v_pk_fma_f32 %5, %9, %9, %11 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
+                     "v_pk_add_f32 %0, %0, %2\n\t"
+                     "v_pk_add_f32 %1, %1, %4\n\t"
+                     "v_pk_add_f32 %0, %0, %3\n\t"
+                     "v_pk_add_f32 %1, %1, %5"
+                     : "+v"(cand[t0]), "+v"(cand[t0 + 1]), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                     : "v"(x01), "v"(x23), "v"(y01), "v"(y23), "v"(tbv[t0]), "v"(tbv[t0 + 1]));
+    };
+    const int G = (n + 15) >> 4;
+    const uint4 *A = rfrag + (size_t)pair * ((rp.n_max + 15) >> 4) * 64;
+    const int n_tiles = (G + A_TILE_GROUPS - 1) / A_TILE_GROUPS;
+    uint4 stage[4];
+    auto fetch = [&](int tile) { // 256 threads x 4 x 16 B = one tile; past the last group: zeros (C = 0: never an outlier)
+        const int g0 = tile * A_TILE_GROUPS;
 #pragma unroll
-        for (int t = 0; t < CNT_TILES; ++t)
-            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=&v"(acc[t]) : "v"(a), "v"(bfrag[t]));
-#pragma unroll
-        for (int t = 0; t < CNT_TILES; ++t) {
-            const float c0 = acc[t][0], c1 = acc[t][1], c2 = acc[t][2], c3 = acc[t][3];
-            unsigned long long k0, k1, k2, k3, co;
-            asm volatile("v_cmp_gt_f32_e64 %1, |%6|, %10\n\t"
-                         "v_cmp_gt_f32_e64 %2, |%7|, %10\n\t"
-                         "v_cmp_gt_f32_e64 %3, |%8|, %10\n\t"
-                         "v_cmp_gt_f32_e64 %4, |%9|, %10\n\t"
-                         "v_addc_co_u32_e64 %0, %5, %0, 0, %1\n\t"
-                         "v_addc_co_u32_e64 %0, %5, %0, 0, %2\n\t"
-                         "v_addc_co_u32_e64 %0, %5, %0, 0, %3\n\t"
-                         "v_addc_co_u32_e64 %0, %5, %0, 0, %4"
-                         : "+v"(outl[t]), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3), "=&s"(co)
-                         : "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(tbv[t])); // NaN never compares greater: not an outlier
+        for (int k = 0; k < 4; ++k) {
+            const int idx = k * CNT_THREADS + tid; // uint4 index inside the tile
+            stage[k] = (g0 + (idx >> 6)) < G ? A[(size_t)g0 * 64 + idx] : make_uint4(0u, 0u, 0u, 0u);
         }
     };
-    // four fragments in flight: a register is refilled right after its group is done, three groups ahead of its next use.
-    // The refills are unconditional (index clamped to the last group) so that the waits are counted (vmcnt(3)), not vmcnt(0).
-    const int last = G - 1;
-    uint4 a0 = A[0], a1 = A[(size_t)min(1, last) * 64], a2 = A[(size_t)min(2, last) * 64], a3 = A[(size_t)min(3, last) * 64];
-    int g = 0;
-    for (; g + 4 <= G; g += 4) {
-        group(a0); a0 = A[(size_t)min(g + 4, last) * 64];
-        group(a1); a1 = A[(size_t)min(g + 5, last) * 64];
-        group(a2); a2 = A[(size_t)min(g + 6, last) * 64];
-        group(a3); a3 = A[(size_t)min(g + 7, last) * 64];
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_lds[buf * A_TILE_GROUPS * 64 + k * CNT_THREADS + tid] = stage[k];
+    };
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    // every tile is swept as 16 groups (zero rows past the end cost nothing but their share of the last tile)
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        const int buf = tile & 1;
+        if (tile + 1 < n_tiles) fetch(tile + 1);
+        if (!idle) {
+            const uint4 *T = s_lds + buf * A_TILE_GROUPS * 64 + lane;
+            uint4 f0 = T[0], f1 = T[64];
+#pragma unroll
+            for (int t = 0; t < CNT_TILES; t += 2) mfma2(f0, t);
+#pragma unroll
+            for (int g = 0; g < A_TILE_GROUPS; g += 2) {
+                // group g is in the accumulators; f1 = fragment of g + 1
+                f0 = T[(size_t)min(g + 2, A_TILE_GROUPS - 1) * 64];
+#pragma unroll
+                for (int t = 0; t < CNT_TILES; t += 2) { test2(t); mfma2(f1, t); }
+                f1 = T[(size_t)min(g + 3, A_TILE_GROUPS - 1) * 64];
+                if (g + 2 < A_TILE_GROUPS) {
+#pragma unroll
+                    for (int t = 0; t < CNT_TILES; t += 2) { test2(t); mfma2(f0, t); }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < CNT_TILES; t += 2) test2(t);
+                }
+            }
+        }
+        if (tile + 1 < n_tiles) commit(buf ^ 1); // the other buffer was last read before the previous barrier
+        __syncthreads();
     }
-    if (g < G) group(a0);
-    if (g + 1 < G) group(a1);
-    if (g + 2 < G) group(a2);
+    if (idle) return;
     // ---- epilogue: totals per hypothesis, retirement, survivor list
     uint32_t *s_out = reinterpret_cast<uint32_t *>(&s_frag[wave][0][0]); // wave-private, fragments are in registers now
+    const int pad = n_tiles * A_TILE_GROUPS * 16 - n; // zero rows past the end always count as candidates
 #pragma unroll
     for (int t = 0; t < CNT_TILES; ++t) {
-        uint32_t o = outl[t];
+        float o = cand[t][0] + cand[t][1];
         o += __shfl_xor(o, 16, 64);
         o += __shfl_xor(o, 32, 64);
-        if (ksl == 0) s_out[16 * t + col] = o;
+        if (ksl == 0) s_out[16 * t + col] = (uint32_t)((int)o - pad);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -877,9 +930,9 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     for (int r = 0; r < 2; ++r) {
         const int i = m0 + 64 * r + lane;
         const bool live = i < cnt;
-        const int cand = live ? n - (int)s_out[64 * r + lane] : 0;
-        if (cand_out && live) cand_out[i] = cand;
-        const bool surv = live && ((long long)cand > rec_cnt || thr * (double)(n - cand) < rec_score);
+        const int cnd = live ? (int)s_out[64 * r + lane] : 0;
+        if (cand_out && live) cand_out[i] = cnd;
+        const bool surv = live && ((long long)cnd > rec_cnt || thr * (double)(n - cnd) < rec_score);
         if (live && !surv) slot_inl[slot_base + slot_r[r]] = -2;
         const unsigned long long ball = __ballot(surv);
         if (ball) {
@@ -888,15 +941,134 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
             if (lane == first) base = atomicAdd(&surv_count[pair], __popcll(ball));
             base = __shfl(base, first, 64);
             if (surv) {
-                const uint32_t key = (uint32_t)min(PROBE_PTS, (int)(((long long)cand * PROBE_PTS + n - 1) / n));
+                const uint32_t key = (uint32_t)min(PROBE_PTS, (int)(((long long)cnd * PROBE_PTS + n - 1) / n));
                 tags_surv[slot_base + base + __popcll(ball & ((1ull << lane) - 1ull))] = slot_r[r] | (key << 24);
             }
         }
     }
     if (stats && lane == 0 && wave == 0 && blk == 0) { // per pair, once: evaluations the CPU loop would do, and those the MFMA sweep does
         atomicAdd(&stats[0], (unsigned long long)cnt * (unsigned long long)n);
-        atomicAdd(&stats[1], (unsigned long long)(((cnt + 15) / 16) * 16) * (unsigned long long)(G * 16));
+        atomicAdd(&stats[1], (unsigned long long)(((cnt + 15) / 16) * 16) * (unsigned long long)(n_tiles * A_TILE_GROUPS * 16));
     }
+}
+
+// ------------------------------------------------------------------------------------------------ bound (fp32)
+// Second retirement stage, for the hypotheses k_count let through (at 50 % outliers: the ~6 % with more candidates than
+// roughly half of the record's inliers; on outlier-free data: all of them).  One lane per hypothesis sweeps the pair's
+// correspondences in fp32 and sums a LOWER bound of every MSAC term (mdrp_math.h bound_r2_32); with its own count of
+// k_count as the upper bound of the inlier count, the two record tests of score_models<> are decided for everything except
+// true record candidates and near-ties, and only those reach the fp64 sweep.  Branch-free: ~23 fp32 instructions per
+// evaluation against ~12 (mostly fp64, divergent) of the exact sweep's survivors, and no second phase.
+constexpr int BND_THREADS = 256;
+constexpr int BND_TILE = 1024; // correspondences per LDS tile (16 B each, fp32)
+
+template <bool POSE>
+__global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags_in,
+                                                          const int32_t *__restrict__ cnt_in, const int32_t *__restrict__ plan,
+                                                          int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_out,
+                                                          int32_t *__restrict__ cnt_out, unsigned long long *__restrict__ stats) {
+    __shared__ float4 s_rec[BND_TILE];
+    const int total = plan[rp.batch];
+    const int w = blockIdx.x;
+    if (w >= total) return;
+    const int pair = plan_find(plan, rp.batch, w);
+    const int blk = w - plan[pair];
+    const PairState &ps = st[pair];
+    const int n = ps.n, cnt = cnt_in[pair];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int i = blk * BND_THREADS + tid;
+    const bool live = i < cnt;
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    const double thr = ps.sq_thr;
+    uint32_t tag = 0;
+    float Ef[9], eC = 0.f, eD = 1.f, thr_dn = 0.f;
+    bool sane = false;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ef[q] = 0.f;
+    if (live) {
+        tag = tags_in[slot_base + i];
+        const Model m = models[slot_base + (tag & 0xFFFFFFu)];
+        double R[9], Em[9], E[9];
+        quat_to_R(m.q, R);
+        essential_from_Rt(R, m.t, Em);
+        if (POSE) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) E[q] = Em[q];
+        } else fundamental_from_E(Em, m.f1, m.f2, E);
+        sane = bound_setup32(E, ps.box, thr, Ef, eC, eD, thr_dn);
+    }
+    // Two correspondences per step in packed fp32 (every VALU instruction costs 4 cycles per wavefront; v_pk_* carry two
+    // values): 16 v_pk_fma for C and den of both, then per element |C| - eC, max, rcp, min.  The inlier-count upper bound is a
+    // clamped packed FMA: clamp((thr_cnt - q) * 2^80) is 1 for q < thr_cnt, 0 for q >= thr_cnt (and for NaN), summed in fp32.
+    double total_lb = 0.0;
+    f32x2 cnt2 = {0.f, 0.f}; // correspondences whose lower bound is below the threshold: an upper bound of the inlier count
+    const float thr_cnt = (float)(thr * (1.0 + 1e-5)) * (1.0f + 1e-6f); // q may exceed r^2 by its own roundings (<= 8u)
+    const float BIG = 1.2089258e24f; // 2^80
+    const f32x2 nbig = {-BIG, -BIG}, kcnt = {thr_cnt * BIG, thr_cnt * BIG};
+    f32x2 Ev[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) Ev[q] = (f32x2){Ef[q], Ef[q]};
+    const f32x2 eDv = {eD, eD};
+    float4 *s_pair = s_rec; // two correspondences per 32 B, component-major: (a0 a1 b0 b1)(c0 c1 d0 d1)
+    const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    for (int t0 = 0; t0 < n; t0 += BND_TILE) {
+        const int npts = min(BND_TILE, n - t0);
+        __syncthreads();
+        for (int j = tid; j < npts; j += BND_THREADS) {
+            const double2 *src = reinterpret_cast<const double2 *>(gp + (size_t)(t0 + j) * PT_STRIDE);
+            const double2 p0 = src[0], p1 = src[1];
+            store_rec32(s_pair, j, p0.x, p0.y, p1.x, p1.y);
+        }
+        __syncthreads();
+        const int npairs = npts >> 1;
+        for (int j0 = 0; j0 < npairs; j0 += 32) { // partial sums of <= 64 terms in fp32, then fp64
+            const int je = min(32, npairs - j0);
+            f32x2 part = {0.f, 0.f};
+#pragma unroll 2
+            for (int j = 0; j < je; ++j) {
+                const float4 ab = s_pair[2 * (j0 + j)], cd = s_pair[2 * (j0 + j) + 1];
+                const f32x2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, c = {cd.x, cd.y}, d = {cd.z, cd.w};
+                const f32x2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
+                const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
+                const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
+                const f32x2 g0 = __builtin_elementwise_fma(Ev[0], c, __builtin_elementwise_fma(Ev[3], d, Ev[6]));
+                const f32x2 g1 = __builtin_elementwise_fma(Ev[1], c, __builtin_elementwise_fma(Ev[4], d, Ev[7]));
+                const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
+                const f32x2 den = __builtin_elementwise_fma(e0, e0, __builtin_elementwise_fma(e1, e1, __builtin_elementwise_fma(g0, g0, __builtin_elementwise_fma(g1, g1, eDv))));
+                const f32x2 t = {fmaxf(fabsf(C.x) - eC, 0.0f), fmaxf(fabsf(C.y) - eC, 0.0f)};
+                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)}; // v_rcp_f32: 1 ulp, inside BOUND_SLACK
+                const f32x2 q = (t * t) * rc;
+                const f32x2 term = {__builtin_fminf(q.x, thr_dn), __builtin_fminf(q.y, thr_dn)}; // v_min_f32: NaN -> thr, like the reference's `r2 < thr`
+                part += term;
+                f32x2 o;
+                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(q), "v"(nbig), "v"(kcnt));
+                cnt2 += o;
+            }
+            total_lb += (double)part.x + (double)part.y;
+        }
+        if (npts & 1) { // odd tail of the last tile
+            const float *fl = reinterpret_cast<const float *>(s_pair) + (npts >> 1) * 8;
+            const float q = bound_r2_32(Ef, eC, eD, fl[0], fl[2], fl[4], fl[6]);
+            total_lb += (double)__builtin_fminf(q, thr_dn);
+            cnt2.x += (q < thr_cnt) ? 1.0f : 0.0f;
+        }
+    }
+    const int cnt_ub = (int)(cnt2.x + cnt2.y) + 1; // + 1: the sum of the clamped values may carry a fraction
+    const long long rec_cnt = (long long)ps.best_min_cnt;
+    const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
+    const bool dead = live && sane && (long long)cnt_ub <= rec_cnt && total_lb * (1.0 - BOUND_SLACK) >= rec_score;
+    if (dead) slot_inl[slot_base + (tag & 0xFFFFFFu)] = -2;
+    const bool surv = live && !dead;
+    const unsigned long long ball = __ballot(surv);
+    if (ball) {
+        int base = 0;
+        const int first = __ffsll((long long)ball) - 1;
+        if (lane == first) base = atomicAdd(&cnt_out[pair], __popcll(ball));
+        base = __shfl(base, first, 64);
+        if (surv) tags_out[slot_base + base + __popcll(ball & ((1ull << lane) - 1ull))] = tag;
+    }
+    if (stats && tid == 0 && blk == 0) atomicAdd(stats, (unsigned long long)cnt * (unsigned long long)n);
 }
 
 // The survivors of k_count, classified and ordered by their candidate density.  One workgroup per pair: key >= DENSE_KEY of

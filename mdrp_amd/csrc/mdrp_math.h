@@ -676,8 +676,12 @@ MDRP_HD bool filter_keeps(const float Ef[9], float tb, float a, float b, float c
 //     fp32 accumulation of 27 exact products inside the MFMA (<= 1 ulp per add assumed):   <= 27 * 2^-23 * A = 3.2e-6 * A
 // with A <= M = sum |E_ij| |x2_i|max |x1_j|max over the pair's coordinate box.  KAPPA carries a 4x margin on the sum
 // (tests/test_hostmath.py emulates the arithmetic; the GPU test measures the real instruction against fp64).
-// A correspondence is counted as a DEFINITE outlier iff |C_mfma| > tb, tb = (T + KAPPA M)(1 + 1e-6), T = sqrt(thr Dmax) as
-// in filter_setup; NaN never compares greater, so broken models keep every correspondence (count = N, nothing pruned).
+// A correspondence is a CANDIDATE iff |C_mfma| <= tb, tb = (T + KAPPA M)(1 + 1e-6), T = sqrt(thr Dmax) as in filter_setup.
+// The kernel tests the sign of tb^2 - C^2 with ONE packed FMA whose clamp modifier turns it into 0 / 1 directly: the model's
+// coefficients are pre-scaled by S = 2^k (exact in bf16) so that tb S lies in [2^20, 2^21); then (tb S)^2 - (C S)^2 is either
+// <= 0 (definite outlier -> 0) or >= one fp32 ulp at 2^40, far above 1 (candidate -> 1), and the sum of the clamped values is
+// the candidate count.  M S <= 2^21 / KAPPA < 2^36, so nothing overflows; models the filter cannot judge (non-finite, or
+// beyond the fp32 range) get zero coefficients and tb^2 = 1: every correspondence stays a candidate.
 constexpr double COUNT_KAPPA = 6e-5;
 
 MDRP_HD uint16_t bf16_bits(float x) { // round to nearest even; NaN stays NaN
@@ -720,6 +724,80 @@ MDRP_HD void count_setup(const double E[9], const double box[4], double thr, uin
     tb = (M < 1e30) ? (float)((T + COUNT_KAPPA * M) * (1.0 + 1e-6)) + 1e-30f : __builtin_inff(); // !(M < 1e30) also catches NaN
     for (int j = 0; j < 8; ++j) bf16_split(E[j], eh[j], el[j]);
     bf16_split3(E[8], e8[0], e8[1], e8[2]);
+}
+
+// the same with the power-of-two scale of the clamp test folded in: coefficients of S E, tb2 = (tb S)^2 rounded up
+MDRP_HD void count_setup_scaled(const double E[9], const double box[4], double thr, uint16_t eh[8], uint16_t el[8], uint16_t e8[3], float &tb2) {
+    float tb;
+    count_setup(E, box, thr, eh, el, e8, tb);
+    if (!(tb < 1e30f) || !(tb > 0.0f)) { // not judgeable: C = 0 against tb^2 = 1 keeps everything
+        for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
+        e8[0] = e8[1] = e8[2] = 0;
+        tb2 = 1.0f;
+        return;
+    }
+    int ex;
+    (void)frexpf(tb, &ex);            // tb = m 2^ex, m in [0.5, 1)
+    const int k = 21 - ex;            // tb 2^k in [2^20, 2^21)
+    const double S = ldexp(1.0, k);
+    for (int j = 0; j < 8; ++j) bf16_split(E[j] * S, eh[j], el[j]);
+    bf16_split3(E[8] * S, e8[0], e8[1], e8[2]);
+    const float tbs = ldexpf(tb, k);
+    tb2 = (tbs * tbs) * (1.0f + 2e-7f);
+}
+
+// ---------------------------------------------------------------- fp32 LOWER bound of the MSAC score (k_bound)
+// compute_sampson_msac_score adds min(r^2, thr) per correspondence (cheirality failures add thr >= r^2), r^2 = C^2 / den.
+// In fp32, with E and the coordinates rounded once (u = 2^-24) and the bounds of the pair's coordinate box:
+//     |C32 - C|     <= 7u M            (8 FMAs, depth 7; M as in filter_setup)                 -> eC = 2e-6 M      (5x margin)
+//     |den32 - den| <= 14u Dmax        (|e32 - e| <= 5u e_bar per linear form, squares, 4 adds) -> eD = 4e-6 Dmax   (5x margin)
+// so  r^2 >= max(|C32| - eC, 0)^2 / (den32 + eD)  =: q, and the sum over the correspondences of min(q, thr_down) is a lower
+// bound of the exact score up to the fp32 roundings of q itself (<= 8u relative per term) and of the summation (partial
+// sums of 64 terms in fp32, flushed to fp64: <= 64u relative); BOUND_SLACK covers both with a 4x margin.
+// A hypothesis whose lower bound is no better than a record score — and whose candidate count (k_count) is no better than
+// the record count — cannot break a record, whatever its exact score is.  Models outside the fp32 range (setup returns
+// false) are never judged by the bound; a NaN / inf correspondence yields a NaN quotient, which adds thr like the reference's
+// `r2 < thr` test does.
+constexpr double BOUND_SLACK = 2e-5;
+
+MDRP_HD bool bound_setup32(const double E[9], const double box[4], double thr, float Ef[9], float &eC, float &eD, float &thr_dn) {
+    const double ax = box[0], ay = box[1], cx = box[2], cy = box[3];
+    const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
+    const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
+    const double dmax = e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1;
+    const double e2 = fabs(E[6]) * ax + fabs(E[7]) * ay + fabs(E[8]);
+    const double M = e0 * cx + e1 * cy + e2;
+    const bool sane = (M < 1e15) && (dmax < 1e30) && (dmax > 1e-30); // fp32 range: squares must neither overflow nor vanish
+    eC = sane ? (float)(2e-6 * M * (1.0 + 1e-6)) + 1e-30f : 0.0f;
+    eD = sane ? (float)(4e-6 * dmax * (1.0 + 1e-6)) + 1e-37f : 1.0f;
+    float t = (float)thr;
+    if ((double)t > thr && t > 0.0f) { // next float towards zero
+        uint32_t bits;
+        __builtin_memcpy(&bits, &t, 4);
+        --bits;
+        __builtin_memcpy(&t, &bits, 4);
+    }
+    thr_dn = t;
+    for (int i = 0; i < 9; ++i) Ef[i] = (float)E[i];
+    return sane;
+}
+
+// lower bound q of r^2 for one correspondence, everything fp32 (the MSAC term is min(q, thr_dn); NaN for a NaN / inf
+// correspondence, which the callers turn into thr as the reference's `r2 < thr` test does)
+MDRP_HD float bound_r2_32(const float Ef[9], float eC, float eD, float a, float b, float c, float d) {
+    const float e0 = fmaf(Ef[0], a, fmaf(Ef[1], b, Ef[2]));
+    const float e1 = fmaf(Ef[3], a, fmaf(Ef[4], b, Ef[5]));
+    const float e2 = fmaf(Ef[6], a, fmaf(Ef[7], b, Ef[8]));
+    const float g0 = fmaf(Ef[0], c, fmaf(Ef[3], d, Ef[6]));
+    const float g1 = fmaf(Ef[1], c, fmaf(Ef[4], d, Ef[7]));
+    const float C = fmaf(c, e0, fmaf(d, e1, e2));
+    const float den = fmaf(e0, e0, fmaf(e1, e1, fmaf(g0, g0, fmaf(g1, g1, eD))));
+    const float t = fmaxf(fabsf(C) - eC, 0.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (t * t) * __builtin_amdgcn_rcpf(den); // v_rcp_f32: 1 ulp, inside the 8u budget of BOUND_SLACK (an IEEE division is ~10 instructions)
+#else
+    return (t * t) / den;
+#endif
 }
 
 // ---------------------------------------------------------------- refinement: per-correspondence residuals
