@@ -785,8 +785,24 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const int m0 = blk * CNT_WG_MODELS + wave * CNT_WAVE_MODELS; // first hypothesis of this wavefront in the pair's tag list
     const size_t slot_base = (size_t)pair * rp.slot_stride;
     const double thr = ps.sq_thr;
-    // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS)
+    // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS); the loads of both rounds
+    // are issued before the arithmetic of the first (tag -> model is a dependent pair of L2 round trips)
     uint32_t slot_r[2] = {0, 0};
+    double mq[2][4], mt[2][3], mf[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = m0 + 64 * r + lane;
+        if (i < cnt) slot_r[r] = tags[slot_base + i] & 0xFFFFFFu;
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const Model *mp = models + slot_base + slot_r[r]; // slot 0 of the pair for idle lanes: a valid address
+        const double2 *P = reinterpret_cast<const double2 *>(mp);
+        const double2 q01 = P[0], q23 = P[1], t01 = P[2], t2s = P[3], f12 = P[5];
+        mq[r][0] = q01.x; mq[r][1] = q01.y; mq[r][2] = q23.x; mq[r][3] = q23.y;
+        mt[r][0] = t01.x; mt[r][1] = t01.y; mt[r][2] = t2s.x;
+        mf[r][0] = f12.x; mf[r][1] = f12.y;
+    }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = m0 + 64 * r + lane;
@@ -796,16 +812,13 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
         for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
         e8[0] = e8[1] = e8[2] = 0;
         if (i < cnt) {
-            const uint32_t slot = tags[slot_base + i] & 0xFFFFFFu;
-            slot_r[r] = slot;
-            const Model m = models[slot_base + slot];
             double R[9], Em[9], E[9];
-            quat_to_R(m.q, R);
-            essential_from_Rt(R, m.t, Em);
+            quat_to_R(mq[r], R);
+            essential_from_Rt(R, mt[r], Em);
             if (POSE) {
 #pragma unroll
                 for (int q = 0; q < 9; ++q) E[q] = Em[q];
-            } else fundamental_from_E(Em, m.f1, m.f2, E);
+            } else fundamental_from_E(Em, mf[r][0], mf[r][1], E);
             count_setup_scaled(E, ps.box, thr, eh, el, e8, tb);
         }
         uint4 *dst = s_frag[wave][64 * r + lane];

@@ -726,22 +726,36 @@ MDRP_HD void count_setup(const double E[9], const double box[4], double thr, uin
     bf16_split3(E[8], e8[0], e8[1], e8[2]);
 }
 
-// the same with the power-of-two scale of the clamp test folded in: coefficients of S E, tb2 = (tb S)^2 rounded up
+// the same with the power-of-two scale of the clamp test folded in: coefficients of S E, tb2 = (tb S)^2 rounded up.
+// This is k_count's per-hypothesis prologue, so it is kept cheap: the bounds M and Dmax in fp64 (they decide correctness),
+// the threshold and the splits in fp32 — S E is rounded to fp32 once (2^-24 relative, a 250th of the 2^-18 split remainder
+// that KAPPA already carries with a 4x margin) and split exactly from there; the fp32 roundings of tb (sqrt, add, two
+// products: <= 5 * 2^-24) are covered by its (1 + 1e-6) factor.
+MDRP_HD void bf16_split_f32(float x, uint16_t &h, uint16_t &l) {
+    h = bf16_bits(x);
+    l = bf16_bits(x - bf16_value(h)); // exact difference
+}
 MDRP_HD void count_setup_scaled(const double E[9], const double box[4], double thr, uint16_t eh[8], uint16_t el[8], uint16_t e8[3], float &tb2) {
-    float tb;
-    count_setup(E, box, thr, eh, el, e8, tb);
-    if (!(tb < 1e30f) || !(tb > 0.0f)) { // not judgeable: C = 0 against tb^2 = 1 keeps everything
-        for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
-        e8[0] = e8[1] = e8[2] = 0;
-        tb2 = 1.0f;
-        return;
-    }
+    const double ax = box[0], ay = box[1], cx = box[2], cy = box[3];
+    const double e0 = fabs(E[0]) * ax + fabs(E[1]) * ay + fabs(E[2]), e1 = fabs(E[3]) * ax + fabs(E[4]) * ay + fabs(E[5]);
+    const double g0 = fabs(E[0]) * cx + fabs(E[3]) * cy + fabs(E[6]), g1 = fabs(E[1]) * cx + fabs(E[4]) * cy + fabs(E[7]);
+    const double dmax = (1.0 + 1e-9) * (e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1);
+    const double e2 = fabs(E[6]) * ax + fabs(E[7]) * ay + fabs(E[8]);
+    const double M = e0 * cx + e1 * cy + e2;
+    const float td = (float)(thr * (1.0 + 1e-12) * dmax), km = (float)(COUNT_KAPPA * M);
+    const float tb = (sqrtf(td) + km) * (1.0f + 1e-6f) + 1e-30f;
+    for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
+    e8[0] = e8[1] = e8[2] = 0;
+    tb2 = 1.0f;
+    if (!(M < 1e30) || !(tb < 1e30f) || !(tb > 0.0f)) return; // not judgeable: C = 0 against tb^2 = 1 keeps everything
     int ex;
     (void)frexpf(tb, &ex);            // tb = m 2^ex, m in [0.5, 1)
     const int k = 21 - ex;            // tb 2^k in [2^20, 2^21)
     const double S = ldexp(1.0, k);
-    for (int j = 0; j < 8; ++j) bf16_split(E[j] * S, eh[j], el[j]);
-    bf16_split3(E[8] * S, e8[0], e8[1], e8[2]);
+    for (int j = 0; j < 8; ++j) bf16_split_f32((float)(E[j] * S), eh[j], el[j]);
+    const float c8 = (float)(E[8] * S);
+    bf16_split_f32(c8, e8[0], e8[1]);
+    e8[2] = bf16_bits((c8 - bf16_value(e8[0])) - bf16_value(e8[1]));
     const float tbs = ldexpf(tb, k);
     tb2 = (tbs * tbs) * (1.0f + 2e-7f);
 }

@@ -94,3 +94,90 @@ extern "C" long hm_filter_check(const double *E, const double *x1, const double 
     *kept = k; *exact = ex;
     return missed;
 }
+
+// ---- k_count's filter, emulated: bf16 operands, exact products, fp32 accumulation in slot order, the clamp test.
+// Returns the number of correspondences the EXACT fp64 test accepts but the filter calls definite outliers (must be 0);
+// *kept = candidates of the filter, *exact = correspondences the exact test accepts.  order = 0: slots ascending,
+// 1: descending, 2: pairwise tree — the hardware's accumulation order is not documented, the bound must hold for any.
+extern "C" long hm_count_check(const double *E, const double *x1, const double *x2, long n, double thr, int order, long *kept, long *exact) {
+    double box[4] = {0, 0, 0, 0};
+    for (long i = 0; i < n; ++i) {
+        box[0] = fmax(box[0], fabs(x1[2 * i])); box[1] = fmax(box[1], fabs(x1[2 * i + 1]));
+        box[2] = fmax(box[2], fabs(x2[2 * i])); box[3] = fmax(box[3], fabs(x2[2 * i + 1]));
+    }
+    uint16_t eh[8], el[8], e8[3];
+    float tb2;
+    count_setup_scaled(E, box, thr, eh, el, e8, tb2);
+    long missed = 0, k = 0, ex = 0;
+    for (long i = 0; i < n; ++i) {
+        const double a = x1[2 * i], b = x1[2 * i + 1], c = x2[2 * i], d = x2[2 * i + 1];
+        double m[8];
+        count_monomials(a, b, c, d, m);
+        float prod[27];
+        for (int j = 0; j < 8; ++j) {
+            uint16_t mh, ml;
+            bf16_split(m[j], mh, ml);
+            prod[j] = bf16_value(eh[j]) * bf16_value(mh);       // exact in fp32 (8 x 8 significand bits)
+            prod[8 + j] = bf16_value(eh[j]) * bf16_value(ml);
+            prod[16 + j] = bf16_value(el[j]) * bf16_value(mh);
+        }
+        prod[24] = bf16_value(e8[0]); prod[25] = bf16_value(e8[1]); prod[26] = bf16_value(e8[2]);
+        float Cs = 0.f;
+        if (order == 0) for (int j = 0; j < 27; ++j) Cs += prod[j];
+        else if (order == 1) for (int j = 26; j >= 0; --j) Cs += prod[j];
+        else {
+            float t[32];
+            for (int j = 0; j < 32; ++j) t[j] = j < 27 ? prod[j] : 0.f;
+            for (int w = 16; w >= 1; w >>= 1) for (int j = 0; j < w; ++j) t[j] += t[j + w];
+            Cs = t[0];
+        }
+        const float dd = fmaf(-Cs, Cs, tb2);
+        const bool keep = dd > 0.f; // clamp(dd) is 1 for every positive dd here (dd is either <= 0 or >= 2^17)
+        if (dd > 0.f && dd < 1.f) return -1; // the scale must leave nothing between 0 and 1
+        const long double e0 = (long double)E[0] * a + (long double)E[1] * b + E[2], e1 = (long double)E[3] * a + (long double)E[4] * b + E[5],
+                          e2 = (long double)E[6] * a + (long double)E[7] * b + E[8];
+        const long double g0 = (long double)E[0] * c + (long double)E[3] * d + E[6], g1 = (long double)E[1] * c + (long double)E[4] * d + E[7];
+        const long double Cv = c * e0 + d * e1 + e2, den = e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1;
+        const bool inl = Cv * Cv < (long double)thr * (1.0L + 1e-12L) * den;
+        k += keep; ex += inl;
+        if (inl && !keep) ++missed;
+    }
+    *kept = k; *exact = ex;
+    return missed;
+}
+
+// ---- k_bound's lower bound: sum over the correspondences of min(q, thr_dn), times (1 - BOUND_SLACK), against the exact
+// MSAC score without cheirality (sum of min(r^2, thr)) in long double.  Returns 1 if lower bound <= exact (or the model is
+// not judged), 0 otherwise; *lb, *exact_score out; *cnt_ub = correspondences with q below the (inflated) threshold.
+extern "C" int hm_bound_check(const double *E, const double *x1, const double *x2, long n, double thr, double *lb, double *exact_score, long *cnt_ub, long *cnt_exact) {
+    double box[4] = {0, 0, 0, 0};
+    for (long i = 0; i < n; ++i) {
+        box[0] = fmax(box[0], fabs(x1[2 * i])); box[1] = fmax(box[1], fabs(x1[2 * i + 1]));
+        box[2] = fmax(box[2], fabs(x2[2 * i])); box[3] = fmax(box[3], fabs(x2[2 * i + 1]));
+    }
+    float Ef[9], eC, eD, thr_dn;
+    const bool sane = bound_setup32(E, box, thr, Ef, eC, eD, thr_dn);
+    const float thr_cnt = (float)(thr * (1.0 + 1e-5)) * (1.0f + 1e-6f);
+    double total = 0;
+    long double exact = 0;
+    long cu = 0, ce = 0;
+    for (long j0 = 0; j0 < n; j0 += 64) {
+        float part = 0.f;
+        for (long i = j0; i < n && i < j0 + 64; ++i) {
+            const double a = x1[2 * i], b = x1[2 * i + 1], c = x2[2 * i], d = x2[2 * i + 1];
+            const float q = bound_r2_32(Ef, eC, eD, (float)a, (float)b, (float)c, (float)d);
+            part += q < thr_dn ? q : thr_dn;
+            cu += q < thr_cnt;
+            const long double e0 = (long double)E[0] * a + (long double)E[1] * b + E[2], e1 = (long double)E[3] * a + (long double)E[4] * b + E[5],
+                              e2 = (long double)E[6] * a + (long double)E[7] * b + E[8];
+            const long double g0 = (long double)E[0] * c + (long double)E[3] * d + E[6], g1 = (long double)E[1] * c + (long double)E[4] * d + E[7];
+            const long double Cv = c * e0 + d * e1 + e2, den = e0 * e0 + e1 * e1 + g0 * g0 + g1 * g1;
+            const long double r2 = Cv * Cv / den;
+            if (r2 < (long double)thr) { exact += r2; ++ce; } else exact += thr;
+        }
+        total += (double)part;
+    }
+    *lb = total * (1.0 - BOUND_SLACK); *exact_score = (double)exact; *cnt_ub = cu; *cnt_exact = ce;
+    if (!sane) return 1;
+    return (*lb <= (double)exact) && (cu >= ce);
+}

@@ -176,3 +176,74 @@ def test_fp32_prefilter_is_conservative(hm):
         kept, exact = C.c_long(), C.c_long()
         assert hm.hm_filter_check(P(np.ascontiguousarray(E)), P(x1), P(x2), C.c_long(64), C.c_double(1e-5), C.byref(kept), C.byref(exact)) == 0
         assert kept.value == 64
+
+
+def _planted(rng, E, n, thr, scale):
+    """correspondences with half of them moved onto (or within a few thresholds of) their epipolar lines"""
+    x1 = rng.uniform(-1, 1, (n, 2)) * np.array([0.8, 0.6]) * scale
+    x2 = rng.uniform(-1, 1, (n, 2)) * np.array([0.8, 0.6]) * scale
+    Em = E.reshape(3, 3)
+    l = (Em @ np.c_[x1, np.ones(n)].T).T
+    nl = np.hypot(l[:, 0], l[:, 1]) + 1e-300
+    dist = (l[:, 0] * x2[:, 0] + l[:, 1] * x2[:, 1] + l[:, 2]) / nl
+    k = n // 2
+    off = rng.uniform(-3, 3, k) * np.sqrt(thr)
+    x2[:k, 0] -= (dist[:k] - off) * l[:k, 0] / nl[:k]
+    x2[:k, 1] -= (dist[:k] - off) * l[:k, 1] / nl[:k]
+    return np.ascontiguousarray(x1), np.ascontiguousarray(x2)
+
+
+def test_mfma_count_filter_is_conservative(hm):
+    """mdrp_math.h count_setup_scaled + the arithmetic of k_count (bf16-split contraction, fp32 accumulation in three
+    different orders, clamp test), emulated on the host: every correspondence the exact fp64 test accepts stays a
+    candidate; the scale leaves no value between 0 and 1; and the filter stays selective (candidates < 3 x the exact
+    inliers + 15 % of the outliers on these planted sets)."""
+    hm.hm_count_check.restype = C.c_long
+    rng = np.random.default_rng(21)
+    n = 3000
+    tot_kept = tot_exact = 0
+    for trial in range(240):
+        kind = trial % 2
+        E = _rand_E(rng, kind)
+        scale = 10.0 ** rng.uniform(-3, 3) if trial % 3 == 0 else 1.0
+        thr = 10.0 ** rng.uniform(-8, -2) * scale * scale
+        x1, x2 = _planted(rng, E, n, thr, scale)
+        if trial % 7 == 0:
+            x1[-8:] = np.abs(x1).max(0) * np.array([[1, 1], [1, -1], [-1, 1], [-1, -1]] * 2)
+        for order in (0, 1, 2):
+            kept, exact = C.c_long(), C.c_long()
+            missed = hm.hm_count_check(P(E), P(x1), P(x2), C.c_long(n), C.c_double(thr), C.c_int(order), C.byref(kept), C.byref(exact))
+            assert missed == 0, (trial, kind, scale, thr, order)
+            assert kept.value >= exact.value
+        tot_kept += kept.value; tot_exact += exact.value
+    assert tot_exact > 10000
+    x1 = rng.uniform(-1, 1, (64, 2)); x2 = rng.uniform(-1, 1, (64, 2))
+    for E in (np.zeros(9), np.full(9, np.nan), _rand_E(rng, 0) * 1e35, _rand_E(rng, 0) * 1e-35):
+        kept, exact = C.c_long(), C.c_long()
+        assert hm.hm_count_check(P(np.ascontiguousarray(E)), P(x1), P(x2), C.c_long(64), C.c_double(1e-5), C.c_int(0), C.byref(kept), C.byref(exact)) == 0
+        assert kept.value == 64
+
+
+def test_fp32_score_lower_bound_is_a_lower_bound(hm):
+    """mdrp_math.h bound_setup32 / bound_r2_32 (k_bound): the fp32 sum of min(q, thr) times (1 - BOUND_SLACK) never
+    exceeds the exact MSAC score (cheirality aside), its inlier count never undercounts, and it is tight (within 5 % of the
+    exact score on these sets) — otherwise it would retire nothing."""
+    rng = np.random.default_rng(22)
+    n = 3000
+    ratios = []
+    for trial in range(240):
+        kind = trial % 2
+        E = _rand_E(rng, kind)
+        scale = 10.0 ** rng.uniform(-2, 2) if trial % 3 == 0 else 1.0
+        thr = 10.0 ** rng.uniform(-7, -3) * scale * scale
+        x1, x2 = _planted(rng, E, n, thr, scale)
+        lb, ex = C.c_double(), C.c_double()
+        cu, ce = C.c_long(), C.c_long()
+        ok = hm.hm_bound_check(P(E), P(x1), P(x2), C.c_long(n), C.c_double(thr), C.byref(lb), C.byref(ex), C.byref(cu), C.byref(ce))
+        assert ok == 1, (trial, kind, scale, thr, lb.value, ex.value, cu.value, ce.value)
+        ratios.append(lb.value / ex.value)
+    assert min(ratios) > 0.5 and np.median(ratios) > 0.95, (min(ratios), np.median(ratios))
+    for E in (np.full(9, np.nan), _rand_E(rng, 0) * 1e35):
+        lb, ex = C.c_double(), C.c_double()
+        cu, ce = C.c_long(), C.c_long()
+        assert hm.hm_bound_check(P(np.ascontiguousarray(E)), P(x1), P(x2), C.c_long(n), C.c_double(1e-5), C.byref(lb), C.byref(ex), C.byref(cu), C.byref(ce)) == 1
