@@ -5,10 +5,12 @@ A step = one pass of estimate_monodepth_relative_pose over one batch of syntheti
 HBM: calibrated 3-point solver (P3P path, shift off), 2000 correspondences per pair, max_iterations = min_iterations
 = 10000 (BASELINE.json configs[1]; /root/reference/make_video.py:192-194), 50 % outliers, 0.5 px / 2 % noise,
 1024 pairs per GPU.  Pairs shard across ranks with no data-path collective (weak scaling); for N > 1 the step ends
-with one RCCL all_gather of the fixed-size result records.
+with one device-side RCCL all_gather of the fixed-size result records.  --total-pairs P switches to BASELINE.json
+configs[4]: P pairs in total, ceil(P/N) contiguous pairs per rank, each rank generating only its own block (strong scaling).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+    python -m torch.distributed.run ... bench.py --gpus 8 --total-pairs 100000
 """
 import argparse
 import json
@@ -34,8 +36,6 @@ WORKLOADS = {
     "calib_p3p_n2000_i10k_clean": (0, 2000, 10000, 0.0, False, None),
     "calib_shift_n2000_i10k_clean": (0, 2000, 10000, 0.0, True, None),
 }
-FP64_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md: fp64 vector peak
-FLOPS_PER_EVAL = 35.0      # fp64 flops of one Sampson evaluation (cheirality of inliers not counted)
 
 
 def make_inputs(workload, first_index, batch):
@@ -98,21 +98,28 @@ def cpu_baseline(workload, pairs):
     return out
 
 
-def pmc_traffic(workload, batch):
-    """HBM bytes per k_score launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, per the gfx950
-    correction in MI355X_MICROARCH.md) when they were taken on this workload and batch; else None."""
+def pmc_profile(workload, batch, kernel):
+    """Per-launch PMC numbers of `kernel` from the committed rocprofv3 passes of this round (profiles/r*_pmc_*.json, written
+    by tools/pmc_json.py on the GPU box): HBM bytes (FETCH_SIZE x2 + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md) and the SQ issue counters, when they were taken on this workload and batch; else {}."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm.json"))):
+    out = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("workload") == workload and d.get("pairs_per_gpu") == batch:
-            for k, v in d.get("kernels", {}).items():
-                if "k_score" in k:
-                    best = (v["hbm_bytes_corrected"], os.path.basename(f))
-    return best
+        if d.get("workload") != workload or d.get("pairs_per_gpu") != batch:
+            continue
+        for k, v in d.get("kernels", {}).items():
+            if k.split("<")[0] == "mdrp::" + kernel:
+                out.update(v)
+                out["source"] = os.path.basename(f)
+    return out
+
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s; 512 MAC per cycle and SIMD)
+FLOP_PER_MFMA_EVAL = 64.0       # one (model x correspondence) evaluation in k_count = 32 bf16 MACs of the K = 32 contraction
 
 
 def main():
@@ -120,9 +127,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="image pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="image pairs per GPU per step (weak scaling)")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="BASELINE configs[4]: this many pairs in total, ceil(P/G) contiguous pairs per rank (strong scaling); "
+                         "e.g. --total-pairs 100000 --gpus 8, or --total-pairs 12500 --gpus 1 for one rank's share")
     ap.add_argument("--workload", default="calib_p3p_n2000_i10k", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--host-steps", type=int, default=2, help="extra steps through the host-buffer (PCIe-inclusive) entry point, N = 1 only (0 = skip)")
     args = ap.parse_args()
 
     cpu_line = None
@@ -132,6 +143,7 @@ def main():
     import torch
     import torch.distributed as dist
     from mdrp_amd import _capi
+    from mdrp_amd import dist as mdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,26 +162,37 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     kind, n, iters, of, es, rf = WORKLOADS[args.workload]
-    B = args.batch
-    b = make_inputs(args.workload, rank * B, B)
+    strong = args.total_pairs > 0
+    if strong:  # contiguous block of ceil(P/G) pairs per rank, generated by the rank that owns it (never replicated)
+        total = args.total_pairs
+        lo, hi, per = mdist.shard_bounds(total, rank, world)
+    else:
+        total = args.batch * world
+        lo, hi, per = rank * args.batch, (rank + 1) * args.batch, args.batch
+    B = hi - lo
+    b = make_inputs(args.workload, lo, max(B, 1))
     x1 = torch.from_numpy(b["x1"]).to(dev); x2 = torch.from_numpy(b["x2"]).to(dev)
     d1 = torch.from_numpy(b["d1"]).to(dev); d2 = torch.from_numpy(b["d2"]).to(dev)
-    mask = torch.zeros((B, n), dtype=torch.uint8, device=dev)
-    cams = np.zeros(B, dtype=_capi.CAMERA_DTYPE)
+    mask = torch.zeros((max(B, 1), n), dtype=torch.uint8, device=dev)
+    cams = np.zeros(max(B, 1), dtype=_capi.CAMERA_DTYPE)
     cams["params"][:, 0] = 800.0
     ro = _capi.ransac_opt_from_dict({"max_iterations": iters, "min_iterations": iters, "max_epipolar_error": 2.0,
                                      "max_reproj_error": 16.0, "monodepth_estimate_shift": es})
     bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
-    h = _capi.Handle(local_rank)  # its own stream; the sweep is timed with HIP events recorded on that stream
-    from mdrp_amd import dist as mdist
+    h = _capi.Handle(local_rank)  # its own stream; k_count / k_score are timed with HIP events recorded on that stream
+    rec_local = torch.zeros((per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev)  # this rank's block of the gather
+    rec_all = torch.empty((world * per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def step():
-        h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, n, ro, bo, None,
-                                cams if kind == 0 else None, cams if kind == 0 else None, mask.data_ptr())
-        res = h.fetch_results(B)
-        if world > 1:  # final gather of the pose records over RCCL/xGMI: 136 B per pair
-            mdist.gather_results(res, B * world, None, dev)
-        return res
+        if B > 0:
+            h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, n, ro, bo, None,
+                                    cams if kind == 0 else None, cams if kind == 0 else None, mask.data_ptr())
+        if world > 1:  # final gather of the pose records over RCCL/xGMI, device to device: 136 B per pair
+            if B > 0:
+                h.copy_results_device(rec_local.data_ptr(), B)
+            dist.all_gather_into_tensor(rec_all, rec_local)
+            return None
+        return h.fetch_results(B)
 
     def barrier():
         if world > 1:
@@ -178,56 +201,81 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    sweep_ms = 0.0
-    sweep_launches = 0
-    sweep_evals = 0
+    acc = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-        ms, ln, ev = h.last_sweep_stats()
-        sweep_ms += ms; sweep_launches += ln; sweep_evals += ev
+        if B > 0:
+            for k, v in h.last_stats().items():
+                acc[k] = acc.get(k, 0) + v
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        res = h.fetch_results(B) if B > 0 else np.zeros(0, dtype=_capi.RESULT_DTYPE)
+        gathered = mdist._unpad(rec_all.cpu().numpy(), total, world, per)
+        assert gathered.shape[0] == total
+
+    host_rate = None
+    if world == 1 and args.host_steps > 0 and B > 0:  # the same step through mdrp_estimate_batch with HOST buffers: H2D of the
+        xs = [b["x1"], b["x2"], b["d1"], b["d2"]]      # correspondences (48 B each) and D2H of records + masks inside the timed region
+        h.estimate_batch(kind, *xs, ro, bo, None, cams if kind == 0 else None, cams if kind == 0 else None)
+        th = time.perf_counter()
+        for _ in range(args.host_steps):
+            h.estimate_batch(kind, *xs, ro, bo, None, cams if kind == 0 else None, cams if kind == 0 else None)
+        host_rate = B * args.host_steps / (time.perf_counter() - th)
 
     if rank == 0:
-        pairs = B * world * args.steps
+        pairs = total * args.steps
         value = pairs / dt
-        # roofline of the dominant kernel (k_score): algorithmic bytes per launch / average launch duration
-        avg_launch_s = (sweep_ms / 1e3) / max(sweep_launches, 1)
-        bytes_per_launch = BYTES_PER_EVAL * sweep_evals / max(sweep_launches, 1)
-        achieved = bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        valu_tf = FLOPS_PER_EVAL * sweep_evals / max(sweep_launches, 1) / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         from mdrp_amd import synth
         from mdrp_amd.poselib import _quat_to_R
         R_err = float(np.median([synth.rotation_error_deg(g["R"], _quat_to_R(r["model"]["q"])) for r, g in zip(res[:64], b["gt"][:64])]))
-        traffic = pmc_traffic(args.workload, B)
-        phys = (traffic[0] / avg_launch_s / 1e9) if (traffic and avg_launch_s > 0) else None
+        # ---- roofline of the dominant scoring kernel, k_count: executed MFMA work / its own launch durations (HIP events)
+        cl = max(acc.get("count_launches", 0), 1)
+        count_s = acc.get("count_ms", 0.0) / 1e3
+        flop = FLOP_PER_MFMA_EVAL * acc.get("evals_mfma", 0)
+        achieved = flop / count_s / 1e12 if count_s > 0 else 0.0
+        prof = pmc_profile(args.workload, B, "k_count")
+        hbm = prof.get("hbm_bytes_corrected")
+        avg_launch_s = count_s / cl
         line = {
             "metric": "image-pairs/sec (2000 corrs, 10k RANSAC iters)", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": args.workload, "pairs_per_gpu": B, "correspondences": n, "ransac_iterations": iters,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "pairs_per_gpu": per, "total_pairs": total, "correspondences": n, "ransac_iterations": iters,
                        "outlier_fraction": of, "estimator": ["calibrated", "shared_focal", "varying_focal"][kind],
-                       "monodepth_estimate_shift": es, "parallelism": f"pairs sharded x{world}, all_gather of results"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (traffic or (None, None))[0], "traffic_unit": "bytes per launch (PMC)",
-                         "traffic_source": (traffic or (None, None))[1], "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "k_score", "evals_per_launch": sweep_evals / max(sweep_launches, 1),
-                         "avg_launch_ms": 1e3 * avg_launch_s, "sweep_share_of_step": (sweep_ms / 1e3) / dt,
-                         # physical HBM-side rate of the sweep: PMC bytes per launch / this run's launch duration
-                         "physical_GBs": phys, "physical_frac": (phys / HBM_PEAK_GBS) if phys else None},
-            # SURVEY.md §8(d) asks for both fractions: the physically binding limit of the sweep is VALU issue, not HBM
-            "roofline_valu": {"bound": "valu-fp64", "achieved": valu_tf, "frac": valu_tf / FP64_PEAK_TFLOPS,
-                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (algorithmic: 35 flop per evaluation the CPU loop would do)",
-                              "note": "the exact bail-out and the fp32 pre-filter skip work, so algorithmic flops are not executed flops"},
+                       "monodepth_estimate_shift": es,
+                       "parallelism": f"{'ceil(P/G) contiguous pairs per rank' if strong else 'fixed pairs per rank'} x{world}, device-side all_gather of the 136-B records"},
+            # bound: the matrix pipe.  achieved = 64 flop x the (model x correspondence) evaluations k_count EXECUTED (16 x 16 tiles,
+            # padding included, counted on the device) / the summed duration of its launches -> a fraction of the dense bf16
+            # MFMA peak that is <= 1 by construction.  traffic: HBM-side bytes of one launch (PMC), from profiles/.
+            "roofline": {"bound": "mfma", "kernel": "k_count (v_mfma_f32_16x16x32_bf16)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": hbm, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+                         "traffic_source": prof.get("source"), "avg_launch_ms": 1e3 * avg_launch_s, "launches_per_step": cl / args.steps,
+                         "executed_evals_per_step": acc.get("evals_mfma", 0) / args.steps,
+                         "share_of_step": count_s / dt,
+                         "hbm_GBs": (hbm / avg_launch_s / 1e9) if (hbm and avg_launch_s > 0) else None,
+                         "hbm_frac": (hbm / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (hbm and avg_launch_s > 0) else None,
+                         "valu_issue_frac_pmc": prof.get("valu_issue_frac"), "mfma_busy_frac_pmc": prof.get("mfma_busy_frac")},
+            # what the CPU loop would do vs what runs: SURVEY.md 8(d)'s 32 B per evaluation is an ALGORITHMIC figure (kept as an
+            # extra key: the correspondences stay in LDS / L2, HBM is not the bound), next to the evaluations actually executed
+            "work": {"evals_algorithmic_per_step": acc.get("evals_algorithmic", 0) / args.steps, "algorithmic_bytes_per_eval": BYTES_PER_EVAL,
+                     "algorithmic_GBs_whole_step": BYTES_PER_EVAL * acc.get("evals_algorithmic", 0) / dt / 1e9,
+                     "evals_mfma_count_per_step": acc.get("evals_mfma", 0) / args.steps,
+                     "evals_fp32_bound_per_step": acc.get("evals_bound", 0) / args.steps,
+                     "evals_fp64_sweep_per_step": acc.get("evals_fp64", 0) / args.steps,
+                     "k_count_ms_per_step": acc.get("count_ms", 0.0) / args.steps, "k_score_ms_per_step": acc.get("sweep_ms", 0.0) / args.steps},
             "quality": {"median_rotation_error_deg_first64": R_err,
-                        "mean_inlier_ratio": float(np.mean(res["num_inliers"] / n))},
+                        "mean_inlier_ratio": float(np.mean(res["num_inliers"] / n)) if len(res) else None},
         }
+        if host_rate is not None:
+            line["host_buffers"] = {"value": host_rate, "unit": "image-pairs/s", "ratio_to_resident": host_rate / value,
+                                    "note": "mdrp_estimate_batch with MDRP_MEM_HOST: pageable numpy buffers, H2D of 48 B per correspondence and D2H of "
+                                            "records + inlier masks inside the timed region (PCIe-inclusive; never `value`)"}
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
             line["speedup_vs_cpu_1thread"] = value / line["cpu_baseline"]["value"]

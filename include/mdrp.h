@@ -122,6 +122,9 @@ int mdrp_estimate_batch_async(mdrp_handle *h, int kind, const double *x1_dev, co
                               const mdrp_camera *cam1_host, const mdrp_camera *cam2_host, const mdrp_ransac_opt *ropt,
                               const mdrp_bundle_opt *bopt, uint8_t *inlier_mask_dev);
 int mdrp_fetch_results(mdrp_handle *h, mdrp_result *out_host, int batch);
+/* The same records into DEVICE memory (e.g. a torch tensor that goes straight into the RCCL all-gather of the poses,
+ * SURVEY.md 8e) — nothing crosses PCIe.  Returns after the handle's stream has drained. */
+int mdrp_copy_results_device(mdrp_handle *h, void *dst_dev, int batch);
 
 /* ---- unit-parity entry points (the reference exposes the same pieces: _core.pyi:614-619, 871-876, 914-919) ---- */
 /* Minimal solvers on `count` independent 3-point problems (host memory).  x1h,x2h: [count][3][3] homogeneous points

@@ -18,7 +18,7 @@ SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
     "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
-    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_refine_models",
+    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_copy_results_device", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_refine_models",
     "mdrp_last_sweep_stats", "mdrp_last_stats",
 )
 
@@ -90,6 +90,7 @@ def load_library():
         lib.mdrp_estimate_batch_async.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int, C.c_int, ip, vp, vp,
                                                   C.POINTER(RansacOpt), C.POINTER(BundleOpt), vp]
         lib.mdrp_fetch_results.argtypes = [vp, vp, C.c_int]
+        lib.mdrp_copy_results_device.argtypes = [vp, vp, C.c_int]
         lib.mdrp_solver_batch.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int, vp, vp]
         lib.mdrp_score_models.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp, vp]
         lib.mdrp_count_candidates.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp]
@@ -212,6 +213,10 @@ class Handle:
         out = np.zeros(batch, dtype=RESULT_DTYPE)
         _check(self._lib, self._lib.mdrp_fetch_results(self._h, _ptr(out), int(batch)))
         return out
+
+    def copy_results_device(self, dst_ptr, batch):
+        """the result records of the last device-resident estimate into device memory at dst_ptr (batch x 136 bytes)"""
+        _check(self._lib, self._lib.mdrp_copy_results_device(self._h, C.c_void_p(dst_ptr), int(batch)))
 
     def last_sweep_stats(self):
         ms, launches, evals = C.c_double(0), C.c_int64(0), C.c_int64(0)

@@ -628,6 +628,13 @@ static int fetch_results_locked(mdrp_handle *h, mdrp_result *out, int batch) {
     return finish_timing(h);
 }
 
+int mdrp_copy_results_device(mdrp_handle *h, void *dst_dev, int batch) {
+    if (!h || !dst_dev || batch < 0 || batch > h->last_batch) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    MDRP_ENTER(h);
+    HIPCHK(hipMemcpyAsync(dst_dev, h->results.p, sizeof(ResultDev) * batch, hipMemcpyDeviceToDevice, h->stream));
+    return finish_timing(h); // waits for the handle's stream: the records may be consumed on any other stream afterwards
+}
+
 int mdrp_fetch_results(mdrp_handle *h, mdrp_result *out, int batch) {
     if (!h) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     MDRP_ENTER(h);

@@ -1,14 +1,17 @@
-"""Pair-level data parallelism over the GPUs of one node.
+"""Pair-level data parallelism over the GPUs of one node (BASELINE.json configs[4]).
 
 Image pairs are independent units — the reference itself only ever parallelises over pairs (a process pool,
 /root/reference/eval.py:355-359; one SLURM job per scene, slurm_scripts/eval_mdrp_spawn_all.sh:78-80).  Each rank
-(one process per GPU, torch.distributed, backend "nccl" = RCCL over xGMI) takes a contiguous block of ceil(P/G) pairs;
-there is NO collective on the data path.  The only exchange is one all_gather of the fixed-size result records
-(136 B per pair; 100k pairs = 13.6 MB, far below a single xGMI link), optionally the N-byte inlier masks.
+(one process per GPU, torch.distributed, backend "nccl" = RCCL over xGMI) owns a contiguous block of ceil(P/G) pairs and
+holds ONLY that block; there is NO collective on the data path.  The only exchange is one all_gather_into_tensor of the
+fixed-size result records (136 B per pair; 100k pairs = 13.6 MB, far below a single xGMI link) — device to device when
+the records are on the GPU — and, on request, of the N-byte inlier masks.
 """
 import numpy as np
 
 from . import _capi
+
+RECORD_BYTES = _capi.RESULT_DTYPE.itemsize
 
 
 def shard_bounds(total, rank, world):
@@ -18,64 +21,86 @@ def shard_bounds(total, rank, world):
     return lo, min(lo + per, total), per
 
 
-def gather_results(local, total, group=None, device=None):
-    """all_gather of RESULT_DTYPE records; local covers this rank's shard (len <= per).  Returns all `total` records."""
+def _world(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _unpad(allbuf, total, world, per):
+    """(world * per, ...) gathered blocks -> the `total` real rows in pair order"""
+    parts = [allbuf[r * per: r * per + (shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0])] for r in range(world)]
+    return np.concatenate(parts) if parts else allbuf[:0]
+
+
+def gather_records(local, total, group=None, device=None):
+    """All `total` result records on every rank.  `local`: this rank's records, either a numpy RESULT_DTYPE array or a
+    (rows, 136) uint8 torch tensor already on the GPU (then the all-gather runs device to device).  Blocks are padded to
+    ceil(total / world) rows for the collective and trimmed afterwards."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    if world == 1:
-        return local[:total].copy()
-    _, _, per = shard_bounds(total, 0, world)
-    buf = np.zeros(per, dtype=_capi.RESULT_DTYPE)
-    buf[: len(local)] = local
-    mine = torch.from_numpy(buf.view(np.uint8).reshape(per, -1).copy())
-    if device is not None:
-        mine = mine.to(device)
-    out = torch.empty((world * per, mine.shape[1]), dtype=torch.uint8, device=mine.device)
-    dist.all_gather_into_tensor(out, mine, group=group)
-    allrec = out.cpu().numpy().reshape(world, per, -1)
-    parts = []
-    for r in range(world):
-        lo, hi, _ = shard_bounds(total, r, world)
-        parts.append(np.ascontiguousarray(allrec[r, : hi - lo]).view(_capi.RESULT_DTYPE).reshape(-1))
-    return np.concatenate(parts)
+    rank, world = _world(group)
+    per = (total + world - 1) // world
+    if isinstance(local, np.ndarray):
+        if world == 1:
+            return local[:total].copy()
+        mine = torch.zeros((per, RECORD_BYTES), dtype=torch.uint8)
+        if len(local):
+            mine[: len(local)] = torch.from_numpy(np.ascontiguousarray(local).view(np.uint8).reshape(len(local), RECORD_BYTES).copy())
+        if device is not None:
+            mine = mine.to(device)
+    else:
+        if world == 1:
+            return local[:total].cpu().numpy().reshape(-1).view(_capi.RESULT_DTYPE).copy()
+        mine = local
+        if mine.shape[0] != per:
+            padded = torch.zeros((per, RECORD_BYTES), dtype=torch.uint8, device=mine.device)
+            padded[: mine.shape[0]] = mine
+            mine = padded
+    out = torch.empty((world * per, RECORD_BYTES), dtype=torch.uint8, device=mine.device)
+    dist.all_gather_into_tensor(out, mine.contiguous(), group=group)
+    rows = _unpad(out.cpu().numpy(), total, world, per)
+    return np.ascontiguousarray(rows).reshape(-1).view(_capi.RESULT_DTYPE)
+
+
+gather_results = gather_records  # older name
 
 
 def gather_masks(local_mask, total, group=None, device=None):
-    """all_gather of the (pairs, N) uint8 inlier masks"""
+    """all_gather of the (pairs, N) uint8 inlier masks (numpy array or device tensor)"""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank, world = _world(group)
+    per = (total + world - 1) // world
+    is_np = isinstance(local_mask, np.ndarray)
     if world == 1:
-        return local_mask[:total].copy()
-    _, _, per = shard_bounds(total, 0, world)
+        return local_mask[:total].copy() if is_np else local_mask[:total].cpu().numpy()
     n = local_mask.shape[1]
-    buf = np.zeros((per, n), dtype=np.uint8)
-    buf[: len(local_mask)] = local_mask
-    mine = torch.from_numpy(buf)
-    if device is not None:
-        mine = mine.to(device)
+    mine = torch.zeros((per, n), dtype=torch.uint8, device=(device if is_np else local_mask.device) or "cpu")
+    if local_mask.shape[0]:
+        mine[: local_mask.shape[0]] = torch.from_numpy(np.ascontiguousarray(local_mask)).to(mine.device) if is_np else local_mask
     out = torch.empty((world * per, n), dtype=torch.uint8, device=mine.device)
     dist.all_gather_into_tensor(out, mine, group=group)
-    allm = out.cpu().numpy().reshape(world, per, n)
-    return np.concatenate([allm[r, : shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0]] for r in range(world)])
+    return _unpad(out.cpu().numpy(), total, world, per)
 
 
-def estimate_sharded(kind, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_per_pair=None, cam1=None, cam2=None, group=None,
-                     local_fn=None, want_mask=False):
-    """Every rank passes the SAME full arrays (or at least its own block filled in); each estimates its block and all ranks
-    receive all results.  local_fn(kind, x1, x2, d1, d2, ropt, bopt, n_per_pair, cam1, cam2) -> (results, mask) defaults to
-    the HIP handle of this rank's device; tests inject a CPU function to exercise the sharding/gather logic under gloo."""
+def estimate_local_shard(kind, total, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_per_pair=None, cam1=None, cam2=None,
+                         group=None, local_fn=None, want_mask=False):
+    """BASELINE.json configs[4]: `total` pairs over the ranks of `group`; THIS rank passes only its own block — the pairs
+    shard_bounds(total, rank, world) names, (rows, N, 2) / (rows, N) arrays plus optional per-pair counts and cameras —
+    estimates it on its GPU and receives all `total` records (and masks) back.
+    local_fn(kind, x1, x2, d1, d2, ropt, bopt, n_per_pair, cam1, cam2) -> (records, mask) defaults to this rank's HIP
+    handle; the CPU tests inject a function to exercise sharding and gather under gloo."""
     import torch
-    import torch.distributed as dist
 
-    initialized = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if initialized else 0
-    world = dist.get_world_size(group) if initialized else 1
-    total = len(d1)
-    lo, hi, _ = shard_bounds(total, rank, world)
+    rank, world = _world(group)
+    lo, hi, per = shard_bounds(total, rank, world)
+    rows = hi - lo
+    if len(d1) != rows:
+        raise ValueError(f"rank {rank} owns pairs [{lo}, {hi}) = {rows} rows, got {len(d1)}")
     ro = ransac_opt if isinstance(ransac_opt, _capi.RansacOpt) else _capi.ransac_opt_from_dict(ransac_opt)
     bo = bundle_opt if isinstance(bundle_opt, _capi.BundleOpt) else _capi.bundle_opt_from_dict(bundle_opt)
     device = None
@@ -87,13 +112,24 @@ def estimate_sharded(kind, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_p
         def local_fn(kind, a, b, c, d, ro, bo, npp, c1, c2):
             return handle.estimate_batch(kind, a, b, c, d, ro, bo, npp, c1, c2)
 
-    sl = slice(lo, hi)
-    if hi > lo:
-        res, mask = local_fn(kind, x1[sl], x2[sl], d1[sl], d2[sl], ro, bo, None if n_per_pair is None else n_per_pair[sl],
-                             None if cam1 is None else cam1[sl], None if cam2 is None else cam2[sl])
+    if rows > 0:
+        res, mask = local_fn(kind, x1, x2, d1, d2, ro, bo, n_per_pair, cam1, cam2)
     else:
-        res, mask = np.zeros(0, dtype=_capi.RESULT_DTYPE), np.zeros((0, d1.shape[1]), dtype=np.uint8)
-    all_res = gather_results(res, total, group, device)
+        res, mask = np.zeros(0, dtype=_capi.RESULT_DTYPE), np.zeros((0, np.shape(d1)[1] if np.ndim(d1) == 2 else 0), dtype=np.uint8)
+    all_res = gather_records(res, total, group, device)
     if want_mask:
         return all_res, gather_masks(mask, total, group, device)
     return all_res
+
+
+def estimate_sharded(kind, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_per_pair=None, cam1=None, cam2=None, group=None,
+                     local_fn=None, want_mask=False):
+    """Convenience for callers that hold the FULL arrays on every rank: slices this rank's block and calls
+    estimate_local_shard.  (Large data sets should never be replicated: build each rank's block only.)"""
+    rank, world = _world(group)
+    total = len(d1)
+    lo, hi, _ = shard_bounds(total, rank, world)
+    sl = slice(lo, hi)
+    return estimate_local_shard(kind, total, x1[sl], x2[sl], d1[sl], d2[sl], ransac_opt, bundle_opt,
+                                None if n_per_pair is None else n_per_pair[sl], None if cam1 is None else cam1[sl],
+                                None if cam2 is None else cam2[sl], group, local_fn, want_mask)

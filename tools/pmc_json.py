@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Merge the rocprofv3 --pmc passes of one workload into profiles/rNN_pmc_<workload>.json (read by bench.py).
+
+usage: pmc_json.py WORKLOAD PAIRS_PER_GPU STEPS_PROFILED pass1.csv [pass2.csv ...] > profiles/r02_pmc_WORKLOAD.json
+
+Per kernel, means per launch over the profiled steps:
+  hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE   (KiB -> bytes; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide
+                        coalesced reads, MI355X_MICROARCH.md "HBM"; WRITE_SIZE is exact)
+  valu_issue_frac     = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024)    SQ_ACTIVE_INST_* count quad-cycles summed over the
+                        1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GRBM / 8 = the kernel's cycles at the clock it ran at
+  mfma_busy_frac      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024)       (cycles)
+  cycles_per_valu     = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
+Both fractions are <= 1 by construction; numerator and denominator of each come from the SAME pass."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+workload, pairs, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+per_pass = []
+for path in sys.argv[4:]:
+    acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        a = acc[name][r["Counter_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    per_pass.append(acc)
+
+kernels = {}
+names = sorted({k for acc in per_pass for k in acc if k.startswith("mdrp::")})
+for name in names:
+    out = {}
+    for acc in per_pass:
+        c = acc.get(name)
+        if not c:
+            continue
+        launches = max(v[0] for v in c.values())
+        mean = {k: v[1] / v[0] for k, v in c.items()}
+        out["launches_per_step"] = launches / steps
+        for k, v in mean.items():
+            out[k] = v
+        if "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACTIVE"] > 0:
+            simd_cycles = mean["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+            if "SQ_ACTIVE_INST_VALU" in mean:
+                out["valu_issue_frac"] = 4.0 * mean["SQ_ACTIVE_INST_VALU"] / simd_cycles
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
+                out["mfma_busy_frac"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
+            if "SQ_WAVE_CYCLES" in mean:
+                out["mean_waves_per_simd"] = 4.0 * mean["SQ_WAVE_CYCLES"] / simd_cycles
+        if "SQ_INSTS_VALU" in mean and "SQ_ACTIVE_INST_VALU" in mean and mean["SQ_INSTS_VALU"] > 0:
+            out["cycles_per_valu"] = 4.0 * mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_INSTS_VALU"]
+    if "FETCH_SIZE" in out or "WRITE_SIZE" in out:
+        out["hbm_bytes_corrected"] = (2.0 * out.get("FETCH_SIZE", 0.0) + out.get("WRITE_SIZE", 0.0)) * 1024.0
+    kernels[name] = out
+json.dump({"command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 "
+                      "(one pass per counter set; tools/profile_round.sh)",
+           "workload": workload, "pairs_per_gpu": pairs, "unit": "mean per launch over the launches of the profiled steps",
+           "kernels": kernels}, sys.stdout, indent=1)
+print()
