@@ -58,6 +58,12 @@ typedef struct {
     uint64_t seed;              /* 0 */
     int32_t monodepth_estimate_shift; /* calibrated estimator only; ignored elsewhere exactly like the reference */
     float monodepth_weight_sampson;   /* 1.0 */
+    int32_t score_initial_model;      /* 0.  RansacOptions +0x49, set by the binding when an initial pose is passed with it.  What the
+                                       * reference then scores first is NOT the caller's pose: ransac_*_relpose reset it to the identity
+                                       * (black-box: any initial pose gives the same result).  The reset model has E = 0: no inliers,
+                                       * score N eps^2; its LO changes nothing.  Reproduced as that state: records start at
+                                       * (0, N eps^2) and `refinements` at 1 (tests/golden/initial.npz). */
+    int32_t reserved_;
 } mdrp_ransac_opt;
 
 /* BundleOptions (wheel METADATA:94-106) */

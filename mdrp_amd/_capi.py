@@ -31,7 +31,8 @@ class Model(C.Structure):
 class RansacOpt(C.Structure):
     _fields_ = [("max_iterations", C.c_uint64), ("min_iterations", C.c_uint64), ("dyn_num_trials_mult", C.c_double),
                 ("success_prob", C.c_double), ("max_reproj_error", C.c_double), ("max_epipolar_error", C.c_double),
-                ("seed", C.c_uint64), ("monodepth_estimate_shift", C.c_int32), ("monodepth_weight_sampson", C.c_float)]
+                ("seed", C.c_uint64), ("monodepth_estimate_shift", C.c_int32), ("monodepth_weight_sampson", C.c_float),
+                ("score_initial_model", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class BundleOpt(C.Structure):
@@ -119,7 +120,7 @@ def ransac_opt_from_dict(d=None):
                      float(d.get("dyn_num_trials_mult", 3.0)), float(d.get("success_prob", 0.9999)),
                      float(d.get("max_reproj_error", 12.0)), float(d.get("max_epipolar_error", 1.0)),
                      int(d.get("seed", 0)), int(bool(d.get("monodepth_estimate_shift", False))),
-                     float(d.get("monodepth_weight_sampson", 1.0)))
+                     float(d.get("monodepth_weight_sampson", 1.0)), int(bool(d.get("score_initial_model", False))), 0)
 
 
 LOSS_TYPES = {"TRIVIAL": 0, "TRUNCATED": 1, "HUBER": 2, "CAUCHY": 3, "TRUNCATED_CAUCHY": 4, "TRUNCATED_LE_ZACH": 5}

@@ -230,6 +230,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.solver = solver_for(kind, est_shift); rp.est_shift = est_shift;
+    rp.score_initial = ro->score_initial_model ? 1 : 0;
     rp.batch = batch; rp.n_max = n_max;
     rp.max_iterations = ro->max_iterations; rp.min_iterations = ro->min_iterations;
     rp.dyn_mult = ro->dyn_num_trials_mult; rp.log_prob_missing = std::log(1.0 - ro->success_prob);

@@ -96,6 +96,8 @@ struct RunParams {
     int kind;           // MDRP_CALIB / SHARED / VARYING
     int solver;         // SOLVER_*
     int est_shift;
+    int score_initial;  // RansacOptions::score_initial_model: the run starts from the state the reference is in after scoring (and
+                        // LO-refining, to no effect) its reset initial model: records (0 inliers, N eps^2), one refinement
     int batch, n_max;
     int chunk_len;      // iterations in this chunk (one solve/score/scan launch train)
     int chunk_off;      // offset of this chunk inside its super-chunk
@@ -264,6 +266,11 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
         s.iterations = 0; s.refinements = 0; s.num_inliers = 0;
         s.inlier_ratio = 0.0; s.model_score = DBL_MAX;
         model_identity(s.best);
+        if (rp.score_initial && n >= 3) { // the identity pose has E = 0: every r^2 is 0 / 0, nothing is an inlier
+            s.best_min_score = s.sq_thr * (double)n;
+            s.model_score = s.best_min_score;
+            s.refinements = 1;
+        }
         st[pair] = s;
     }
 }

@@ -17,6 +17,8 @@ import time
 
 import numpy as np
 
+from . import _capi
+
 # utils/data.py:22-46 — depth estimator id -> the two columns of corr_* holding (depth in image 1, depth in image 2)
 _DEPTH_COLUMNS = {1: (8, 9), 2: (10, 11), 3: (12, 13), 4: (14, 15), 5: (16, 17), 6: (18, 19), 7: (20, 21), 8: (22, 23),
                   9: (24, 25), 10: (26, 27), 11: (28, 29), 12: (30, 31)}
@@ -192,12 +194,11 @@ def focal_options(experiment, iters=None, threshold=1.0, reproj_threshold=16.0, 
           "solver_shift": "shift" in experiment, "solver_scale": "scale" in experiment, "use_reproj": "reproj" in experiment,
           "optimize_shift": "reproj-s" in experiment, "use_madpose_shift_optim": "noshift" not in experiment,
           "graduated_steps": 3 if "GLO" in experiment else 0}
-    if varying:
+    ro.update({"optimize_hybrid": "hybrid" in experiment, "sym_repro": "sym_reproj" in experiment, "no_normalization": "NN" in experiment})
+    if varying:  # eval_varying_f.py:134-136
         ro.update({"use_fundamental": "7p" in experiment, "use_4p4d": "4p4d" in experiment, "use_eigen": "eigen" in experiment})
-    else:
-        ro.update({"all_permutations": "perm" in experiment, "use_reldepth": "reldepth" in experiment,
-                   "optimize_hybrid": "hybrid" in experiment, "sym_repro": "sym_reproj" in experiment,
-                   "no_normalization": "NN" in experiment})
+    else:        # eval_shared_f.py:130-131
+        ro.update({"all_permutations": "perm" in experiment, "use_reldepth": "reldepth" in experiment})
     bo = {"max_iterations": 0 if lo_iterations == 0 else 100, "verbose": False}
     if "truncated" in experiment:
         bo["loss_type"] = "TRUNCATED"
@@ -250,7 +251,7 @@ def evaluate_focal(h5, experiments, shared=True, iters=None, threshold=1.0, repr
     for experiment in experiments:
         depth = int(experiment.split("+")[1]) if "+" in experiment else None
         ro, bo = focal_options(experiment, iters, threshold, reproj_threshold, varying=not shared)
-        ro = poselib._map_fork_options(ro)
+        ro = poselib._map_fork_options(ro, _capi.SHARED_FOCAL if shared else _capi.VARYING_FOCAL)
         loaded = [p for p in (load_pair_focal(h5, a, b, depth, shared) for a, b in pairs) if len(p["kp1"]) >= min_n]
         for s in range(0, len(loaded), batch):
             chunk = loaded[s:s + batch]

@@ -153,9 +153,27 @@ def _as_points(p):
     return p
 
 
-def _check_initial(initial, ransac_opt):
-    if initial is not None and (ransac_opt or {}).get("score_initial_model", False):
-        raise NotImplementedError("score_initial_model / initial pose is not on the accelerated path")
+def _with_initial(initial, ransac_opt):
+    """The reference binding sets RansacOptions::score_initial_model whenever an initial pose / image pair is passed
+    (_core.pyi:455; upstream pybind wrapper).  What the reference does with it, pinned in tests/golden/initial.npz from the
+    binary: the POSE handed in is never read — ransac_*_relpose reset it to the identity — and the reset model (no inliers,
+    score N eps^2) is scored and LO-refined first, to no effect except `refinements` + 1 and the records it sets."""
+    ro = dict(ransac_opt or {})
+    if initial is not None:
+        ro["score_initial_model"] = True
+    return ro
+
+
+def _initial_fallback(initial, geometry):
+    """When RANSAC adopts nothing the reference returns the caller's model with its pose reset: scale and shifts of the
+    initial geometry survive (cameras of an initial image pair do not: they come back as the normalisation focal)."""
+    if initial is None:
+        return geometry
+    g0 = getattr(initial, "geometry", initial)
+    p = geometry.pose
+    if tuple(p.q) == (1.0, 0.0, 0.0, 0.0) and not p.t.any() and geometry.scale == 1.0:
+        geometry.scale, geometry.shift1, geometry.shift2 = float(g0.scale), float(g0.shift1), float(g0.shift2)
+    return geometry
 
 
 # ------------------------------------------------------------------------------------------------ batch API
@@ -215,18 +233,17 @@ def estimate_monodepth_varying_focal_relative_pose_batch(points2D_1, points2D_2,
 def estimate_monodepth_relative_pose(points2D_1, points2D_2, depth_1, depth_2, camera1, camera2, ransac_opt={},
                                      bundle_opt={}, initial_pose=None):
     """Pose estimation using depth estimates with non-linear refinement (_core.pyi:446-475)."""
-    _check_initial(initial_pose, ransac_opt)
     g, i = estimate_monodepth_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], [depth_1], [depth_2],
-                                                  camera1, camera2, ransac_opt, bundle_opt)
-    return g[0], i[0]
+                                                  camera1, camera2, _with_initial(initial_pose, ransac_opt), bundle_opt)
+    return _initial_fallback(initial_pose, g[0]), i[0]
 
 
 def estimate_monodepth_shared_focal_relative_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt={}, bundle_opt={},
                                                   initial_image_pair=None):
     """Unknown equal focal lengths; points principal-point-centred (_core.pyi:477-488, README.md:88-90)."""
-    _check_initial(initial_image_pair, ransac_opt)
     p, i = estimate_monodepth_shared_focal_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], [depth_1],
-                                                               [depth_2], ransac_opt, bundle_opt)
+                                                               [depth_2], _with_initial(initial_image_pair, ransac_opt), bundle_opt)
+    _initial_fallback(initial_image_pair, p[0].geometry)
     return p[0], i[0]
 
 
@@ -234,9 +251,9 @@ def estimate_monodepth_varying_focal_relative_pose(points2D_1, points2D_2, depth
                                                    initial_image_pair=None):
     """Two unknown focal lengths (_core.pyi:490-501, README.md:94-96).  `monodepth_estimate_shift` is ignored here
     exactly like in the reference."""
-    _check_initial(initial_image_pair, ransac_opt)
     p, i = estimate_monodepth_varying_focal_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], [depth_1],
-                                                                [depth_2], ransac_opt, bundle_opt)
+                                                                [depth_2], _with_initial(initial_image_pair, ransac_opt), bundle_opt)
+    _initial_fallback(initial_image_pair, p[0].geometry)
     return p[0], i[0]
 
 
@@ -264,21 +281,69 @@ def varying_focal_monodepth_pose_4pt(x1, x2, d1, d2):
 
 
 # ------------------------------------------------------------------------------------------------ fork-name adapters
-_FORK_ONLY_FLAGS = ("use_reldepth", "use_madpose", "use_4p4d", "use_fundamental", "optimize_symmetric", "graduated_steps",
-                    "no_normalization", "use_reproj")
+# The paper scripts were written against kocurvik/PoseLib-mdrp@iccv-eval, whose RansacOptions carry experiment switches the
+# released PR-152 binary (the wheel in /root/reference/demo, the only behaviour that can be pinned here) does not have.
+# Every switch eval.py:93-127 / eval_shared_f.py:111-152 / eval_varying_f.py:105-150 can emit is listed: either it selects
+# exactly what the PR-152 estimators do (-> mapped), or it selects a fork-only variant (-> NotImplementedError; parity
+# unpinned).  Nothing is mapped "to the nearest behaviour" silently.
+#   PR-152 calibrated estimator:  monodepth_estimate_shift=False: P3P on the depth of image 1, hybrid LM (Sampson + both
+#       reprojections) of R, t, scale, Sampson scoring;  =True: 3-point scale + two shifts solver, the same LM also over both shifts.
+#   PR-152 shared / varying focal estimators: 3-point scale + focal(s) solver without shifts, hybrid LM, Sampson scoring.
+FORK_FLAG_TABLE = {
+    # flag:               (values PR-152 behaviour corresponds to,                                   what any other value selects)
+    "use_madpose":        ((False,), "MADPose solvers / optimisation (mad_poselib_*)"),
+    "use_reldepth":       ((False,), "3p_reldepth relative-depth solver"),
+    "use_4p4d":           ((False,), "4p4d solver (varying focal)"),
+    "use_fundamental":    ((False,), "7-point fundamental-matrix baseline inside the monodepth estimator"),
+    "use_eigen":          ((False,), "eigen-decomposition variant of the varying-focal solver"),
+    "use_reproj":         ((False,), "reprojection-error scoring instead of Sampson (…_reproj)"),
+    "optimize_symmetric": ((False,), "symmetric reprojection cost (…_sym_reproj, calibrated)"),
+    "sym_repro":          ((False,), "symmetric reprojection cost (…_sym_reproj, focal)"),
+    "no_normalization":   ((False,), "no scale normalisation of the pixel coordinates (NN)"),
+    "graduated_steps":    ((0,), "graduated LO (GLO)"),
+    "optimize_hybrid":    ((True,), "Sampson-only (or reprojection-only) LM instead of the hybrid cost"),
+    "lo_iterations":      ((25,), "LO iteration count other than the binary's fixed 25 (nLO)"),
+    "progressive_sampling": ((False,), "PROSAC sampling"),
+}
+_FORK_KEYS = tuple(FORK_FLAG_TABLE) + ("use_p3p", "use_ours", "solver_shift", "solver_scale", "optimize_shift", "all_permutations",
+                                       "use_madpose_shift_optim", "weight_sampson")
 
 
-def _map_fork_options(ransac_opt):
-    """eval*.py build option dicts for kocurvik/PoseLib-mdrp@iccv-eval (eval.py:105-123).  Flags with a PR-152
-    equivalent are mapped; fork-only solver/optimiser variants have no pinned behaviour here -> NotImplementedError."""
+def _map_fork_options(ransac_opt, kind=_capi.CALIB):
+    """Option dict of the paper scripts -> option dict of the PR-152 estimators, or NotImplementedError naming the
+    fork-only variant.  Plain PR-152 dicts (none of the fork keys) pass through unchanged."""
     ro = dict(ransac_opt or {})
-    for k in _FORK_ONLY_FLAGS:
-        if ro.get(k):
-            raise NotImplementedError(f"ransac option {k!r} selects a fork-only variant (parity unpinned, SURVEY.md §8b)")
-    if ro.get("use_ours") and ro.get("solver_shift"):
-        ro["monodepth_estimate_shift"] = True
-    if ro.get("use_p3p"):
-        ro["monodepth_estimate_shift"] = False
+    if not any(k in ro for k in _FORK_KEYS):
+        return ro
+
+    def fork_only(what):
+        raise NotImplementedError(f"ransac options select a fork-only variant — {what} — whose behaviour cannot be pinned against "
+                                  "the released PoseLib binary (SURVEY.md 8b; mdrp_amd.poselib.FORK_FLAG_TABLE)")
+
+    for flag, (ok, what) in FORK_FLAG_TABLE.items():
+        if flag in ro and ro[flag] not in ok and not (isinstance(ro[flag], bool) and int(ro[flag]) in [int(v) for v in ok if isinstance(v, bool)]):
+            fork_only(f"{flag}={ro[flag]!r}: {what}")
+    p3p, ours = bool(ro.get("use_p3p")), bool(ro.get("use_ours"))
+    shift, scale, opt_shift = bool(ro.get("solver_shift")), bool(ro.get("solver_scale")), bool(ro.get("optimize_shift"))
+    if kind == _capi.CALIB:
+        if p3p and not ours and not shift and not opt_shift:
+            ro["monodepth_estimate_shift"] = False          # p3p_hybrid*: P3P, LM without shifts
+        elif ours and not p3p and shift and scale and opt_shift:
+            ro["monodepth_estimate_shift"] = True           # 3p_ours_shift_scale_hybrid-s*: shift solver, LM over the shifts too
+        elif p3p or ours or shift or scale or opt_shift:
+            fork_only(f"use_p3p={p3p}, use_ours={ours}, solver_shift={shift}, solver_scale={scale}, optimize_shift={opt_shift}: the "
+                      "released estimator ties the shift solver and the shift optimisation together (monodepth_estimate_shift) and "
+                      "has no scale-only / shift-only 3-point solver")
+        # all_permutations: the calibrated 3-point solvers are symmetric in the sample, permutations change nothing -> accepted
+    else:
+        if ours and not p3p and scale and not shift and not opt_shift:
+            pass                                            # 3p_ours_scale_hybrid*: the PR-152 focal estimators
+        elif p3p or ours or shift or scale or opt_shift:
+            fork_only(f"use_p3p={p3p}, use_ours={ours}, solver_shift={shift}, solver_scale={scale}, optimize_shift={opt_shift}: the "
+                      "released focal estimators are the 3-point scale + focal solvers without shifts")
+        if ro.get("all_permutations"):
+            fork_only("all_permutations=True: the shared-focal solver treats the third correspondence differently; the released "
+                      "estimator runs the sample order as drawn")
     if "weight_sampson" in ro:
         ro["monodepth_weight_sampson"] = ro["weight_sampson"]
     return ro
@@ -296,13 +361,13 @@ def estimate_relative_pose_w_mono_depth(kp1, kp2, d, camera1, camera2, ransac_op
 def estimate_shared_focal_monodepth_relative_pose(kp1, kp2, d, ransac_opt={}, bundle_opt={}):
     """eval_shared_f.py:177"""
     d = np.asarray(d, dtype=np.float64)
-    return estimate_monodepth_shared_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt), bundle_opt)
+    return estimate_monodepth_shared_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt, _capi.SHARED_FOCAL), bundle_opt)
 
 
 def estimate_varying_focal_monodepth_relative_pose(kp1, kp2, d, ransac_opt={}, bundle_opt={}):
     """eval_varying_f.py:168"""
     d = np.asarray(d, dtype=np.float64)
-    return estimate_monodepth_varying_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt), bundle_opt)
+    return estimate_monodepth_varying_focal_relative_pose(kp1, kp2, d[:, 0], d[:, 1], _map_fork_options(ransac_opt, _capi.VARYING_FOCAL), bundle_opt)
 
 
 def _not_on_path(name, where):

@@ -34,6 +34,9 @@ typedef struct { /* RansacOptions, wheel METADATA:72-91 */
     uint64_t seed;
     int estimate_shift; /* monodepth_estimate_shift */
     double weight_sampson; /* monodepth_weight_sampson (float in the reference) */
+    int score_initial_model; /* RansacOptions +0x49: score (and LO-refine) the model handed in before the first iteration.
+                              * ransac_*_relpose reset its POSE to the identity first (black-box: any initial pose gives the same
+                              * result), so what is scored is (identity, initial scale / shifts). */
 } orc_ransac_opt;
 
 typedef struct { /* BundleOptions, wheel METADATA:94-106 */

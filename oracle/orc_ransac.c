@@ -80,8 +80,16 @@ orc_ransac_stats orc_ransac(int kind, const double *x1, const double *x2, const 
     uint64_t dynamic_max_iter = opt->max_iterations;
     const double log_prob_missing = log(1.0 - opt->success_prob);
     orc_model models[4];
+    /* ransac_*_relpose @0x228c20 / 0x2298e0 / 0x22a3a0 reset the pose of the caller's model (black-box probe: results do not
+     * depend on it; with nothing found the caller gets identity + its own scale back) */
+    best->q[0] = 1.0; best->q[1] = best->q[2] = best->q[3] = 0.0;
+    best->t[0] = best->t[1] = best->t[2] = 0.0;
+    if (kind != ORC_CALIB) { best->f1 = 1.0; best->f2 = 1.0; }
+    int pending_initial = opt->score_initial_model != 0; /* ransac<> branch @0x22f2c8: score_models on {*best} first */
     for (;;) {
-        const int nm = generate_models(&e, models);
+        int nm;
+        if (pending_initial) { models[0] = *best; nm = 1; }
+        else nm = generate_models(&e, models);
         int best_ind = -1;
         for (int i = 0; i < nm; ++i) {
             uint64_t cnt;
@@ -117,6 +125,7 @@ orc_ransac_stats orc_ransac(int kind, const double *x1, const double *x2, const 
                 dynamic_max_iter = (uint64_t)ceil(log_prob_missing / log(prob_outlier) * opt->dyn_num_trials_mult);
             }
         }
+        if (pending_initial) { pending_initial = 0; continue; } /* not an iteration */
         ++stats.iterations;
         if (stats.iterations >= opt->max_iterations) break;
         if (stats.iterations <= opt->min_iterations) continue;

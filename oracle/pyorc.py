@@ -20,7 +20,7 @@ CALIB, SHARED, VARYING = 0, 1, 2
 class RansacOpt(C.Structure):
     _fields_ = [("max_iterations", C.c_uint64), ("min_iterations", C.c_uint64), ("dyn_num_trials_mult", C.c_double),
                 ("success_prob", C.c_double), ("max_reproj_error", C.c_double), ("max_epipolar_error", C.c_double),
-                ("seed", C.c_uint64), ("estimate_shift", C.c_int), ("weight_sampson", C.c_double)]
+                ("seed", C.c_uint64), ("estimate_shift", C.c_int), ("weight_sampson", C.c_double), ("score_initial_model", C.c_int)]
 
 
 class BundleOpt(C.Structure):
@@ -68,9 +68,10 @@ def f64(a):
 
 
 def ransac_opt(max_iterations=100000, min_iterations=1000, dyn_num_trials_mult=3.0, success_prob=0.9999,
-               max_reproj_error=12.0, max_epipolar_error=1.0, seed=0, estimate_shift=False, weight_sampson=1.0):
+               max_reproj_error=12.0, max_epipolar_error=1.0, seed=0, estimate_shift=False, weight_sampson=1.0, score_initial_model=False):
     return RansacOpt(int(max_iterations), int(min_iterations), dyn_num_trials_mult, success_prob, max_reproj_error,
-                     max_epipolar_error, int(seed), int(bool(estimate_shift)), float(np.float32(weight_sampson)))
+                     max_epipolar_error, int(seed), int(bool(estimate_shift)), float(np.float32(weight_sampson)),
+                     int(bool(score_initial_model)))
 
 
 def bundle_opt(max_iterations=100, loss_type=3, loss_scale=1.0, gradient_tol=1e-8, step_tol=1e-8,
@@ -181,9 +182,9 @@ def refine(kind, x1, x2, d1, d2, model, scale_reproj, weight_sampson, bopt, esti
     return m, st
 
 
-def ransac(kind, x1, x2, d1, d2, ropt):
+def ransac(kind, x1, x2, d1, d2, ropt, initial=None):
     x1, x2, d1, d2 = f64(x1), f64(x2), f64(d1), f64(d2)
-    m = new_model()
+    m = new_model() if initial is None else f64(initial).copy()
     mask = np.zeros(len(x1), dtype=np.uint8)
     st = lib().orc_ransac(C.c_int(kind), _p(x1), _p(x2), _p(d1), _p(d2), C.c_int(len(x1)), C.byref(ropt), _p(m),
                           mask.ctypes.data_as(C.c_void_p))
@@ -194,9 +195,10 @@ def cam_flat(model_id, params):
     return f64([model_id, len(params)] + list(params))
 
 
-def estimate(kind, x1, x2, d1, d2, ropt, bopt, cam1=None, cam2=None):
+def estimate(kind, x1, x2, d1, d2, ropt, bopt, cam1=None, cam2=None, initial=None):
+    """initial: 12-wide model handed in (its pose is reset by the reference; scale / shifts survive when nothing is found)"""
     x1, x2, d1, d2 = f64(x1), f64(x2), f64(d1), f64(d2)
-    m = new_model()
+    m = new_model() if initial is None else f64(initial).copy()
     mask = np.zeros(len(x1), dtype=np.uint8)
     c1 = f64(cam1) if cam1 is not None else np.zeros(8)
     c2 = f64(cam2) if cam2 is not None else np.zeros(8)

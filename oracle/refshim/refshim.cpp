@@ -123,6 +123,9 @@ void pair_out(const MDIP &p, double *g) {
     g[10] = p.camera1.params.empty() ? 0.0 : p.camera1.params[0];
     g[11] = p.camera2.params.empty() ? 0.0 : p.camera2.params[0];
 }
+// RansacOptions::score_initial_model (+0x49) for the calls that follow: the model passed in is then scored first
+// (ransac<> branch @0x22f2c8); set through ref_set_score_initial()
+bool g_score_initial = false;
 // flat ransac opt: max_it,min_it,dyn_mult,success_prob,max_reproj,max_epi,seed,estimate_shift,weight_sampson (9)
 RansacOptions ropt_in(const double *o) {
     RansacOptions r;
@@ -130,7 +133,7 @@ RansacOptions ropt_in(const double *o) {
     r.max_iterations = (size_t)o[0]; r.min_iterations = (size_t)o[1];
     r.dyn_num_trials_mult = o[2]; r.success_prob = o[3]; r.max_reproj_error = o[4]; r.max_epipolar_error = o[5];
     r.seed = (unsigned long)o[6]; r.progressive_sampling = false; r.max_prosac_iterations = 100000;
-    r.real_focal_check = false; r.score_initial_model = false; r.monodepth_estimate_shift = o[7] != 0.0;
+    r.real_focal_check = false; r.score_initial_model = g_score_initial; r.monodepth_estimate_shift = o[7] != 0.0;
     r.monodepth_weight_sampson = (float)o[8];
     return r;
 }
@@ -284,6 +287,8 @@ void ref_refine_focal(int varying, const double *x1, const double *x2, const dou
     pair_out(p, pair12);
     bstats_out(s, stats7);
 }
+
+void ref_set_score_initial(int on) { g_score_initial = on != 0; }
 
 // kind: 0 calibrated (normalised inputs), 1 shared, 2 varying. model: 10 (calib) or 12 doubles, in/out.
 void ref_ransac(int kind, const double *x1, const double *x2, const double *d1, const double *d2, int n,

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Model) == 96 and C.sizeof(_capi.Camera) == 40 and C.sizeof(_capi.Result) == 136
-    assert C.sizeof(_capi.RansacOpt) == 64 and C.sizeof(_capi.BundleOpt) == 64
+    assert C.sizeof(_capi.RansacOpt) == 72 and C.sizeof(_capi.BundleOpt) == 64
 
 
 def test_no_cpu_fallback_in_product():

@@ -73,7 +73,7 @@ def test_layout_options_and_records_with_stub_estimator(tmp_path):
                  for kp in k1]
         return out, infos
 
-    exps = ["3p_ours_shift_scale_hybrid+10", "p3p+10"]
+    exps = ["3p_ours_shift_scale_hybrid-s+10", "p3p_hybrid+10"]
     res = evalio.evaluate_calibrated(h5, exps, iters=500, batch=4, estimate_batch=stub)
     assert len(res) == 2 * 5                      # the 4-correspondence pair is skipped (eval.py:338-339)
     assert seen["ro"]["monodepth_estimate_shift"] is False and seen["n"] == 1    # last call: p3p, second batch of 5 pairs
@@ -97,7 +97,7 @@ def test_layout_options_and_records_with_stub_estimator(tmp_path):
 @pytest.mark.gpu
 def test_evaluate_calibrated_end_to_end_gpu():
     h5, gt = fake_h5(n_pairs=8, n=400, seed=40)
-    exps = ["3p_ours_scale_hybrid_ctruncated+10", "3p_ours_shift_scale_hybrid_ctruncated+10"]
+    exps = ["p3p_hybrid_ctruncated+10", "3p_ours_shift_scale_hybrid-s_ctruncated+10"]
     res = evalio.evaluate_calibrated(h5, exps, iters=1000, threshold=2.0)
     assert len(res) == 2 * 7
     rows = evalio.summarize(exps, res)
@@ -153,3 +153,39 @@ def test_evaluate_focal_end_to_end_gpu(shared):
     assert len(res) == 7 and {"f1", "f2", "f_err", "f1_gt"} <= set(res[0])
     (row,) = evalio.summarize_focal(exps, res)
     assert row[1] < 1.0 and row[2] < 0.02 and row[3] > 0.85 and row[4] > 0.85, row
+
+
+def test_fork_flag_table_covers_every_experiment_name():
+    """Every experiment family of the reference's lists (utils/data.py:86-200 get_experiments, eval.py:212-239) goes through
+    the option builders and mdrp_amd.poselib._map_fork_options: the ones that ARE the released PR-152 estimators map, with the
+    right monodepth_estimate_shift; every other one raises NotImplementedError — none runs the default estimator silently."""
+    from mdrp_amd import _capi, poselib
+    calib_ok = {"3p_ours_shift_scale_hybrid-s+10": True, "3p_ours_shift_scale_hybrid-s_truncated+10": True,
+                "3p_ours_shift_scale_hybrid-s_ctruncated+6": True, "p3p_hybrid+12": False, "p3p_hybrid_ctruncated+1": False}
+    calib_fork = ["3p_reldepth+10", "3p_ours_shift_scale+10", "3p_ours_shift_scale_reproj+10", "3p_ours_shift_scale_sym_reproj+10",
+                  "3p_ours_shift_scale_reproj-s+10", "3p_ours_shift_scale_reproj-sfix+10", "3p_ours_shift_scale_hybrid+10",
+                  "3p_ours_shift_scale_hybrid_reproj+10", "3p_ours_shift_scale_hybrid-s_reproj+10", "p3p+10", "p3p_reproj+10",
+                  "p3p_reproj-s+10", "p3p_sym_reproj+10", "p3p_hybrid_reproj+10", "p3p_hybrid-s+10", "p3p_hybrid-s_reproj+10",
+                  "mad_poselib_shift_scale+10", "mad_poselib_shift_scale_reproj+10", "mad_poselib_shift_scale_reproj-s+10",
+                  "3p_ours_scale_hybrid+10", "3p_ours_hybrid+10", "3p_ours_shift_scale_hybrid-s_GLO+10", "p3p_hybrid_nLO+10"]
+    for name, shift in calib_ok.items():
+        ro = poselib._map_fork_options(evalio.experiment_options(name)[0], _capi.CALIB)
+        assert ro["monodepth_estimate_shift"] is shift and ro["monodepth_weight_sampson"] == 1.0, name
+    for name in calib_fork:
+        with pytest.raises(NotImplementedError):
+            poselib._map_fork_options(evalio.experiment_options(name)[0], _capi.CALIB)
+    for varying in (False, True):
+        kind = _capi.VARYING_FOCAL if varying else _capi.SHARED_FOCAL
+        for name in ("3p_ours_scale_hybrid+10", "3p_ours_scale_hybrid_ctruncated+12"):
+            ro = poselib._map_fork_options(evalio.focal_options(name, varying=varying)[0], kind)
+            assert "monodepth_estimate_shift" not in ro or not ro["monodepth_estimate_shift"]
+        fork = ["3p_ours_scale+10", "3p_ours_scale_reproj+10", "4p_ours_scale_shift+10", "4p_ours_scale_shift_reproj+10", "3p_reldepth+10",
+                "mad_poselib_shift_scale+10", "3p_ours_scale_hybrid_sym_reproj+10", "3p_ours_scale_hybrid_NN+10", "3p_ours_scale_hybrid_GLO+10",
+                "p3p_hybrid+10"]
+        fork += ["4p4d+10", "7p", "3p_ours_scale_hybrid_eigen+10"] if varying else ["3p_ours_scale_hybrid_perm+10"]
+        for name in fork:
+            with pytest.raises(NotImplementedError):
+                poselib._map_fork_options(evalio.focal_options(name, varying=varying)[0], kind)
+    # plain PR-152 dicts (make_pair.py:31-33, notebook) are not touched
+    plain = {"max_epipolar_error": 2.0, "max_reproj_error": 16.0, "lo_iterations_typo": 3, "monodepth_estimate_shift": True}
+    assert poselib._map_fork_options(plain) == plain

@@ -116,3 +116,39 @@ def test_two_threads_two_handles_run_concurrently_and_agree():
     for (r0, m0), (r1, m1) in zip(ref, got):
         assert r0.tobytes() == r1.tobytes() and np.array_equal(m0, m1)
     h.close()
+
+
+def test_initial_pose_and_score_initial_model_vs_reference_golden(golden):
+    """the drop-in signatures with initial_pose / initial_image_pair against tests/golden/initial.npz (reference binary): stats,
+    model, mask; the pose handed in must not matter, its scale must come back when nothing is adopted"""
+    import mdrp_amd.poselib as poselib
+    from helpers import model_diff
+    from test_oracle_golden import initial_cases
+    g = golden("initial")
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [800.0, 640.0, 480.0]}
+    for i, kind, flag, its, seed, deg in initial_cases(g):
+        ro = {"max_iterations": its, "min_iterations": its, "max_epipolar_error": 2.0, "max_reproj_error": 16.0, "seed": seed}
+        ini = g[f"initial_{i}"]
+        geom = poselib.MonoDepthTwoViewGeometry(poselib.CameraPose(ini[:4], ini[4:7]), ini[7], ini[8], ini[9])
+        x = (g[f"x1_{i}"], g[f"x2_{i}"], g[f"d1_{i}"], g[f"d2_{i}"])
+        if flag:   # the binding sets score_initial_model when an initial model is passed
+            if kind == 0:
+                out, info = poselib.estimate_monodepth_relative_pose(*x, cam, cam, ro, {"loss_type": "TRUNCATED_CAUCHY"}, initial_pose=geom)
+            else:
+                fn = poselib.estimate_monodepth_shared_focal_relative_pose if kind == 1 else poselib.estimate_monodepth_varying_focal_relative_pose
+                pair = poselib.MonoDepthImagePair(geom, poselib.Camera("SIMPLE_PINHOLE", [ini[10], 0, 0]), poselib.Camera("SIMPLE_PINHOLE", [ini[11], 0, 0]))
+                out, info = fn(*x, ro, {"loss_type": "TRUNCATED_CAUCHY"}, initial_image_pair=pair)
+        else:
+            if kind == 0:
+                out, info = poselib.estimate_monodepth_relative_pose(*x, cam, cam, ro, {"loss_type": "TRUNCATED_CAUCHY"})
+            else:
+                fn = poselib.estimate_monodepth_shared_focal_relative_pose if kind == 1 else poselib.estimate_monodepth_varying_focal_relative_pose
+                out, info = fn(*x, ro, {"loss_type": "TRUNCATED_CAUCHY"})
+        gm = out if kind == 0 else out.geometry
+        m = np.r_[gm.pose.q, gm.pose.t, gm.scale, gm.shift1, gm.shift2, 1.0 if kind == 0 else out.camera1.focal(), 1.0 if kind == 0 else out.camera2.focal()]
+        ref_m, ref_st = g[f"model_{i}"], g[f"stats_{i}"]
+        assert (info["refinements"], info["iterations"], info["num_inliers"]) == tuple(int(v) for v in ref_st[:3]), (i, info, ref_st)
+        assert info["model_score"] == pytest.approx(ref_st[4], rel=1e-9)
+        if flag or not deg:
+            assert model_diff(m, ref_m) < 1e-6, (i, m, ref_m)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), g[f"mask_{i}"])

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import pyorc as po
-from helpers import KNOWN_LO_COUNT_DEVIATIONS, REFERENCE_NAN_SOLUTIONS, match_solution_sets, model_diff, widen
+from helpers import INITIAL_ORACLE_DEVIATIONS, KNOWN_LO_COUNT_DEVIATIONS, REFERENCE_NAN_SOLUTIONS, match_solution_sets, model_diff, widen
 
 
 def test_sampler_known_answers(golden):
@@ -125,3 +125,29 @@ def test_estimate_full_size_matches_reference(golden):
         assert model_diff(m, ref_m) < 1e-6, (i, model_diff(m, ref_m))
         assert abs(st.model_score - ref_st[4]) <= 1e-9 * ref_st[4]
         assert st.refinements == int(ref_st[0]) + KNOWN_LO_COUNT_DEVIATIONS.get(i, 0), (i, st.refinements, ref_st[0])
+
+
+def initial_cases(g):
+    for case in g["cases"]:
+        i, kind, flag, its, seed, deg = [int(v) for v in case]
+        yield i, kind, bool(flag), its, seed, bool(deg)
+
+
+def test_initial_model_and_score_initial_match_reference(golden):
+    """initial_pose / score_initial_model (_core.pyi:455; ransac<> @0x22f2c8) against the reference binary: the pose handed in
+    is never read, its scale survives only when nothing is adopted, and the flag costs one refinement — normal and fully
+    degenerate data, 1 and 200 iterations, all three estimators."""
+    g = golden("initial")
+    for i, kind, flag, its, seed, deg in initial_cases(g):
+        if i in INITIAL_ORACLE_DEVIATIONS:
+            continue
+        ro = po.ransac_opt(max_iterations=its, min_iterations=its, max_epipolar_error=2.0, max_reproj_error=16.0, seed=seed, score_initial_model=flag)
+        cam = po.cam_flat(0, [800.0, 640.0, 480.0]) if kind == 0 else None
+        ini = g[f"initial_{i}"]
+        m, st, mask = po.estimate(kind, g[f"x1_{i}"], g[f"x2_{i}"], g[f"d1_{i}"], g[f"d2_{i}"], ro, po.bundle_opt(loss_type=4), cam, cam,
+                                  initial=np.r_[ini, 1.0, 1.0] if kind == 0 else ini)
+        ref_m, ref_st = g[f"model_{i}"], g[f"stats_{i}"]
+        assert (st.refinements, st.iterations, st.num_inliers) == tuple(int(v) for v in ref_st[:3]), (i, st.refinements, ref_st)
+        assert abs(st.model_score - ref_st[4]) <= 1e-9 * ref_st[4]
+        assert model_diff(m, ref_m) < 1e-6, i
+        assert (mask == g[f"mask_{i}"]).all()

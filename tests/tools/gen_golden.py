@@ -224,6 +224,38 @@ def gen_estimate_full():
     np.savez_compressed(os.path.join(OUT, "estimate_full.npz"), **d)
 
 
+def gen_initial():
+    """initial_pose / score_initial_model (_core.pyi:455, RansacOptions +0x49) through the reference binary.  Black-box finding
+    pinned here: the pose handed in is never read (ransac_*_relpose reset it), its scale / shifts survive only when RANSAC
+    adopts nothing, and score_initial_model scores that reset model first (one more refinement, records start at N eps^2)."""
+    d = {}
+    cases = []
+    rng = np.random.default_rng(5)
+    for i in range(12):
+        kind = i % 3
+        degenerate = i >= 9           # all correspondences identical: the solvers return nothing (or NaN models)
+        flag = (i // 3) % 2 == 0 or degenerate
+        n = 150
+        p = synth.make_pair(1500 + i, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3, random_focal=[None, "shared", "varying"][kind],
+                            pp=(640.0, 480.0) if kind == 0 else (0.0, 0.0))
+        x1, x2, d1, d2 = p["x1"], p["x2"], p["d1"], p["d2"]
+        if degenerate:
+            x1 = np.tile(x1[:1], (n, 1)); x2 = np.tile(x2[:1], (n, 1)); d1 = np.full(n, 2.0); d2 = np.full(n, 3.0)
+        ini = np.r_[quat_of(rodrigues(rng.normal(0, 0.5, 3))), rng.normal(0, 1, 3), 0.8 + 0.1 * i, 0.0, 0.0]
+        if kind:
+            ini = np.r_[ini, 1.3, 0.7]
+        its = 1 if i % 4 == 1 else 200
+        kw = dict(max_iterations=its, min_iterations=its, max_epipolar_error=2.0, max_reproj_error=16.0, seed=i % 3)
+        c = rs.cam_flat(0, 1280, 960, [800.0, 640.0, 480.0]) if kind == 0 else None
+        m, st, mask = rs.estimate(kind, x1, x2, d1, d2, rs.ropt(**kw), rs.bopt(loss_type=4), c, c, initial=ini, score_initial=flag)
+        d.update({f"x1_{i}": x1, f"x2_{i}": x2, f"d1_{i}": d1, f"d2_{i}": d2, f"initial_{i}": ini,
+                  f"model_{i}": np.r_[m, 1.0, 1.0] if kind == 0 else m, f"stats_{i}": st, f"mask_{i}": mask})
+        cases.append([i, kind, int(flag), its, kw["seed"], int(degenerate)])
+        print("initial", i, kind, flag, its, st, np.round(m[:8], 3), flush=True)
+    d["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "initial.npz"), **d)
+
+
 if __name__ == "__main__":
     if not rs.available():
         sys.exit("reference shim not built: run `make -C oracle ref` in the build container")
@@ -234,5 +266,6 @@ if __name__ == "__main__":
     gen_refine()
     gen_estimate()
     gen_estimate_full()
+    gen_initial()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

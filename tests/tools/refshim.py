@@ -165,13 +165,16 @@ def cam_flat(model_id, width, height, params):
     return f64([model_id, width, height, len(params)] + list(params))
 
 
-def estimate(kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None):
+def estimate(kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None, initial=None, score_initial=False):
+    """initial: model handed in (10 / 12 doubles; identity if None); score_initial: RansacOptions::score_initial_model"""
     x1, x2, d1, d2 = f64(x1), f64(x2), f64(d1), f64(d2)
-    model = _init_model(kind)
+    model = _init_model(kind) if initial is None else f64(initial).copy()
+    lib().ref_set_score_initial(C.c_int(int(bool(score_initial))))
     st = np.zeros(5)
     mask = np.zeros(len(x1), dtype=np.uint8)
     c1 = cam1 if cam1 is not None else np.zeros(8)
     c2 = cam2 if cam2 is not None else np.zeros(8)
     lib().ref_estimate(C.c_int(kind), _p(x1), _p(x2), _p(d1), _p(d2), C.c_int(len(x1)), _p(c1), _p(c2), _p(ro), _p(bo),
                        _p(model), _p(st), mask.ctypes.data_as(C.c_void_p))
+    lib().ref_set_score_initial(C.c_int(0))
     return model, st, mask
