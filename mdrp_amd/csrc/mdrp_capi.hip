@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -89,7 +90,7 @@ struct mdrp_handle {
     hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
     hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
-    hipEvent_t ev_lo = nullptr, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
+    hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
@@ -250,6 +251,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0;
     const int lo_overlap_waves = env_int("MDRP_LO_OVERLAP_WAVES", 8); // LO wavefronts per CU while it shares the chip
     const bool lo_after_solve = env_int("MDRP_LO_AFTER_SOLVE", 1) != 0; // LO of chunk c starts when chunk c + 1 is solved (the solver is on the critical path)
+    // ... and counted: LO then runs beside k_bound / k_score instead of beside k_count.  Same step time either way (12.2 ms both:
+    // the chip is throughput-bound in aggregate), but the MFMA kernel keeps the chip to itself (1.9-2.2 ms instead of 3.7)
+    const bool lo_after_count = env_int("MDRP_LO_AFTER_COUNT", 1) != 0;
     const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
     const bool use_bound = env_int("MDRP_BOUND", 1) != 0; // fp32 lower-bound stage between k_count and the fp64 sweep
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
@@ -345,6 +349,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         };
         if ((rc = issue_solve(0, s))) return rc;
         if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
+        std::function<int()> pending_lo; // LO of the previous chunk, held back until this chunk's k_count is queued (MDRP_LO_AFTER_COUNT)
         for (int c = 0; c < n_chunks; ++c) {
             const int len = (int)lens[c];
             rp.chunk_len = len; rp.chunk_off = offs[c];
@@ -381,6 +386,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                        h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
                 HIPCHK(hipEventRecord(c1, s));
                 h->count_launches++;
+                if (pending_lo) {
+                    HIPCHK(hipEventRecord(h->ev_counted, s));
+                    HIPCHK(hipStreamWaitEvent(aux2, h->ev_counted, 0));
+                    if ((rc = pending_lo())) return rc;
+                    pending_lo = nullptr;
+                }
                 const uint32_t *surv_tags = h->tags_v.as<uint32_t>();
                 const int32_t *surv_cnt = h->surv_count.as<int32_t>();
                 if (use_bound && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
@@ -429,9 +440,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int lo_waves_c = (piped && c + 1 < n_chunks) ? lo_overlap_waves : 8; // the last chunk's LO has the chip to itself
             const int lo_threads_c = (c + 1 == n_chunks) ? lo_threads_last : lo_threads;
             const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
-            MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
-                             h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                             trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max));
+            const RunParams rp_lo = rp;
+            auto launch_lo = [=]() -> int {
+                MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
+                                 h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
+                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max));
+                return MDRP_OK;
+            };
+            if (piped && lo_after_count && c + 1 < n_chunks) pending_lo = launch_lo;
+            else if ((rc = launch_lo())) return rc;
         }
         if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
@@ -572,6 +589,7 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
         HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio2));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_counted, hipEventDisableTiming));
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_solved[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scanned[i], hipEventDisableTiming));
@@ -600,6 +618,7 @@ void mdrp_destroy(mdrp_handle *h) {
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
+    if (h->ev_counted) (void)hipEventDestroy(h->ev_counted);
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         if (h->ev_solved[i]) (void)hipEventDestroy(h->ev_solved[i]);
         if (h->ev_scanned[i]) (void)hipEventDestroy(h->ev_scanned[i]);

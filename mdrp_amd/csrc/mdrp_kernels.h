@@ -396,14 +396,15 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * 4;
     int pos = base + pre - n;
     const size_t tag_base = (size_t)pair * rp.slot_stride;
+    // slot states of the iteration in one 16-byte store: -1 = empty, -2 = "no record" — the default of every live slot:
+    // k_count / k_bound retire most hypotheses without touching their slots again, k_score overwrites the survivors'
+    *reinterpret_cast<int4 *>(slot_inl + slot0) = make_int4(n > 0 ? -2 : -1, n > 1 ? -2 : -1, n > 2 ? -2 : -1, n > 3 ? -2 : -1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < n) {
             models[slot0 + k] = out[k];
             tags[tag_base + pos] = (uint32_t)((rp.chunk_off + it) * 4 + k);
             ++pos;
-        } else {
-            slot_inl[slot0 + k] = -1;
         }
     }
 }
@@ -745,7 +746,12 @@ __device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int
 // resident: every wavefront of the pair reads the same 64 N bytes).  Output tile: lane l holds hypothesis l & 15 against
 // correspondences 4 (l >> 4) .. + 3 of the group, so the four |C| > tb tests of a lane belong to ONE hypothesis and add into
 // one counter per tile.  Per 16 x 16 evaluations: one MFMA (16 cycles) + 4 x (v_cmp + v_addc).
-constexpr int CNT_TILES = 8;                       // MFMA tiles (16 hypotheses) per wavefront
+#ifndef MDRP_CNT_TILES
+#define MDRP_CNT_TILES 8
+#endif
+constexpr int CNT_TILES = MDRP_CNT_TILES;          // MFMA tiles (16 hypotheses) per wavefront: 4 or 8
+constexpr int CNT_ROUNDS = (16 * CNT_TILES) / 64;  // prologue / epilogue rounds of 64 hypotheses
+static_assert(CNT_TILES == 4 || CNT_TILES == 8, "a wavefront owns 64 or 128 hypotheses");
 constexpr int CNT_WAVE_MODELS = 16 * CNT_TILES;    // 128
 constexpr int CNT_THREADS = 256;
 constexpr int CNT_WG_MODELS = CNT_WAVE_MODELS * (CNT_THREADS / 64);
@@ -794,15 +800,15 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const double thr = ps.sq_thr;
     // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS); the loads of both rounds
     // are issued before the arithmetic of the first (tag -> model is a dependent pair of L2 round trips)
-    uint32_t slot_r[2] = {0, 0};
-    double mq[2][4], mt[2][3], mf[2][2];
+    uint32_t slot_r[CNT_ROUNDS] = {};
+    double mq[CNT_ROUNDS][4], mt[CNT_ROUNDS][3], mf[CNT_ROUNDS][2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
         if (i < cnt) slot_r[r] = tags[slot_base + i] & 0xFFFFFFu;
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < CNT_ROUNDS; ++r) {
         const Model *mp = models + slot_base + slot_r[r]; // slot 0 of the pair for idle lanes: a valid address
         const double2 *P = reinterpret_cast<const double2 *>(mp);
         const double2 q01 = P[0], q23 = P[1], t01 = P[2], t2s = P[3], f12 = P[5];
@@ -811,7 +817,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
         mf[r][0] = f12.x; mf[r][1] = f12.y;
     }
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
         uint16_t eh[8], el[8], e8[3];
         float tb = 1.0f; // here: (tb S)^2 of count_setup_scaled; zero coefficients against 1 keep everything
@@ -839,29 +845,31 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const int col = lane & 15, ksl = lane >> 4;
     const int part = ksl < 2 ? 0 : ksl - 1; // lanes 0..31 carry Eh, 32..47 El, 48..63 the constant term
     bf16x8_t bfrag[CNT_TILES];
-    f32x2 tbv[CNT_TILES];  // (tb S)^2 in both halves
-    f32x2 cand[CNT_TILES]; // running candidate counts (exact in fp32: <= 2^24)
+    float tbv[CNT_TILES];  // (tb S)^2
+    float cand[CNT_TILES]; // running candidate counts (exact in fp32: <= 2^24)
 #pragma unroll
     for (int t = 0; t < CNT_TILES; ++t) {
         const uint4 *src = s_frag[wave][16 * t + col];
         bfrag[t] = __builtin_bit_cast(bf16x8_t, src[part]);
         const float tb2 = __uint_as_float(src[3].x);
-        tbv[t] = (f32x2){tb2, tb2};
-        cand[t] = (f32x2){0.f, 0.f};
+        tbv[t] = tb2;
+        cand[t] = 0.f;
     }
     __syncthreads(); // the fragments are in registers: the buffer now holds correspondence tiles
     // ---- sweep.  The pair's A fragments (64 N bytes, k_prep) are staged through LDS one 16-group tile at a time, double
     // buffered: read from global memory ONCE per workgroup instead of once per wavefront.
     // The group body is a hand-ordered software pipeline (inline asm; hipcc's own schedule reuses one accumulator quad
     // and pads every dependence with s_nop: 3x slower).  Per pair of MFMA tiles:
-    //     8 VALU on the accumulators of group g   |   2 MFMAs of group g + 1 into the same accumulators
-    // so the matrix pipe works on the next group while the vector pipe tests this one, and every accumulator is read >= 24
-    // instructions after its MFMA issued (no wait states needed; hipcc pads nothing around inline asm).
-    // The test (every VALU instruction costs 4 cycles per wavefront here; packed fp32 ones carry two values):
-    //     v_pk_fma_f32 d = -C * C + tb^2, clamp      1 = candidate, 0 = definite outlier (scaled so that nothing falls between)
-    //     v_pk_add_f32 cand += d
-    // = one VALU instruction per evaluation, 16 cycles per MFMA tile against the MFMA's own 16.  C is never NaN: rows of
-    // non-finite correspondences and the coefficients of unjudgeable models are zeroed when the fragments are built.
+    //     16 VALU on the accumulators of group g   |   2 MFMAs of group g + 1 into the same accumulators
+    // so every accumulator is read >= 40 instructions after its MFMA issued (no wait states needed; hipcc pads nothing
+    // around inline asm).  The test, per evaluation:
+    //     v_fma_f32 d = -C * C + tb^2, clamp      1 = candidate, 0 = definite outlier (scaled so that nothing falls between)
+    //     v_add_f32                               tree of the eight values of a tile pair into the two counters
+    // Plain fp32, not packed: tools/ubench/valu_rates.hip measures, per MFMA at 4 wavefronts per SIMD, 13.5 cycles for the
+    // v_mfma_f32_16x16x32_bf16 alone, 20.5 with four v_fma_f32 beside it (the two pipes do not overlap within a SIMD: the
+    // costs add), but 35.8 with four v_pk_fma_f32 / v_pk_add_f32 — packed fp32 next to MFMAs is an anti-lever on gfx950.
+    // C is never NaN: rows of non-finite correspondences and the coefficients of unjudgeable models are zeroed when the
+    // fragments are built.
     f32x4_t acc[CNT_TILES];
     auto mfma2 = [&](const uint4 &araw, int t0) {
         const bf16x8_t a = __builtin_bit_cast(bf16x8_t, araw);
@@ -870,19 +878,26 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
                      : "=&v"(acc[t0]), "=&v"(acc[t0 + 1]) : "v"(a), "v"(bfrag[t0]), "v"(bfrag[t0 + 1]));
     };
     auto test2 = [&](int t0) {
-        const f32x2 x01 = {acc[t0][0], acc[t0][1]}, x23 = {acc[t0][2], acc[t0][3]};
-        const f32x2 y01 = {acc[t0 + 1][0], acc[t0 + 1][1]}, y23 = {acc[t0 + 1][2], acc[t0 + 1][3]};
-        f32x2 d0, d1, d2, d3;
-        asm volatile("v_pk_fma_f32 %2, %6, %6, %10 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
-                     "v_pk_fma_f32 %3, %7, %7, %10 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
-                     "v_pk_fma_f32 %4, %8, %8, %11 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
-                     "v_pk_fma_f32 %5, %9, %9, %11 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp\n\t"
-                     "v_pk_add_f32 %0, %0, %2\n\t"
-                     "v_pk_add_f32 %1, %1, %4\n\t"
-                     "v_pk_add_f32 %0, %0, %3\n\t"
-                     "v_pk_add_f32 %1, %1, %5"
-                     : "+v"(cand[t0]), "+v"(cand[t0 + 1]), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-                     : "v"(x01), "v"(x23), "v"(y01), "v"(y23), "v"(tbv[t0]), "v"(tbv[t0 + 1]));
+        float d0, d1, d2, d3, d4, d5, d6, d7;
+        asm volatile("v_fma_f32 %2, -%10, %10, %18 clamp\n\t"
+                     "v_fma_f32 %3, -%11, %11, %18 clamp\n\t"
+                     "v_fma_f32 %4, -%12, %12, %18 clamp\n\t"
+                     "v_fma_f32 %5, -%13, %13, %18 clamp\n\t"
+                     "v_fma_f32 %6, -%14, %14, %19 clamp\n\t"
+                     "v_fma_f32 %7, -%15, %15, %19 clamp\n\t"
+                     "v_fma_f32 %8, -%16, %16, %19 clamp\n\t"
+                     "v_fma_f32 %9, -%17, %17, %19 clamp\n\t"
+                     "v_add_f32 %2, %2, %3\n\t"
+                     "v_add_f32 %4, %4, %5\n\t"
+                     "v_add_f32 %6, %6, %7\n\t"
+                     "v_add_f32 %8, %8, %9\n\t"
+                     "v_add_f32 %0, %0, %2\n\t"
+                     "v_add_f32 %1, %1, %6\n\t"
+                     "v_add_f32 %0, %0, %4\n\t"
+                     "v_add_f32 %1, %1, %8"
+                     : "+v"(cand[t0]), "+v"(cand[t0 + 1]), "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                     : "v"(acc[t0][0]), "v"(acc[t0][1]), "v"(acc[t0][2]), "v"(acc[t0][3]), "v"(acc[t0 + 1][0]), "v"(acc[t0 + 1][1]),
+                       "v"(acc[t0 + 1][2]), "v"(acc[t0 + 1][3]), "v"(tbv[t0]), "v"(tbv[t0 + 1]));
     };
     const int G = (n + 15) >> 4;
     const uint4 *A = rfrag + (size_t)pair * ((rp.n_max + 15) >> 4) * 64;
@@ -937,7 +952,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const int pad = n_tiles * A_TILE_GROUPS * 16 - n; // zero rows past the end always count as candidates
 #pragma unroll
     for (int t = 0; t < CNT_TILES; ++t) {
-        float o = cand[t][0] + cand[t][1];
+        float o = cand[t];
         o += __shfl_xor(o, 16, 64);
         o += __shfl_xor(o, 32, 64);
         if (ksl == 0) s_out[16 * t + col] = (uint32_t)((int)o - pad);
@@ -947,13 +962,12 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const long long rec_cnt = (long long)ps.best_min_cnt;
     const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
         const bool live = i < cnt;
         const int cnd = live ? (int)s_out[64 * r + lane] : 0;
         if (cand_out && live) cand_out[i] = cnd;
-        const bool surv = live && ((long long)cnd > rec_cnt || thr * (double)(n - cnd) < rec_score);
-        if (live && !surv) slot_inl[slot_base + slot_r[r]] = -2;
+        const bool surv = live && ((long long)cnd > rec_cnt || thr * (double)(n - cnd) < rec_score); // else: its slot keeps k_solve's -2
         const unsigned long long ball = __ballot(surv);
         if (ball) {
             int base = 0;
@@ -1077,8 +1091,7 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
     const int cnt_ub = (int)(cnt2.x + cnt2.y) + 1; // + 1: the sum of the clamped values may carry a fraction
     const long long rec_cnt = (long long)ps.best_min_cnt;
     const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
-    const bool dead = live && sane && (long long)cnt_ub <= rec_cnt && total_lb * (1.0 - BOUND_SLACK) >= rec_score;
-    if (dead) slot_inl[slot_base + (tag & 0xFFFFFFu)] = -2;
+    const bool dead = live && sane && (long long)cnt_ub <= rec_cnt && total_lb * (1.0 - BOUND_SLACK) >= rec_score; // its slot keeps k_solve's -2
     const bool surv = live && !dead;
     const unsigned long long ball = __ballot(surv);
     if (ball) {

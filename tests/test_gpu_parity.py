@@ -463,8 +463,9 @@ def test_full_size_properties(handle, capi):
 
 @pytest.mark.gpu
 def test_schedule_does_not_change_results(handle, capi, monkeypatch):
-    """The chunk split, the three-stream pipeline and the LO grid are scheduling only: every setting must reproduce the
-    same records bit for bit (single chunk on one stream is the plain sequential schedule)."""
+    """The chunk split (and with it which hypotheses k_count / k_bound retire against which records), the three-stream
+    pipeline, the fp32 bound stage and the LO grid are scheduling only: every setting must reproduce the same records bit
+    for bit (single chunk on one stream, where nothing is ever retired, is the plain sequential schedule)."""
     from mdrp_amd import synth
     B, N = 12, 700
     b = synth.make_batch(4000, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4)
@@ -482,9 +483,11 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
     ref, ref_mask = run()
     assert int(ref["iterations"].min()) == 4000 and int(ref["num_inliers"].min()) > 300
     for env in ({"MDRP_CHUNKS": "512"}, {"MDRP_CHUNKS": "256,1024"}, {"MDRP_CHUNKS": "512", "MDRP_LO_OVERLAP": "0"},
-                {"MDRP_CHUNKS": "128,256,512", "MDRP_LO_OVERLAP_WAVES": "4", "MDRP_LO_AFTER_SOLVE": "1"},
+                {"MDRP_CHUNKS": "128,256,512", "MDRP_LO_OVERLAP_WAVES": "4", "MDRP_LO_AFTER_SOLVE": "0", "MDRP_LO_AFTER_COUNT": "0"},
+                {"MDRP_CHUNKS": "128", "MDRP_BOUND": "0"}, {"MDRP_CHUNKS": "64,128", "MDRP_LO_AFTER_COUNT": "0"},
                 {"MDRP_CHUNKS": "512", "MDRP_LO_THREADS": "256", "MDRP_FINAL_THREADS": "64"}):
-        for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_THREADS", "MDRP_FINAL_THREADS"):
+        for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_AFTER_COUNT", "MDRP_BOUND",
+                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
