@@ -121,8 +121,11 @@ int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x
                         const mdrp_camera *cam2, const mdrp_ransac_opt *ropt, const mdrp_bundle_opt *bopt,
                         mdrp_result *out, uint8_t *inlier_mask);
 
-/* Same work, but nothing is copied back: results stay in the handle's device buffers until mdrp_fetch_results.
- * Used by bench.py so that the timed region holds device work only (inputs resident in HBM). */
+/* Same work on buffers that already live on the device, and nothing is copied back: results stay in the handle's device
+ * buffers until mdrp_fetch_results / mdrp_copy_results_device.  Used by bench.py so that the timed region holds device work
+ * only (inputs resident in HBM).  "async" is relative to the RESULTS, not to the host: the call queues every kernel of a
+ * super-chunk without waiting, but the LO-RANSAC stop rule needs one 48-byte progress record per super-chunk on the host
+ * (one short hipStreamSynchronize each; a single one when max_iterations == min_iterations). */
 int mdrp_estimate_batch_async(mdrp_handle *h, int kind, const double *x1_dev, const double *x2_dev, const double *d1_dev,
                               const double *d2_dev, int batch, int n_max, const int32_t *n_per_pair_host,
                               const mdrp_camera *cam1_host, const mdrp_camera *cam2_host, const mdrp_ransac_opt *ropt,
