@@ -260,7 +260,7 @@ def main():
                          "share_of_step": count_s / dt,
                          "hbm_GBs": (hbm / avg_launch_s / 1e9) if (hbm and avg_launch_s > 0) else None,
                          "hbm_frac": (hbm / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (hbm and avg_launch_s > 0) else None,
-                         "valu_issue_frac_pmc": prof.get("valu_issue_frac"), "mfma_busy_frac_pmc": prof.get("mfma_busy_frac")},
+                         "mfma_busy_frac_pmc": prof.get("mfma_busy_frac"), "valu_active_per_simd_cycle_pmc": prof.get("valu_active_per_simd_cycle")},
             # what the CPU loop would do vs what runs: SURVEY.md 8(d)'s 32 B per evaluation is an ALGORITHMIC figure (kept as an
             # extra key: the correspondences stay in LDS / L2, HBM is not the bound), next to the evaluations actually executed
             "work": {"evals_algorithmic_per_step": acc.get("evals_algorithmic", 0) / args.steps, "algorithmic_bytes_per_eval": BYTES_PER_EVAL,

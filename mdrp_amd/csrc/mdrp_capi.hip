@@ -90,7 +90,7 @@ struct mdrp_handle {
     hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
     hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
-    hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
+    hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
@@ -223,6 +223,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->table_of_pair.p, table_of.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->nper.p, n_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
+    HIPCHK(hipEventRecord(h->ev_tables, s)); // sample tables can be drawn from here on
     if (kind == MDRP_CALIB) {
         HIPCHK(hipMemcpyAsync(h->cams1.p, cam1, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(h->cams2.p, cam2, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
@@ -325,6 +326,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         hipStream_t aux = piped ? h->aux_stream : s, aux2 = piped ? h->aux_stream2 : s;
         int offs[mdrp_handle::NC_MAX] = {0};
         for (int c = 1; c < n_chunks; ++c) offs[c] = offs[c - 1] + (int)lens[c - 1];
+        // The sample tables of the first two chunks do not depend on anything but (seed, N): they are drawn on the (still idle)
+        // LO stream while k_prep runs, so the one-wavefront-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
+        bool presampled[2] = {false, false};
+        if (piped && it0 == 0) {
+            HIPCHK(hipStreamWaitEvent(aux2, h->ev_tables, 0));
+            for (int c = 0; c < 2 && c < n_chunks; ++c) {
+                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, aux2, n_tables, h->table_n.as<int32_t>(),
+                                   h->table_state.as<uint64_t>(), (int)lens[c], ((c & 1) ? h->samples2 : h->samples).as<uint32_t>());
+                HIPCHK(hipEventRecord(h->ev_sampled[c], aux2));
+                presampled[c] = true;
+            }
+        }
         auto issue_solve = [&](int c, hipStream_t st_) -> int {
             RunParams r = rp;
             r.chunk_len = (int)lens[c]; r.chunk_off = offs[c];
@@ -333,8 +346,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             uint32_t *smp = (odd ? h->samples2 : h->samples).as<uint32_t>();
             int32_t *mc = (odd ? h->model_count2 : h->model_count).as<int32_t>();
             HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
-            hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(),
-                               h->table_state.as<uint64_t>(), r.chunk_len, smp);
+            if (c < 2 && presampled[c]) HIPCHK(hipStreamWaitEvent(st_, h->ev_sampled[c], 0));
+            else
+                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(),
+                                   h->table_state.as<uint64_t>(), r.chunk_len, smp);
 #define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
     hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp, \
                        h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc)
@@ -590,6 +605,9 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_counted, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_tables, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[1], hipEventDisableTiming));
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_solved[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scanned[i], hipEventDisableTiming));
@@ -619,6 +637,8 @@ void mdrp_destroy(mdrp_handle *h) {
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
     if (h->ev_counted) (void)hipEventDestroy(h->ev_counted);
+    if (h->ev_tables) (void)hipEventDestroy(h->ev_tables);
+    for (int i = 0; i < 2; ++i) if (h->ev_sampled[i]) (void)hipEventDestroy(h->ev_sampled[i]);
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         if (h->ev_solved[i]) (void)hipEventDestroy(h->ev_solved[i]);
         if (h->ev_scanned[i]) (void)hipEventDestroy(h->ev_scanned[i]);

@@ -6,11 +6,14 @@ usage: pmc_json.py WORKLOAD PAIRS_PER_GPU STEPS_PROFILED pass1.csv [pass2.csv ..
 Per kernel, means per launch over the profiled steps:
   hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE   (KiB -> bytes; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide
                         coalesced reads, MI355X_MICROARCH.md "HBM"; WRITE_SIZE is exact)
-  valu_issue_frac     = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024)    SQ_ACTIVE_INST_* count quad-cycles summed over the
-                        1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GRBM / 8 = the kernel's cycles at the clock it ran at
-  mfma_busy_frac      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024)       (cycles)
-  cycles_per_valu     = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU
-Both fractions are <= 1 by construction; numerator and denominator of each come from the SAME pass."""
+  mfma_busy_frac      = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024)    cycles the matrix pipes were busy / SIMD-cycles of the
+                        kernel (GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GRBM / 8 = the kernel's cycles at the clock it ran at;
+                        1024 SIMDs).  <= 1 by construction; numerator and denominator come from the SAME pass.
+  valu_active_per_simd_cycle = 4 x SQ_ACTIVE_INST_VALU / (GRBM_GUI_ACTIVE / 8 x 1024)    SQ_ACTIVE_INST_* count, per WAVEFRONT, the
+                        quad-cycles it spends in VALU instructions; two wavefronts' 2-cycle fp32 instructions overlap on one SIMD, so
+                        this is an occupancy-weighted activity, NOT an issue-port fraction: it exceeds 1 in fp32-heavy kernels (k_count)
+                        and equals the issue fraction only where every instruction holds the port for its 4 cycles (fp64: k_lo, k_final)
+  cycles_per_valu     = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU"""
 import csv
 import json
 import sys
@@ -43,7 +46,7 @@ for name in names:
         if "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACTIVE"] > 0:
             simd_cycles = mean["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
             if "SQ_ACTIVE_INST_VALU" in mean:
-                out["valu_issue_frac"] = 4.0 * mean["SQ_ACTIVE_INST_VALU"] / simd_cycles
+                out["valu_active_per_simd_cycle"] = 4.0 * mean["SQ_ACTIVE_INST_VALU"] / simd_cycles
             if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
                 out["mfma_busy_frac"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles
             if "SQ_WAVE_CYCLES" in mean:
