@@ -87,6 +87,23 @@ orc_ransac_stats orc_estimate(int kind, const double *x1, const double *x2, cons
                               const double *cam1, const double *cam2, const orc_ransac_opt *ropt,
                               const orc_bundle_opt *bopt, orc_model *best, uint8_t *mask);
 
+/* ---- non-monodepth baselines of the same binary, orc_classic.c.  Bearings row-major k x 3. */
+void orc_fullpiv_qr_Q(double *A /*9 x m col-major, destroyed*/, int m, double *Q /*9 x 9 col-major*/);
+int orc_real_roots(const double *coef /*ascending powers*/, int degree, double *roots);
+int orc_relpose_5pt_E(const double *x1h, const double *x2h, double *E_out /*<=10 x 9 row-major*/);
+int orc_relpose_5pt(const double *x1h, const double *x2h, orc_model *out /*<=40*/);
+int orc_motion_from_essential(const double *E /*row-major*/, const double *x1h, const double *x2h, int npts, orc_model *out /*<=4*/);
+int orc_relpose_7pt(const double *x1h, const double *x2h, double *F_out /*<=3 x 9 row-major*/);
+/* kind 3 = relative pose (blob: q, t), 4 = shared focal (q, t, f1 = f2 = f), 5 = fundamental (F row-major in the first 9 doubles) */
+enum { ORC_RELPOSE = 3, ORC_SHARED_RELPOSE = 4, ORC_FUNDAMENTAL = 5 };
+orc_bundle_stats orc_refine_classic(int kind, const double *x1, const double *x2, int n, orc_model *blob, const orc_bundle_opt *opt,
+                                    const double *weights);
+orc_ransac_stats orc_ransac_classic(int kind, const double *x1, const double *x2, int n, const orc_ransac_opt *opt, orc_model *best,
+                                    uint8_t *mask);
+orc_ransac_stats orc_estimate_classic(int kind, const double *x1, const double *x2, int n, const double *cam1, const double *cam2,
+                                      const double *pp, const orc_ransac_opt *ropt, const orc_bundle_opt *bopt, orc_model *best,
+                                      uint8_t *mask);
+
 #ifdef __cplusplus
 }
 #endif

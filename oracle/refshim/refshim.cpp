@@ -68,6 +68,25 @@ typedef RansacStats (*est_calib_t)(const VV2 &, const VV2 &, const VD &, const V
 typedef RansacStats (*est_focal_t)(const VV2 &, const VV2 &, const VD &, const VD &, const RansacOptions &,
                                    const BundleOptions &, MDIP *, std::vector<char> *);
 typedef void (*draw_sample_t)(size_t, size_t, std::vector<size_t> *, unsigned long &);
+// non-monodepth baselines of the same binary: 5-point, 7-point, 6-point shared focal
+struct M33 { double m[9]; }; // Eigen::Matrix3d, column-major
+struct alignas(32) ImagePair { CameraPose pose; Camera camera1, camera2; };
+typedef std::vector<M33> VM33;
+typedef int (*solver5E_t)(const VV3 &, const VV3 &, VM33 *);
+typedef int (*solver5_t)(const VV3 &, const VV3 &, std::vector<CameraPose> *);
+typedef int (*solver6_t)(const VV3 &, const VV3 &, std::vector<ImagePair> *);
+typedef void (*motion_t)(const M33 &, const VV3 &, const VV3 &, std::vector<CameraPose> *);
+typedef BundleStats (*refine_pose_t)(const VV2 &, const VV2 &, CameraPose *, const BundleOptions &, const VD &);
+typedef BundleStats (*refine_F_t)(const VV2 &, const VV2 &, M33 *, const BundleOptions &, const VD &);
+typedef BundleStats (*refine_ip_t)(const VV2 &, const VV2 &, ImagePair *, const BundleOptions &, const VD &);
+typedef RansacStats (*ransac_pose_t)(const VV2 &, const VV2 &, const RansacOptions &, CameraPose *, std::vector<char> *);
+typedef RansacStats (*ransac_F_t)(const VV2 &, const VV2 &, const RansacOptions &, M33 *, std::vector<char> *);
+typedef RansacStats (*ransac_ip_t)(const VV2 &, const VV2 &, const RansacOptions &, ImagePair *, std::vector<char> *);
+typedef RansacStats (*est_pose_t)(const VV2 &, const VV2 &, const Camera &, const Camera &, const RansacOptions &,
+                                  const BundleOptions &, CameraPose *, std::vector<char> *);
+typedef RansacStats (*est_F_t)(const VV2 &, const VV2 &, const RansacOptions &, const BundleOptions &, M33 *, std::vector<char> *);
+typedef RansacStats (*est_ip_t)(const VV2 &, const VV2 &, const V2 &, const RansacOptions &, const BundleOptions &, ImagePair *,
+                                std::vector<char> *);
 
 void *H = nullptr;
 solver3_t f_solver_calib;
@@ -85,6 +104,19 @@ ransac_focal_t f_ransac_shared, f_ransac_varying;
 est_calib_t f_est_calib;
 est_focal_t f_est_shared, f_est_varying;
 draw_sample_t f_draw;
+solver5E_t f_5pt_E, f_7pt;
+solver5_t f_5pt;
+solver6_t f_6pt;
+motion_t f_motion;
+refine_pose_t f_refine_relpose;
+refine_F_t f_refine_F;
+refine_ip_t f_refine_sf;
+ransac_pose_t f_ransac_relpose;
+ransac_F_t f_ransac_F;
+ransac_ip_t f_ransac_sf;
+est_pose_t f_est_relpose;
+est_F_t f_est_F;
+est_ip_t f_est_sf;
 
 template <typename T> bool sym(T &f, const char *name) {
     f = (T)dlsym(H, name);
@@ -192,7 +224,145 @@ int ref_init(const char *so_path) {
     ok &= sym(f_est_shared, "_ZN7poselib45estimate_shared_focal_monodepth_relative_poseERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKS0_IdSaIdEESB_RKNS_13RansacOptionsERKNS_13BundleOptionsEPNS_18MonoDepthImagePairEPS0_IcSaIcEE");
     ok &= sym(f_est_varying, "_ZN7poselib46estimate_varying_focal_monodepth_relative_poseERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKS0_IdSaIdEESB_RKNS_13RansacOptionsERKNS_13BundleOptionsEPNS_18MonoDepthImagePairEPS0_IcSaIcEE");
     ok &= sym(f_draw, "_ZN7poselib11draw_sampleEmmPSt6vectorImSaImEERm");
+    ok &= sym(f_5pt_E, "_ZN7poselib11relpose_5ptERKSt6vectorIN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEESaIS3_EES7_PS0_INS2_IdLi3ELi3ELi0ELi3ELi3EEESaIS8_EE");
+    ok &= sym(f_5pt, "_ZN7poselib11relpose_5ptERKSt6vectorIN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEESaIS3_EES7_PS0_INS_10CameraPoseESaIS8_EE");
+    ok &= sym(f_7pt, "_ZN7poselib11relpose_7ptERKSt6vectorIN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEESaIS3_EES7_PS0_INS2_IdLi3ELi3ELi0ELi3ELi3EEESaIS8_EE");
+    ok &= sym(f_6pt, "_ZN7poselib24relpose_6pt_shared_focalERKSt6vectorIN5Eigen6MatrixIdLi3ELi1ELi0ELi3ELi1EEESaIS3_EES7_PS0_INS_9ImagePairESaIS8_EE");
+    ok &= sym(f_motion, "_ZN7poselib21motion_from_essentialERKN5Eigen6MatrixIdLi3ELi3ELi0ELi3ELi3EEERKSt6vectorINS1_IdLi3ELi1ELi0ELi3ELi1EEESaIS6_EESA_PS5_INS_10CameraPoseESaISB_EE");
+    ok &= sym(f_refine_relpose, "_ZN7poselib14refine_relposeERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_PNS_10CameraPoseERKNS_13BundleOptionsERKS0_IdSaIdEE");
+    ok &= sym(f_refine_F, "_ZN7poselib18refine_fundamentalERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_PNS2_IdLi3ELi3ELi0ELi3ELi3EEERKNS_13BundleOptionsERKS0_IdSaIdEE");
+    ok &= sym(f_refine_sf, "_ZN7poselib27refine_shared_focal_relposeERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_PNS_9ImagePairERKNS_13BundleOptionsERKS0_IdSaIdEE");
+    ok &= sym(f_ransac_relpose, "_ZN7poselib14ransac_relposeERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKNS_13RansacOptionsEPNS_10CameraPoseEPS0_IcSaIcEE");
+    ok &= sym(f_ransac_F, "_ZN7poselib18ransac_fundamentalERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKNS_13RansacOptionsEPNS2_IdLi3ELi3ELi0ELi3ELi3EEEPS0_IcSaIcEE");
+    ok &= sym(f_ransac_sf, "_ZN7poselib27ransac_shared_focal_relposeERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKNS_13RansacOptionsEPNS_9ImagePairEPS0_IcSaIcEE");
+    ok &= sym(f_est_relpose, "_ZN7poselib22estimate_relative_poseERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKNS_6CameraESA_RKNS_13RansacOptionsERKNS_13BundleOptionsEPNS_10CameraPoseEPS0_IcSaIcEE");
+    ok &= sym(f_est_F, "_ZN7poselib20estimate_fundamentalERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKNS_13RansacOptionsERKNS_13BundleOptionsEPNS2_IdLi3ELi3ELi0ELi3ELi3EEEPS0_IcSaIcEE");
+    ok &= sym(f_est_sf, "_ZN7poselib35estimate_shared_focal_relative_poseERKSt6vectorIN5Eigen6MatrixIdLi2ELi1ELi0ELi2ELi1EEESaIS3_EES7_RKS3_RKNS_13RansacOptionsERKNS_13BundleOptionsEPNS_9ImagePairEPS0_IcSaIcEE");
     return ok ? 0 : -2;
+}
+
+// ---- non-monodepth baselines.  Flat models: pose = q[4] t[3]; shared focal = pose + f (8); F = 9 doubles column-major.
+void ref_draw_samples_k(unsigned long seed, size_t N, int k, int count, long long *out) {
+    unsigned long state = seed;
+    std::vector<size_t> s(k);
+    for (int i = 0; i < count; ++i) {
+        f_draw((size_t)k, N, &s, state);
+        for (int j = 0; j < k; ++j) out[(size_t)k * i + j] = (long long)s[j];
+    }
+}
+int ref_relpose_5pt_E(const double *x1h, const double *x2h, double *out /*10*9*/) {
+    VM33 Es;
+    int n = f_5pt_E(mk3(x1h, 5), mk3(x2h, 5), &Es);
+    for (size_t i = 0; i < Es.size() && i < 10; ++i) memcpy(out + 9 * i, Es[i].m, 72);
+    return n;
+}
+int ref_relpose_5pt(const double *x1h, const double *x2h, double *out /*40*7*/) {
+    std::vector<CameraPose> poses;
+    int n = f_5pt(mk3(x1h, 5), mk3(x2h, 5), &poses);
+    for (size_t i = 0; i < poses.size() && i < 40; ++i) { memcpy(out + 7 * i, poses[i].q, 32); memcpy(out + 7 * i + 4, poses[i].t, 24); }
+    return n;
+}
+int ref_motion_from_essential(const double *E_colmajor, const double *x1h, const double *x2h, int npts, double *out /*4*7*/) {
+    M33 E; memcpy(E.m, E_colmajor, 72);
+    std::vector<CameraPose> poses;
+    f_motion(E, mk3(x1h, npts), mk3(x2h, npts), &poses);
+    for (size_t i = 0; i < poses.size() && i < 4; ++i) { memcpy(out + 7 * i, poses[i].q, 32); memcpy(out + 7 * i + 4, poses[i].t, 24); }
+    return (int)poses.size();
+}
+int ref_relpose_7pt(const double *x1h, const double *x2h, double *out /*3*9*/) {
+    VM33 Fs;
+    int n = f_7pt(mk3(x1h, 7), mk3(x2h, 7), &Fs);
+    for (size_t i = 0; i < Fs.size() && i < 3; ++i) memcpy(out + 9 * i, Fs[i].m, 72);
+    return n;
+}
+int ref_relpose_6pt(const double *x1h, const double *x2h, double *out /*60*8*/) {
+    std::vector<ImagePair> ips;
+    int n = f_6pt(mk3(x1h, 6), mk3(x2h, 6), &ips);
+    for (size_t i = 0; i < ips.size() && i < 60; ++i) {
+        memcpy(out + 8 * i, ips[i].pose.q, 32); memcpy(out + 8 * i + 4, ips[i].pose.t, 24);
+        out[8 * i + 7] = ips[i].camera1.params.empty() ? 0.0 : ips[i].camera1.params[0];
+    }
+    return n;
+}
+namespace {
+void ip_in(const double *g, ImagePair *p) {
+    memcpy(p->pose.q, g, 32); memcpy(p->pose.t, g + 4, 24);
+    p->camera1.model_id = 0; p->camera1.width = 0; p->camera1.height = 0; p->camera1.params = {g[7], 0.0, 0.0};
+    p->camera2 = p->camera1;
+}
+void ip_out(const ImagePair &p, double *g) {
+    memcpy(g, p.pose.q, 32); memcpy(g + 4, p.pose.t, 24);
+    g[7] = p.camera1.params.empty() ? 0.0 : p.camera1.params[0];
+    g[8] = p.camera2.params.empty() ? 0.0 : p.camera2.params[0];
+}
+}
+// kind: 3 = relative pose (model 7), 4 = shared focal (model 9: pose, f1, f2), 5 = fundamental (model 9, column-major)
+void ref_refine_classic(int kind, const double *x1, const double *x2, int n, double *model, const double *bopt8,
+                        const double *weights, int nw, double *stats7) {
+    BundleOptions b = bopt_in(bopt8);
+    VD w = nw ? mkd(weights, nw) : VD();
+    BundleStats s;
+    if (kind == 3) {
+        CameraPose p; memcpy(p.q, model, 32); memcpy(p.t, model + 4, 24);
+        s = f_refine_relpose(mk2(x1, n), mk2(x2, n), &p, b, w);
+        memcpy(model, p.q, 32); memcpy(model + 4, p.t, 24);
+    } else if (kind == 4) {
+        ImagePair ip; ip_in(model, &ip);
+        s = f_refine_sf(mk2(x1, n), mk2(x2, n), &ip, b, w);
+        ip_out(ip, model);
+    } else {
+        M33 F; memcpy(F.m, model, 72);
+        s = f_refine_F(mk2(x1, n), mk2(x2, n), &F, b, w);
+        memcpy(model, F.m, 72);
+    }
+    bstats_out(s, stats7);
+}
+void ref_ransac_classic(int kind, const double *x1, const double *x2, int n, const double *ropt9, double *model,
+                        double *stats5, unsigned char *mask) {
+    RansacOptions r = ropt_in(ropt9);
+    std::vector<char> inl;
+    RansacStats s;
+    if (kind == 3) {
+        CameraPose p; memcpy(p.q, model, 32); memcpy(p.t, model + 4, 24);
+        s = f_ransac_relpose(mk2(x1, n), mk2(x2, n), r, &p, &inl);
+        memcpy(model, p.q, 32); memcpy(model + 4, p.t, 24);
+    } else if (kind == 4) {
+        ImagePair ip; ip_in(model, &ip);
+        s = f_ransac_sf(mk2(x1, n), mk2(x2, n), r, &ip, &inl);
+        ip_out(ip, model);
+    } else {
+        M33 F; memcpy(F.m, model, 72);
+        s = f_ransac_F(mk2(x1, n), mk2(x2, n), r, &F, &inl);
+        memcpy(model, F.m, 72);
+    }
+    rstats_out(s, stats5);
+    mask_out(inl, mask, n);
+}
+// cam1/cam2 (flat, as ref_estimate) for kind 3; pp[2] for kind 4
+void ref_estimate_classic(int kind, const double *x1, const double *x2, int n, const double *cam1, const double *cam2,
+                          const double *pp, const double *ropt9, const double *bopt8, double *model, double *stats5,
+                          unsigned char *mask) {
+    RansacOptions r = ropt_in(ropt9);
+    BundleOptions b = bopt_in(bopt8);
+    std::vector<char> inl;
+    RansacStats s;
+    if (kind == 3) {
+        CameraPose p; memcpy(p.q, model, 32); memcpy(p.t, model + 4, 24);
+        Camera c1 = cam_in(cam1), c2 = cam_in(cam2);
+        s = f_est_relpose(mk2(x1, n), mk2(x2, n), c1, c2, r, b, &p, &inl);
+        memcpy(model, p.q, 32); memcpy(model + 4, p.t, 24);
+    } else if (kind == 4) {
+        ImagePair ip; ip_in(model, &ip);
+        V2 c; c.v[0] = pp[0]; c.v[1] = pp[1];
+        s = f_est_sf(mk2(x1, n), mk2(x2, n), c, r, b, &ip, &inl);
+        ip_out(ip, model);
+    } else {
+        M33 F; memcpy(F.m, model, 72);
+        s = f_est_F(mk2(x1, n), mk2(x2, n), r, b, &F, &inl);
+        memcpy(model, F.m, 72);
+    }
+    rstats_out(s, stats5);
+    mask_out(inl, mask, n);
 }
 
 // count samples of size 3 drawn consecutively from rng state `seed`; out: count*3 indices

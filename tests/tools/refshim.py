@@ -178,3 +178,100 @@ def estimate(kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None, initial=None, s
                        _p(model), _p(st), mask.ctypes.data_as(C.c_void_p))
     lib().ref_set_score_initial(C.c_int(0))
     return model, st, mask
+
+
+# ---- non-monodepth baselines of the same binary: kind 3 = 5-point relative pose (model: q, t),
+# ---- 4 = 6-point shared focal (q, t, f1, f2), 5 = 7-point fundamental (F, row-major on this side)
+def draw_samples_k(seed, N, k, count):
+    out = np.zeros((count, k), dtype=np.int64)
+    lib().ref_draw_samples_k(C.c_ulong(seed), C.c_size_t(N), C.c_int(k), C.c_int(count), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def relpose_5pt_E(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((10, 9))
+    n = lib().ref_relpose_5pt_E(_p(x1h), _p(x2h), _p(out))
+    return out[:n].reshape(-1, 3, 3).transpose(0, 2, 1).copy()
+
+
+def relpose_5pt(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((40, 7))
+    n = lib().ref_relpose_5pt(_p(x1h), _p(x2h), _p(out))
+    return out[:n]
+
+
+def motion_from_essential(E, x1h, x2h):
+    Ec = f64(np.asarray(E).T.reshape(-1))
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((4, 7))
+    n = lib().ref_motion_from_essential(_p(Ec), _p(x1h), _p(x2h), C.c_int(len(x1h)), _p(out))
+    return out[:n]
+
+
+def relpose_7pt(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((3, 9))
+    n = lib().ref_relpose_7pt(_p(x1h), _p(x2h), _p(out))
+    return out[:n].reshape(-1, 3, 3).transpose(0, 2, 1).copy()
+
+
+def relpose_6pt(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((60, 8))
+    n = lib().ref_relpose_6pt(_p(x1h), _p(x2h), _p(out))
+    return out[:n]
+
+
+def _classic_model(kind, initial=None):
+    if initial is not None:
+        m = f64(initial).copy()
+        return f64(m.reshape(3, 3).T.reshape(-1)) if kind == 5 else m
+    m = np.zeros(9)
+    if kind != 5:
+        m[0] = 1.0
+        m[7] = m[8] = 1.0
+    return m
+
+
+def _classic_out(kind, m):
+    return m.reshape(3, 3).T.reshape(-1).copy() if kind == 5 else (m[:7].copy() if kind == 3 else m.copy())
+
+
+def refine_classic(kind, x1, x2, model, bo, weights=None):
+    x1, x2 = f64(x1), f64(x2)
+    m = np.zeros(9)
+    mm = _classic_model(kind, model)
+    m[:len(mm)] = mm
+    st = np.zeros(7)
+    w = f64(weights) if weights is not None else np.zeros(1)
+    nw = len(weights) if weights is not None else 0
+    lib().ref_refine_classic(C.c_int(kind), _p(x1), _p(x2), C.c_int(len(x1)), _p(m), _p(bo), _p(w), C.c_int(nw), _p(st))
+    return _classic_out(kind, m), st
+
+
+def ransac_classic(kind, x1, x2, ro):
+    x1, x2 = f64(x1), f64(x2)
+    m = _classic_model(kind)
+    st = np.zeros(5)
+    mask = np.zeros(len(x1), dtype=np.uint8)
+    lib().ref_ransac_classic(C.c_int(kind), _p(x1), _p(x2), C.c_int(len(x1)), _p(ro), _p(m), _p(st), mask.ctypes.data_as(C.c_void_p))
+    return _classic_out(kind, m), st, mask
+
+
+def estimate_classic(kind, x1, x2, ro, bo, cam1=None, cam2=None, pp=(0.0, 0.0), score_initial=False, initial=None):
+    x1, x2 = f64(x1), f64(x2)
+    m = np.zeros(9)
+    mm = _classic_model(kind, initial)
+    m[:len(mm)] = mm
+    lib().ref_set_score_initial(C.c_int(int(bool(score_initial))))
+    st = np.zeros(5)
+    mask = np.zeros(len(x1), dtype=np.uint8)
+    c1 = cam1 if cam1 is not None else np.zeros(8)
+    c2 = cam2 if cam2 is not None else np.zeros(8)
+    ppv = f64(pp)
+    lib().ref_estimate_classic(C.c_int(kind), _p(x1), _p(x2), C.c_int(len(x1)), _p(c1), _p(c2), _p(ppv), _p(ro), _p(bo), _p(m),
+                               _p(st), mask.ctypes.data_as(C.c_void_p))
+    lib().ref_set_score_initial(C.c_int(0))
+    return _classic_out(kind, m), st, mask
