@@ -35,6 +35,9 @@ WORKLOADS = {
     # SURVEY.md §8(d) C2 also asks for the outlier-free shape
     "calib_p3p_n2000_i10k_clean": (0, 2000, 10000, 0.0, False, None),
     "calib_shift_n2000_i10k_clean": (0, 2000, 10000, 0.0, True, None),
+    # non-monodepth baselines on the same kernels: 5-point relative pose, 7-point fundamental matrix
+    "relpose_5pt_n2000_i10k": (3, 2000, 10000, 0.5, False, None),
+    "fundamental_7pt_n2000_i10k": (5, 2000, 10000, 0.5, False, None),
 }
 
 
@@ -68,7 +71,10 @@ def _cpu_worker(args):
     po.lib()
     t0 = time.perf_counter()
     for i in range(count):
-        po.estimate(kind, b["x1"][i], b["x2"][i], b["d1"][i], b["d2"][i], ro, bo, cam if kind == 0 else None, cam if kind == 0 else None)
+        if kind >= 3:
+            po.estimate_classic(kind, b["x1"][i], b["x2"][i], ro, bo, cam, cam)
+        else:
+            po.estimate(kind, b["x1"][i], b["x2"][i], b["d1"][i], b["d2"][i], ro, bo, cam if kind == 0 else None, cam if kind == 0 else None)
     return time.perf_counter() - t0
 
 
@@ -183,10 +189,13 @@ def main():
     rec_local = torch.zeros((per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev)  # this rank's block of the gather
     rec_all = torch.empty((world * per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
 
+    with_cams = kind in (0, 3)
+    classic = kind >= 3
+
     def step():
         if B > 0:
-            h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, n, ro, bo, None,
-                                    cams if kind == 0 else None, cams if kind == 0 else None, mask.data_ptr())
+            h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), 0 if classic else d1.data_ptr(), 0 if classic else d2.data_ptr(), B, n, ro, bo, None,
+                                    cams if with_cams else None, cams if with_cams else None, mask.data_ptr())
         if world > 1:  # final gather of the pose records over RCCL/xGMI, device to device: 136 B per pair
             if B > 0:
                 h.copy_results_device(rec_local.data_ptr(), B)
@@ -222,10 +231,10 @@ def main():
     host_rate = None
     if world == 1 and args.host_steps > 0 and B > 0:  # the same step through mdrp_estimate_batch with HOST buffers: H2D of the
         xs = [b["x1"], b["x2"], b["d1"], b["d2"]]      # correspondences (48 B each) and D2H of records + masks inside the timed region
-        h.estimate_batch(kind, *xs, ro, bo, None, cams if kind == 0 else None, cams if kind == 0 else None)
+        h.estimate_batch(kind, *xs, ro, bo, None, cams if with_cams else None, cams if with_cams else None)
         th = time.perf_counter()
         for _ in range(args.host_steps):
-            h.estimate_batch(kind, *xs, ro, bo, None, cams if kind == 0 else None, cams if kind == 0 else None)
+            h.estimate_batch(kind, *xs, ro, bo, None, cams if with_cams else None, cams if with_cams else None)
         host_rate = B * args.host_steps / (time.perf_counter() - th)
 
     if rank == 0:
@@ -233,7 +242,7 @@ def main():
         value = pairs / dt
         from mdrp_amd import synth
         from mdrp_amd.poselib import _quat_to_R
-        R_err = float(np.median([synth.rotation_error_deg(g["R"], _quat_to_R(r["model"]["q"])) for r, g in zip(res[:64], b["gt"][:64])]))
+        R_err = None if kind == 5 else float(np.median([synth.rotation_error_deg(g["R"], _quat_to_R(r["model"]["q"])) for r, g in zip(res[:64], b["gt"][:64])]))
         # ---- roofline of the dominant scoring kernel, k_count: executed MFMA work / its own launch durations (HIP events)
         cl = max(acc.get("count_launches", 0), 1)
         count_s = acc.get("count_ms", 0.0) / 1e3
@@ -247,7 +256,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "pairs_per_gpu": per, "total_pairs": total, "correspondences": n, "ransac_iterations": iters,
-                       "outlier_fraction": of, "estimator": ["calibrated", "shared_focal", "varying_focal"][kind],
+                       "outlier_fraction": of, "estimator": ["calibrated", "shared_focal", "varying_focal", "relative_pose_5pt", "shared_focal_6pt", "fundamental_7pt"][kind],
                        "monodepth_estimate_shift": es,
                        "parallelism": f"{'ceil(P/G) contiguous pairs per rank' if strong else 'fixed pairs per rank'} x{world}, device-side all_gather of the 136-B records"},
             # bound: the matrix pipe.  achieved = 64 flop x the (model x correspondence) evaluations k_count EXECUTED (16 x 16 tiles,

@@ -24,7 +24,12 @@
 extern "C" {
 #endif
 
-enum { MDRP_CALIB = 0, MDRP_SHARED_FOCAL = 1, MDRP_VARYING_FOCAL = 2 };
+enum { MDRP_CALIB = 0, MDRP_SHARED_FOCAL = 1, MDRP_VARYING_FOCAL = 2,
+       /* non-monodepth baselines of the same binary on the same kernels (d1 = d2 = NULL):
+        * estimate_relative_pose (wheel _core.pyi:504-529; 5-point, cameras as for MDRP_CALIB; model: q, t) and
+        * estimate_fundamental (_core.pyi:309-323; 7-point; model: F row-major in the first nine doubles of mdrp_model).
+        * 4 is reserved for estimate_shared_focal_relative_pose (6-point), not built. */
+       MDRP_RELPOSE_5PT = 3, MDRP_FUNDAMENTAL_7PT = 5 };
 
 enum { /* return codes */
     MDRP_OK = 0,
@@ -142,8 +147,15 @@ int mdrp_copy_results_device(mdrp_handle *h, void *dst_dev, int batch);
 int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const double *x2h, const double *d1,
                       const double *d2, int count, mdrp_model *out, int32_t *n_out);
 
+/* The baselines' minimal solvers (relpose_5pt @0x14ae80, relpose_7pt @0x4ff2e0) on `count` independent problems, host memory.
+ * x1h, x2h: [count][K][3] unit bearings, K = 5 / 7.  out: [count][M] models, M = 10 / 3 (solutions in the reference's order);
+ * n_out: [count]. */
+int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const double *x2h, int count, mdrp_model *out,
+                              int32_t *n_out);
+
 /* Sampson/MSAC sweep only (compute_sampson_msac_score @0x4f61d0 / @0x4f65d0): `num_models` models against the n
- * normalised correspondences of ONE pair.  kind selects pose scoring with cheirality (MDRP_CALIB) or F scoring.
+ * normalised correspondences of ONE pair.  kind selects pose scoring with cheirality (MDRP_CALIB, MDRP_RELPOSE_5PT), F built
+ * from pose and focals (focal estimators), or the raw F of MDRP_FUNDAMENTAL_7PT models.
  * All pointers in `mem_space`.  scores: [num_models], counts: [num_models]. */
 int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model *models, int num_models,
                       const double *x1, const double *x2, int n, double sq_threshold, double *scores, int32_t *counts);
@@ -155,7 +167,8 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
                           const double *x2, int n, double sq_threshold, int32_t *candidates);
 
 /* Hybrid LM refinement of `count` models, each over the correspondences of ONE pair (refine_monodepth_*relpose
- * @0x261030/@0x2592e0/@0x260fa0).  Host memory.  models in/out. */
+ * @0x261030/@0x2592e0/@0x260fa0).  Host memory.  models in/out.  For MDRP_RELPOSE_5PT / MDRP_FUNDAMENTAL_7PT: the Sampson-only
+ * refine_relpose @0x258f50 / refine_fundamental @0x2590d0 (d1, d2, scale_reproj, weight_sampson, estimate_shift ignored). */
 int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,
                        const double *d1, const double *d2, int n, double scale_reproj, double weight_sampson,
                        const mdrp_bundle_opt *opt, int estimate_shift, double *final_cost /*[count] or NULL*/);

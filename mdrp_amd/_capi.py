@@ -13,13 +13,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDRP_LIB") or os.path.join(_HERE, "libmdrp_hip.so")  # MDRP_LIB: experiment builds (tools/)
 
 CALIB, SHARED_FOCAL, VARYING_FOCAL = 0, 1, 2
+RELPOSE_5PT, FUNDAMENTAL_7PT = 3, 5  # non-monodepth baselines (d1 = d2 = None)
 MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
     "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
     "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_copy_results_device", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_refine_models",
-    "mdrp_last_sweep_stats", "mdrp_last_stats",
+    "mdrp_last_sweep_stats", "mdrp_last_stats", "mdrp_classic_solver_batch",
 )
 
 
@@ -99,6 +100,7 @@ def load_library():
                                            C.POINTER(BundleOpt), C.c_int, vp]
         lib.mdrp_last_sweep_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.mdrp_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        lib.mdrp_classic_solver_batch.argtypes = [vp, C.c_int, dp, dp, C.c_int, vp, vp]
         _lib = lib
         return lib
 
@@ -184,11 +186,16 @@ class Handle:
     def estimate_batch(self, kind, x1, x2, d1, d2, ropt, bopt, n_per_pair=None, cam1=None, cam2=None, want_mask=True):
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
         x2 = np.ascontiguousarray(x2, dtype=np.float64)
-        d1 = np.ascontiguousarray(d1, dtype=np.float64)
-        d2 = np.ascontiguousarray(d2, dtype=np.float64)
-        if x1.ndim != 3 or x1.shape[2] != 2 or x2.shape != x1.shape or d1.shape != x1.shape[:2] or d2.shape != d1.shape:
-            raise ValueError("expected x1,x2 (B,N,2) and d1,d2 (B,N)")
-        B, N = d1.shape
+        if x1.ndim != 3 or x1.shape[2] != 2 or x2.shape != x1.shape:
+            raise ValueError("expected x1,x2 (B,N,2)")
+        if kind >= RELPOSE_5PT:
+            d1 = d2 = None  # the non-monodepth baselines take no depths
+        else:
+            d1 = np.ascontiguousarray(d1, dtype=np.float64)
+            d2 = np.ascontiguousarray(d2, dtype=np.float64)
+            if d1.shape != x1.shape[:2] or d2.shape != d1.shape:
+                raise ValueError("expected d1,d2 (B,N)")
+        B, N = x1.shape[:2]
         npp = None if n_per_pair is None else np.ascontiguousarray(n_per_pair, dtype=np.int32)
         out = np.zeros(B, dtype=RESULT_DTYPE)
         mask = np.zeros((B, N), dtype=np.uint8) if want_mask else None
@@ -206,7 +213,7 @@ class Handle:
         c1 = None if cam1 is None else np.ascontiguousarray(cam1, dtype=CAMERA_DTYPE)
         c2 = None if cam2 is None else np.ascontiguousarray(cam2, dtype=CAMERA_DTYPE)
         _check(self._lib, self._lib.mdrp_estimate_batch_async(self._h, kind, C.c_void_p(x1_ptr), C.c_void_p(x2_ptr),
-                                                              C.c_void_p(d1_ptr), C.c_void_p(d2_ptr), int(batch), int(n_max),
+                                                              C.c_void_p(d1_ptr) if d1_ptr else None, C.c_void_p(d2_ptr) if d2_ptr else None, int(batch), int(n_max),
                                                               _ptr(npp), _ptr(c1), _ptr(c2), C.byref(ropt), C.byref(bopt),
                                                               C.c_void_p(mask_ptr) if mask_ptr else None))
 
@@ -243,6 +250,18 @@ class Handle:
                                                       _ptr(out), _ptr(n_out)))
         return out, n_out
 
+    def classic_solver_batch(self, kind, x1h, x2h):
+        """relpose_5pt (kind 3: x1h, x2h (count, 5, 3) unit bearings -> up to 10 poses) / relpose_7pt (kind 5: (count, 7, 3) ->
+        up to 3 fundamental matrices in the models' first nine doubles)"""
+        K, M = (5, 10) if kind == RELPOSE_5PT else (7, 3)
+        x1h = np.ascontiguousarray(x1h, dtype=np.float64).reshape(-1, K, 3)
+        x2h = np.ascontiguousarray(x2h, dtype=np.float64).reshape(-1, K, 3)
+        count = len(x1h)
+        out = np.zeros((count, M), dtype=MODEL_DTYPE)
+        n_out = np.zeros(count, dtype=np.int32)
+        _check(self._lib, self._lib.mdrp_classic_solver_batch(self._h, int(kind), _ptr(x1h), _ptr(x2h), count, _ptr(out), _ptr(n_out)))
+        return out, n_out
+
     def score_models(self, kind, models, x1, x2, sq_threshold):
         models = np.ascontiguousarray(models, dtype=MODEL_DTYPE).reshape(-1)
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
@@ -272,8 +291,8 @@ class Handle:
         models = np.ascontiguousarray(models, dtype=MODEL_DTYPE).reshape(-1).copy()
         x1 = np.ascontiguousarray(x1, dtype=np.float64)
         x2 = np.ascontiguousarray(x2, dtype=np.float64)
-        d1 = np.ascontiguousarray(d1, dtype=np.float64)
-        d2 = np.ascontiguousarray(d2, dtype=np.float64)
+        d1 = None if d1 is None else np.ascontiguousarray(d1, dtype=np.float64)
+        d2 = None if d2 is None else np.ascontiguousarray(d2, dtype=np.float64)
         cost = np.zeros(len(models))
         _check(self._lib, self._lib.mdrp_refine_models(self._h, int(kind), _ptr(models), len(models), _ptr(x1), _ptr(x2), _ptr(d1),
                                                        _ptr(d2), len(x1), float(scale_reproj), float(weight_sampson), C.byref(bopt),
@@ -295,6 +314,19 @@ def default_handle(device=0):
     if h is None:
         h = handles[device] = Handle(device)
     return h
+
+
+def fundamental_to_model(F):
+    """a 3 x 3 fundamental matrix as an MDRP_FUNDAMENTAL_7PT model record (row-major in the first nine doubles)"""
+    m = np.zeros((), dtype=MODEL_DTYPE)
+    flat = np.asarray(F, dtype=np.float64).reshape(9)
+    m["q"] = flat[:4]; m["t"] = flat[4:7]; m["scale"] = flat[7]; m["shift1"] = flat[8]
+    m["f1"] = m["f2"] = 1.0
+    return m
+
+
+def model_to_fundamental(m):
+    return np.r_[m["q"], m["t"], m["scale"], m["shift1"]].reshape(3, 3).copy()
 
 
 def model_to_array(m):

@@ -12,6 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mdrp_capi.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "mdrp_kernels.h"), os.path.join(HERE, "csrc", "mdrp_math.h"),
+        os.path.join(HERE, "csrc", "mdrp_classic.h"), os.path.join(HERE, "csrc", "mdrp_classic_math.h"),
         os.path.join(HERE, "..", "include", "mdrp.h")]
 OUT = os.path.join(HERE, "libmdrp_hip.so")
 _MARK = b"MDRP_SRC_HASH="
@@ -25,7 +26,7 @@ def hipcc():
 
 
 def source_hash():
-    """sha256 over the four source files (name + content), first 16 hex digits"""
+    """sha256 over the source files (name + content), first 16 hex digits"""
     h = hashlib.sha256()
     for d in DEPS:
         h.update(os.path.basename(d).encode() + b"\0")

@@ -3,6 +3,7 @@
 // correspondence count (one sample table per distinct N) and reads back one 16-byte progress record per chunk.
 #include "../../include/mdrp.h"
 #include "mdrp_kernels.h"
+#include "mdrp_classic.h"
 
 #include <algorithm>
 #include <cmath>
@@ -101,6 +102,7 @@ struct mdrp_handle {
     DevBuf rfrag;              // MFMA A fragments of the correspondences (k_prep): [pair][ceil(n_max/16)][64] x 16 B
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
+    DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -134,6 +136,23 @@ namespace {
     do {                                                                                                             \
         if ((threads) == 64) MDRP_LM_DISPATCH_T(KERNEL, 64, kind, shift, grid, smem, stream, __VA_ARGS__);           \
         else MDRP_LM_DISPATCH_T(KERNEL, 256, kind, shift, grid, smem, stream, __VA_ARGS__);                          \
+    } while (0)
+
+// scoring sweeps: pose models with cheirality (calibrated monodepth, 5-point), F = diag(1,1,f2) E diag(1,1,f1) (focal estimators),
+// or a raw fundamental matrix in the model's first nine doubles (7-point)
+#define MDRP_SWEEP_DISPATCH(KERNEL, kind, grid, block, smem, stream, ...)                                                       \
+    do {                                                                                                                        \
+        if ((kind) == MDRP_CALIB || (kind) == MDRP_RELPOSE_5PT) hipLaunchKernelGGL((KERNEL<true, false>), grid, block, smem, stream, __VA_ARGS__); \
+        else if ((kind) == MDRP_FUNDAMENTAL_7PT) hipLaunchKernelGGL((KERNEL<false, true>), grid, block, smem, stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<false, false>), grid, block, smem, stream, __VA_ARGS__);                                 \
+    } while (0)
+// classic LM kernels: (kind, threads per problem)
+#define MDRP_CLASSIC_LM_DISPATCH(KERNEL, threads, kind, grid, smem, stream, ...)                                                 \
+    do {                                                                                                                        \
+        if ((kind) == MDRP_RELPOSE_5PT && (threads) == 64) hipLaunchKernelGGL((KERNEL<CLASSIC_RELPOSE, 64>), grid, dim3(64), smem, stream, __VA_ARGS__); \
+        else if ((kind) == MDRP_RELPOSE_5PT) hipLaunchKernelGGL((KERNEL<CLASSIC_RELPOSE, 256>), grid, dim3(256), smem, stream, __VA_ARGS__); \
+        else if ((threads) == 64) hipLaunchKernelGGL((KERNEL<CLASSIC_FUND, 64>), grid, dim3(64), smem, stream, __VA_ARGS__);      \
+        else hipLaunchKernelGGL((KERNEL<CLASSIC_FUND, 256>), grid, dim3(256), smem, stream, __VA_ARGS__);                        \
     } while (0)
 
 int env_int(const char *name, int dflt) {
@@ -171,6 +190,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
              const mdrp_bundle_opt *bo, int chunk_cap, uint8_t *mask_dev, ResultDev *results_dev) {
     hipStream_t s = h->stream;
     const int est_shift = (kind == MDRP_CALIB && ro->monodepth_estimate_shift) ? 1 : 0;
+    const bool classic = kind >= MDRP_RELPOSE_5PT;              // non-monodepth baselines (mdrp_classic.h)
+    const int mps = kind == MDRP_RELPOSE_5PT ? 12 : 4;          // model slots per sample
+    const int ssz = kind == MDRP_RELPOSE_5PT ? 5 : (kind == MDRP_FUNDAMENTAL_7PT ? 7 : 3); // sample size
 
     // ---- group pairs by correspondence count: one sample table per distinct N
     std::vector<int32_t> table_of(batch), tab_n;
@@ -185,12 +207,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int n_tables = (int)tab_n.size();
     std::vector<uint64_t> tab_state(n_tables, ro->seed);
 
-    const size_t slots = (size_t)batch * chunk_cap * 4;
+    const size_t slots = (size_t)batch * chunk_cap * mps;
     int rc;
     if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * batch * n_max))) return rc;
-    if ((rc = h->dep.ensure(sizeof(double) * 2 * batch * n_max))) return rc;
+    if (!classic && (rc = h->dep.ensure(sizeof(double) * 2 * batch * n_max))) return rc;
     if ((rc = h->st.ensure(sizeof(PairState) * batch))) return rc;
-    if ((rc = h->samples.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
+    if ((rc = h->samples.ensure(sizeof(uint32_t) * ssz * (size_t)n_tables * chunk_cap))) return rc;
     if ((rc = h->table_n.ensure(sizeof(int32_t) * n_tables))) return rc;
     if ((rc = h->table_state.ensure(sizeof(uint64_t) * n_tables))) return rc;
     if ((rc = h->table_of_pair.ensure(sizeof(int32_t) * batch))) return rc;
@@ -206,7 +228,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->tags2.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->tags_s.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->tags2_s.ensure(sizeof(uint32_t) * slots))) return rc;
-    if ((rc = h->samples2.ensure(sizeof(uint32_t) * 3 * (size_t)n_tables * chunk_cap))) return rc;
+    if ((rc = h->samples2.ensure(sizeof(uint32_t) * ssz * (size_t)n_tables * chunk_cap))) return rc;
     if ((rc = h->tags_v.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
     if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
@@ -224,7 +246,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     HIPCHK(hipMemcpyAsync(h->table_of_pair.p, table_of.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->nper.p, n_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(h->ev_tables, s)); // sample tables can be drawn from here on
-    if (kind == MDRP_CALIB) {
+    if (kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT) {
         HIPCHK(hipMemcpyAsync(h->cams1.p, cam1, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(h->cams2.p, cam2, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
     }
@@ -240,12 +262,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     rp.final_max_it = (int)std::min<uint64_t>(bo->max_iterations, 1u << 30); rp.final_loss = bo->loss_type;
     rp.grad_tol = bo->gradient_tol; rp.step_tol = bo->step_tol; rp.lambda0 = bo->initial_lambda;
     rp.lambda_min = bo->min_lambda; rp.lambda_max = bo->max_lambda;
-    rp.chunk_len = chunk_cap; rp.chunk_off = 0; rp.slot_stride = chunk_cap * 4; rp.super_len = chunk_cap; rp.chunk_start = 0;
+    rp.chunk_len = chunk_cap; rp.chunk_off = 0; rp.slot_stride = chunk_cap * mps; rp.super_len = chunk_cap; rp.chunk_start = 0;
+    rp.mps = mps; rp.sample_sz = ssz;
 
-    hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, h->nper.as<int32_t>(),
-                       h->table_of_pair.as<int32_t>(), h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error,
-                       ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>(),
-                       h->rfrag.as<uint4>());
+    if (classic)
+        hipLaunchKernelGGL(kc_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, h->nper.as<int32_t>(), h->table_of_pair.as<int32_t>(),
+                           h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error, bo->loss_scale, h->pts.as<double>(),
+                           h->st.as<PairState>(), h->rfrag.as<uint4>());
+    else
+        hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, h->nper.as<int32_t>(),
+                           h->table_of_pair.as<int32_t>(), h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error,
+                           ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>(),
+                           h->rfrag.as<uint4>());
     HIPCHK(hipGetLastError());
 
     // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
@@ -260,6 +288,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
+    // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
+    const size_t lo_mask_rows = (size_t)h->num_cu * 8;
+    if (kind == MDRP_RELPOSE_5PT && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = SCORE_TILE_BYTES;
     int64_t sum_n = 0;
@@ -292,7 +323,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         }
     }
     uint64_t max_needed = 0;
-    rp.slot_stride = chunk_cap * 4;
+    rp.slot_stride = chunk_cap * mps;
     const size_t lo_plan_ints = 3 * (size_t)batch + 2;
     while (true) {
         uint64_t lens[mdrp_handle::NC_MAX] = {0};
@@ -328,12 +359,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         for (int c = 1; c < n_chunks; ++c) offs[c] = offs[c - 1] + (int)lens[c - 1];
         // The sample tables of the first two chunks do not depend on anything but (seed, N): they are drawn on the (still idle)
         // LO stream while k_prep runs, so the one-wavefront-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
+        auto launch_samples = [&](hipStream_t st_, int len_, uint32_t *smp_) {
+            if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+        };
         bool presampled[2] = {false, false};
         if (piped && it0 == 0) {
             HIPCHK(hipStreamWaitEvent(aux2, h->ev_tables, 0));
             for (int c = 0; c < 2 && c < n_chunks; ++c) {
-                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, aux2, n_tables, h->table_n.as<int32_t>(),
-                                   h->table_state.as<uint64_t>(), (int)lens[c], ((c & 1) ? h->samples2 : h->samples).as<uint32_t>());
+                launch_samples(aux2, (int)lens[c], ((c & 1) ? h->samples2 : h->samples).as<uint32_t>());
                 HIPCHK(hipEventRecord(h->ev_sampled[c], aux2));
                 presampled[c] = true;
             }
@@ -347,9 +382,17 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             int32_t *mc = (odd ? h->model_count2 : h->model_count).as<int32_t>();
             HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
             if (c < 2 && presampled[c]) HIPCHK(hipStreamWaitEvent(st_, h->ev_sampled[c], 0));
-            else
-                hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(),
-                                   h->table_state.as<uint64_t>(), r.chunk_len, smp);
+            else launch_samples(st_, r.chunk_len, smp);
+            if (classic) {
+                const dim3 sgrid((r.chunk_len + 63) / 64, batch);
+                if (kind == MDRP_RELPOSE_5PT)
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
+                                       h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+                else
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
+                                       h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+                return MDRP_OK;
+            }
 #define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
     hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp, \
                        h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc)
@@ -388,17 +431,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
                 HIPCHK(hipMemsetAsync(h->surv_count.p, 0, sizeof(int32_t) * batch, s));
                 hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>());
-                const dim3 cgrid((unsigned)batch * (unsigned)((len * 4 + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
+                const dim3 cgrid((unsigned)batch * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                 unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
                 HIPCHK(hipEventRecord(c0, s));
-                if (kind == MDRP_CALIB)
-                    hipLaunchKernelGGL(k_count<true>, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                                       tags_c, mcount_c, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
-                                       h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
-                else
-                    hipLaunchKernelGGL(k_count<false>, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                                       tags_c, mcount_c, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
-                                       h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
+                MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                                    tags_c, mcount_c, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
+                                    h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
                 HIPCHK(hipEventRecord(c1, s));
                 h->count_launches++;
                 if (pending_lo) {
@@ -415,16 +453,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     HIPCHK(hipMemsetAsync(h->surv2_count.p, 0, sizeof(int32_t) * batch, s));
                     hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1,
                                        BND_THREADS, h->cplan.as<int32_t>());
-                    const dim3 bgrid((unsigned)batch * (unsigned)((len * 4 + BND_THREADS - 1) / BND_THREADS));
+                    const dim3 bgrid((unsigned)batch * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
                     unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
-                    if (kind == MDRP_CALIB)
-                        hipLaunchKernelGGL(k_bound<true>, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
-                                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
-                                           tags_b, h->surv2_count.as<int32_t>(), bstats);
-                    else
-                        hipLaunchKernelGGL(k_bound<false>, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
-                                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
-                                           tags_b, h->surv2_count.as<int32_t>(), bstats);
+                    MDRP_SWEEP_DISPATCH(k_bound, kind, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
+                                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                                        tags_b, h->surv2_count.as<int32_t>(), bstats);
                     surv_tags = tags_b; surv_cnt = h->surv2_count.as<int32_t>();
                 }
                 hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, surv_cnt, surv_tags, tags_sc);
@@ -432,19 +465,20 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, mcount_c, plan, totals);
                 HIPCHK(hipEventRecord(e0, s));
                 const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
-                                                        : (unsigned)batch * (unsigned)((len * 4 + SCORE_THREADS - 1) / SCORE_THREADS));
-                if (kind == MDRP_CALIB)
-                    hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
-                else
-                    hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                       h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+                                                        : (unsigned)batch * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
+                MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                                    h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 HIPCHK(hipEventRecord(e1, s));
                 h->sweep_launches++;
             }
-            hipLaunchKernelGGL(k_scan, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                               h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
-                               reinterpret_cast<unsigned long long *>(cnt + 10));
+            if (mps == 12)
+                hipLaunchKernelGGL(k_scan<12>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
+                                   h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
+                                   reinterpret_cast<unsigned long long *>(cnt + 10));
+            else
+                hipLaunchKernelGGL(k_scan<4>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
+                                   h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
+                                   reinterpret_cast<unsigned long long *>(cnt + 10));
             // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
             int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
             const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
@@ -457,6 +491,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
             const RunParams rp_lo = rp;
             auto launch_lo = [=]() -> int {
+                if (classic) {
+                    MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), 0, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
+                                             h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c,
+                                             h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max);
+                    return MDRP_OK;
+                }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
                                  h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
                                  trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max));
@@ -495,8 +535,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         max_needed = h->progress_host->max_needed;
     }
 
-    MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
-                     h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max));
+    if (classic)
+        MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev);
+    else
+        MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
+                         h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max));
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -504,8 +547,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
 int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
                     int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1, const mdrp_camera *cam2,
                     const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
-    if (!h || batch < 0 || n_max < 0 || kind < 0 || kind > 2 || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
-    if (kind == MDRP_CALIB && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
+    const bool known_kind = (kind >= 0 && kind <= 2) || kind == MDRP_RELPOSE_5PT || kind == MDRP_FUNDAMENTAL_7PT;
+    if (!h || batch < 0 || n_max < 0 || !known_kind || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if ((kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT) && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
+    if (kind <= 2 && batch > 0 && n_max > 0 && (!d1 || !d2)) { g_err = "monodepth estimator needs depths"; return MDRP_ERR_INVALID; }
+    const int mps = kind == MDRP_RELPOSE_5PT ? 12 : 4;
     h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
@@ -526,14 +572,15 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     const int chunk_cap = (int)chunk_cap64;
     size_t free_b = 0, total_b = 0;
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
-    const size_t per_pair = (size_t)chunk_cap * 4 * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
+    const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
     for (int p0 = 0; p0 < batch; p0 += per_pass) {
         const int nb = std::min(per_pass, batch - p0);
-        rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 + (size_t)p0 * n_max, d2 + (size_t)p0 * n_max, nb,
+        rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 ? d1 + (size_t)p0 * n_max : nullptr,
+                      d2 ? d2 + (size_t)p0 * n_max : nullptr, nb,
                       n_max, n_host.data() + p0, cam1 ? cam1 + p0 : nullptr, cam2 ? cam2 + p0 : nullptr, ro, bo, chunk_cap,
                       mask + (size_t)p0 * n_max, h->results.as<ResultDev>() + p0);
         if (rc) return rc;
@@ -615,6 +662,7 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     const int tile_bytes = (int)SCORE_TILE_BYTES;
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     *out = h;
     return MDRP_OK;
 }
@@ -629,7 +677,7 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count};
+                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -696,9 +744,12 @@ int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x
             return rc;
         HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * np, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->in_d1.p, d1, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->in_d2.p, d2, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
-        x1 = h->in_x1.as<double>(); x2 = h->in_x2.as<double>(); d1 = h->in_d1.as<double>(); d2 = h->in_d2.as<double>();
+        if (d1 && d2) {
+            HIPCHK(hipMemcpyAsync(h->in_d1.p, d1, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(h->in_d2.p, d2, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
+            d1 = h->in_d1.as<double>(); d2 = h->in_d2.as<double>();
+        }
+        x1 = h->in_x1.as<double>(); x2 = h->in_x2.as<double>();
         mask_dev = nullptr; // handle-owned device mask, copied back below
     }
     rc = estimate_device(h, kind, x1, x2, d1, d2, batch, n_max, n_per_pair, cam1, cam2, ropt, bopt, mask_dev);
@@ -751,9 +802,35 @@ int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const doubl
     return MDRP_OK;
 }
 
+int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const double *x2h, int count, mdrp_model *out, int32_t *n_out) {
+    if (!h || count < 0 || (kind != MDRP_RELPOSE_5PT && kind != MDRP_FUNDAMENTAL_7PT) || !out || !n_out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (count == 0) return MDRP_OK;
+    MDRP_ENTER(h);
+    const int K = kind == MDRP_RELPOSE_5PT ? 5 : 7, M = kind == MDRP_RELPOSE_5PT ? MAX_MODELS_5PT : 3;
+    int rc;
+    if ((rc = h->unit_a.ensure(sizeof(double) * 3 * K * count)) || (rc = h->unit_b.ensure(sizeof(double) * 3 * K * count)) ||
+        (rc = h->unit_e.ensure(sizeof(Model) * M * count)) || (rc = h->unit_f.ensure(sizeof(int32_t) * count)))
+        return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(hipMemcpyAsync(h->unit_a.p, x1h, sizeof(double) * 3 * K * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->unit_b.p, x2h, sizeof(double) * 3 * K * count, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->unit_e.p, 0, sizeof(Model) * M * count, s));
+    if (kind == MDRP_RELPOSE_5PT)
+        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_RELPOSE>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
+                           h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
+    else
+        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_FUND>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
+                           h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out, h->unit_e.p, sizeof(Model) * M * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(n_out, h->unit_f.p, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MDRP_OK;
+}
+
 int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model *models, int num_models, const double *x1,
                       const double *x2, int n, double sq_threshold, double *scores, int32_t *counts) {
-    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 2 || !scores || !counts) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || kind == 4 || !scores || !counts) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (num_models == 0) return MDRP_OK;
     MDRP_ENTER(h);
     hipStream_t s = h->stream;
@@ -794,6 +871,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.batch = 1; rp.n_max = std::max(n, 1); rp.chunk_len = chunk; rp.chunk_off = 0; rp.slot_stride = chunk * 4; rp.super_len = chunk;
+    rp.mps = 4; rp.sample_sz = 3;
     const size_t tile_bytes = SCORE_TILE_BYTES;
     if ((rc = h->plan.ensure(sizeof(int32_t) * 8))) return rc;
     int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 4;
@@ -803,12 +881,8 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     hipEvent_t e0, e1;
     if ((rc = get_events(h, &e0, &e1))) return rc;
     HIPCHK(hipEventRecord(e0, s));
-    if (kind == MDRP_CALIB)
-        hipLaunchKernelGGL(k_score<true>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
-    else
-        hipLaunchKernelGGL(k_score<false>, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
+    MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), md,
+                        h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
     HIPCHK(hipEventRecord(e1, s));
     HIPCHK(hipGetLastError());
     const hipMemcpyKind back = mem_space == MDRP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
@@ -819,7 +893,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
 
 int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1, const double *x2,
                           int n, double sq_threshold, int32_t *candidates) {
-    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 2 || !candidates || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || kind == 4 || !candidates || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (num_models == 0) return MDRP_OK;
     MDRP_ENTER(h);
     hipStream_t s = h->stream;
@@ -854,17 +928,12 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
     hipLaunchKernelGGL(k_frag_unit, dim3((n + 16 + 255) / 256), dim3(256), 0, s, n, h->pts.as<double>(), h->rfrag.as<uint4>());
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
-    rp.kind = kind; rp.batch = 1; rp.n_max = nn; rp.slot_stride = num_models;
+    rp.kind = kind; rp.batch = 1; rp.n_max = nn; rp.slot_stride = num_models; rp.mps = 4; rp.sample_sz = 3;
     hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, 1, h->st.as<PairState>(), h->model_count.as<int32_t>(), 2, CNT_WG_MODELS, h->cplan.as<int32_t>());
     const dim3 grid((unsigned)((num_models + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
-    if (kind == MDRP_CALIB)
-        hipLaunchKernelGGL(k_count<true>, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
-                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
-    else
-        hipLaunchKernelGGL(k_count<false>, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                           h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
-                           h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
+    MDRP_SWEEP_DISPATCH(k_count, kind, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                        h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(candidates, h->unit_f.p, sizeof(int32_t) * num_models, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -874,12 +943,34 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
 int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,
                        const double *d1, const double *d2, int n, double scale_reproj, double weight_sampson,
                        const mdrp_bundle_opt *opt, int estimate_shift, double *final_cost) {
-    if (!h || count < 0 || n < 0 || kind < 0 || kind > 2 || !opt || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || count < 0 || n < 0 || kind < 0 || kind > 5 || kind == 4 || !opt || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (count == 0) return MDRP_OK;
     MDRP_ENTER(h);
     hipStream_t s = h->stream;
     int rc;
     const int nn = std::max(n, 1);
+    if (kind >= MDRP_RELPOSE_5PT) {
+        if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * nn)) || (rc = h->in_x1.ensure(sizeof(double) * 2 * nn)) ||
+            (rc = h->in_x2.ensure(sizeof(double) * 2 * nn)) || (rc = h->unit_e.ensure(sizeof(Model) * count)) ||
+            (rc = h->unit_a.ensure(sizeof(double) * count)))
+            return rc;
+        HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(h->unit_e.p, models, sizeof(Model) * count, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, h->in_x1.as<double>(), h->in_x2.as<double>(),
+                           (const double *)nullptr, (const double *)nullptr, h->pts.as<double>(), (double *)nullptr);
+        LmOpt o;
+        o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
+        o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
+        o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
+        MDRP_CLASSIC_LM_DISPATCH(kc_refine_unit, (count >= 2048 ? 64 : 256), kind, dim3(count), 0, s, count, h->unit_e.as<Model>(),
+                                 h->pts.as<double>(), n, o, h->unit_a.as<double>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(models, h->unit_e.p, sizeof(Model) * count, hipMemcpyDeviceToHost, s));
+        if (final_cost) HIPCHK(hipMemcpyAsync(final_cost, h->unit_a.p, sizeof(double) * count, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return MDRP_OK;
+    }
     if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * nn)) || (rc = h->dep.ensure(sizeof(double) * 2 * nn)) ||
         (rc = h->in_x1.ensure(sizeof(double) * 2 * nn)) || (rc = h->in_x2.ensure(sizeof(double) * 2 * nn)) ||
         (rc = h->in_d1.ensure(sizeof(double) * nn)) || (rc = h->in_d2.ensure(sizeof(double) * nn)) ||

@@ -1,0 +1,696 @@
+// mdrp_classic.h — kernels of the non-monodepth baselines on the same phase-split LO-RANSAC:
+//   kind 3  estimate_relative_pose @0x21f800      RelativePoseEstimator: 5-point samples, pose models, Sampson + cheirality
+//   kind 5  estimate_fundamental   @0x221a00      FundamentalEstimator: 7-point samples, F models, Sampson
+// The sampler, the three scoring sweeps (k_count on the matrix cores, k_bound, k_score), k_scan, k_lo_plan and k_walk are the
+// monodepth path's own kernels (a fundamental matrix travels in the first nine doubles of a Model: RAWF instantiations);
+// this file adds what differs: the normalisation (kc_prep), samples of K > 3 points (kc_samples), the minimal solvers
+// (kc_solve, mdrp_classic_math.h), and the Sampson-only LM of refine_relpose @0x258f50 / refine_fundamental @0x2590d0 with
+// the estimators' LO rules (kc_lo) and final stage (kc_final).
+#pragma once
+#include "mdrp_kernels.h"
+#include "mdrp_classic_math.h"
+
+namespace mdrp {
+
+template <int CK> struct ClassicTraits;
+template <> struct ClassicTraits<CLASSIC_RELPOSE> { static constexpr int K = 5, MPS = 12, MAXM = MAX_MODELS_5PT, NP = 5; static constexpr bool POSE = true; };
+template <> struct ClassicTraits<CLASSIC_FUND> { static constexpr int K = 7, MPS = 4, MAXM = 3, NP = 7; static constexpr bool POSE = false; };
+
+// ------------------------------------------------------------------------------------------------ prep
+// kind 3: Camera::unproject, threshold * (1/f1 + 1/f2) / 2 (estimate_relative_pose @0x21f800)
+// kind 5: normalize_points(normalize_scale, normalize_centroid, shared_scale) @0x4f6ae0: x <- (x - centroid) / s,
+//         s = sum(|x1 - c1| + |x2 - c2|) / (sqrt2 N); thresholds / s (estimate_fundamental @0x221a00)
+__global__ __launch_bounds__(256) void kc_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
+                                               const int32_t *__restrict__ n_per_pair, const int32_t *__restrict__ table_of_pair,
+                                               const CamDev *__restrict__ cam1, const CamDev *__restrict__ cam2, double max_epi,
+                                               double bundle_loss_scale, double *__restrict__ pts, PairState *__restrict__ st,
+                                               uint4 *__restrict__ rfrag) {
+    __shared__ double red[4][5];
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int n = n_per_pair[pair];
+    const size_t base = (size_t)pair * rp.n_max;
+    double k = 1.0, norm = 1.0;
+    double fx1 = 1, fy1 = 1, cx1 = 0, cy1 = 0, fx2 = 1, fy2 = 1, cx2 = 0, cy2 = 0;
+    if (rp.kind == CLASSIC_RELPOSE) {
+        const CamDev a = cam1[pair], b = cam2[pair];
+        if (a.model_id == 1) { fx1 = a.p[0]; fy1 = a.p[1]; cx1 = a.p[2]; cy1 = a.p[3]; } else { fx1 = fy1 = a.p[0]; cx1 = a.p[1]; cy1 = a.p[2]; }
+        if (b.model_id == 1) { fx2 = b.p[0]; fy2 = b.p[1]; cx2 = b.p[2]; cy2 = b.p[3]; } else { fx2 = fy2 = b.p[0]; cx2 = b.p[1]; cy2 = b.p[2]; }
+        k = 0.5 * (1.0 / (0.5 * (fx1 + fy1)) + 1.0 / (0.5 * (fx2 + fy2)));
+    } else {
+        double s[4] = {0, 0, 0, 0};
+        for (int i = tid; i < n; i += 256) {
+            s[0] += x1[2 * (base + i)]; s[1] += x1[2 * (base + i) + 1]; s[2] += x2[2 * (base + i)]; s[3] += x2[2 * (base + i) + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { s[q] = wave_sum(s[q]); if ((tid & 63) == 0) red[tid >> 6][q] = s[q]; }
+        __syncthreads();
+        const double inv_n = 1.0 / (double)(n > 0 ? n : 1);
+        cx1 = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * inv_n; cy1 = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * inv_n;
+        cx2 = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * inv_n; cy2 = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) * inv_n;
+        double acc = 0;
+        for (int i = tid; i < n; i += 256) {
+            const double a = x1[2 * (base + i)] - cx1, b = x1[2 * (base + i) + 1] - cy1, c = x2[2 * (base + i)] - cx2, d = x2[2 * (base + i) + 1] - cy2;
+            acc += sqrt(a * a + b * b) + sqrt(c * c + d * d);
+        }
+        acc = wave_sum(acc);
+        if ((tid & 63) == 0) red[tid >> 6][4] = acc;
+        __syncthreads();
+        norm = (red[0][4] + red[1][4] + red[2][4] + red[3][4]) / (1.4142135623730951 * (double)(n > 0 ? n : 1));
+        k = 1.0 / norm;
+        fx1 = fy1 = fx2 = fy2 = norm;
+    }
+    double bx[4] = {0, 0, 0, 0};
+    for (int i = tid; i < n; i += 256) {
+        const double a = (x1[2 * (base + i)] - cx1) / fx1, b = (x1[2 * (base + i) + 1] - cy1) / fy1;
+        const double c = (x2[2 * (base + i)] - cx2) / fx2, d = (x2[2 * (base + i) + 1] - cy2) / fy2;
+        bx[0] = fmax(bx[0], fabs(a)); bx[1] = fmax(bx[1], fabs(b)); bx[2] = fmax(bx[2], fabs(c)); bx[3] = fmax(bx[3], fabs(d));
+        double *p = pts + (base + i) * PT_STRIDE;
+        p[0] = a; p[1] = b; p[2] = c; p[3] = d;
+        p[4] = 1.0 / sqrt(a * a + b * b + 1.0);
+        p[5] = 1.0 / sqrt(c * c + d * d + 1.0);
+        if (rfrag) store_record_fragment(rfrag + (size_t)pair * ((rp.n_max + 15) / 16) * 64, i, a, b, c, d);
+    }
+    if (rfrag) {
+        const int g_end = ((n + 15) / 16) * 16;
+        for (int i = n + tid; i < g_end; i += 256) clear_record_fragment(rfrag + (size_t)pair * ((rp.n_max + 15) / 16) * 64, i);
+    }
+    __shared__ double redbox[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v = bx[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+        if ((tid & 63) == 0) redbox[tid >> 6][q] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        PairState s;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s.box[q] = fmax(fmax(redbox[0][q], redbox[1][q]), fmax(redbox[2][q], redbox[3][q]));
+        const bool ok = n >= rp.sample_sz;
+        s.n = ok ? n : 0;
+        s.table = table_of_pair[pair];
+        s.active = ok;
+        s.n_triggers = 0;
+        s.eps = max_epi * k;
+        s.sq_thr = s.eps * s.eps;
+        s.scale_reproj = 0.0;
+        s.lo_loss_scale = s.eps;
+        s.final_loss_scale = bundle_loss_scale * k;
+        s.norm = norm;
+        s.cen[0] = cx1; s.cen[1] = cy1; s.cen[2] = cx2; s.cen[3] = cy2;
+        s.best_min_cnt = 0; s.best_min_score = DBL_MAX;
+        s.dyn_max_iter = rp.max_iterations;
+        s.iterations = 0; s.refinements = 0; s.num_inliers = 0;
+        s.inlier_ratio = 0.0; s.model_score = DBL_MAX;
+        model_identity(s.best);
+        if (rp.kind == CLASSIC_FUND) { double *F = model_F(s.best); for (int q = 0; q < 9; ++q) F[q] = (q % 4 == 0) ? 1.0 : 0.0; }
+        if (rp.score_initial && ok && rp.kind == CLASSIC_RELPOSE) { // the reset identity pose has E = 0: no inliers, score N eps^2, one LO
+            s.best_min_score = s.sq_thr * (double)n;
+            s.model_score = s.best_min_score;
+            s.refinements = 1;
+        }
+        st[pair] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ samples of K points
+// k_samples' wave-speculative scheme with K raw draws per sample (RandomSampler @0x4f8970, draw_sample @0x4f87f0)
+template <int K>
+__device__ __forceinline__ void draw_sample_k(uint64_t n, uint64_t &state, uint32_t *out) {
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        bool dup;
+        do {
+            out[i] = (uint32_t)((uint64_t)(int64_t)splitmix_int(state) % n);
+            dup = false;
+#pragma unroll
+            for (int j = 0; j < K; ++j) dup = dup || (j < i && out[j] == out[i]);
+        } while (dup);
+    }
+}
+template <int K>
+__global__ __launch_bounds__(64) void kc_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
+                                                 int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][K]*/) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= n_tables) return;
+    const uint64_t n = (uint64_t)table_n[t];
+    if (n < (uint64_t)K) return;
+    const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
+    uint64_t state = table_state[t];
+    uint32_t *out = samples + (size_t)t * chunk_len * K;
+    int done = 0;
+    while (done < chunk_len) {
+        uint64_t s = state + (uint64_t)(K * lane) * GAMMA;
+        const uint64_t s0 = s;
+        uint32_t smp[K];
+        draw_sample_k<K>(n, s, smp);
+        const bool rejected = (s - s0) != (uint64_t)K * GAMMA;
+        const unsigned long long ball = __ballot(rejected);
+        const int first = ball ? (__ffsll((long long)ball) - 1) : 63;
+        const int nvalid = min(first + 1, chunk_len - done);
+        if (lane < nvalid) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[(size_t)K * (done + lane) + k] = smp[k];
+        }
+        state = __shfl(s, nvalid - 1, 64);
+        done += nvalid;
+    }
+    if (lane == 0) table_state[t] = state;
+}
+
+// ------------------------------------------------------------------------------------------------ solve
+// One lane per minimal sample (64-lane workgroups: the solvers live in scratch-backed arrays and their trip counts
+// diverge with the number of real roots).  Same slot / tag conventions as k_solve with MPS slots per sample.
+template <int CK>
+__global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+                                               const double *__restrict__ pts, Model *__restrict__ models, int32_t *__restrict__ slot_inl,
+                                               uint32_t *__restrict__ tags, int32_t *__restrict__ model_count) {
+    using TR = ClassicTraits<CK>;
+    constexpr int K = TR::K, MPS = TR::MPS, MAXM = TR::MAXM;
+    const int pair = blockIdx.y;
+    const int it = blockIdx.x * 64 + threadIdx.x;
+    const PairState &ps = st[pair];
+    if (!ps.active) return;
+    const bool live = it < rp.chunk_len;
+    int n = 0;
+    Model out[MAXM];
+    if (live) {
+        const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it) * K;
+        double x1h[K][3], x2h[K][3];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const double *p = pts + ((size_t)pair * rp.n_max + sm[k]) * PT_STRIDE;
+            const double2 p01 = *reinterpret_cast<const double2 *>(p), p23 = *reinterpret_cast<const double2 *>(p + 2),
+                          p45 = *reinterpret_cast<const double2 *>(p + 4);
+            x1h[k][0] = p01.x * p45.x; x1h[k][1] = p01.y * p45.x; x1h[k][2] = p45.x;
+            x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
+        }
+        if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt(x1h, x2h, out);
+        else n = solver_fundamental_7pt(x1h, x2h, out);
+    }
+    const int lane = threadIdx.x & 63;
+    int pre = n;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += v;
+    }
+    const int tot = __shfl(pre, 63, 64);
+    int base = 0;
+    if (lane == 63 && tot > 0) base = atomicAdd(&model_count[2 * pair], tot);
+    base = __shfl(base, 63, 64);
+    if (!live) return;
+    const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * MPS;
+    int pos = base + pre - n;
+    const size_t tag_base = (size_t)pair * rp.slot_stride;
+#pragma unroll
+    for (int g = 0; g < MPS / 4; ++g)
+        *reinterpret_cast<int4 *>(slot_inl + slot0 + 4 * g) =
+            make_int4(n > 4 * g ? -2 : -1, n > 4 * g + 1 ? -2 : -1, n > 4 * g + 2 ? -2 : -1, n > 4 * g + 3 ? -2 : -1);
+    for (int k = 0; k < n; ++k) {
+        models[slot0 + k] = out[k];
+        tags[tag_base + pos] = (uint32_t)((rp.chunk_off + it) * MPS + k);
+        ++pos;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Sampson-only LM
+// refine_relpose @0x258f50: 5 parameters — R <- R exp([w]x), t <- t + B d with B an orthonormal basis of the tangent plane of t
+//   (set up from the CURRENT t at every accumulate);  refine_fundamental @0x2590d0: F = U diag(1, sigma, 0) V' with rotations
+//   U, V: U <- exp([a]x) U, V <- exp([b]x) V, sigma <- sigma + d.  Inside the LM a factorised F lives in the Model as
+//   q = qU, (t[0], t[1], t[2], scale) = qV, shift1 = sigma.
+template <int CK>
+struct ClmState {
+    LmState st;      // kinds 3 / 4
+    double tb[6];
+    double F[9], u1[3], v1[3]; // kind 5
+};
+
+__device__ __forceinline__ void clm_tangent_basis(const double *t, double *tb) {
+    double e[3] = {0, 0, 0};
+    if (fabs(t[0]) < fabs(t[1])) { if (fabs(t[0]) < fabs(t[2])) e[0] = 1; else e[2] = 1; }
+    else { if (fabs(t[1]) < fabs(t[2])) e[1] = 1; else e[2] = 1; }
+    cross3(t, e, tb);
+    double n = 1.0 / sqrt(dot3(tb, tb));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tb[i] *= n;
+    cross3(tb, t, tb + 3);
+    n = 1.0 / sqrt(dot3(tb + 3, tb + 3));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tb[3 + i] *= n;
+}
+
+template <int CK>
+__device__ __forceinline__ void clm_setup(const Model &m, ClmState<CK> &s) {
+    if (CK == CLASSIC_FUND) {
+        double U[9], V[9];
+        const double qV[4] = {m.t[0], m.t[1], m.t[2], m.scale};
+        quat_to_R(m.q, U);
+        quat_to_R(qV, V);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { s.u1[i] = U[3 * i + 1]; s.v1[i] = V[3 * i + 1]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s.F[3 * i + j] = U[3 * i] * V[3 * j] + m.shift1 * U[3 * i + 1] * V[3 * j + 1];
+    } else {
+        lm_state_from_model(m, CK == CLASSIC_SHARED, s.st);
+        clm_tangent_basis(m.t, s.tb);
+    }
+}
+
+// residual r = C / |J_C| and (WITH_J) the Jacobian row of the NP parameters
+template <int CK, bool WITH_J>
+__device__ __forceinline__ double clm_point(const ClmState<CK> &s, double a, double b, double c, double d, double *J) {
+    if (CK != CLASSIC_FUND) {
+        double r0, J0[LM_NPAR];
+        lm_sampson_term<WITH_J, CK == CLASSIC_SHARED>(s.st, a, b, c, d, r0, J0);
+        if (WITH_J) {
+            J[0] = J0[0]; J[1] = J0[1]; J[2] = J0[2];
+            J[3] = s.tb[0] * J0[3] + s.tb[1] * J0[4] + s.tb[2] * J0[5];
+            J[4] = s.tb[3] * J0[3] + s.tb[4] * J0[4] + s.tb[5] * J0[5];
+            if (CK == CLASSIC_SHARED) J[5] = J0[9] + J0[10];
+        }
+        return r0;
+    }
+    const double *F = s.F;
+    const double Fh1_0 = F[0] * a + F[1] * b + F[2], Fh1_1 = F[3] * a + F[4] * b + F[5], Fh1_2 = F[6] * a + F[7] * b + F[8];
+    const double Ft2_0 = F[0] * c + F[3] * d + F[6], Ft2_1 = F[1] * c + F[4] * d + F[7];
+    const double C = c * Fh1_0 + d * Fh1_1 + Fh1_2;
+    const double den = Fh1_0 * Fh1_0 + Fh1_1 * Fh1_1 + Ft2_0 * Ft2_0 + Ft2_1 * Ft2_1;
+    const double isd = 1.0 / sqrt(den);
+    const double r0 = C * isd;
+    if (!WITH_J) return r0;
+    const double h1[3] = {a, b, 1.0}, h2[3] = {c, d, 1.0};
+    const double Fh1[3] = {Fh1_0, Fh1_1, Fh1_2}, Ft2[3] = {Ft2_0, Ft2_1, 0.0};
+    const double k = C * isd * isd * isd;
+    double G[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double g = h2[i] * h1[j] * isd;
+            if (i < 2) g -= k * Fh1[i] * h1[j];
+            if (j < 2) g -= k * Ft2[j] * h2[i];
+            G[3 * i + j] = g;
+        }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int q = (p + 1) % 3, w = (p + 2) % 3;
+        double au = 0, av = 0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            au += -G[3 * q + j] * F[3 * w + j] + G[3 * w + j] * F[3 * q + j]; // [e_p]x F : row q = -F row w, row w = +F row q
+            av += -G[3 * j + q] * F[3 * j + w] + G[3 * j + w] * F[3 * j + q]; // F [e_p]x': col q = -F col w, col w = +F col q
+        }
+        J[p] = au; J[3 + p] = av;
+    }
+    double gs = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gs += G[3 * i + j] * s.u1[i] * s.v1[j];
+    J[6] = gs;
+    return r0;
+}
+
+template <int CK, int T>
+__device__ double clm_cost(const Model &m, const double *__restrict__ pts, int n, const uint8_t *__restrict__ mask, const LmOpt &o,
+                           double *scratch) {
+    ClmState<CK> s;
+    clm_setup<CK>(m, s);
+    double cost = 0;
+    for (int i = threadIdx.x; i < n; i += T) {
+        if (mask && !mask[i]) continue;
+        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
+        const double2 p01 = P[0], p23 = P[1];
+        const double r = clm_point<CK, false>(s, p01.x, p01.y, p23.x, p23.y, nullptr);
+        cost += loss_value(o.loss, o.loss_scale, r * r);
+    }
+    double v[1] = {cost};
+    block_sum<1, T>(v, scratch);
+    return v[0];
+}
+
+template <int CK, int T>
+__device__ void clm_accumulate(const Model &m, const double *__restrict__ pts, int n, const uint8_t *__restrict__ mask, const LmOpt &o,
+                               double *acc, double *tb_out, double *scratch) {
+    constexpr int NP = ClassicTraits<CK>::NP, NT = NP * (NP + 1) / 2;
+    ClmState<CK> s;
+    clm_setup<CK>(m, s);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) tb_out[i] = (CK == CLASSIC_FUND) ? 0.0 : s.tb[i];
+#pragma unroll
+    for (int i = 0; i < NT + NP; ++i) acc[i] = 0;
+    for (int i = threadIdx.x; i < n; i += T) {
+        if (mask && !mask[i]) continue;
+        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
+        const double2 p01 = P[0], p23 = P[1];
+        double J[NP];
+        const double r = clm_point<CK, true>(s, p01.x, p01.y, p23.x, p23.y, J);
+        const double w = loss_weight(o.loss, o.loss_scale, r * r, o.mu);
+        if (w == 0.0) continue;
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            const double wa = w * J[a];
+#pragma unroll
+            for (int b = 0; b <= a; ++b) acc[idx++] += wa * J[b];
+        }
+#pragma unroll
+        for (int a = 0; a < NP; ++a) acc[NT + a] += w * r * J[a];
+    }
+    block_sum<NT + NP, T>(acc, scratch);
+}
+
+__device__ __forceinline__ void clm_quat_exp(const double *w, double *q) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2], th = sqrt(th2);
+    double re, im;
+    if (th > 1e-6) { re = cos(0.5 * th); im = sin(0.5 * th) / th; }
+    else { re = 1.0 - th2 / 8.0; im = 0.5 - th2 / 48.0; const double nq = 1.0 / sqrt(re * re + im * im * th2); re *= nq; im *= nq; }
+    q[0] = re; q[1] = im * w[0]; q[2] = im * w[1]; q[3] = im * w[2];
+}
+__device__ __forceinline__ void clm_quat_mul(const double *a, const double *b, double *o) {
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+}
+
+template <int CK>
+__device__ __forceinline__ void clm_step(const Model &m, const double *dp, const double *tb, Model &o) {
+    o = m;
+    double dq[4];
+    if (CK == CLASSIC_FUND) {
+        double qn[4];
+        const double qV[4] = {m.t[0], m.t[1], m.t[2], m.scale};
+        clm_quat_exp(dp, dq); clm_quat_mul(dq, m.q, o.q);
+        clm_quat_exp(dp + 3, dq); clm_quat_mul(dq, qV, qn);
+        o.t[0] = qn[0]; o.t[1] = qn[1]; o.t[2] = qn[2]; o.scale = qn[3];
+        o.shift1 = m.shift1 + dp[6];
+    } else {
+        clm_quat_exp(dp, dq); clm_quat_mul(m.q, dq, o.q);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o.t[i] = m.t[i] + tb[i] * dp[3] + tb[3 + i] * dp[4];
+        if (CK == CLASSIC_SHARED) { o.f1 = m.f1 + dp[5]; o.f2 = o.f1; }
+    }
+}
+
+// 3 x 3 SVD by one-sided Jacobi (FactorizedFundamentalMatrix(F): JacobiSVD, proper rotations, sigma = s1 / s0)
+__device__ void clm_factorize(const double *Fin, Model &m) {
+    double B[9], W[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+#pragma unroll
+    for (int i = 0; i < 9; ++i) B[i] = Fin[i];
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+#pragma unroll
+        for (int pq = 0; pq < 3; ++pq) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            double a = 0, b = 0, c = 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { a += B[3 * i + p] * B[3 * i + p]; b += B[3 * i + q] * B[3 * i + q]; c += B[3 * i + p] * B[3 * i + q]; }
+            off = fmax(off, fabs(c) / sqrt(fmax(a * b, 2.2250738585072014e-308)));
+            if (fabs(c) <= 1e-300) continue;
+            const double zeta = (b - a) / (2.0 * c);
+            const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double bp = B[3 * i + p], bq = B[3 * i + q];
+                B[3 * i + p] = cs * bp - sn * bq; B[3 * i + q] = sn * bp + cs * bq;
+                const double wp = W[3 * i + p], wq = W[3 * i + q];
+                W[3 * i + p] = cs * wp - sn * wq; W[3 * i + q] = sn * wp + cs * wq;
+            }
+        }
+        if (off < 1e-16) break;
+    }
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(B[j] * B[j] + B[3 + j] * B[3 + j] + B[6 + j] * B[6 + j]);
+    if (nrm[ord[1]] > nrm[ord[0]]) { const int t = ord[0]; ord[0] = ord[1]; ord[1] = t; }
+    if (nrm[ord[2]] > nrm[ord[0]]) { const int t = ord[0]; ord[0] = ord[2]; ord[2] = t; }
+    if (nrm[ord[2]] > nrm[ord[1]]) { const int t = ord[1]; ord[1] = ord[2]; ord[2] = t; }
+    double U[9], V[9], s[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        double nj = 0, bj[3], wj[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { bj[i] = ord[j] == 0 ? B[3 * i] : (ord[j] == 1 ? B[3 * i + 1] : B[3 * i + 2]); wj[i] = ord[j] == 0 ? W[3 * i] : (ord[j] == 1 ? W[3 * i + 1] : W[3 * i + 2]); }
+        nj = ord[j] == 0 ? nrm[0] : (ord[j] == 1 ? nrm[1] : nrm[2]);
+        s[j] = nj;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { V[3 * i + j] = wj[i]; U[3 * i + j] = nj > 0 ? bj[i] / nj : 0.0; }
+    }
+    if (s[2] <= 1e-12 * s[0]) { // rank 2: the third left vector from the first two
+        const double u0[3] = {U[0], U[3], U[6]}, u1[3] = {U[1], U[4], U[7]};
+        double u2[3];
+        cross3(u0, u1, u2);
+        const double nn = 1.0 / sqrt(dot3(u2, u2));
+#pragma unroll
+        for (int i = 0; i < 3; ++i) U[3 * i + 2] = u2[i] * nn;
+    }
+    const double dU = U[0] * (U[4] * U[8] - U[5] * U[7]) - U[1] * (U[3] * U[8] - U[5] * U[6]) + U[2] * (U[3] * U[7] - U[4] * U[6]);
+    const double dV = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+    if (dU < 0) { for (int i = 0; i < 9; ++i) U[i] = -U[i]; }
+    if (dV < 0) { for (int i = 0; i < 9; ++i) V[i] = -V[i]; }
+    double qV[4];
+    model_identity(m);
+    R_to_quat(U, m.q);
+    R_to_quat(V, qV);
+    m.t[0] = qV[0]; m.t[1] = qV[1]; m.t[2] = qV[2]; m.scale = qV[3];
+    m.shift1 = s[1] / s[0];
+}
+__device__ __forceinline__ void clm_compose(const Model &ff, Model &out) {
+    ClmState<CLASSIC_FUND> s;
+    clm_setup<CLASSIC_FUND>(ff, s);
+    model_identity(out);
+    double *F = model_F(out);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) F[i] = s.F[i];
+    out.shift2 = 0.0;
+}
+
+// lm_impl<> loop, executed uniformly by all threads of the problem's workgroup; the two sweeps are distributed
+template <int CK, int T>
+__device__ void clm_refine(Model &model, const double *__restrict__ pts, int n, const uint8_t *__restrict__ mask, const LmOpt &o_in,
+                           double *scratch) {
+    constexpr int NP = ClassicTraits<CK>::NP, NT = NP * (NP + 1) / 2;
+    LmOpt o = o_in;
+    o.mu = 0.5;
+    Model m = model;
+    if (CK == CLASSIC_FUND) clm_factorize(model_F(model), m);
+    double cost = clm_cost<CK, T>(m, pts, n, mask, o, scratch);
+    double lambda = o.lambda0;
+    bool recompute = true;
+    double acc[NT + NP], A[NP * NP], g[NP], sol[NP], tb[6];
+    for (int it = 0; it < o.max_it; ++it) {
+        if (recompute) {
+            clm_accumulate<CK, T>(m, pts, n, mask, o, acc, tb, scratch);
+            double gn = 0;
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) A[a * NP + b] = acc[idx++];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) { g[a] = acc[NT + a]; gn += g[a] * g[a]; }
+            if (sqrt(gn) < o.grad_tol) break;
+        }
+        double Ad[NP * NP];
+#pragma unroll
+        for (int a = 0; a < NP; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) Ad[a * NP + b] = A[a * NP + b] + (a == b ? lambda : 0.0);
+        chol_solve<NP>(Ad, g, sol);
+        double sn = 0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) { sol[a] = -sol[a]; sn += sol[a] * sol[a]; }
+        if (sqrt(sn) < o.step_tol) break;
+        Model cand;
+        clm_step<CK>(m, sol, tb, cand);
+        const double cost_new = clm_cost<CK, T>(cand, pts, n, mask, o, scratch);
+        if (cost_new < cost) {
+            m = cand;
+            lambda = fmax(o.lambda_min, lambda / 10.0);
+            cost = cost_new;
+            recompute = true;
+        } else {
+            lambda = fmin(o.lambda_max, lambda * 10.0);
+            recompute = false;
+        }
+        o.mu *= 1.5;
+    }
+    if (CK == CLASSIC_FUND) clm_compose(m, model);
+    else model = m;
+}
+
+// workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask
+template <int CK, int T>
+__device__ void cblock_score(const Model &m, const double *__restrict__ pts, int n, double thr, double *scratch, double &score_out,
+                             int &cnt_out, uint8_t *__restrict__ mask_out) {
+    double R[9], E[9];
+    if (CK == CLASSIC_FUND) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { E[i] = model_F(m)[i]; R[i] = 0.0; }
+    } else {
+        double Em[9];
+        quat_to_R(m.q, R);
+        essential_from_Rt(R, m.t, Em);
+        if (CK == CLASSIC_RELPOSE) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) E[i] = Em[i];
+        } else fundamental_from_E(Em, m.f1, m.f2, E);
+    }
+    double score = 0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n; i += T) {
+        double s1 = 0;
+        int c1 = 0;
+        score_point<CK == CLASSIC_RELPOSE>(pts + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
+        score += s1; cnt += c1;
+        if (mask_out) mask_out[i] = (uint8_t)c1;
+    }
+    double v[2] = {score, (double)cnt};
+    block_sum<2, T>(v, scratch);
+    cnt_out = (int)v[1];
+    score_out = v[0] + thr * (double)(n - cnt_out);
+    if (mask_out) __syncthreads(); // the mask is read by other threads of the workgroup next
+}
+
+// refine_model of the estimators: RelativePoseEstimator refines on the inliers at 5 thr^2 of the incoming model (get_inliers,
+// kept only if more than the sample size), FundamentalEstimator on all correspondences; 25 iterations, TRUNCATED at eps
+template <int CK, int T>
+__device__ void clm_lo(Model &m, const PairState &ps, const double *__restrict__ pp, uint8_t *__restrict__ wg_mask, double *scratch) {
+    LmOpt o;
+    o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+    o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+    if (CK == CLASSIC_FUND) { clm_refine<CK, T>(m, pp, ps.n, nullptr, o, scratch); return; }
+    double sc;
+    int ni;
+    cblock_score<CK, T>(m, pp, ps.n, 5.0 * ps.sq_thr, scratch, sc, ni, wg_mask);
+    if (ni > ClassicTraits<CK>::K) clm_refine<CK, T>(m, pp, ps.n, wg_mask, o, scratch);
+    __syncthreads(); // wg_mask is rewritten by the next problem
+}
+
+// ------------------------------------------------------------------------------------------------ LO
+template <int CK, int T>
+__global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                              const Model *__restrict__ models, Trigger *__restrict__ triggers, int trig_cap,
+                                              const int32_t *__restrict__ plan, int32_t *__restrict__ head /*zeroed*/,
+                                              uint8_t *__restrict__ lo_mask /*[gridDim.x][n_max]*/) {
+    __shared__ double scratch[4 * MAX_ACC];
+    __shared__ int s_item;
+    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
+    const int total = plan[3 * (size_t)rp.batch + 1];
+    uint8_t *wg_mask = lo_mask + (size_t)blockIdx.x * rp.n_max;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
+        __syncthreads();
+        const int w = s_item;
+        if (w >= total) break;
+        const int pair = plan_find(prefix, rp.batch, w);
+        const int pos = begin[pair] + (w - prefix[pair]);
+        const PairState &ps = st[pair];
+        Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+        const size_t slot_base = (size_t)pair * rp.slot_stride;
+        Model m = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_ref];
+        const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+        clm_lo<CK, T>(m, ps, pp, wg_mask, scratch);
+        double sc;
+        int cn;
+        cblock_score<CK, T>(m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+        if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ final
+// ransac<> tail + get_inliers + the estimator's inlier-only refinement with the user's BundleOptions (estimate_relative_pose
+// @0x21f800: if more than 5 inliers; estimate_fundamental @0x221a00: more than 7, then F <- T2' F T1 / |.|)
+template <int CK, int T>
+__global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
+                                                 uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results) {
+    __shared__ double scratch[4 * MAX_ACC];
+    const int pair = blockIdx.x;
+    PairState &ps = st[pair];
+    ResultDev res;
+    res.model = ps.best;
+    res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
+    res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
+    uint8_t *mask = mask_all + (size_t)pair * rp.n_max;
+    if (ps.n < ClassicTraits<CK>::K) {
+        for (int i = threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
+        if (threadIdx.x == 0) results[pair] = res;
+        return;
+    }
+    const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    Model m = ps.best;
+    for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
+    clm_lo<CK, T>(m, ps, pp, mask, scratch); // the output mask doubles as the LO's subset mask
+    res.refinements++;
+    double sc;
+    int cn;
+    cblock_score<CK, T>(m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+    Model best = ps.best;
+    if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
+    cblock_score<CK, T>(best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
+    if (res.num_inliers > (uint64_t)ClassicTraits<CK>::K) {
+        LmOpt f;
+        f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
+        f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
+        clm_refine<CK, T>(best, pp, ps.n, mask, f, scratch);
+    }
+    if (CK == CLASSIC_FUND) { // F <- T2' F T1, T = [1/s 0 -cx/s; 0 1/s -cy/s; 0 0 1], unit Frobenius norm
+        double *F = model_F(best);
+        const double is = 1.0 / ps.norm;
+        const double T1[9] = {is, 0, -ps.cen[0] * is, 0, is, -ps.cen[1] * is, 0, 0, 1}, T2[9] = {is, 0, -ps.cen[2] * is, 0, is, -ps.cen[3] * is, 0, 0, 1};
+        double M[9], O[9], nrm = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) M[3 * i + j] = F[3 * i] * T1[j] + F[3 * i + 1] * T1[3 + j] + F[3 * i + 2] * T1[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { O[3 * i + j] = T2[i] * M[j] + T2[3 + i] * M[3 + j] + T2[6 + i] * M[6 + j]; nrm += O[3 * i + j] * O[3 * i + j]; }
+        nrm = 1.0 / sqrt(nrm);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) F[i] = O[i] * nrm;
+    }
+    res.model = best;
+    if (threadIdx.x == 0) results[pair] = res;
+}
+
+// ------------------------------------------------------------------------------------------------ unit-parity kernels
+template <int CK>
+__global__ void kc_solver_unit(int count, const double *__restrict__ x1h, const double *__restrict__ x2h, Model *__restrict__ out,
+                               int32_t *__restrict__ n_out) {
+    constexpr int K = ClassicTraits<CK>::K, MAXM = ClassicTraits<CK>::MAXM;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    double a[K][3], b[K][3];
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < 3; ++c) { a[k][c] = x1h[(size_t)3 * K * i + 3 * k + c]; b[k][c] = x2h[(size_t)3 * K * i + 3 * k + c]; }
+    Model m[MAXM];
+    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m) : solver_fundamental_7pt(a, b, m);
+    n_out[i] = n;
+    for (int k = 0; k < n; ++k) out[(size_t)MAXM * i + k] = m[k];
+}
+
+template <int CK, int T>
+__global__ __launch_bounds__(T) void kc_refine_unit(int count, Model *__restrict__ models, const double *__restrict__ pts, int n, LmOpt o,
+                                                    double *__restrict__ final_cost) {
+    __shared__ double scratch[4 * MAX_ACC];
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    Model m = models[i];
+    clm_refine<CK, T>(m, pts, n, nullptr, o, scratch);
+    Model f = m;
+    if (CK == CLASSIC_FUND) clm_factorize(model_F(m), f);
+    const double c = clm_cost<CK, T>(f, pts, n, nullptr, o, scratch);
+    if (threadIdx.x == 0) { models[i] = m; if (final_cost) final_cost[i] = c; }
+}
+
+} // namespace mdrp

@@ -1,0 +1,449 @@
+// mdrp_classic_math.h — minimal solvers of the non-monodepth baselines: 5-point relative pose and
+// 7-point fundamental matrix, as the reference binary computes them (upstream PoseLib 2.0.5):
+//   relpose_5pt @0x145900 / @0x14ae80   Nistér 2004: null space of the 5 epipolar constraints, 10 cubic constraints in
+//                                       (x, y, z), Gauss-Jordan, det B(z) = 0 of degree 10, real roots in ascending order,
+//                                       motion_from_essential @0x1dd540 with the cheirality of all five sample points
+//   relpose_7pt @0x4ff2e0               null space, det(r N0 + N1) = 0, roots in descending order
+// The null-space basis is the one Eigen's FullPivHouseholderQR gives (last columns of matrixQ()): the parametrisation, and
+// with it the ORDER of the solutions — which the LO-RANSAC trajectory depends on — follows from it.
+// Compiles for host and device (MDRP_HD) so that tests/hostmath can pin it against the oracle on the CPU.
+#pragma once
+#include "mdrp_math.h"
+
+namespace mdrp {
+
+constexpr int CLASSIC_RELPOSE = 3, CLASSIC_SHARED = 4, CLASSIC_FUND = 5; // == MDRP_RELPOSE_5PT / MDRP_SHARED_6PT / MDRP_FUNDAMENTAL_7PT
+
+// ---------------------------------------------------------------- null space (Eigen::FullPivHouseholderQR + matrixQ)
+// A: 9 x M column-major (destroyed).  N: the last 9 - M columns of Q, each the column-major vec of a 3 x 3 matrix.
+template <int M>
+MDRP_HD void fullpiv_nullspace(double *A, double *N /*[9 - M][9]*/) {
+    constexpr int rows = 9, NN = 9 - M;
+    double tau[M];
+    int rt[M];
+    const double prec = 2.220446049250313e-16 * (double)M;
+    double biggest = 0.0;
+    bool degenerate = false;
+    for (int k = 0; k < M; ++k) {
+        if (degenerate) { rt[k] = k; tau[k] = 0.0; continue; }
+        int br = k, bc = k;
+        double big = -1.0;
+        for (int c = k; c < M; ++c)
+            for (int r = k; r < rows; ++r) {
+                const double v = fabs(A[c * 9 + r]);
+                if (v > big) { big = v; br = r; bc = c; }
+            }
+        if (k == 0) biggest = big;
+        if (big <= biggest * prec) { degenerate = true; rt[k] = k; tau[k] = 0.0; continue; }
+        rt[k] = br;
+        if (br != k)
+            for (int c = k; c < M; ++c) { const double t = A[c * 9 + k]; A[c * 9 + k] = A[c * 9 + br]; A[c * 9 + br] = t; }
+        if (bc != k)
+            for (int r = 0; r < rows; ++r) { const double t = A[k * 9 + r]; A[k * 9 + r] = A[bc * 9 + r]; A[bc * 9 + r] = t; }
+        double tail = 0.0;
+        for (int r = k + 1; r < rows; ++r) tail += A[k * 9 + r] * A[k * 9 + r];
+        const double c0 = A[k * 9 + k];
+        double beta;
+        if (tail <= 2.2250738585072014e-308) {
+            tau[k] = 0.0; beta = c0;
+            for (int r = k + 1; r < rows; ++r) A[k * 9 + r] = 0.0;
+        } else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            const double inv = 1.0 / (c0 - beta); // Eigen divides; the reciprocal differs by an ulp at most
+            for (int r = k + 1; r < rows; ++r) A[k * 9 + r] *= inv;
+            tau[k] = (beta - c0) / beta;
+        }
+        A[k * 9 + k] = beta;
+        for (int c = k + 1; c < M; ++c) {
+            double tmp = 0.0;
+            for (int r = k + 1; r < rows; ++r) tmp += A[k * 9 + r] * A[c * 9 + r];
+            tmp += A[c * 9 + k];
+            A[c * 9 + k] -= tau[k] * tmp;
+            for (int r = k + 1; r < rows; ++r) A[c * 9 + r] -= tau[k] * A[k * 9 + r] * tmp;
+        }
+    }
+    // only the last NN columns of Q = H_0 P_0 ... H_{M-1} P_{M-1} I are needed: start from unit vectors e_M .. e_8
+    for (int j = 0; j < NN; ++j) {
+        double *q = N + 9 * j;
+        for (int r = 0; r < 9; ++r) q[r] = (r == M + j) ? 1.0 : 0.0;
+        for (int k = M - 1; k >= 0; --k) {
+            double tmp = 0.0;
+            for (int r = k + 1; r < rows; ++r) tmp += A[k * 9 + r] * q[r];
+            tmp += q[k];
+            q[k] -= tau[k] * tmp;
+            for (int r = k + 1; r < rows; ++r) q[r] -= tau[k] * A[k * 9 + r] * tmp;
+            if (rt[k] != k) { const double t = q[k]; q[k] = q[rt[k]]; q[rt[k]] = t; }
+        }
+    }
+}
+
+// epipolar constraint columns kron(x1, x2): entry 3 j + i multiplies E(i, j)  (x2' E x1 = 0)
+template <int M>
+MDRP_HD void epipolar_columns(const double (*x1h)[3], const double (*x2h)[3], double *A /*9 x M col-major*/) {
+    for (int p = 0; p < M; ++p)
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) A[p * 9 + 3 * j + i] = x1h[p][j] * x2h[p][i];
+}
+
+// ---------------------------------------------------------------- real roots, ascending (Sturm isolation, bisection, Newton)
+// chain rows are stored triangularly: row i has degree <= D - i
+template <int D>
+struct SturmChain {
+    double c[D + 1][D + 1];
+    int deg[D + 1];
+    int n;
+};
+template <int D>
+MDRP_HD int sturm_changes(const SturmChain<D> &s, double x) {
+    int changes = 0, last = 0;
+    for (int i = 0; i < s.n; ++i) {
+        double v = 0.0;
+        for (int k = s.deg[i]; k >= 0; --k) v = v * x + s.c[i][k];
+        const int sg = (v > 0) - (v < 0);
+        if (sg != 0) { if (last != 0 && sg != last) ++changes; last = sg; }
+    }
+    return changes;
+}
+template <int D>
+MDRP_HD int real_roots(const double *coef /*ascending powers, degree D*/, double *roots) {
+    int d = D;
+    while (d > 0 && coef[d] == 0.0) --d;
+    if (d <= 0) return 0;
+    SturmChain<D> s;
+    for (int k = 0; k <= d; ++k) s.c[0][k] = coef[k] / coef[d];
+    s.deg[0] = d;
+    for (int k = 1; k <= d; ++k) s.c[1][k - 1] = (double)k * s.c[0][k];
+    s.deg[1] = d - 1;
+    s.n = 2;
+    while (s.deg[s.n - 1] > 0) {
+        double r[D + 1];
+        const int dp = s.deg[s.n - 2], dq = s.deg[s.n - 1];
+        for (int k = 0; k <= dp; ++k) r[k] = s.c[s.n - 2][k];
+        const double *q = s.c[s.n - 1];
+        for (int k = dp; k >= dq; --k) {
+            const double f = r[k] / q[dq];
+            for (int j = 0; j <= dq; ++j) r[k - dq + j] -= f * q[j];
+            r[k] = 0.0;
+        }
+        int dr = dq - 1;
+        while (dr > 0 && fabs(r[dr]) < 1e-300) --dr;
+        double mx = 0.0;
+        for (int k = 0; k <= dr; ++k) mx = fmax(mx, fabs(r[k]));
+        if (mx == 0.0) break;
+        const double inv = -1.0 / mx;
+        for (int k = 0; k <= dr; ++k) s.c[s.n][k] = r[k] * inv;
+        s.deg[s.n] = dr;
+        ++s.n;
+    }
+    double bound = 0.0;
+    for (int k = 0; k < d; ++k) bound = fmax(bound, fabs(s.c[0][k]));
+    bound += 1.0;
+    // explicit stack of intervals (lo, hi] with their sign-change counts; the left half is pushed last: ascending order
+    double lo_s[D + 2], hi_s[D + 2];
+    int clo_s[D + 2], chi_s[D + 2], depth_s[D + 2];
+    int sp = 0, nr = 0;
+    lo_s[0] = -bound; hi_s[0] = bound; clo_s[0] = sturm_changes<D>(s, -bound); chi_s[0] = sturm_changes<D>(s, bound); depth_s[0] = 0;
+    sp = 1;
+    while (sp > 0 && nr < D) {
+        --sp;
+        const double lo = lo_s[sp], hi = hi_s[sp];
+        const int clo = clo_s[sp], chi = chi_s[sp], depth = depth_s[sp];
+        const int n = clo - chi;
+        if (n <= 0) continue;
+        if (n == 1 || depth > 200 || hi - lo < 1e-15 * fmax(1.0, fmax(fabs(lo), fabs(hi)))) {
+            if (n == 1) {
+                double a = lo, b = hi, fa = 0.0;
+                for (int k = d; k >= 0; --k) fa = fa * a + s.c[0][k];
+                for (int it = 0; it < 200; ++it) {
+                    const double mid = 0.5 * (a + b);
+                    if (mid == a || mid == b) break;
+                    double fm = 0.0;
+                    for (int k = d; k >= 0; --k) fm = fm * mid + s.c[0][k];
+                    if (fm == 0.0) { a = b = mid; break; }
+                    if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
+                    if (it >= 12 && b - a < 1e-3 * fmax(1e-300, fabs(a) + fabs(b))) break; // Newton takes over from a tight bracket
+                }
+                double x = 0.5 * (a + b);
+                for (int it = 0; it < 8; ++it) {
+                    double v = 0.0, dv = 0.0;
+                    for (int k = d; k >= 0; --k) { dv = dv * x + v; v = v * x + s.c[0][k]; }
+                    if (dv == 0.0) break;
+                    double xn = x - v / dv;
+                    if (!(xn >= a && xn <= b)) { // outside the bracket: bisect instead
+                        double fm = 0.0;
+                        const double mid = 0.5 * (a + b);
+                        for (int k = d; k >= 0; --k) fm = fm * mid + s.c[0][k];
+                        if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
+                        xn = 0.5 * (a + b);
+                    }
+                    const bool done = fabs(xn - x) <= 4e-16 * fabs(xn);
+                    x = xn;
+                    if (done) break;
+                }
+                roots[nr++] = x;
+            } else {
+                for (int i = 0; i < n && nr < D; ++i) roots[nr++] = 0.5 * (lo + hi); // multiple / unresolvable cluster
+            }
+            continue;
+        }
+        const double mid = 0.5 * (lo + hi);
+        const int cm = sturm_changes<D>(s, mid);
+        if (cm - chi > 0) { lo_s[sp] = mid; hi_s[sp] = hi; clo_s[sp] = cm; chi_s[sp] = chi; depth_s[sp] = depth + 1; ++sp; }
+        if (clo - cm > 0) { lo_s[sp] = lo; hi_s[sp] = mid; clo_s[sp] = clo; chi_s[sp] = cm; depth_s[sp] = depth + 1; ++sp; }
+    }
+    return nr;
+}
+
+// ---------------------------------------------------------------- polynomials in (x, y, z)
+// linear: [x, y, z, 1]; quadratic: [xx, yy, zz, xy, xz, yz, x, y, z, 1]; cubic: Nistér's order — the first ten monomials are
+// eliminated, the last ten are [x, y, 1] (x) powers of z:
+//   x3 y3 x2y xy2 x2z x2 xyz xy y2z y2 | xz2 xz x | yz2 yz y | z3 z2 z 1
+MDRP_HD constexpr int quad_index(int a, int b, int c) { // exponents of x, y, z (sum <= 2)
+    return a == 2 ? 0 : b == 2 ? 1 : c == 2 ? 2 : (a == 1 && b == 1) ? 3 : (a == 1 && c == 1) ? 4 : (b == 1 && c == 1) ? 5 : a == 1 ? 6 : b == 1 ? 7 : c == 1 ? 8 : 9;
+}
+MDRP_HD constexpr int cubic_index(int a, int b, int c) {
+    return a == 3 ? 0 : b == 3 ? 1 : (a == 2 && b == 1) ? 2 : (a == 1 && b == 2) ? 3 : (a == 2 && c == 1) ? 4 : (a == 2) ? 5
+         : (a == 1 && b == 1 && c == 1) ? 6 : (a == 1 && b == 1) ? 7 : (b == 2 && c == 1) ? 8 : (b == 2) ? 9
+         : (a == 1 && c == 2) ? 10 : (a == 1 && c == 1) ? 11 : (a == 1) ? 12 : (b == 1 && c == 2) ? 13 : (b == 1 && c == 1) ? 14 : (b == 1) ? 15
+         : c == 3 ? 16 : c == 2 ? 17 : c == 1 ? 18 : 19;
+}
+MDRP_HD constexpr int lin_exp(int i, int v) { return i == v ? 1 : 0; } // exponent of variable v in linear monomial i (i = 3: constant)
+MDRP_HD constexpr int quad_exp(int i, int v) {
+    constexpr int T[10][3] = {{2, 0, 0}, {0, 2, 0}, {0, 0, 2}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+    return T[i][v];
+}
+// q += s * a * b   (linear x linear)
+MDRP_HD void lin_mul_add(const double *a, const double *b, double s, double *q) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            q[quad_index(lin_exp(i, 0) + lin_exp(j, 0), lin_exp(i, 1) + lin_exp(j, 1), lin_exp(i, 2) + lin_exp(j, 2))] += s * a[i] * b[j];
+}
+// c += s * q * l   (quadratic x linear)
+MDRP_HD void quad_lin_mul_add(const double *q, const double *l, double s, double *c) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            c[cubic_index(quad_exp(i, 0) + lin_exp(j, 0), quad_exp(i, 1) + lin_exp(j, 1), quad_exp(i, 2) + lin_exp(j, 2))] += s * q[i] * l[j];
+}
+
+// ---------------------------------------------------------------- 5-point: essential matrices
+// x1h, x2h: the five sample bearings (unit vectors).  Es: up to 10 matrices, row-major, unit Frobenius norm.
+MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9]) {
+    double A[45], N[36];
+    epipolar_columns<5>(x1h, x2h, A);
+    fullpiv_nullspace<5>(A, N);
+    // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]
+    double El[3][3][4];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 4; ++k) El[i][j][k] = N[k * 9 + 3 * j + i];
+    double C[10][20];
+    {
+        double EEt[3][3][10], tr[10];
+        for (int k = 0; k < 10; ++k) tr[k] = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = i; j < 3; ++j) {
+                for (int k = 0; k < 10; ++k) EEt[i][j][k] = 0.0;
+                for (int k = 0; k < 3; ++k) lin_mul_add(El[i][k], El[j][k], 1.0, EEt[i][j]);
+                if (j != i) for (int k = 0; k < 10; ++k) EEt[j][i][k] = EEt[i][j][k];
+            }
+        for (int i = 0; i < 3; ++i) for (int k = 0; k < 10; ++k) tr[k] += EEt[i][i][k];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double *row = C[3 * i + j];
+                for (int k = 0; k < 20; ++k) row[k] = 0.0;
+                for (int k = 0; k < 3; ++k) quad_lin_mul_add(EEt[i][k], El[k][j], 2.0, row);
+                quad_lin_mul_add(tr, El[i][j], -1.0, row);
+            }
+        double *det = C[9], m[10];
+        for (int k = 0; k < 20; ++k) det[k] = 0.0;
+        for (int k = 0; k < 10; ++k) m[k] = 0.0;
+        lin_mul_add(El[1][1], El[2][2], 1.0, m); lin_mul_add(El[1][2], El[2][1], -1.0, m); quad_lin_mul_add(m, El[0][0], 1.0, det);
+        for (int k = 0; k < 10; ++k) m[k] = 0.0;
+        lin_mul_add(El[1][0], El[2][2], 1.0, m); lin_mul_add(El[1][2], El[2][0], -1.0, m); quad_lin_mul_add(m, El[0][1], -1.0, det);
+        for (int k = 0; k < 10; ++k) m[k] = 0.0;
+        lin_mul_add(El[1][0], El[2][1], 1.0, m); lin_mul_add(El[1][1], El[2][0], -1.0, m); quad_lin_mul_add(m, El[0][2], 1.0, det);
+    }
+    // Gauss-Jordan on the ten eliminated monomials, partial pivoting
+    for (int col = 0; col < 10; ++col) {
+        int piv = col;
+        double pv = fabs(C[col][col]);
+        for (int r = col + 1; r < 10; ++r) { const double v = fabs(C[r][col]); if (v > pv) { pv = v; piv = r; } }
+        if (!(pv > 0.0)) return 0;
+        if (piv != col) for (int k = col; k < 20; ++k) { const double t = C[col][k]; C[col][k] = C[piv][k]; C[piv][k] = t; }
+        const double inv = 1.0 / C[col][col];
+        for (int k = col; k < 20; ++k) C[col][k] *= inv;
+        for (int r = 0; r < 10; ++r) {
+            if (r == col) continue;
+            const double f = C[r][col];
+            if (f != 0.0) for (int k = col; k < 20; ++k) C[r][k] -= f * C[col][k];
+        }
+    }
+    // rows (4,5), (6,7), (8,9): <x2 z> - z <x2>, <xyz> - z <xy>, <y2 z> - z <y2>  ->  B(z) [x y 1]' = 0
+    double bx[3][4], by[3][4], b1[3][5];
+    for (int i = 0; i < 3; ++i) {
+        const double *u = C[4 + 2 * i] + 10, *v = C[5 + 2 * i] + 10;
+        bx[i][3] = -v[0]; bx[i][2] = u[0] - v[1]; bx[i][1] = u[1] - v[2]; bx[i][0] = u[2];
+        by[i][3] = -v[3]; by[i][2] = u[3] - v[4]; by[i][1] = u[4] - v[5]; by[i][0] = u[5];
+        b1[i][4] = -v[6]; b1[i][3] = u[6] - v[7]; b1[i][2] = u[7] - v[8]; b1[i][1] = u[8] - v[9]; b1[i][0] = u[9];
+    }
+    double c[11];
+    for (int k = 0; k < 11; ++k) c[k] = 0.0;
+    constexpr int PERM[6][4] = {{0, 1, 2, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {2, 1, 0, -1}};
+    for (int p = 0; p < 6; ++p) { // sign * bx[r0] * by[r1] * b1[r2] over the permutations (r0, r1, r2)
+        const int r0 = PERM[p][0], r1 = PERM[p][1], r2 = PERM[p][2];
+        const double sgn = (double)PERM[p][3];
+        double ab[7];
+        for (int k = 0; k < 7; ++k) ab[k] = 0.0;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) ab[i + j] += bx[r0][i] * by[r1][j];
+        for (int i = 0; i < 7; ++i) for (int j = 0; j < 5; ++j) c[i + j] += sgn * ab[i] * b1[r2][j];
+    }
+    double roots[10];
+    const int nr = real_roots<10>(c, roots);
+    int n_out = 0;
+    for (int s = 0; s < nr; ++s) {
+        const double z = roots[s];
+        double B[3][3];
+        for (int i = 0; i < 3; ++i) {
+            B[i][0] = ((bx[i][3] * z + bx[i][2]) * z + bx[i][1]) * z + bx[i][0];
+            B[i][1] = ((by[i][3] * z + by[i][2]) * z + by[i][1]) * z + by[i][0];
+            B[i][2] = (((b1[i][4] * z + b1[i][3]) * z + b1[i][2]) * z + b1[i][1]) * z + b1[i][0];
+        }
+        int r0 = 0, r1 = 1;
+        double best = 0.0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = a + 1; b < 3; ++b) {
+                const double dd = fabs(B[a][0] * B[b][1] - B[a][1] * B[b][0]);
+                if (dd > best) { best = dd; r0 = a; r1 = b; }
+            }
+        if (!(best > 0.0)) continue;
+        const double det = B[r0][0] * B[r1][1] - B[r0][1] * B[r1][0];
+        const double x = (-B[r0][2] * B[r1][1] + B[r0][1] * B[r1][2]) / det;
+        const double y = (-B[r0][0] * B[r1][2] + B[r0][2] * B[r1][0]) / det;
+        double e[9], nrm = 0.0;
+        for (int k = 0; k < 9; ++k) { e[k] = x * N[k] + y * N[9 + k] + z * N[18 + k] + N[27 + k]; nrm += e[k] * e[k]; }
+        nrm = 1.0 / sqrt(nrm);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Es[n_out][3 * i + j] = e[3 * j + i] * nrm;
+        ++n_out;
+    }
+    return n_out;
+}
+
+// ---------------------------------------------------------------- E -> poses (motion_from_essential @0x1dd540)
+// check_cheirality @0x1dce00 on unit bearings, min_depth 0
+MDRP_HD bool cheirality_bearing(const double R[9], const double t[3], const double x1[3], const double x2[3]) {
+    const double u0 = R[0] * x1[0] + R[1] * x1[1] + R[2] * x1[2], u1 = R[3] * x1[0] + R[4] * x1[1] + R[5] * x1[2],
+                 u2 = R[6] * x1[0] + R[7] * x1[1] + R[8] * x1[2];
+    const double a = -(u0 * x2[0] + u1 * x2[1] + u2 * x2[2]);
+    const double b1 = -(u0 * t[0] + u1 * t[1] + u2 * t[2]);
+    const double b2 = x2[0] * t[0] + x2[1] * t[1] + x2[2] * t[2];
+    return (b1 - a * b2) > 0.0 && (-a * b1 + b2) > 0.0;
+}
+MDRP_HD int motion_from_essential(const double E[9], const double (*x1h)[3], const double (*x2h)[3], int npts, Model *out) {
+    const double c0[3] = {E[0], E[3], E[6]}, c1[3] = {E[1], E[4], E[7]}, c2[3] = {E[2], E[5], E[8]};
+    double u12[3], u13[3], u23[3];
+    cross3(c0, c1, u12); cross3(c0, c2, u13); cross3(c1, c2, u23);
+    const double n12 = dot3(u12, u12), n13 = dot3(u13, u13), n23 = dot3(u23, u23);
+    double UW[3][3], Vt[3][3]; // UW[col][.]
+    const double *a, *u;
+    double nu;
+    if (n12 > n13) { if (n12 > n23) { a = c0; u = u12; nu = n12; } else { a = c1; u = u23; nu = n23; } }
+    else { if (n13 > n23) { a = c0; u = u13; nu = n13; } else { a = c1; u = u23; nu = n23; } }
+    const double na = 1.0 / sqrt(dot3(a, a)), su = 1.0 / sqrt(nu);
+    for (int k = 0; k < 3; ++k) { UW[1][k] = a[k] * na; UW[2][k] = u[k] * su; }
+    double t0[3];
+    cross3(UW[2], UW[1], t0);
+    for (int k = 0; k < 3; ++k) UW[0][k] = -t0[k];
+    for (int j = 0; j < 3; ++j) {
+        Vt[0][j] = UW[1][0] * E[j] + UW[1][1] * E[3 + j] + UW[1][2] * E[6 + j];
+        Vt[1][j] = -(UW[0][0] * E[j] + UW[0][1] * E[3 + j] + UW[0][2] * E[6 + j]);
+    }
+    double n0 = 1.0 / sqrt(dot3(Vt[0], Vt[0]));
+    for (int j = 0; j < 3; ++j) Vt[0][j] *= n0;
+    const double d = dot3(Vt[0], Vt[1]);
+    for (int j = 0; j < 3; ++j) Vt[1][j] -= d * Vt[0][j];
+    n0 = 1.0 / sqrt(dot3(Vt[1], Vt[1]));
+    for (int j = 0; j < 3; ++j) Vt[1][j] *= n0;
+    cross3(Vt[0], Vt[1], Vt[2]);
+    int n_out = 0;
+    double t[3] = {UW[2][0], UW[2][1], UW[2][2]};
+    for (int pass = 0; pass < 2; ++pass) { // candidates in the order (R1, t), (R1, -t), (R2, -t), (R2, t)
+        double R[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = UW[0][i] * Vt[0][j] + UW[1][i] * Vt[1][j] + UW[2][i] * Vt[2][j];
+        for (int sgn = 0; sgn < 2; ++sgn) {
+            bool ok = true;
+            for (int k = 0; k < npts; ++k) ok = ok && cheirality_bearing(R, t, x1h[k], x2h[k]);
+            if (ok) {
+                Model m;
+                model_identity(m);
+                R_to_quat(R, m.q);
+                m.t[0] = t[0]; m.t[1] = t[1]; m.t[2] = t[2];
+                out[n_out++] = m;
+            }
+            for (int k = 0; k < 3; ++k) t[k] = -t[k];
+        }
+        // after two flips t is back at +t; the reference continues from -t: (R2, -t) then (R2, +t)
+        for (int k = 0; k < 3; ++k) { t[k] = -t[k]; UW[0][k] = -UW[0][k]; UW[1][k] = -UW[1][k]; }
+    }
+    return n_out;
+}
+
+constexpr int MAX_MODELS_5PT = 10; // one pose per essential matrix passes the cheirality of all five points (generic data)
+MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_5PT]*/) {
+    double Es[10][9];
+    const int ne = relpose_5pt_E(x1h, x2h, Es);
+    int n = 0;
+    for (int i = 0; i < ne && n < MAX_MODELS_5PT; ++i) {
+        Model tmp[4];
+        const int k = motion_from_essential(Es[i], x1h, x2h, 5, tmp);
+        for (int j = 0; j < k && n < MAX_MODELS_5PT; ++j) out[n++] = tmp[j];
+    }
+    return n;
+}
+
+// ---------------------------------------------------------------- 7-point
+// A fundamental matrix travels in the first nine doubles of a Model, row-major (q[0..3], t[0..2], scale, shift1).
+MDRP_HD double *model_F(Model &m) { return m.q; }
+MDRP_HD const double *model_F(const Model &m) { return m.q; }
+MDRP_HD int solver_fundamental_7pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[3]*/) {
+    double A[63], N[18];
+    epipolar_columns<7>(x1h, x2h, A);
+    fullpiv_nullspace<7>(A, N);
+    const double *N0 = N, *N1 = N + 9;
+    // det(r A + B), A = mat(N0), B = mat(N1), vec index of (i, j) = 3 j + i
+    double c[4] = {0, 0, 0, 0};
+    constexpr int PERM[6][4] = {{0, 1, 2, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {2, 1, 0, -1}};
+    for (int p = 0; p < 6; ++p) {
+        const int js[3] = {PERM[p][0], PERM[p][1], PERM[p][2]};
+        const double sgn = (double)PERM[p][3];
+        double l1[3], l0[3];
+        for (int i = 0; i < 3; ++i) { l1[i] = N0[3 * js[i] + i]; l0[i] = N1[3 * js[i] + i]; }
+        const double q0 = l0[0] * l0[1], q1 = l0[0] * l1[1] + l1[0] * l0[1], q2 = l1[0] * l1[1];
+        c[0] += sgn * q0 * l0[2];
+        c[1] += sgn * (q0 * l1[2] + q1 * l0[2]);
+        c[2] += sgn * (q1 * l1[2] + q2 * l0[2]);
+        c[3] += sgn * q2 * l1[2];
+    }
+    double roots[3];
+    const int nr = real_roots<3>(c, roots);
+    for (int s = 0; s < nr; ++s) { // solve_cubic_real of the binary lists the roots in DESCENDING order
+        const double r = roots[nr - 1 - s];
+        double f[9], nrm = 0.0;
+        for (int k = 0; k < 9; ++k) { f[k] = N0[k] * r + N1[k]; nrm += f[k] * f[k]; }
+        nrm = 1.0 / sqrt(nrm);
+        Model m;
+        model_identity(m);
+        double *F = model_F(m);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) F[3 * i + j] = f[3 * j + i] * nrm;
+        m.shift2 = 0.0; m.f1 = 1.0; m.f2 = 1.0;
+        out[s] = m;
+    }
+    return nr;
+}
+
+} // namespace mdrp

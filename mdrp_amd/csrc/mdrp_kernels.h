@@ -72,6 +72,7 @@ struct PairState {
     double final_loss_scale; // user bundle loss_scale, normalised
     double norm;        // un-normalisation factor of the focals (1 for calibrated)
     double box[4];      // max |x1.x|, |x1.y|, |x2.x|, |x2.y| of the normalised correspondences (k_score's denominator bound)
+    double cen[4];      // centroids subtracted by the 7-point baseline's normalisation (c1.x, c1.y, c2.x, c2.y); 0 otherwise
     uint64_t best_min_cnt;
     double best_min_score;
     uint64_t dyn_max_iter;
@@ -101,7 +102,9 @@ struct RunParams {
     int batch, n_max;
     int chunk_len;      // iterations in this chunk (one solve/score/scan launch train)
     int chunk_off;      // offset of this chunk inside its super-chunk
-    int slot_stride;    // slots per pair in models/slot_*/tags: 4 * (iterations a super-chunk can hold)
+    int slot_stride;    // slots per pair in models/slot_*/tags: mps * (iterations a super-chunk can hold)
+    int mps;            // model slots per sample: 4 (monodepth solvers, 7-point) or 12 (5-point: up to 10 poses)
+    int sample_sz;      // 3 (monodepth), 5, 7: exponent of the inlier ratio in the dynamic stopping rule
     int super_len;      // iterations of the whole super-chunk (chunks that share one LO + walk pass)
     uint64_t chunk_start; // absolute iteration number of the super-chunk's first iteration
     uint64_t max_iterations, min_iterations;
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
         s.lo_loss_scale = rp.kind == 2 ? 1.0 : s.eps;
         s.final_loss_scale = bundle_loss_scale * k;
         s.norm = norm;
+        s.cen[0] = s.cen[1] = s.cen[2] = s.cen[3] = 0.0;
         s.best_min_cnt = 0; s.best_min_score = DBL_MAX;
         s.dyn_max_iter = rp.max_iterations;
         s.iterations = 0; s.refinements = 0; s.num_inliers = 0;
@@ -775,7 +779,7 @@ __global__ __launch_bounds__(64) void k_count_plan(int batch, const PairState *_
     if (lane == 0) plan[batch] = run;
 }
 
-template <bool POSE>
+template <bool POSE, bool RAWF = false> // RAWF: the model IS a fundamental matrix (first nine doubles, row-major) — 7-point baseline
 __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const PairState *__restrict__ st, const uint4 *__restrict__ rfrag,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags,
                                                           const int32_t *__restrict__ model_count, const int32_t *__restrict__ plan,
@@ -801,7 +805,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS); the loads of both rounds
     // are issued before the arithmetic of the first (tag -> model is a dependent pair of L2 round trips)
     uint32_t slot_r[CNT_ROUNDS] = {};
-    double mq[CNT_ROUNDS][4], mt[CNT_ROUNDS][3], mf[CNT_ROUNDS][2];
+    double mq[CNT_ROUNDS][4], mt[CNT_ROUNDS][3], mf[CNT_ROUNDS][2], ms[CNT_ROUNDS][2];
 #pragma unroll
     for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
@@ -815,6 +819,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
         mq[r][0] = q01.x; mq[r][1] = q01.y; mq[r][2] = q23.x; mq[r][3] = q23.y;
         mt[r][0] = t01.x; mt[r][1] = t01.y; mt[r][2] = t2s.x;
         mf[r][0] = f12.x; mf[r][1] = f12.y;
+        ms[r][0] = t2s.y; ms[r][1] = RAWF ? P[4].x : 0.0;
     }
 #pragma unroll
     for (int r = 0; r < CNT_ROUNDS; ++r) {
@@ -826,12 +831,18 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
         e8[0] = e8[1] = e8[2] = 0;
         if (i < cnt) {
             double R[9], Em[9], E[9];
-            quat_to_R(mq[r], R);
-            essential_from_Rt(R, mt[r], Em);
-            if (POSE) {
+            if (RAWF) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) E[q] = Em[q];
-            } else fundamental_from_E(Em, mf[r][0], mf[r][1], E);
+                for (int q = 0; q < 4; ++q) E[q] = mq[r][q];
+                E[4] = mt[r][0]; E[5] = mt[r][1]; E[6] = mt[r][2]; E[7] = ms[r][0]; E[8] = ms[r][1];
+            } else {
+                quat_to_R(mq[r], R);
+                essential_from_Rt(R, mt[r], Em);
+                if (POSE) {
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) E[q] = Em[q];
+                } else fundamental_from_E(Em, mf[r][0], mf[r][1], E);
+            }
             count_setup_scaled(E, ps.box, thr, eh, el, e8, tb);
         }
         uint4 *dst = s_frag[wave][64 * r + lane];
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
 constexpr int BND_THREADS = 256;
 constexpr int BND_TILE = 1024; // correspondences per LDS tile (16 B each, fp32)
 
-template <bool POSE>
+template <bool POSE, bool RAWF = false>
 __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags_in,
                                                           const int32_t *__restrict__ cnt_in, const int32_t *__restrict__ plan,
@@ -1024,12 +1035,17 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
         tag = tags_in[slot_base + i];
         const Model m = models[slot_base + (tag & 0xFFFFFFu)];
         double R[9], Em[9], E[9];
-        quat_to_R(m.q, R);
-        essential_from_Rt(R, m.t, Em);
-        if (POSE) {
+        if (RAWF) {
 #pragma unroll
-            for (int q = 0; q < 9; ++q) E[q] = Em[q];
-        } else fundamental_from_E(Em, m.f1, m.f2, E);
+            for (int q = 0; q < 9; ++q) E[q] = reinterpret_cast<const double *>(&m)[q];
+        } else {
+            quat_to_R(m.q, R);
+            essential_from_Rt(R, m.t, Em);
+            if (POSE) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) E[q] = Em[q];
+            } else fundamental_from_E(Em, m.f1, m.f2, E);
+        }
         sane = bound_setup32(E, ps.box, thr, Ef, eC, eD, thr_dn);
     }
     // Two correspondences per step in packed fp32 (every VALU instruction costs 4 cycles per wavefront; v_pk_* carry two
@@ -1193,7 +1209,7 @@ __global__ __launch_bounds__(64) void k_plan(int batch, const int32_t *__restric
 // 2048-iteration chunk took as long as a 7440-iteration one.  With the compacted plan consecutive workgroups are
 // consecutive live items, so every XCD gets the same mix.  (A persistent variant pulling items from an atomic queue
 // was 3x slower; a persistent static-stride loop 25 % slower from imbalance.)
-template <bool POSE>
+template <bool POSE, bool RAWF = false>
 __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                          const Model *__restrict__ models, const uint32_t *__restrict__ tags,
                                                          const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
@@ -1233,13 +1249,18 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     if (live) {
         const Model m = *mp;
         double R[9], Em[9];
-        quat_to_R(m.q, R);
-        essential_from_Rt(R, m.t, Em);
-        if (POSE) {
+        if (RAWF) {
 #pragma unroll
-            for (int i = 0; i < 9; ++i) E[i] = Em[i];
+            for (int i = 0; i < 9; ++i) E[i] = reinterpret_cast<const double *>(&m)[i];
         } else {
-            fundamental_from_E(Em, m.f1, m.f2, E);
+            quat_to_R(m.q, R);
+            essential_from_Rt(R, m.t, Em);
+            if (POSE) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) E[i] = Em[i];
+            } else {
+                fundamental_from_E(Em, m.f1, m.f2, E);
+            }
         }
     }
     bound_setup(E, ps, thr, Ef, tb, thr_dmax);
@@ -1287,6 +1308,7 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
 // ------------------------------------------------------------------------------------------------ scan
 // One wave per pair walks the chunk's slots in iteration order, 64 iterations per step: per-lane local records ->
 // wave exclusive prefix (max count, min score) -> per-lane replay against the true running records.
+template <int MPS = 4>
 __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict__ st, const double *__restrict__ slot_score,
                                              const int32_t *__restrict__ slot_inl, Trigger *__restrict__ triggers,
                                              int trig_cap, const int32_t *__restrict__ model_count,
@@ -1298,18 +1320,23 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     long long run_cnt = (long long)ps.best_min_cnt;
     double run_score = ps.best_min_score;
     int ntrig = rp.chunk_off > 0 ? ps.n_triggers : 0; // later chunks of a super-chunk append to its trigger list
-    const size_t slot_base = (size_t)pair * rp.slot_stride + (size_t)rp.chunk_off * 4;
+    static_assert(MPS % 4 == 0, "slots of an iteration are read as 16-byte groups");
+    constexpr int NG = MPS / 4;
+    const size_t slot_base = (size_t)pair * rp.slot_stride + (size_t)rp.chunk_off * MPS;
     // one wavefront walks ~150 steps of 64 iterations: the slots of the next step are requested before this step is
     // examined, and a step in which no lane beats the running records (most of them) skips the prefix and the replay
-    struct Slots { int4 c; double2 s01, s23; };
+    struct Slots { int4 c[NG]; double2 s01[NG], s23[NG]; };
     auto fetch = [&](int it0) {
         Slots r;
         const int it = it0 + lane;
-        if (it < rp.chunk_len) {
-            r.c = *reinterpret_cast<const int4 *>(slot_inl + slot_base + (size_t)it * 4);
-            const double2 *sp = reinterpret_cast<const double2 *>(slot_score + slot_base + (size_t)it * 4);
-            r.s01 = sp[0]; r.s23 = sp[1]; // empty slots hold stale scores: masked by the count below
-        } else { r.c = make_int4(-1, -1, -1, -1); r.s01 = r.s23 = make_double2(DBL_MAX, DBL_MAX); }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (it < rp.chunk_len) {
+                r.c[g] = *reinterpret_cast<const int4 *>(slot_inl + slot_base + (size_t)it * MPS + 4 * g);
+                const double2 *sp = reinterpret_cast<const double2 *>(slot_score + slot_base + (size_t)it * MPS + 4 * g);
+                r.s01[g] = sp[0]; r.s23[g] = sp[1]; // empty slots hold stale scores: masked by the count below
+            } else { r.c[g] = make_int4(-1, -1, -1, -1); r.s01[g] = r.s23[g] = make_double2(DBL_MAX, DBL_MAX); }
+        }
         return r;
     };
     Slots nxt = fetch(0);
@@ -1317,13 +1344,18 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
         const int it = it0 + lane;
         const Slots cur = nxt;
         if (it0 + 64 < rp.chunk_len) nxt = fetch(it0 + 64);
-        const int c[4] = {cur.c.x, cur.c.y, cur.c.z, cur.c.w};
-        const double s[4] = {c[0] >= 0 ? cur.s01.x : DBL_MAX, c[1] >= 0 ? cur.s01.y : DBL_MAX, c[2] >= 0 ? cur.s23.x : DBL_MAX,
-                             c[3] >= 0 ? cur.s23.y : DBL_MAX};
+        int c[MPS];
+        double s[MPS];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            c[4 * g] = cur.c[g].x; c[4 * g + 1] = cur.c[g].y; c[4 * g + 2] = cur.c[g].z; c[4 * g + 3] = cur.c[g].w;
+            s[4 * g] = c[4 * g] >= 0 ? cur.s01[g].x : DBL_MAX; s[4 * g + 1] = c[4 * g + 1] >= 0 ? cur.s01[g].y : DBL_MAX;
+            s[4 * g + 2] = c[4 * g + 2] >= 0 ? cur.s23[g].x : DBL_MAX; s[4 * g + 3] = c[4 * g + 3] >= 0 ? cur.s23[g].y : DBL_MAX;
+        }
         long long lc = -1;
         double ls = DBL_MAX;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (c[k] >= 0) { lc = max(lc, (long long)c[k]); ls = fmin(ls, s[k]); }
+        for (int k = 0; k < MPS; ++k) if (c[k] >= 0) { lc = max(lc, (long long)c[k]); ls = fmin(ls, s[k]); }
         if (__all(lc <= run_cnt && !(ls < run_score))) continue; // nothing in these 64 iterations improves a record
         // exclusive prefix over lanes
         long long pc = lc;
@@ -1345,7 +1377,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
         int k_ref = -1, k_min = -1, cnt_min = 0, cnt_ref = 0;
         double score_min = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < MPS; ++k) {
             if (c[k] >= 0) {
                 const bool more = (long long)c[k] > bc, better = s[k] < bs;
                 if (more || better) {
@@ -1744,7 +1776,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
         const PairState &ps = st[pair];
         Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
         const size_t slot_base = (size_t)pair * rp.slot_stride;
-        Model m = models[slot_base + (size_t)tr.iter * 4 + tr.k_ref];
+        Model m = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_ref];
         LmOpt o;
         o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
         o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
@@ -1791,7 +1823,7 @@ __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__
         // execute iteration ti
         if (tr.k_min >= 0 && tr.score_min < ps.model_score) {
             ps.model_score = tr.score_min;
-            ps.best = models[slot_base + (size_t)tr.iter * 4 + tr.k_min];
+            ps.best = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_min];
             ps.num_inliers = (uint64_t)tr.cnt_min;
         }
         ps.refinements++;
@@ -1804,7 +1836,8 @@ __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__
         if (ps.inlier_ratio >= 0.9999) ps.dyn_max_iter = rp.min_iterations;
         else if (ps.inlier_ratio <= 0.0001) ps.dyn_max_iter = rp.max_iterations;
         else {
-            const double prob_outlier = 1.0 - ps.inlier_ratio * ps.inlier_ratio * ps.inlier_ratio;
+            // pow(ratio, sample size) of the reference: x * x * x for 3 (pinned against the binary), libm pow otherwise
+            const double prob_outlier = 1.0 - (rp.sample_sz == 3 ? ps.inlier_ratio * ps.inlier_ratio * ps.inlier_ratio : pow(ps.inlier_ratio, (double)rp.sample_sz));
             ps.dyn_max_iter = (uint64_t)ceil(rp.log_prob_missing / log(prob_outlier) * rp.dyn_mult);
         }
         it = ti + 1;

@@ -379,9 +379,82 @@ def _not_on_path(name, where):
     return stub
 
 
-# names the reference scripts also reach for (baseline rows of the paper tables): present so that a swapped import fails
-# with a clear message at the call, not with an AttributeError
-estimate_relative_pose = _not_on_path("estimate_relative_pose", "5-point baseline, eval.py:136")
+# ------------------------------------------------------------------------------------------------ non-monodepth baselines
+# the comparison rows of the paper tables run through the same kernels (sampler, MFMA candidate counts,
+# fp32 bound, exact sweep, scan, walk) with the upstream estimators' solvers and Sampson-only LM (mdrp_classic.h).
+def _stack2(points1, points2):
+    if isinstance(points1, np.ndarray) and points1.ndim == 3:
+        B, N = points1.shape[:2]
+        return np.ascontiguousarray(points1, np.float64), np.ascontiguousarray(points2, np.float64), np.full(B, N, np.int32)
+    B = len(points1)
+    ns = np.array([len(p) for p in points1], dtype=np.int32)
+    N = int(ns.max()) if B else 0
+    x1 = np.zeros((B, N, 2)); x2 = np.zeros((B, N, 2))
+    for i in range(B):
+        x1[i, :ns[i]] = _as_points(points1[i]); x2[i, :ns[i]] = _as_points(points2[i])
+    return x1, x2, ns
+
+
+def estimate_relative_pose_batch(points2D_1, points2D_2, cameras1, cameras2, ransac_opt=None, bundle_opt=None, device=0):
+    """B calibrated pairs through the 5-point estimator.  Returns (list[CameraPose], list[info dict])."""
+    x1, x2, ns = _stack2(points2D_1, points2D_2)
+    B = len(ns)
+
+    def cams(c):
+        lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
+        return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
+
+    h = _capi.default_handle(device)
+    res, mask = h.estimate_batch(_capi.RELPOSE_5PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
+                                 _capi.bundle_opt_from_dict(bundle_opt), ns, cams(cameras1), cams(cameras2))
+    return [CameraPose(r["model"]["q"].copy(), r["model"]["t"].copy()) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(B)]
+
+
+def estimate_fundamental_batch(points2D_1, points2D_2, ransac_opt=None, bundle_opt=None, device=0):
+    """B pairs through the 7-point estimator.  Returns (list[3 x 3 ndarray], list[info dict])."""
+    x1, x2, ns = _stack2(points2D_1, points2D_2)
+    h = _capi.default_handle(device)
+    res, mask = h.estimate_batch(_capi.FUNDAMENTAL_7PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
+                                 _capi.bundle_opt_from_dict(bundle_opt), ns)
+    return [_capi.model_to_fundamental(r["model"]) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(len(ns))]
+
+
+def estimate_relative_pose(points2D_1, points2D_2, camera1, camera2, ransac_opt={}, bundle_opt={}, initial_pose=None):
+    """Relative pose estimation with non-linear refinement (_core.pyi:504-529; eval.py:136 — the 5-point baseline).  As in the
+    monodepth estimators, an initial pose only sets score_initial_model: ransac_relpose resets the pose itself."""
+    poses, infos = estimate_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], camera1, camera2,
+                                                _with_initial(initial_pose, ransac_opt), bundle_opt)
+    return poses[0], infos[0]
+
+
+def estimate_fundamental(points2D_1, points2D_2, ransac_opt={}, bundle_opt={}, initial_F=None):
+    """Fundamental matrix estimation with non-linear refinement (_core.pyi:309-323; the 7-point baseline)."""
+    if initial_F is not None:
+        raise NotImplementedError("estimate_fundamental with initial_F (score_initial_model on a caller's F) is not built")
+    Fs, infos = estimate_fundamental_batch([_as_points(points2D_1)], [_as_points(points2D_2)], ransac_opt, bundle_opt)
+    return Fs[0], infos[0]
+
+
+def _bearings(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    if x.ndim != 2 or x.shape[1] != 3:
+        raise ValueError("bearings must have shape (K, 3)")
+    return x
+
+
+def relpose_5pt(x1, x2):
+    """_core.pyi:851-854: five unit bearings per view -> list[CameraPose] in the reference's order"""
+    out, n = _capi.default_handle(0).classic_solver_batch(_capi.RELPOSE_5PT, _bearings(x1)[None], _bearings(x2)[None])
+    return [CameraPose(m["q"].copy(), m["t"].copy()) for m in out[0][:n[0]]]
+
+
+def relpose_7pt(x1, x2):
+    """seven unit bearings per view -> list of 3 x 3 fundamental matrices (unit Frobenius norm) in the reference's order"""
+    out, n = _capi.default_handle(0).classic_solver_batch(_capi.FUNDAMENTAL_7PT, _bearings(x1)[None], _bearings(x2)[None])
+    return [_capi.model_to_fundamental(m) for m in out[0][:n[0]]]
+
+
+# names the reference scripts also reach for: present so that a swapped import fails with a clear message at the call
 estimate_shared_focal_relative_pose = _not_on_path("estimate_shared_focal_relative_pose", "6-point baseline, eval_shared_f.py:161")
 estimate_relative_pose_w_relative_depth = _not_on_path("estimate_relative_pose_w_relative_depth", "fork-only variant, eval.py:140 (commented out upstream)")
 

@@ -52,7 +52,8 @@ def lib():
         l = C.CDLL(_SO)
         l.orc_msac_pose.restype = C.c_double
         l.orc_msac_F.restype = C.c_double
-        for name, rt in (("orc_refine", BundleStats), ("orc_ransac", RansacStats), ("orc_estimate", RansacStats)):
+        for name, rt in (("orc_refine", BundleStats), ("orc_ransac", RansacStats), ("orc_estimate", RansacStats),
+                         ("orc_refine_classic", BundleStats), ("orc_ransac_classic", RansacStats), ("orc_estimate_classic", RansacStats)):
             if hasattr(l, name):
                 getattr(l, name).restype = rt
         _lib = l
@@ -204,4 +205,73 @@ def estimate(kind, x1, x2, d1, d2, ropt, bopt, cam1=None, cam2=None, initial=Non
     c2 = f64(cam2) if cam2 is not None else np.zeros(8)
     st = lib().orc_estimate(C.c_int(kind), _p(x1), _p(x2), _p(d1), _p(d2), C.c_int(len(x1)), _p(c1), _p(c2),
                             C.byref(ropt), C.byref(bopt), _p(m), mask.ctypes.data_as(C.c_void_p))
+    return m, st, mask
+
+
+# ---- non-monodepth baselines (orc_classic.c).  kind 3: 5-point relative pose — model = q, t of the 12-wide blob;
+# ---- kind 5: 7-point fundamental — model = F row-major in the blob's first nine doubles.
+RELPOSE, FUNDAMENTAL = 3, 5
+
+
+def relpose_5pt(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((40, MODEL_W))
+    n = lib().orc_relpose_5pt(_p(x1h), _p(x2h), _p(out))
+    return out[:n]
+
+
+def relpose_5pt_E(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((10, 9))
+    n = lib().orc_relpose_5pt_E(_p(x1h), _p(x2h), _p(out))
+    return out[:n].reshape(-1, 3, 3)
+
+
+def relpose_7pt(x1h, x2h):
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((3, 9))
+    n = lib().orc_relpose_7pt(_p(x1h), _p(x2h), _p(out))
+    return out[:n].reshape(-1, 3, 3)
+
+
+def classic_blob(kind, model=None):
+    m = np.zeros(MODEL_W)
+    if model is None:
+        if kind == FUNDAMENTAL:
+            m[[0, 4, 8]] = 1.0
+        else:
+            m[0] = 1.0; m[7] = 1.0; m[10] = m[11] = 1.0
+        return m
+    model = f64(model).reshape(-1)
+    m[:len(model)] = model
+    if kind != FUNDAMENTAL and len(model) <= 7:
+        m[7] = 1.0; m[10] = m[11] = 1.0
+    return m
+
+
+def refine_classic(kind, x1, x2, model, bopt, weights=None):
+    x1, x2 = f64(x1), f64(x2)
+    m = classic_blob(kind, model)
+    w = f64(weights) if weights is not None else None
+    st = lib().orc_refine_classic(C.c_int(kind), _p(x1), _p(x2), C.c_int(len(x1)), _p(m), C.byref(bopt), _p(w) if w is not None else None)
+    return m, st
+
+
+def ransac_classic(kind, x1, x2, ropt):
+    x1, x2 = f64(x1), f64(x2)
+    m = classic_blob(kind)
+    mask = np.zeros(len(x1), dtype=np.uint8)
+    st = lib().orc_ransac_classic(C.c_int(kind), _p(x1), _p(x2), C.c_int(len(x1)), C.byref(ropt), _p(m), mask.ctypes.data_as(C.c_void_p))
+    return m, st, mask
+
+
+def estimate_classic(kind, x1, x2, ropt, bopt, cam1=None, cam2=None, pp=(0.0, 0.0)):
+    x1, x2 = f64(x1), f64(x2)
+    m = classic_blob(kind)
+    mask = np.zeros(len(x1), dtype=np.uint8)
+    c1 = f64(cam1) if cam1 is not None else np.zeros(8)
+    c2 = f64(cam2) if cam2 is not None else np.zeros(8)
+    ppv = f64(pp)
+    st = lib().orc_estimate_classic(C.c_int(kind), _p(x1), _p(x2), C.c_int(len(x1)), _p(c1), _p(c2), _p(ppv), C.byref(ropt), C.byref(bopt),
+                                    _p(m), mask.ctypes.data_as(C.c_void_p))
     return m, st, mask

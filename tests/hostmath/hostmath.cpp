@@ -181,3 +181,27 @@ extern "C" int hm_bound_check(const double *E, const double *x1, const double *x
     if (!sane) return 1;
     return (*lb <= (double)exact) && (cu >= ce);
 }
+
+// ---- non-monodepth baselines (mdrp_classic_math.h)
+#include "../../mdrp_amd/csrc/mdrp_classic_math.h"
+extern "C" {
+int hm_relpose_5pt_E(const double *x1h, const double *x2h, double *out /*10*9*/) {
+    double Es[10][9];
+    const int n = relpose_5pt_E(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), Es);
+    std::memcpy(out, Es, sizeof(double) * 9 * n);
+    return n;
+}
+int hm_relpose_5pt(const double *x1h, const double *x2h, double *out /*10*12*/) {
+    Model m[MAX_MODELS_5PT];
+    const int n = solver_relpose_5pt(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), m);
+    std::memcpy(out, m, sizeof(Model) * n);
+    return n;
+}
+int hm_relpose_7pt(const double *x1h, const double *x2h, double *out /*3*12*/) {
+    Model m[3];
+    const int n = solver_fundamental_7pt(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), m);
+    std::memcpy(out, m, sizeof(Model) * n);
+    return n;
+}
+int hm_real_roots10(const double *c, double *roots) { return real_roots<10>(c, roots); }
+}

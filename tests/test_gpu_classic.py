@@ -1,0 +1,151 @@
+"""Non-monodepth baselines on the GPU, through the C ABI / the drop-in module: 5-point relative pose and
+7-point fundamental matrix against tests/golden/classic.npz (reference binary) and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from oracle import pyorc as po
+from test_oracle_classic import check_solver_lists, classic_cam, est_cases, fund_diff, pose_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def model_row(kind, m):
+    """C-ABI model record -> flat vector comparable with the fixtures (pose: q, t; fundamental: nine entries)"""
+    return np.r_[m["q"], m["t"]] if kind == 3 else np.r_[m["q"], m["t"], m["scale"], m["shift1"]]
+
+
+@pytest.mark.parametrize("kind", [3, 5])
+def test_solver_lists_equal_reference_in_order(golden, kind):
+    from mdrp_amd import _capi
+    h = _capi.default_handle(0)
+
+    def solve(a, b):
+        out, n = h.classic_solver_batch(kind, a[None], b[None])
+        return np.array([model_row(kind, m) for m in out[0][:n[0]]]).reshape(-1, 7 if kind == 3 else 9)
+
+    check_solver_lists(kind, golden("classic"), solve)
+
+
+def test_solvers_equal_oracle_on_random_samples():
+    from mdrp_amd import _capi
+    h = _capi.default_handle(0)
+    rng = np.random.default_rng(12)
+
+    def unit(x):
+        hh = np.concatenate([x, np.ones(x.shape[:-1] + (1,))], axis=-1)
+        return np.ascontiguousarray(hh / np.linalg.norm(hh, axis=-1, keepdims=True))
+
+    for kind, K in ((3, 5), (5, 7)):
+        x1 = rng.uniform(-1, 1, (3000, K, 2))
+        x2 = x1 + rng.normal(size=x1.shape) * np.where(np.arange(3000) % 2, 0.1, 1.0)[:, None, None]
+        a, b = unit(x1), unit(x2)
+        out, n = h.classic_solver_batch(kind, a, b)
+        bad = 0
+        for i in range(3000):
+            ref = po.relpose_5pt(a[i], b[i]) if kind == 3 else po.relpose_7pt(a[i], b[i]).reshape(-1, 9)
+            if len(ref) != n[i]:
+                bad += 1      # a root at the edge of existence (double root): the count may differ under FMA contraction
+                continue
+            for k in range(n[i]):
+                d = pose_diff(model_row(3, out[i][k]), ref[k]) if kind == 3 else fund_diff(model_row(5, out[i][k]), ref[k])
+                assert d < (1e-3 if kind == 3 else 1e-9), (kind, i, k, d)
+        assert bad <= 3, (kind, bad)
+
+
+def test_refine_equals_reference(golden):
+    from mdrp_amd import _capi
+    h = _capi.default_handle(0)
+    g = golden("classic")
+    for i, kind, loss, its in g["refine_cases"]:
+        kind = int(kind)
+        bo = _capi.bundle_opt_from_dict({"max_iterations": int(its), "loss_scale": 0.004})
+        bo.loss_type = int(loss)
+        m0 = g[f"refine_m0_{i}"]
+        rec = np.zeros(1, dtype=_capi.MODEL_DTYPE)
+        if kind == 3:
+            rec["q"] = m0[:4]; rec["t"] = m0[4:7]; rec["scale"] = 1.0; rec["f1"] = rec["f2"] = 1.0
+        else:
+            rec[0] = _capi.fundamental_to_model(m0.reshape(3, 3))
+        out, cost = h.refine_models(kind, rec, g[f"refine_x1_{i}"], g[f"refine_x2_{i}"], None, None, 0.0, 1.0, bo)
+        ref, rst = g[f"refine_m_{i}"], g[f"refine_stats_{i}"]
+        d = pose_diff(model_row(3, out[0]), ref) if kind == 3 else fund_diff(model_row(5, out[0]), ref)
+        assert d < 1e-6, (i, kind, loss, its, d)          # north_star tolerance; trajectories agree to ~1e-9 in practice
+        assert cost[0] == pytest.approx(rst[2], rel=1e-6, abs=1e-18)
+
+
+def run_case(poselib, g, i, kind, its, min_its, loss, thr, seed, f):
+    ro = {"max_iterations": its, "min_iterations": min_its, "max_epipolar_error": thr, "seed": seed}
+    names = {0: "TRIVIAL", 1: "TRUNCATED", 2: "HUBER", 3: "CAUCHY", 4: "TRUNCATED_CAUCHY", 5: "TRUNCATED_LE_ZACH"}
+    bo = {"loss_type": names[loss], "loss_scale": thr}
+    if kind == 3:
+        cam1 = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [f, 640.0, 480.0]}
+        cam2 = {"model": "PINHOLE", "width": 1280, "height": 960, "params": [f * 1.01, f * 0.99, 640.0, 480.0]}
+        pose, info = poselib.estimate_relative_pose(g[f"est_x1_{i}"], g[f"est_x2_{i}"], cam1, cam2, ro, bo)
+        return np.r_[pose.q, pose.t], info
+    F, info = poselib.estimate_fundamental(g[f"est_x1_{i}"], g[f"est_x2_{i}"], ro, bo)
+    return F.reshape(-1), info
+
+
+def test_estimators_equal_reference_golden(golden):
+    """every fixture of the reference binary's estimate_relative_pose / estimate_fundamental, incl. the two BASELINE-sized ones
+    (N = 2000, 10^4 iterations), through the drop-in signatures: refinements, iterations, inliers, score, mask, model"""
+    import mdrp_amd.poselib as poselib
+    g = golden("classic")
+    for i, kind, n, its, min_its, loss, thr, seed, f in est_cases(g):
+        m, info = run_case(poselib, g, i, kind, its, min_its, loss, thr, seed, f)
+        rst = g[f"est_stats_{i}"]
+        assert (info["refinements"], info["iterations"], info["num_inliers"]) == tuple(int(v) for v in rst[:3]), (i, kind, info["refinements"], info["iterations"], info["num_inliers"], rst)
+        assert info["model_score"] == pytest.approx(rst[4], rel=1e-9)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), g[f"est_mask_{i}"]), (i, kind)
+        d = pose_diff(m, g[f"est_model_{i}"]) if kind == 3 else fund_diff(m, g[f"est_model_{i}"])
+        assert d < 1e-6, (i, kind, d)
+
+
+@pytest.mark.parametrize("kind", [3, 5])
+def test_batches_follow_the_oracle_trajectory(kind):
+    """noisy pairs with outliers, ragged sizes, batched: every pair must land on the sequential oracle's exact trajectory"""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    pairs = [synth.make_pair(8800 + 7 * k, [200, 350, 120, 500][k % 4], f1=900.0, f2=900.0, pp=(640.0, 480.0), noise_px=0.7,
+                             outlier_frac=[0.3, 0.5, 0.15, 0.4][k % 4]) for k in range(24)]
+    ro = {"max_iterations": 800, "min_iterations": 100, "max_epipolar_error": 1.5, "seed": 2}
+    bo = {"loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.5}
+    x1, x2 = [p["x1"] for p in pairs], [p["x2"] for p in pairs]
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [900.0, 640.0, 480.0]}
+    if kind == 3:
+        models, infos = poselib.estimate_relative_pose_batch(x1, x2, cam, cam, ro, bo)
+        models = [np.r_[m.q, m.t] for m in models]
+    else:
+        models, infos = poselib.estimate_fundamental_batch(x1, x2, ro, bo)
+    off = 0
+    for k, p in enumerate(pairs):
+        c = po.cam_flat(0, [900.0, 640.0, 480.0])
+        m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], po.ransac_opt(max_iterations=800, min_iterations=100, max_epipolar_error=1.5, seed=2),
+                                          po.bundle_opt(loss_type=4, loss_scale=1.5), c, c)
+        info = infos[k]
+        same = (info["refinements"], info["iterations"], info["num_inliers"]) == (st.refinements, st.iterations, st.num_inliers) and \
+            np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask)
+        if not same:
+            off += 1
+            continue
+        assert info["model_score"] == pytest.approx(st.model_score, rel=1e-9)
+        d = pose_diff(models[k], m) if kind == 3 else fund_diff(np.asarray(models[k]).reshape(-1), m)
+        assert d < 1e-6, (k, d)
+    assert off == 0, off
+
+
+def test_too_few_correspondences_and_ragged_batch():
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    p = synth.make_pair(8700, 300, f1=900.0, f2=900.0, noise_px=0.5, outlier_frac=0.3)
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [900.0, 0.0, 0.0]}
+    ro = {"max_iterations": 300, "min_iterations": 300, "max_epipolar_error": 1.5}
+    x1 = [p["x1"], p["x1"][:4], p["x1"][:6], p["x1"][:0]]
+    x2 = [p["x2"], p["x2"][:4], p["x2"][:6], p["x2"][:0]]
+    poses, infos = poselib.estimate_relative_pose_batch(x1, x2, cam, cam, ro, {})
+    assert infos[0]["num_inliers"] > 150 and infos[1]["iterations"] == 0 and infos[3]["iterations"] == 0
+    assert infos[2]["iterations"] == 300 and len(infos[2]["inliers"]) == 6
+    Fs, infos = poselib.estimate_fundamental_batch(x1, x2, ro, {})
+    assert infos[0]["num_inliers"] > 150 and infos[1]["iterations"] == 0 and infos[2]["iterations"] == 0 and infos[3]["iterations"] == 0
+    single, info1 = poselib.estimate_relative_pose(p["x1"], p["x2"], cam, cam, ro, {})
+    assert info1["num_inliers"] == poselib.estimate_relative_pose_batch(x1[:1], x2[:1], cam, cam, ro, {})[1][0]["num_inliers"]

@@ -1,0 +1,185 @@
+"""Non-monodepth baselines: the CPU oracle and the host build of the device arithmetic against
+tests/golden/classic.npz — outputs of the reference binary's relpose_5pt / relpose_7pt / refine_relpose / refine_fundamental /
+estimate_relative_pose / estimate_fundamental (tests/tools/gen_golden.py::gen_classic)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pyorc as po
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+def pose_diff(a, b):
+    """rotation (quaternion up to sign) and translation DIRECTION: |t| is a gauge of the 5-parameter LM (t moves in its tangent
+    plane and is never renormalised), and ties between equally good local minima pick LO results that differ only in |t|"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    dq = min(np.abs(a[:4] - b[:4]).max(), np.abs(a[:4] + b[:4]).max())
+    return dq + np.abs(a[4:7] / np.linalg.norm(a[4:7]) - b[4:7] / np.linalg.norm(b[4:7])).max()
+
+
+def fund_diff(a, b):
+    a, b = np.asarray(a, float).reshape(-1)[:9], np.asarray(b, float).reshape(-1)[:9]
+    a, b = a / np.linalg.norm(a), b / np.linalg.norm(b)
+    return min(np.abs(a - b).max(), np.abs(a + b).max())
+
+
+def classic_cam(f):
+    return po.cam_flat(0, [f, 640.0, 480.0]), po.cam_flat(1, [f * 1.01, f * 0.99, 640.0, 480.0])
+
+
+def est_cases(g):
+    for row in g["est_cases"]:
+        i, kind, n, its, min_its, loss = (int(v) for v in row[:6])
+        yield i, kind, n, its, min_its, loss, float(row[6]), int(row[7]), float(row[8])
+
+
+def test_samples_of_5_and_7(golden):
+    g = golden("classic")
+    l = po.lib()
+    for K in (5, 7):
+        for n in (9, 200, 2000):
+            ref = g[f"samples_k{K}_n{n}"]
+            # the oracle's K-point sampler is static inside orc_classic.c: replay it through random_int
+            st = C.c_uint64(3)
+            out = np.zeros_like(ref)
+            for s in range(len(ref)):
+                for i in range(K):
+                    while True:
+                        r = l.orc_random_int(C.byref(st))
+                        v = (r + (1 << 64)) % (1 << 64) % n  # sign-extended int32, unsigned modulo
+                        if v not in out[s, :i]:
+                            out[s, i] = v
+                            break
+            assert np.array_equal(out, ref), (K, n)
+
+
+def sample_residual(kind, sol, a, b):
+    """largest |x2' E x1| of a solution over the sample's bearings"""
+    M = po.essential(np.r_[sol[:7], 1, 0, 0, 1, 1]) if kind == 3 else np.asarray(sol[:9]).reshape(3, 3)
+    return np.abs(np.einsum("ki,ij,kj->k", b, M / np.linalg.norm(M), a)).max()
+
+
+def check_solver_lists(kind, g, solve):
+    """same number of solutions in the same ORDER as the binary.  Values: equal to 1e-8, except where the binary's own root
+    polishing stopped early (its residual on the sample reaches 4e-4 on ill-conditioned 5-point samples, ours stays below
+    1e-8): there ours must be the more accurate one and within 1e-2 of it."""
+    loose = 0
+    for i in range(len(g[f"solver{kind}_n"])):
+        a, b = np.ascontiguousarray(g[f"solver{kind}_x1"][i]), np.ascontiguousarray(g[f"solver{kind}_x2"][i])
+        n_ref = int(g[f"solver{kind}_n"][i])
+        ref = g[f"solver{kind}_sols"][i][:n_ref]
+        ours = solve(a, b)
+        assert len(ours) == n_ref, (kind, i, len(ours), n_ref)
+        for k in range(n_ref):
+            d = pose_diff(ours[k], ref[k]) if kind == 3 else fund_diff(ours[k], ref[k])
+            if d > 1e-8:
+                loose += 1
+                assert kind == 3 and d < 1e-2, (kind, i, k, d)
+                assert sample_residual(kind, ours[k], a, b) <= 10 * sample_residual(kind, ref[k], a, b) + 1e-9, (i, k)
+    assert loose <= 12, loose
+
+
+@pytest.mark.parametrize("kind", [3, 5])
+def test_solver_lists_equal_reference_in_order(golden, kind):
+    check_solver_lists(kind, golden("classic"), (lambda a, b: po.relpose_5pt(a, b)) if kind == 3 else (lambda a, b: po.relpose_7pt(a, b).reshape(-1, 9)))
+
+
+def test_refine_equals_reference(golden):
+    g = golden("classic")
+    for i, kind, loss, its in g["refine_cases"]:
+        bo = po.bundle_opt(max_iterations=int(its), loss_type=int(loss), loss_scale=0.004)
+        m, st = po.refine_classic(int(kind), g[f"refine_x1_{i}"], g[f"refine_x2_{i}"], g[f"refine_m0_{i}"], bo)
+        ref, rst = g[f"refine_m_{i}"], g[f"refine_stats_{i}"]
+        d = pose_diff(m, ref) if kind == 3 else fund_diff(m, ref)
+        assert d < 1e-9, (i, kind, loss, its, d)
+        assert st.initial_cost == pytest.approx(rst[1], rel=1e-12) and st.cost == pytest.approx(rst[2], rel=1e-9)
+        assert st.iterations == int(rst[0])
+
+
+def test_estimators_equal_reference(golden):
+    g = golden("classic")
+    for i, kind, n, its, min_its, loss, thr, seed, f in est_cases(g):
+        if n >= 2000:
+            continue  # the BASELINE-sized cases run in test_full_size_estimators_equal_reference
+        ro = po.ransac_opt(max_iterations=its, min_iterations=min_its, max_epipolar_error=thr, seed=seed)
+        bo = po.bundle_opt(loss_type=loss, loss_scale=thr)
+        c1, c2 = classic_cam(f)
+        m, st, mask = po.estimate_classic(kind, g[f"est_x1_{i}"], g[f"est_x2_{i}"], ro, bo, c1, c2)
+        ref, rst = g[f"est_model_{i}"], g[f"est_stats_{i}"]
+        assert (st.refinements, st.iterations, st.num_inliers) == tuple(int(v) for v in rst[:3]), (i, kind, rst)
+        assert st.model_score == pytest.approx(rst[4], rel=1e-9)
+        assert np.array_equal(mask, g[f"est_mask_{i}"])
+        d = pose_diff(m, ref) if kind == 3 else fund_diff(m, ref)
+        assert d < 1e-7, (i, kind, d)
+
+
+def test_full_size_estimators_equal_reference(golden):
+    g = golden("classic")
+    for i, kind, n, its, min_its, loss, thr, seed, f in est_cases(g):
+        if n < 2000:
+            continue
+        ro = po.ransac_opt(max_iterations=its, min_iterations=min_its, max_epipolar_error=thr, seed=seed)
+        bo = po.bundle_opt(loss_type=loss, loss_scale=thr)
+        c1, c2 = classic_cam(f)
+        m, st, mask = po.estimate_classic(kind, g[f"est_x1_{i}"], g[f"est_x2_{i}"], ro, bo, c1, c2)
+        rst = g[f"est_stats_{i}"]
+        assert (st.iterations, st.num_inliers) == (int(rst[1]), int(rst[2])), (i, kind, rst)
+        assert int(st.refinements) == int(rst[0]), (i, st.refinements, rst[0])
+        assert st.model_score == pytest.approx(rst[4], rel=1e-9)
+        assert np.array_equal(mask, g[f"est_mask_{i}"])
+        d = pose_diff(m, g[f"est_model_{i}"]) if kind == 3 else fund_diff(m, g[f"est_model_{i}"])
+        assert d < 1e-7, (i, kind, d)
+
+
+# ---- the device arithmetic (mdrp_classic_math.h) compiled for the host
+@pytest.fixture(scope="module")
+def hm():
+    src = os.path.join(HERE, "hostmath", "hostmath.cpp")
+    so = os.path.join(HERE, "hostmath", "libhostmath.so")
+    hdrs = [os.path.join(HERE, "..", "mdrp_amd", "csrc", h) for h in ("mdrp_math.h", "mdrp_classic_math.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(p) for p in [src] + hdrs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas", src, "-o", so])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("kind", [3, 5])
+def test_device_solvers_equal_reference_in_order(hm, golden, kind):
+    def solve(a, b):
+        out = np.zeros((10, 12))
+        n = (hm.hm_relpose_5pt if kind == 3 else hm.hm_relpose_7pt)(P(a), P(b), P(out))
+        return out[:n]
+
+    check_solver_lists(kind, golden("classic"), solve)
+
+
+def test_device_solvers_equal_oracle_on_random_samples(hm):
+    rng = np.random.default_rng(11)
+
+    def unit(x):
+        h = np.c_[x, np.ones(len(x))]
+        return np.ascontiguousarray(h / np.linalg.norm(h, axis=1, keepdims=True))
+
+    for trial in range(600):
+        K = 5 if trial % 2 == 0 else 7
+        x1 = rng.uniform(-1, 1, (K, 2))
+        a, b = unit(x1), unit(x1 + rng.normal(size=(K, 2)) * (0.1 if trial % 4 < 2 else 1.0))
+        out = np.zeros((10, 12))
+        if K == 5:
+            ref = po.relpose_5pt(a, b)
+            n = hm.hm_relpose_5pt(P(a), P(b), P(out))
+            assert n == len(ref), trial
+            assert all(pose_diff(out[k], ref[k]) < 1e-4 for k in range(n)), trial
+        else:
+            ref = po.relpose_7pt(a, b).reshape(-1, 9)
+            n = hm.hm_relpose_7pt(P(a), P(b), P(out))
+            assert n == len(ref), trial
+            assert all(fund_diff(out[k], ref[k]) < 1e-10 for k in range(n)), trial

@@ -256,6 +256,85 @@ def gen_initial():
     np.savez_compressed(os.path.join(OUT, "initial.npz"), **d)
 
 
+def unit_rows(x):
+    h = np.c_[x, np.ones(len(x))]
+    return np.ascontiguousarray(h / np.linalg.norm(h, axis=1, keepdims=True))
+
+
+def gen_classic():
+    """Non-monodepth baselines of the same binary: relpose_5pt / relpose_7pt solution lists IN THE BINARY'S ORDER,
+    refine_relpose / refine_fundamental, estimate_relative_pose / estimate_fundamental (kind 3 / 5)."""
+    d = {}
+    rng = np.random.default_rng(77)
+    # ---- solvers: geometric problems (with a little noise) and random ones
+    for kind, K, width in ((3, 5, 7), (5, 7, 9)):
+        xs1, xs2, sols, cnts = [], [], [], []
+        for i in range(96):
+            if i % 3 != 2:
+                pr = synth.make_pair(9000 + 100 * kind + i, K, f1=1.0, f2=1.0, noise_px=0.0 if i % 3 == 0 else 1e-3)
+                a, b = unit_rows(pr["x1"]), unit_rows(pr["x2"])
+            else:
+                a, b = unit_rows(rng.uniform(-1, 1, (K, 2))), unit_rows(rng.uniform(-1, 1, (K, 2)))
+            out = rs.relpose_5pt(a, b) if kind == 3 else rs.relpose_7pt(a, b).reshape(-1, 9)
+            full = np.full((10, width), np.nan)
+            full[: len(out)] = out
+            xs1.append(a); xs2.append(b); sols.append(full); cnts.append(len(out))
+        d[f"solver{kind}_x1"] = np.array(xs1); d[f"solver{kind}_x2"] = np.array(xs2)
+        d[f"solver{kind}_sols"] = np.array(sols); d[f"solver{kind}_n"] = np.array(cnts)
+        print("classic solver", kind, "solutions per problem:", np.bincount(cnts), flush=True)
+    # ---- refinement
+    ref_cases = []
+    for i in range(24):
+        kind = 3 if i % 2 == 0 else 5
+        loss = [1, 4, 3, 0, 5, 2][(i // 2) % 6]
+        its = [1, 5, 100][(i // 2) % 3]
+        pr = synth.make_pair(9500 + i, 80, f1=1.0 if kind == 3 else 1.3, f2=1.0 if kind == 3 else 1.3, noise_px=2e-3, outlier_frac=0.2)
+        Rp = rodrigues(rng.normal(0, 0.03, 3)) @ pr["R"]
+        tp = pr["t"] / np.linalg.norm(pr["t"]) + rng.normal(0, 0.05, 3)
+        if kind == 3:
+            m0 = np.r_[quat_of(Rp), tp]
+        else:
+            # a GENERIC rank-2 F (distinct singular values).  For an exact essential matrix the factorisation U diag(1, s, 0) V'
+            # refine_fundamental works in is not unique (any common rotation of the first two singular vectors), and the
+            # per-iteration path then depends on Eigen's JacobiSVD picking one member — the estimators never hit that case
+            tx = np.array([[0, -tp[2], tp[1]], [tp[2], 0, -tp[0]], [-tp[1], tp[0], 0]])
+            K = np.diag([1.0, 1.0, 1.3])
+            F = K @ tx @ Rp @ K
+            m0 = (F / np.linalg.norm(F)).reshape(-1)
+        bo = rs.bopt(max_iterations=its, loss_type=loss, loss_scale=0.004)
+        m, st = rs.refine_classic(kind, pr["x1"], pr["x2"], m0, bo)
+        d.update({f"refine_x1_{i}": pr["x1"], f"refine_x2_{i}": pr["x2"], f"refine_m0_{i}": m0, f"refine_m_{i}": m, f"refine_stats_{i}": st})
+        ref_cases.append([i, kind, loss, its])
+    d["refine_cases"] = np.array(ref_cases)
+    # ---- estimators: small shapes with every loss type + one BASELINE-sized case per estimator (N = 2000, 10^4 iterations)
+    est_cases = []
+    for i in range(18):
+        kind = 3 if i % 2 == 0 else 5
+        big = i >= 16
+        n = 2000 if big else [60, 150, 400, 1000][(i // 2) % 4]
+        outl = 0.5 if big else [0.1, 0.3, 0.5, 0.0][(i // 2) % 4]
+        its = 10000 if big else [50, 300, 1000, 200][(i // 2) % 4]
+        min_its = its if (big or i % 4 < 2) else 20          # half of the small cases stop by the dynamic rule
+        loss = 4 if big else [4, 1, 3, 0, 5, 2][(i // 2) % 6]
+        f = 800.0 if i % 3 else 1100.0
+        pr = synth.make_pair(9700 + i, n, f1=f, f2=f, pp=(640.0, 480.0), noise_px=0.5, outlier_frac=outl)
+        thr = [2.0, 1.0][i % 2 if not big else 0]
+        ro = rs.ropt(max_iterations=its, min_iterations=min_its, max_epipolar_error=thr, seed=i % 5)
+        bo = rs.bopt(loss_type=loss, loss_scale=thr)
+        cam1 = rs.cam_flat(0, 1280, 960, [f, 640.0, 480.0])
+        cam2 = rs.cam_flat(1, 1280, 960, [f * 1.01, f * 0.99, 640.0, 480.0])
+        m, st, mask = rs.estimate_classic(kind, pr["x1"], pr["x2"], ro, bo, cam1, cam2)
+        d.update({f"est_x1_{i}": pr["x1"], f"est_x2_{i}": pr["x2"], f"est_model_{i}": m, f"est_stats_{i}": st, f"est_mask_{i}": mask})
+        est_cases.append([i, kind, n, its, min_its, loss, thr, i % 5, f])
+        print("classic estimate", i, kind, n, its, st, flush=True)
+    d["est_cases"] = np.array(est_cases)
+    # samples of 5 / 7 indices (draw_sample @0x4f87f0)
+    for K in (5, 7):
+        for n in (9, 200, 2000):
+            d[f"samples_k{K}_n{n}"] = rs.draw_samples_k(3, n, K, 64).astype(np.int32)
+    np.savez_compressed(os.path.join(OUT, "classic.npz"), **d)
+
+
 if __name__ == "__main__":
     if not rs.available():
         sys.exit("reference shim not built: run `make -C oracle ref` in the build container")
@@ -267,5 +346,6 @@ if __name__ == "__main__":
     gen_estimate()
     gen_estimate_full()
     gen_initial()
+    gen_classic()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
