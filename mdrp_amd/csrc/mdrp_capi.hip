@@ -386,7 +386,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (classic) {
                 const dim3 sgrid((r.chunk_len + 63) / 64, batch);
                 if (kind == MDRP_RELPOSE_5PT)
-                    hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
                                        h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
                 else
                     hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
@@ -663,6 +663,8 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_solve<CLASSIC_RELPOSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE5_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_solver_unit<CLASSIC_RELPOSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE5_LDS_BYTES));
     *out = h;
     return MDRP_OK;
 }
@@ -815,13 +817,21 @@ int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const
     HIPCHK(hipMemcpyAsync(h->unit_a.p, x1h, sizeof(double) * 3 * K * count, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->unit_b.p, x2h, sizeof(double) * 3 * K * count, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(h->unit_e.p, 0, sizeof(Model) * M * count, s));
+#ifdef MDRP_5PT_STAGES
+    { const int stage = env_int("MDRP_5PT_STAGE", 99); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_5pt_stage), &stage, sizeof(int))); }
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, s));
+#endif
     if (kind == MDRP_RELPOSE_5PT)
-        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_RELPOSE>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
+        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_RELPOSE>, dim3((count + 63) / 64), dim3(64), SOLVE5_LDS_BYTES, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
     else
         hipLaunchKernelGGL(kc_solver_unit<CLASSIC_FUND>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
+#ifdef MDRP_5PT_STAGES
+    { HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+      fprintf(stderr, "[mdrp] classic solver kernel: %d problems in %.3f ms (%.1f ns each)\n", count, ms, 1e6 * ms / count); }
+#endif
     HIPCHK(hipMemcpyAsync(out, h->unit_e.p, sizeof(Model) * M * count, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(n_out, h->unit_f.p, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -159,6 +159,19 @@ __global__ __launch_bounds__(64) void kc_samples(int n_tables, const int32_t *__
     if (lane == 0) table_state[t] = state;
 }
 
+// LDS storage of the 5-point solver: the 10 x 10 matrix of its LU factorisation, one 64-lane column per element, and — in the
+// same bytes, once the factorisation is dead — the root finder's interval stack (dynamic LDS of the launch: SOLVE5_LDS_BYTES;
+// one wavefront per workgroup, three workgroups per CU)
+constexpr size_t SOLVE5_LDS_BYTES = (size_t)64 * 100 * sizeof(double);
+__device__ __forceinline__ Solve5Store lds_solve5_store() {
+    extern __shared__ double solve5_lds[];
+    const int lane = threadIdx.x & 63;
+    double *C = solve5_lds + lane;
+    double *lo = solve5_lds + lane, *hi = lo + 12 * 64;
+    int *cc = reinterpret_cast<int *>(solve5_lds + 24 * 64) + lane;
+    return Solve5Store{C, 64, RootStack{lo, hi, cc, 64}};
+}
+
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample (64-lane workgroups: the solvers live in scratch-backed arrays and their trip counts
 // diverge with the number of real roots).  Same slot / tag conventions as k_solve with MPS slots per sample.
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
             x1h[k][0] = p01.x * p45.x; x1h[k][1] = p01.y * p45.x; x1h[k][2] = p45.x;
             x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
         }
-        if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt(x1h, x2h, out);
+        if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt(x1h, x2h, out, lds_solve5_store());
         else n = solver_fundamental_7pt(x1h, x2h, out);
     }
     const int lane = threadIdx.x & 63;
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels
 template <int CK>
-__global__ void kc_solver_unit(int count, const double *__restrict__ x1h, const double *__restrict__ x2h, Model *__restrict__ out,
+__global__ __launch_bounds__(64) void kc_solver_unit(int count, const double *__restrict__ x1h, const double *__restrict__ x2h, Model *__restrict__ out,
                                int32_t *__restrict__ n_out) {
     constexpr int K = ClassicTraits<CK>::K, MAXM = ClassicTraits<CK>::MAXM;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -674,7 +687,7 @@ __global__ void kc_solver_unit(int count, const double *__restrict__ x1h, const 
     for (int k = 0; k < K; ++k)
         for (int c = 0; c < 3; ++c) { a[k][c] = x1h[(size_t)3 * K * i + 3 * k + c]; b[k][c] = x2h[(size_t)3 * K * i + 3 * k + c]; }
     Model m[MAXM];
-    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m) : solver_fundamental_7pt(a, b, m);
+    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m, lds_solve5_store()) : solver_fundamental_7pt(a, b, m);
     n_out[i] = n;
     for (int k = 0; k < n; ++k) out[(size_t)MAXM * i + k] = m[k];
 }

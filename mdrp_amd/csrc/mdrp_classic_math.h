@@ -195,6 +195,121 @@ MDRP_HD int real_roots(const double *coef /*ascending powers, degree D*/, double
     return nr;
 }
 
+// The same algorithm with the chain's generic shape (row i has degree exactly D - i) compiled in: every index is a compile-time
+// constant, so the 66 coefficients of a degree-10 chain live in registers instead of scratch memory (the dynamic version spends
+// half of the 5-point solver's time in scratch round trips).  The interval stack is caller-provided strided storage (LDS on the
+// device).  A chain that drops a degree (or a vanishing leading coefficient) goes to the generic routine above — same results.
+struct RootStack { double *lo, *hi; int *cc; int stride; }; // D + 2 entries each
+template <int D>
+MDRP_HD constexpr int chain_off(int i) { return i * (D + 1) - i * (i - 1) / 2; }
+template <int D>
+MDRP_HD int sturm_changes_static(const double *ch, double x) {
+    int changes = 0, last = 0;
+#pragma unroll
+    for (int i = 0; i <= D; ++i) {
+        double v = ch[chain_off<D>(i) + D - i];
+#pragma unroll
+        for (int k = D - i - 1; k >= 0; --k) v = v * x + ch[chain_off<D>(i) + k];
+        const int sg = (v > 0) - (v < 0);
+        if (sg != 0) { if (last != 0 && sg != last) ++changes; last = sg; }
+    }
+    return changes;
+}
+template <int D>
+MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &st) {
+    if (coef[D] == 0.0) return real_roots<D>(coef, roots);
+    double ch[(D + 1) * (D + 2) / 2];
+    bool generic = true;
+    {
+        const double lead = coef[D];
+#pragma unroll
+        for (int k = 0; k <= D; ++k) ch[k] = coef[k] / lead;
+#pragma unroll
+        for (int k = 1; k <= D; ++k) ch[chain_off<D>(1) + k - 1] = (double)k * ch[k];
+    }
+#pragma unroll
+    for (int i = 2; i <= D; ++i) {
+        const int m = D - i + 1; // degree of the divisor, row i - 1
+        double r[D + 1];
+#pragma unroll
+        for (int k = 0; k <= D; ++k) r[k] = (k <= m + 1) ? ch[chain_off<D>(i - 2) + k] : 0.0;
+        const double *q = ch + chain_off<D>(i - 1);
+        const double f1 = r[m + 1] / q[m];
+#pragma unroll
+        for (int j = 0; j <= D; ++j) if (j <= m) r[j + 1] -= f1 * q[j];
+        const double f0 = r[m] / q[m];
+#pragma unroll
+        for (int j = 0; j <= D; ++j) if (j <= m) r[j] -= f0 * q[j];
+        double mx = 0.0;
+#pragma unroll
+        for (int k = 0; k <= D; ++k) if (k < m) mx = fmax(mx, fabs(r[k]));
+        if (!(fabs(r[m - 1]) >= 1e-300) || !(mx > 0.0) || !(mx < 1e300)) generic = false;
+        const double inv = -1.0 / mx;
+#pragma unroll
+        for (int k = 0; k <= D; ++k) if (k < m) ch[chain_off<D>(i) + k] = r[k] * inv;
+    }
+    if (!generic) return real_roots<D>(coef, roots);
+    double bound = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) bound = fmax(bound, fabs(ch[k]));
+    bound += 1.0;
+    const int ss = st.stride;
+    int sp = 1, nr = 0;
+    st.lo[0] = -bound; st.hi[0] = bound;
+    st.cc[0] = sturm_changes_static<D>(ch, -bound) | (sturm_changes_static<D>(ch, bound) << 8);
+    auto peval = [&](double x) { double v = ch[D]; 
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) v = v * x + ch[k];
+        return v; };
+    while (sp > 0 && nr < D) {
+        --sp;
+        const double lo = st.lo[sp * ss], hi = st.hi[sp * ss];
+        const int packed = st.cc[sp * ss];
+        const int clo = packed & 0xFF, chi = (packed >> 8) & 0xFF, depth = packed >> 16;
+        const int n = clo - chi;
+        if (n <= 0) continue;
+        if (n == 1 || depth > 200 || hi - lo < 1e-15 * fmax(1.0, fmax(fabs(lo), fabs(hi)))) {
+            if (n == 1) {
+                double a = lo, b = hi, fa = peval(a);
+                for (int it = 0; it < 200; ++it) {
+                    const double mid = 0.5 * (a + b);
+                    if (mid == a || mid == b) break;
+                    const double fm = peval(mid);
+                    if (fm == 0.0) { a = b = mid; break; }
+                    if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
+                    if (it >= 12 && b - a < 1e-3 * fmax(1e-300, fabs(a) + fabs(b))) break;
+                }
+                double x = 0.5 * (a + b);
+                for (int it = 0; it < 8; ++it) {
+                    double v = ch[D], dv = 0.0;
+#pragma unroll
+                    for (int k = D - 1; k >= 0; --k) { dv = dv * x + v; v = v * x + ch[k]; }
+                    if (dv == 0.0) break;
+                    double xn = x - v / dv;
+                    if (!(xn >= a && xn <= b)) {
+                        const double mid = 0.5 * (a + b);
+                        const double fm = peval(mid);
+                        if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
+                        xn = 0.5 * (a + b);
+                    }
+                    const bool done = fabs(xn - x) <= 4e-16 * fabs(xn);
+                    x = xn;
+                    if (done) break;
+                }
+                roots[nr++] = x;
+            } else {
+                for (int i = 0; i < n && nr < D; ++i) roots[nr++] = 0.5 * (lo + hi);
+            }
+            continue;
+        }
+        const double mid = 0.5 * (lo + hi);
+        const int cm = sturm_changes_static<D>(ch, mid);
+        if (cm - chi > 0) { st.lo[sp * ss] = mid; st.hi[sp * ss] = hi; st.cc[sp * ss] = cm | (chi << 8) | ((depth + 1) << 16); ++sp; }
+        if (clo - cm > 0) { st.lo[sp * ss] = lo; st.hi[sp * ss] = mid; st.cc[sp * ss] = clo | (cm << 8) | ((depth + 1) << 16); ++sp; }
+    }
+    return nr;
+}
+
 // ---------------------------------------------------------------- polynomials in (x, y, z)
 // linear: [x, y, z, 1]; quadratic: [xx, yy, zz, xy, xz, yz, x, y, z, 1]; cubic: Nistér's order — the first ten monomials are
 // eliminated, the last ten are [x, y, 1] (x) powers of z:
@@ -232,16 +347,36 @@ MDRP_HD void quad_lin_mul_add(const double *q, const double *l, double s, double
 
 // ---------------------------------------------------------------- 5-point: essential matrices
 // x1h, x2h: the five sample bearings (unit vectors).  Es: up to 10 matrices, row-major, unit Frobenius norm.
-MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9]) {
+#if defined(__HIPCC__) && defined(MDRP_5PT_STAGES)
+__device__ int g_5pt_stage = 99; // experiment: stop after stage k (tools/stage_5pt.py)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MDRP_5PT_STAGES)
+#define MDRP_5PT_STOP(k, sink) if (g_5pt_stage <= (k)) { Es[0][0] = (sink); return 0; }
+#else
+#define MDRP_5PT_STOP(k, sink)
+#endif
+// Caller-provided strided storage for the two dynamically indexed arrays of the solver: the 10 x 10 matrix that is LU-factorised
+// with partial pivoting (element (r, k) at C[(10 r + k) cs]) and, once that is dead, the root finder's interval stack (the two
+// may alias).  On the device both live in LDS, one column of 64 lanes per element (in scratch memory the solver spent 90 % of
+// its time waiting for them); on the host they are plain local arrays.
+struct Solve5Store { double *C; int cs; RootStack rs; };
+MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9], const Solve5Store &store) {
     double A[45], N[36];
     epipolar_columns<5>(x1h, x2h, A);
     fullpiv_nullspace<5>(A, N);
+    MDRP_5PT_STOP(1, N[0] + N[35])
     // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]
     double El[3][3][4];
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j)
             for (int k = 0; k < 4; ++k) El[i][j][k] = N[k * 9 + 3 * j + i];
-    double C[10][20];
+    // The ten cubic constraints split into  L m_left + R m_right = 0  (ten eliminated monomials | [x y 1] (x) powers of z).  Only rows
+    // 4..9 of X = L^-1 R are needed:  X_i = w_i R  with  L' w_i = e_i.  L' lives in the caller's strided storage (LDS on the
+    // device: LU with partial pivoting needs dynamic row indices), R stays in registers (statically indexed: it is never permuted).
+    double *const M = store.C; // M(r, k) = L(k, r): element at M[(10 r + k) cs]
+    const int cs = store.cs;
+#define M5(r, k) M[(10 * (r) + (k)) * cs]
+    double R[10][10];
     {
         double EEt[3][3][10], tr[10];
         for (int k = 0; k < 10; ++k) tr[k] = 0.0;
@@ -252,14 +387,21 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
                 if (j != i) for (int k = 0; k < 10; ++k) EEt[j][i][k] = EEt[i][j][k];
             }
         for (int i = 0; i < 3; ++i) for (int k = 0; k < 10; ++k) tr[k] += EEt[i][i][k];
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = 0; j < 3; ++j) {
-                double *row = C[3 * i + j];
+                double row[20];
+#pragma unroll
                 for (int k = 0; k < 20; ++k) row[k] = 0.0;
+#pragma unroll
                 for (int k = 0; k < 3; ++k) quad_lin_mul_add(EEt[i][k], El[k][j], 2.0, row);
                 quad_lin_mul_add(tr, El[i][j], -1.0, row);
+#pragma unroll
+                for (int k = 0; k < 10; ++k) { M5(k, 3 * i + j) = row[k]; R[3 * i + j][k] = row[10 + k]; }
             }
-        double *det = C[9], m[10];
+        double det[20], m[10];
+#pragma unroll
         for (int k = 0; k < 20; ++k) det[k] = 0.0;
         for (int k = 0; k < 10; ++k) m[k] = 0.0;
         lin_mul_add(El[1][1], El[2][2], 1.0, m); lin_mul_add(El[1][2], El[2][1], -1.0, m); quad_lin_mul_add(m, El[0][0], 1.0, det);
@@ -267,26 +409,78 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
         lin_mul_add(El[1][0], El[2][2], 1.0, m); lin_mul_add(El[1][2], El[2][0], -1.0, m); quad_lin_mul_add(m, El[0][1], -1.0, det);
         for (int k = 0; k < 10; ++k) m[k] = 0.0;
         lin_mul_add(El[1][0], El[2][1], 1.0, m); lin_mul_add(El[1][1], El[2][0], -1.0, m); quad_lin_mul_add(m, El[0][2], 1.0, det);
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { M5(k, 9) = det[k]; R[9][k] = det[10 + k]; }
     }
-    // Gauss-Jordan on the ten eliminated monomials, partial pivoting
+    MDRP_5PT_STOP(2, M5(0, 0) + M5(9, 9) + R[4][7])
+    // P M = Lo Up, partial pivoting; the multipliers stay in the eliminated positions; perm[i] = original row now at position i
+    int perm[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) perm[i] = i;
     for (int col = 0; col < 10; ++col) {
         int piv = col;
-        double pv = fabs(C[col][col]);
-        for (int r = col + 1; r < 10; ++r) { const double v = fabs(C[r][col]); if (v > pv) { pv = v; piv = r; } }
+        double pv = fabs(M5(col, col));
+        for (int r = col + 1; r < 10; ++r) { const double v = fabs(M5(r, col)); if (v > pv) { pv = v; piv = r; } }
         if (!(pv > 0.0)) return 0;
-        if (piv != col) for (int k = col; k < 20; ++k) { const double t = C[col][k]; C[col][k] = C[piv][k]; C[piv][k] = t; }
-        const double inv = 1.0 / C[col][col];
-        for (int k = col; k < 20; ++k) C[col][k] *= inv;
-        for (int r = 0; r < 10; ++r) {
-            if (r == col) continue;
-            const double f = C[r][col];
-            if (f != 0.0) for (int k = col; k < 20; ++k) C[r][k] -= f * C[col][k];
+        if (piv != col) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) { const double t = M5(col, k); M5(col, k) = M5(piv, k); M5(piv, k) = t; }
+            int pp = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) if (i == piv) pp = perm[i];
+            int pc = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) if (i == col) pc = perm[i];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) perm[i] = (i == piv) ? pc : ((i == col) ? pp : perm[i]);
+        }
+        double prow[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) prow[k] = M5(col, k);
+        double diag = 0.0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) if (k == col) diag = prow[k];
+        const double inv = 1.0 / diag;
+        for (int r = col + 1; r < 10; ++r) {
+            const double f = M5(r, col) * inv;
+            M5(r, col) = f;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) if (k > col) M5(r, k) -= f * prow[k];
         }
     }
+    // rows 4..9 of X: forward / back substitution of e_t, then w R
+    double X[6][10];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        double y[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            double v = (perm[i] == 4 + t) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) if (k < i) v -= M5(i, k) * y[k];
+            y[i] = v;
+        }
+#pragma unroll
+        for (int i = 9; i >= 0; --i) {
+            double v = y[i];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) if (k > i) v -= M5(i, k) * y[k];
+            y[i] = v / M5(i, i);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < 10; ++r) a += y[r] * R[r][k];
+            X[t][k] = a;
+        }
+    }
+#undef M5
     // rows (4,5), (6,7), (8,9): <x2 z> - z <x2>, <xyz> - z <xy>, <y2 z> - z <y2>  ->  B(z) [x y 1]' = 0
     double bx[3][4], by[3][4], b1[3][5];
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double *u = C[4 + 2 * i] + 10, *v = C[5 + 2 * i] + 10;
+        const double *u = X[2 * i], *v = X[2 * i + 1];
         bx[i][3] = -v[0]; bx[i][2] = u[0] - v[1]; bx[i][1] = u[1] - v[2]; bx[i][0] = u[2];
         by[i][3] = -v[3]; by[i][2] = u[3] - v[4]; by[i][1] = u[4] - v[5]; by[i][0] = u[5];
         b1[i][4] = -v[6]; b1[i][3] = u[6] - v[7]; b1[i][2] = u[7] - v[8]; b1[i][1] = u[8] - v[9]; b1[i][0] = u[9];
@@ -302,8 +496,10 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) ab[i + j] += bx[r0][i] * by[r1][j];
         for (int i = 0; i < 7; ++i) for (int j = 0; j < 5; ++j) c[i + j] += sgn * ab[i] * b1[r2][j];
     }
+    MDRP_5PT_STOP(3, c[0] + c[10] + c[5])
     double roots[10];
-    const int nr = real_roots<10>(c, roots);
+    const int nr = real_roots_fast<10>(c, roots, store.rs);
+    MDRP_5PT_STOP(4, roots[0] + (double)nr)
     int n_out = 0;
     for (int s = 0; s < nr; ++s) {
         const double z = roots[s];
@@ -394,9 +590,9 @@ MDRP_HD int motion_from_essential(const double E[9], const double (*x1h)[3], con
 }
 
 constexpr int MAX_MODELS_5PT = 10; // one pose per essential matrix passes the cheirality of all five points (generic data)
-MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_5PT]*/) {
+MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_5PT]*/, const Solve5Store &store) {
     double Es[10][9];
-    const int ne = relpose_5pt_E(x1h, x2h, Es);
+    const int ne = relpose_5pt_E(x1h, x2h, Es, store);
     int n = 0;
     for (int i = 0; i < ne && n < MAX_MODELS_5PT; ++i) {
         Model tmp[4];
@@ -405,6 +601,13 @@ MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], M
     }
     return n;
 }
+
+// plain local storage (host tests; not for the device: these arrays would land in scratch memory)
+struct Solve5Local {
+    double C[100], lo[12], hi[12];
+    int cc[12];
+    MDRP_HD Solve5Store store() { return Solve5Store{C, 1, RootStack{lo, hi, cc, 1}}; }
+};
 
 // ---------------------------------------------------------------- 7-point
 // A fundamental matrix travels in the first nine doubles of a Model, row-major (q[0..3], t[0..2], scale, shift1).

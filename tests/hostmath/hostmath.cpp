@@ -187,13 +187,15 @@ extern "C" int hm_bound_check(const double *E, const double *x1, const double *x
 extern "C" {
 int hm_relpose_5pt_E(const double *x1h, const double *x2h, double *out /*10*9*/) {
     double Es[10][9];
-    const int n = relpose_5pt_E(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), Es);
+    Solve5Local loc;
+    const int n = relpose_5pt_E(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), Es, loc.store());
     std::memcpy(out, Es, sizeof(double) * 9 * n);
     return n;
 }
 int hm_relpose_5pt(const double *x1h, const double *x2h, double *out /*10*12*/) {
     Model m[MAX_MODELS_5PT];
-    const int n = solver_relpose_5pt(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), m);
+    Solve5Local loc;
+    const int n = solver_relpose_5pt(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), m, loc.store());
     std::memcpy(out, m, sizeof(Model) * n);
     return n;
 }
@@ -204,4 +206,8 @@ int hm_relpose_7pt(const double *x1h, const double *x2h, double *out /*3*12*/) {
     return n;
 }
 int hm_real_roots10(const double *c, double *roots) { return real_roots<10>(c, roots); }
+int hm_real_roots10_fast(const double *c, double *roots) {
+    Solve5Local loc;
+    return real_roots_fast<10>(c, roots, loc.store().rs);
+}
 }
