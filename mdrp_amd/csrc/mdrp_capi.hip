@@ -389,7 +389,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
                                        h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
                 else
-                    hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), SOLVE7_LDS_BYTES, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
                                        h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
                 return MDRP_OK;
             }
@@ -825,7 +825,7 @@ int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const
         hipLaunchKernelGGL(kc_solver_unit<CLASSIC_RELPOSE>, dim3((count + 63) / 64), dim3(64), SOLVE5_LDS_BYTES, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
     else
-        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_FUND>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
+        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_FUND>, dim3((count + 63) / 64), dim3(64), SOLVE7_LDS_BYTES, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
 #ifdef MDRP_5PT_STAGES

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(64) void kc_samples(int n_tables, const int32_t *__
 // same bytes, once the factorisation is dead — the root finder's interval stack (dynamic LDS of the launch: SOLVE5_LDS_BYTES;
 // one wavefront per workgroup, three workgroups per CU)
 constexpr size_t SOLVE5_LDS_BYTES = (size_t)64 * 100 * sizeof(double);
+constexpr size_t SOLVE7_LDS_BYTES = (size_t)64 * 63 * sizeof(double); // the 9 x 7 constraint matrix of the 7-point null space
 __device__ __forceinline__ Solve5Store lds_solve5_store() {
     extern __shared__ double solve5_lds[];
     const int lane = threadIdx.x & 63;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
             x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
         }
         if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt(x1h, x2h, out, lds_solve5_store());
-        else n = solver_fundamental_7pt(x1h, x2h, out);
+        else { extern __shared__ double solve5_lds[]; n = solver_fundamental_7pt(x1h, x2h, out, solve5_lds + (threadIdx.x & 63), 64); }
     }
     const int lane = threadIdx.x & 63;
     int pre = n;
@@ -687,7 +688,8 @@ __global__ __launch_bounds__(64) void kc_solver_unit(int count, const double *__
     for (int k = 0; k < K; ++k)
         for (int c = 0; c < 3; ++c) { a[k][c] = x1h[(size_t)3 * K * i + 3 * k + c]; b[k][c] = x2h[(size_t)3 * K * i + 3 * k + c]; }
     Model m[MAXM];
-    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m, lds_solve5_store()) : solver_fundamental_7pt(a, b, m);
+    extern __shared__ double solve5_lds[];
+    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m, lds_solve5_store()) : solver_fundamental_7pt(a, b, m, solve5_lds + (threadIdx.x & 63), 64);
     n_out[i] = n;
     for (int k = 0; k < n; ++k) out[(size_t)MAXM * i + k] = m[k];
 }

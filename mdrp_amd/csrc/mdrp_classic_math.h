@@ -15,75 +15,105 @@ namespace mdrp {
 constexpr int CLASSIC_RELPOSE = 3, CLASSIC_SHARED = 4, CLASSIC_FUND = 5; // == MDRP_RELPOSE_5PT / MDRP_SHARED_6PT / MDRP_FUNDAMENTAL_7PT
 
 // ---------------------------------------------------------------- null space (Eigen::FullPivHouseholderQR + matrixQ)
-// A: 9 x M column-major (destroyed).  N: the last 9 - M columns of Q, each the column-major vec of a 3 x 3 matrix.
+// A: 9 x M column-major in caller-provided strided storage (element (r, c) at A[(9 c + r) as]; destroyed): the full pivoting
+// addresses it with data-dependent row and column indices, so on the device it lives in LDS — everything else is statically
+// indexed and stays in registers.  N: the last 9 - M columns of Q, each the column-major vec of a 3 x 3 matrix.
 template <int M>
-MDRP_HD void fullpiv_nullspace(double *A, double *N /*[9 - M][9]*/) {
+MDRP_HD void fullpiv_nullspace(double *A, int as, double *N /*[9 - M][9]*/) {
     constexpr int rows = 9, NN = 9 - M;
+#define AQ(r, c) A[(9 * (c) + (r)) * as]
     double tau[M];
     int rt[M];
+    double ess[M][9]; // Householder vectors (entries below the diagonal), kept for Q
     const double prec = 2.220446049250313e-16 * (double)M;
     double biggest = 0.0;
     bool degenerate = false;
+#pragma unroll
     for (int k = 0; k < M; ++k) {
-        if (degenerate) { rt[k] = k; tau[k] = 0.0; continue; }
+        tau[k] = 0.0; rt[k] = k;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) ess[k][r] = 0.0;
+        if (degenerate) continue;
         int br = k, bc = k;
         double big = -1.0;
         for (int c = k; c < M; ++c)
             for (int r = k; r < rows; ++r) {
-                const double v = fabs(A[c * 9 + r]);
+                const double v = fabs(AQ(r, c));
                 if (v > big) { big = v; br = r; bc = c; }
             }
         if (k == 0) biggest = big;
-        if (big <= biggest * prec) { degenerate = true; rt[k] = k; tau[k] = 0.0; continue; }
+        if (big <= biggest * prec) { degenerate = true; continue; }
         rt[k] = br;
         if (br != k)
-            for (int c = k; c < M; ++c) { const double t = A[c * 9 + k]; A[c * 9 + k] = A[c * 9 + br]; A[c * 9 + br] = t; }
+            for (int c = k; c < M; ++c) { const double t = AQ(k, c); AQ(k, c) = AQ(br, c); AQ(br, c) = t; }
         if (bc != k)
-            for (int r = 0; r < rows; ++r) { const double t = A[k * 9 + r]; A[k * 9 + r] = A[bc * 9 + r]; A[bc * 9 + r] = t; }
+            for (int r = 0; r < rows; ++r) { const double t = AQ(r, k); AQ(r, k) = AQ(r, bc); AQ(r, bc) = t; }
+        double col[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) col[r] = (r >= k) ? AQ(r, k) : 0.0;
         double tail = 0.0;
-        for (int r = k + 1; r < rows; ++r) tail += A[k * 9 + r] * A[k * 9 + r];
-        const double c0 = A[k * 9 + k];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (r > k) tail += col[r] * col[r];
+        const double c0 = col[k];
         double beta;
         if (tail <= 2.2250738585072014e-308) {
-            tau[k] = 0.0; beta = c0;
-            for (int r = k + 1; r < rows; ++r) A[k * 9 + r] = 0.0;
+            beta = c0;
         } else {
             beta = sqrt(c0 * c0 + tail);
             if (c0 >= 0.0) beta = -beta;
             const double inv = 1.0 / (c0 - beta); // Eigen divides; the reciprocal differs by an ulp at most
-            for (int r = k + 1; r < rows; ++r) A[k * 9 + r] *= inv;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) ess[k][r] = col[r] * inv;
             tau[k] = (beta - c0) / beta;
         }
-        A[k * 9 + k] = beta;
         for (int c = k + 1; c < M; ++c) {
             double tmp = 0.0;
-            for (int r = k + 1; r < rows; ++r) tmp += A[k * 9 + r] * A[c * 9 + r];
-            tmp += A[c * 9 + k];
-            A[c * 9 + k] -= tau[k] * tmp;
-            for (int r = k + 1; r < rows; ++r) A[c * 9 + r] -= tau[k] * A[k * 9 + r] * tmp;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) tmp += ess[k][r] * AQ(r, c);
+            tmp += AQ(k, c);
+            AQ(k, c) -= tau[k] * tmp;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) AQ(r, c) -= tau[k] * ess[k][r] * tmp;
         }
     }
     // only the last NN columns of Q = H_0 P_0 ... H_{M-1} P_{M-1} I are needed: start from unit vectors e_M .. e_8
+#pragma unroll
     for (int j = 0; j < NN; ++j) {
-        double *q = N + 9 * j;
+        double q[9];
+#pragma unroll
         for (int r = 0; r < 9; ++r) q[r] = (r == M + j) ? 1.0 : 0.0;
+#pragma unroll
         for (int k = M - 1; k >= 0; --k) {
-            double tmp = 0.0;
-            for (int r = k + 1; r < rows; ++r) tmp += A[k * 9 + r] * q[r];
-            tmp += q[k];
+            double tmp = q[k];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) tmp += ess[k][r] * q[r];
             q[k] -= tau[k] * tmp;
-            for (int r = k + 1; r < rows; ++r) q[r] -= tau[k] * A[k * 9 + r] * tmp;
-            if (rt[k] != k) { const double t = q[k]; q[k] = q[rt[k]]; q[rt[k]] = t; }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) q[r] -= tau[k] * ess[k][r] * tmp;
+            // swap q[k] <-> q[rt[k]] (rt[k] >= k is data dependent: select chain instead of a dynamic index)
+            const double qk = q[k];
+            double qr = qk;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k && r == rt[k]) qr = q[r];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k && r == rt[k]) q[r] = qk;
+            q[k] = qr;
         }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) N[9 * j + r] = q[r];
     }
+#undef AQ
 }
 
 // epipolar constraint columns kron(x1, x2): entry 3 j + i multiplies E(i, j)  (x2' E x1 = 0)
 template <int M>
-MDRP_HD void epipolar_columns(const double (*x1h)[3], const double (*x2h)[3], double *A /*9 x M col-major*/) {
+MDRP_HD void epipolar_columns(const double (*x1h)[3], const double (*x2h)[3], double *A /*9 x M col-major, strided*/, int as) {
+#pragma unroll
     for (int p = 0; p < M; ++p)
+#pragma unroll
         for (int j = 0; j < 3; ++j)
-            for (int i = 0; i < 3; ++i) A[p * 9 + 3 * j + i] = x1h[p][j] * x2h[p][i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) A[(p * 9 + 3 * j + i) * as] = x1h[p][j] * x2h[p][i];
 }
 
 // ---------------------------------------------------------------- real roots, ascending (Sturm isolation, bisection, Newton)
@@ -361,9 +391,9 @@ __device__ int g_5pt_stage = 99; // experiment: stop after stage k (tools/stage_
 // its time waiting for them); on the host they are plain local arrays.
 struct Solve5Store { double *C; int cs; RootStack rs; };
 MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9], const Solve5Store &store) {
-    double A[45], N[36];
-    epipolar_columns<5>(x1h, x2h, A);
-    fullpiv_nullspace<5>(A, N);
+    double N[36];
+    epipolar_columns<5>(x1h, x2h, store.C, store.cs); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
+    fullpiv_nullspace<5>(store.C, store.cs, N);
     MDRP_5PT_STOP(1, N[0] + N[35])
     // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]
     double El[3][3][4];
@@ -613,10 +643,10 @@ struct Solve5Local {
 // A fundamental matrix travels in the first nine doubles of a Model, row-major (q[0..3], t[0..2], scale, shift1).
 MDRP_HD double *model_F(Model &m) { return m.q; }
 MDRP_HD const double *model_F(const Model &m) { return m.q; }
-MDRP_HD int solver_fundamental_7pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[3]*/) {
-    double A[63], N[18];
-    epipolar_columns<7>(x1h, x2h, A);
-    fullpiv_nullspace<7>(A, N);
+MDRP_HD int solver_fundamental_7pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[3]*/, double *A /*63 doubles, strided*/, int as) {
+    double N[18];
+    epipolar_columns<7>(x1h, x2h, A, as);
+    fullpiv_nullspace<7>(A, as, N);
     const double *N0 = N, *N1 = N + 9;
     // det(r A + B), A = mat(N0), B = mat(N1), vec index of (i, j) = 3 j + i
     double c[4] = {0, 0, 0, 0};
@@ -632,10 +662,15 @@ MDRP_HD int solver_fundamental_7pt(const double (*x1h)[3], const double (*x2h)[3
         c[2] += sgn * (q1 * l1[2] + q2 * l0[2]);
         c[3] += sgn * q2 * l1[2];
     }
+    // solve_cubic_real of the binary: closed form, roots in DESCENDING order (cos(phi), cos(phi - 2 pi / 3), cos(phi - 4 pi / 3))
     double roots[3];
-    const int nr = real_roots<3>(c, roots);
-    for (int s = 0; s < nr; ++s) { // solve_cubic_real of the binary lists the roots in DESCENDING order
-        const double r = roots[nr - 1 - s];
+    int nr = 0;
+    if (c[3] != 0.0) {
+        const double inv = 1.0 / c[3];
+        nr = solve_cubic_real(c[2] * inv, c[1] * inv, c[0] * inv, roots[0], roots[1], roots[2]);
+    }
+    for (int s = 0; s < nr; ++s) {
+        const double r = roots[s];
         double f[9], nrm = 0.0;
         for (int k = 0; k < 9; ++k) { f[k] = N0[k] * r + N1[k]; nrm += f[k] * f[k]; }
         nrm = 1.0 / sqrt(nrm);

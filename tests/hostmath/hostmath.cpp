@@ -201,7 +201,8 @@ int hm_relpose_5pt(const double *x1h, const double *x2h, double *out /*10*12*/) 
 }
 int hm_relpose_7pt(const double *x1h, const double *x2h, double *out /*3*12*/) {
     Model m[3];
-    const int n = solver_fundamental_7pt(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), m);
+    double A[63];
+    const int n = solver_fundamental_7pt(reinterpret_cast<const double(*)[3]>(x1h), reinterpret_cast<const double(*)[3]>(x2h), m, A, 1);
     std::memcpy(out, m, sizeof(Model) * n);
     return n;
 }
