@@ -99,8 +99,8 @@ def estimate_local_shard(kind, total, x1, x2, d1, d2, ransac_opt=None, bundle_op
     rank, world = _world(group)
     lo, hi, per = shard_bounds(total, rank, world)
     rows = hi - lo
-    if len(d1) != rows:
-        raise ValueError(f"rank {rank} owns pairs [{lo}, {hi}) = {rows} rows, got {len(d1)}")
+    if len(x1) != rows:   # d1 / d2 are None for the non-monodepth baselines (kind 3 / 5)
+        raise ValueError(f"rank {rank} owns pairs [{lo}, {hi}) = {rows} rows, got {len(x1)}")
     ro = ransac_opt if isinstance(ransac_opt, _capi.RansacOpt) else _capi.ransac_opt_from_dict(ransac_opt)
     bo = bundle_opt if isinstance(bundle_opt, _capi.BundleOpt) else _capi.bundle_opt_from_dict(bundle_opt)
     device = None
@@ -115,7 +115,7 @@ def estimate_local_shard(kind, total, x1, x2, d1, d2, ransac_opt=None, bundle_op
     if rows > 0:
         res, mask = local_fn(kind, x1, x2, d1, d2, ro, bo, n_per_pair, cam1, cam2)
     else:
-        res, mask = np.zeros(0, dtype=_capi.RESULT_DTYPE), np.zeros((0, np.shape(d1)[1] if np.ndim(d1) == 2 else 0), dtype=np.uint8)
+        res, mask = np.zeros(0, dtype=_capi.RESULT_DTYPE), np.zeros((0, np.shape(x1)[1] if np.ndim(x1) == 3 else 0), dtype=np.uint8)
     all_res = gather_records(res, total, group, device)
     if want_mask:
         return all_res, gather_masks(mask, total, group, device)
@@ -127,9 +127,9 @@ def estimate_sharded(kind, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_p
     """Convenience for callers that hold the FULL arrays on every rank: slices this rank's block and calls
     estimate_local_shard.  (Large data sets should never be replicated: build each rank's block only.)"""
     rank, world = _world(group)
-    total = len(d1)
+    total = len(x1)
     lo, hi, _ = shard_bounds(total, rank, world)
     sl = slice(lo, hi)
-    return estimate_local_shard(kind, total, x1[sl], x2[sl], d1[sl], d2[sl], ransac_opt, bundle_opt,
+    return estimate_local_shard(kind, total, x1[sl], x2[sl], None if d1 is None else d1[sl], None if d2 is None else d2[sl], ransac_opt, bundle_opt,
                                 None if n_per_pair is None else n_per_pair[sl], None if cam1 is None else cam1[sl],
                                 None if cam2 is None else cam2[sl], group, local_fn, want_mask)

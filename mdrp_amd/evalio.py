@@ -119,22 +119,32 @@ def result_record(experiment, info, R, t, R_gt, t_gt):
     return out
 
 
+CORE_RANSAC_KEYS = ("max_iterations", "min_iterations", "dyn_num_trials_mult", "success_prob", "max_reproj_error", "max_epipolar_error",
+                    "seed", "progressive_sampling", "max_prosac_iterations", "real_focal_check", "score_initial_model")
+
+
 def evaluate_calibrated(h5, experiments, iters=None, threshold=1.0, reproj_threshold=16.0, first=None, batch=4096,
-                        estimate_batch=None, device=0):
+                        estimate_batch=None, device=0, estimate_5pt_batch=None):
     """eval.py:316-359 for the calibrated estimator, batched: every experiment's pairs go to the GPU `batch` at a time.
     `estimate_batch(kp1s, kp2s, d1s, d2s, cams1, cams2, ransac_opt, bundle_opt)` defaults to the accelerated
-    `poselib.estimate_monodepth_relative_pose_batch` (injectable for tests).  Pairs with fewer than 5 correspondences are
-    skipped as in the reference.  `info['runtime']` is the batch wall time divided by the batch size, in ms."""
+    `poselib.estimate_monodepth_relative_pose_batch` (injectable for tests).  Experiment names with '5p' are the 5-point
+    baseline row (eval.py:134-137: `poselib.estimate_relative_pose`, which reads only the upstream RansacOptions keys of the
+    dict) and go to `poselib.estimate_relative_pose_batch`.  Pairs with fewer than 5 correspondences are skipped as in the
+    reference.  `info['runtime']` is the batch wall time divided by the batch size, in ms."""
     from . import poselib
     if estimate_batch is None:
         def estimate_batch(k1, k2, a, b, c1, c2, ro, bo):
             return poselib.estimate_monodepth_relative_pose_batch(k1, k2, a, b, c1, c2, ro, bo, device=device)
+    if estimate_5pt_batch is None:
+        def estimate_5pt_batch(k1, k2, c1, c2, ro, bo):
+            return poselib.estimate_relative_pose_batch(k1, k2, c1, c2, ro, bo, device=device)
     pairs = list_pairs(h5, first)
     results = []
     for experiment in experiments:
         depth = int(experiment.split("+")[1]) if "+" in experiment else None
         ro, bo = experiment_options(experiment, iters, threshold, reproj_threshold)
-        ro = poselib._map_fork_options(ro)
+        five_point = "5p" in experiment
+        ro = {k: v for k, v in ro.items() if k in CORE_RANSAC_KEYS} if five_point else poselib._map_fork_options(ro)
         loaded = []
         for a, b in pairs:
             p = load_pair(h5, a, b, depth)
@@ -143,14 +153,19 @@ def evaluate_calibrated(h5, experiments, iters=None, threshold=1.0, reproj_thres
         for s in range(0, len(loaded), batch):
             chunk = loaded[s:s + batch]
             t0 = time.perf_counter()
-            geoms, infos = estimate_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [p["d"][:, 0] for p in chunk],
-                                          [p["d"][:, 1] for p in chunk], [_pinhole(p["K1"]) for p in chunk],
-                                          [_pinhole(p["K2"]) for p in chunk], ro, bo)
+            if five_point:
+                geoms, infos = estimate_5pt_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [_pinhole(p["K1"]) for p in chunk],
+                                                  [_pinhole(p["K2"]) for p in chunk], ro, bo)
+            else:
+                geoms, infos = estimate_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [p["d"][:, 0] for p in chunk],
+                                              [p["d"][:, 1] for p in chunk], [_pinhole(p["K1"]) for p in chunk],
+                                              [_pinhole(p["K2"]) for p in chunk], ro, bo)
             ms = 1000.0 * (time.perf_counter() - t0) / max(len(chunk), 1)
             for p, g, info in zip(chunk, geoms, infos):
                 info = dict(info)
                 info["runtime"] = ms
-                results.append(result_record(experiment, info, g.pose.R, g.pose.t, p["R_gt"], p["t_gt"]))
+                pose = g if five_point else g.pose   # estimate_relative_pose returns the CameraPose itself
+                results.append(result_record(experiment, info, pose.R, pose.t, p["R_gt"], p["t_gt"]))
     return results
 
 

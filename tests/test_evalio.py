@@ -93,13 +93,24 @@ def test_layout_options_and_records_with_stub_estimator(tmp_path):
     with pytest.raises(NotImplementedError):
         evalio.evaluate_calibrated(h5, ["3p_reldepth+10"], estimate_batch=stub)       # fork-only variant
 
+    # the 5-point baseline row (eval.py:134-137): routed to estimate_relative_pose with the upstream RansacOptions keys only
+    def stub5(k1, k2, c1, c2, ro_, bo_):
+        seen["ro5"], seen["cams5"] = ro_, (c1[0], c2[0])
+        poses = [type("P", (), {"R": q["R"], "t": q["t"]})() for kp in k1 for q in gt if len(q["x1"]) == len(kp) and np.allclose(q["x1"], kp)]
+        return poses, [{"refinements": 1, "iterations": 10, "num_inliers": len(kp), "inlier_ratio": 1.0, "model_score": 0.0, "inliers": []} for kp in k1]
+
+    res5 = evalio.evaluate_calibrated(h5, ["5p+10"], iters=700, threshold=1.5, batch=8, estimate_batch=stub, estimate_5pt_batch=stub5)
+    assert len(res5) == 5 and res5[0]["R_err"] < 1e-6 and res5[0]["experiment"] == "5p+10"
+    assert set(seen["ro5"]) <= set(evalio.CORE_RANSAC_KEYS) and seen["ro5"]["max_iterations"] == 700 and seen["ro5"]["max_epipolar_error"] == 1.5
+    assert seen["cams5"][0]["model"] == "PINHOLE" and seen["cams5"][0]["params"][0] == 900.0 and seen["cams5"][1]["params"][0] == 700.0
+
 
 @pytest.mark.gpu
 def test_evaluate_calibrated_end_to_end_gpu():
     h5, gt = fake_h5(n_pairs=8, n=400, seed=40)
-    exps = ["p3p_hybrid_ctruncated+10", "3p_ours_shift_scale_hybrid-s_ctruncated+10"]
+    exps = ["p3p_hybrid_ctruncated+10", "3p_ours_shift_scale_hybrid-s_ctruncated+10", "5p_ctruncated+10"]
     res = evalio.evaluate_calibrated(h5, exps, iters=1000, threshold=2.0)
-    assert len(res) == 2 * 7
+    assert len(res) == 3 * 7
     rows = evalio.summarize(exps, res)
     for exp, med, maa, ms, inl in rows:
         assert med < 0.5 and maa > 0.9 and ms > 0 and 0.5 < inl <= 1.0, rows

@@ -153,3 +153,20 @@ def test_too_few_correspondences_and_ragged_batch():
     assert infos[0]["num_inliers"] > 150 and infos[1]["iterations"] == 0 and infos[2]["iterations"] == 0 and infos[3]["iterations"] == 0
     single, info1 = poselib.estimate_relative_pose(p["x1"], p["x2"], cam, cam, ro, {})
     assert info1["num_inliers"] == poselib.estimate_relative_pose_batch(x1[:1], x2[:1], cam, cam, ro, {})[1][0]["num_inliers"]
+
+
+def test_initial_pose_through_the_drop_in_signature(golden):
+    """estimate_relative_pose(..., initial_pose=...): the pose handed in is never read (ransac_relpose resets it), the reset model is
+    scored first: refinements + 1 — fixtures from the reference binary with score_initial_model"""
+    import mdrp_amd.poselib as poselib
+    g = golden("classic")
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [800.0, 640.0, 480.0]}
+    for i, n, its, min_its, seed in g["init_cases"]:
+        ini = g[f"init_pose_{i}"]
+        ro = {"max_iterations": int(its), "min_iterations": int(min_its), "max_epipolar_error": 2.0, "seed": int(seed)}
+        pose, info = poselib.estimate_relative_pose(g[f"init_x1_{i}"], g[f"init_x2_{i}"], cam, cam, ro, {"loss_type": "TRUNCATED_CAUCHY", "loss_scale": 2.0},
+                                                    initial_pose=poselib.CameraPose(ini[:4], ini[4:7]))
+        rst = g[f"init_stats_{i}"]
+        assert (info["refinements"], info["iterations"], info["num_inliers"]) == tuple(int(v) for v in rst[:3]), (i, info["refinements"], rst)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), g[f"init_mask_{i}"])
+        assert pose_diff(np.r_[pose.q, pose.t], g[f"init_model_{i}"]) < 1e-6

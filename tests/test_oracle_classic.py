@@ -140,6 +140,17 @@ def test_full_size_estimators_equal_reference(golden):
         assert d < 1e-7, (i, kind, d)
 
 
+def test_initial_pose_sets_score_initial_model(golden):
+    g = golden("classic")
+    for i, n, its, min_its, seed in g["init_cases"]:
+        ro = po.ransac_opt(max_iterations=int(its), min_iterations=int(min_its), max_epipolar_error=2.0, seed=int(seed), score_initial_model=True)
+        c = po.cam_flat(0, [800.0, 640.0, 480.0])
+        m, st, mask = po.estimate_classic(3, g[f"init_x1_{i}"], g[f"init_x2_{i}"], ro, po.bundle_opt(loss_type=4, loss_scale=2.0), c, c)
+        rst = g[f"init_stats_{i}"]
+        assert (st.refinements, st.iterations, st.num_inliers) == tuple(int(v) for v in rst[:3]), (i, rst)
+        assert np.array_equal(mask, g[f"init_mask_{i}"]) and pose_diff(m, g[f"init_model_{i}"]) < 1e-7
+
+
 # ---- the device arithmetic (mdrp_classic_math.h) compiled for the host
 @pytest.fixture(scope="module")
 def hm():

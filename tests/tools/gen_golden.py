@@ -328,6 +328,20 @@ def gen_classic():
         est_cases.append([i, kind, n, its, min_its, loss, thr, i % 5, f])
         print("classic estimate", i, kind, n, its, st, flush=True)
     d["est_cases"] = np.array(est_cases)
+    # ---- estimate_relative_pose with an initial pose (the binding sets score_initial_model; ransac_relpose resets the pose itself)
+    init_cases = []
+    for i in range(4):
+        n, its = [150, 400, 60, 300][i], [300, 1000, 1, 500][i]
+        pr = synth.make_pair(9900 + i, n, f1=800.0, f2=800.0, pp=(640.0, 480.0), noise_px=0.5, outlier_frac=[0.3, 0.5, 0.1, 0.4][i])
+        ro = rs.ropt(max_iterations=its, min_iterations=its if i != 1 else 100, max_epipolar_error=2.0, seed=i)
+        bo = rs.bopt(loss_type=4, loss_scale=2.0)
+        cam = rs.cam_flat(0, 1280, 960, [800.0, 640.0, 480.0])
+        ini = np.r_[quat_of(rodrigues(rng.normal(0, 0.5, 3))), rng.normal(0, 1, 3)]
+        m, st, mask = rs.estimate_classic(3, pr["x1"], pr["x2"], ro, bo, cam, cam, score_initial=True, initial=ini)
+        d.update({f"init_x1_{i}": pr["x1"], f"init_x2_{i}": pr["x2"], f"init_pose_{i}": ini, f"init_model_{i}": m, f"init_stats_{i}": st, f"init_mask_{i}": mask})
+        init_cases.append([i, n, its, its if i != 1 else 100, i])
+        print("classic initial", i, st, flush=True)
+    d["init_cases"] = np.array(init_cases)
     # samples of 5 / 7 indices (draw_sample @0x4f87f0)
     for K in (5, 7):
         for n in (9, 200, 2000):
