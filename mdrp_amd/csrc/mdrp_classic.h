@@ -169,8 +169,9 @@ __device__ __forceinline__ Solve5Store lds_solve5_store() {
     const int lane = threadIdx.x & 63;
     double *C = solve5_lds + lane;
     double *lo = solve5_lds + lane, *hi = lo + 12 * 64;
-    int *cc = reinterpret_cast<int *>(solve5_lds + 24 * 64) + lane;
-    return Solve5Store{C, 64, RootStack{lo, hi, cc, 64}};
+    int *cc = reinterpret_cast<int *>(solve5_lds + 24 * 64) + lane; // 12 ints per lane = 6 double columns
+    double *ilo = solve5_lds + 30 * 64 + lane, *ihi = ilo + 10 * 64;
+    return Solve5Store{C, 64, RootStack{lo, hi, cc, ilo, ihi, 64}};
 }
 
 // ------------------------------------------------------------------------------------------------ solve

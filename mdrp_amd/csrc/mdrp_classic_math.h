@@ -229,7 +229,7 @@ MDRP_HD int real_roots(const double *coef /*ascending powers, degree D*/, double
 // constant, so the 66 coefficients of a degree-10 chain live in registers instead of scratch memory (the dynamic version spends
 // half of the 5-point solver's time in scratch round trips).  The interval stack is caller-provided strided storage (LDS on the
 // device).  A chain that drops a degree (or a vanishing leading coefficient) goes to the generic routine above — same results.
-struct RootStack { double *lo, *hi; int *cc; int stride; }; // D + 2 entries each
+struct RootStack { double *lo, *hi; int *cc; double *ilo, *ihi; int stride; }; // stack: D + 2 entries each; isolating intervals: D each
 template <int D>
 MDRP_HD constexpr int chain_off(int i) { return i * (D + 1) - i * (i - 1) / 2; }
 template <int D>
@@ -284,52 +284,21 @@ MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &
     for (int k = 0; k < D; ++k) bound = fmax(bound, fabs(ch[k]));
     bound += 1.0;
     const int ss = st.stride;
-    int sp = 1, nr = 0;
+    // phase 1 — isolation only: every trip of the loop is one Sturm evaluation for every lane (the root polishing used to sit
+    // inside this loop: a wavefront then paid for both branches on every trip).  Isolating intervals come out in ascending order.
+    int sp = 1, ni = 0;
     st.lo[0] = -bound; st.hi[0] = bound;
     st.cc[0] = sturm_changes_static<D>(ch, -bound) | (sturm_changes_static<D>(ch, bound) << 8);
-    auto peval = [&](double x) { double v = ch[D]; 
-#pragma unroll
-        for (int k = D - 1; k >= 0; --k) v = v * x + ch[k];
-        return v; };
-    while (sp > 0 && nr < D) {
+    while (sp > 0 && ni < D) {
         --sp;
         const double lo = st.lo[sp * ss], hi = st.hi[sp * ss];
         const int packed = st.cc[sp * ss];
         const int clo = packed & 0xFF, chi = (packed >> 8) & 0xFF, depth = packed >> 16;
         const int n = clo - chi;
         if (n <= 0) continue;
-        if (n == 1 || depth > 200 || hi - lo < 1e-15 * fmax(1.0, fmax(fabs(lo), fabs(hi)))) {
-            if (n == 1) {
-                double a = lo, b = hi, fa = peval(a);
-                for (int it = 0; it < 200; ++it) {
-                    const double mid = 0.5 * (a + b);
-                    if (mid == a || mid == b) break;
-                    const double fm = peval(mid);
-                    if (fm == 0.0) { a = b = mid; break; }
-                    if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
-                    if (it >= 12 && b - a < 1e-3 * fmax(1e-300, fabs(a) + fabs(b))) break;
-                }
-                double x = 0.5 * (a + b);
-                for (int it = 0; it < 8; ++it) {
-                    double v = ch[D], dv = 0.0;
-#pragma unroll
-                    for (int k = D - 1; k >= 0; --k) { dv = dv * x + v; v = v * x + ch[k]; }
-                    if (dv == 0.0) break;
-                    double xn = x - v / dv;
-                    if (!(xn >= a && xn <= b)) {
-                        const double mid = 0.5 * (a + b);
-                        const double fm = peval(mid);
-                        if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
-                        xn = 0.5 * (a + b);
-                    }
-                    const bool done = fabs(xn - x) <= 4e-16 * fabs(xn);
-                    x = xn;
-                    if (done) break;
-                }
-                roots[nr++] = x;
-            } else {
-                for (int i = 0; i < n && nr < D; ++i) roots[nr++] = 0.5 * (lo + hi);
-            }
+        if (n == 1) { st.ilo[ni * ss] = lo; st.ihi[ni * ss] = hi; ++ni; continue; }
+        if (depth > 200 || hi - lo < 1e-15 * fmax(1.0, fmax(fabs(lo), fabs(hi)))) { // multiple / unresolvable cluster
+            for (int i = 0; i < n && ni < D; ++i) { st.ilo[ni * ss] = 0.5 * (lo + hi); st.ihi[ni * ss] = 0.5 * (lo + hi); ++ni; }
             continue;
         }
         const double mid = 0.5 * (lo + hi);
@@ -337,7 +306,45 @@ MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &
         if (cm - chi > 0) { st.lo[sp * ss] = mid; st.hi[sp * ss] = hi; st.cc[sp * ss] = cm | (chi << 8) | ((depth + 1) << 16); ++sp; }
         if (clo - cm > 0) { st.lo[sp * ss] = lo; st.hi[sp * ss] = mid; st.cc[sp * ss] = clo | (cm << 8) | ((depth + 1) << 16); ++sp; }
     }
-    return nr;
+    // phase 2 — one root per trip: bisection on the sign of p down to a tight bracket, then safeguarded Newton
+    auto peval = [&](double x) {
+        double v = ch[D];
+#pragma unroll
+        for (int k = D - 1; k >= 0; --k) v = v * x + ch[k];
+        return v;
+    };
+    for (int j = 0; j < ni; ++j) {
+        double a = st.ilo[j * ss], b = st.ihi[j * ss];
+        if (a == b) { roots[j] = a; continue; }
+        double fa = peval(a);
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (a + b);
+            if (mid == a || mid == b) break;
+            const double fm = peval(mid);
+            if (fm == 0.0) { a = b = mid; break; }
+            if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
+            if (it >= 12 && b - a < 1e-3 * fmax(1e-300, fabs(a) + fabs(b))) break;
+        }
+        double x = 0.5 * (a + b);
+        for (int it = 0; it < 8; ++it) {
+            double v = ch[D], dv = 0.0;
+#pragma unroll
+            for (int k = D - 1; k >= 0; --k) { dv = dv * x + v; v = v * x + ch[k]; }
+            if (dv == 0.0) break;
+            double xn = x - v / dv;
+            if (!(xn >= a && xn <= b)) {
+                const double mid = 0.5 * (a + b);
+                const double fm = peval(mid);
+                if ((fm > 0) == (fa > 0) && fa != 0.0) { a = mid; fa = fm; } else b = mid;
+                xn = 0.5 * (a + b);
+            }
+            const bool done = fabs(xn - x) <= 4e-16 * fabs(xn);
+            x = xn;
+            if (done) break;
+        }
+        roots[j] = x;
+    }
+    return ni;
 }
 
 // ---------------------------------------------------------------- polynomials in (x, y, z)
@@ -634,9 +641,9 @@ MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], M
 
 // plain local storage (host tests; not for the device: these arrays would land in scratch memory)
 struct Solve5Local {
-    double C[100], lo[12], hi[12];
+    double C[100], lo[12], hi[12], ilo[10], ihi[10];
     int cc[12];
-    MDRP_HD Solve5Store store() { return Solve5Store{C, 1, RootStack{lo, hi, cc, 1}}; }
+    MDRP_HD Solve5Store store() { return Solve5Store{C, 1, RootStack{lo, hi, cc, ilo, ihi, 1}}; }
 };
 
 // ---------------------------------------------------------------- 7-point
