@@ -170,3 +170,61 @@ def test_initial_pose_through_the_drop_in_signature(golden):
         assert (info["refinements"], info["iterations"], info["num_inliers"]) == tuple(int(v) for v in rst[:3]), (i, info["refinements"], rst)
         assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), g[f"init_mask_{i}"])
         assert pose_diff(np.r_[pose.q, pose.t], g[f"init_model_{i}"]) < 1e-6
+
+
+@pytest.mark.timeout(180)
+def test_garbage_inputs_terminate():
+    """NaN / inf coordinates, one correspondence repeated N times, collinear points, absurd scales: the solvers' loops (full
+    pivoting, LU, Sturm isolation, root polishing, LM) must terminate and leave the healthy pair beside them untouched"""
+    from mdrp_amd import _capi, synth
+    h = _capi.default_handle(0)
+    b = synth.make_batch(8600, 6, 300, f1=900.0, f2=900.0, noise_px=0.5, outlier_frac=0.3)
+    x1, x2 = b["x1"].copy(), b["x2"].copy()
+    x1[0, ::7] = np.nan; x2[0, ::5] = np.inf
+    x1[1] = x1[1, :1]; x2[1] = x2[1, :1]                                    # one correspondence repeated 300 times
+    x1[2] *= 1e12; x2[2] *= 1e-12                                           # absurd scales
+    t = np.linspace(-400, 400, 300)
+    x1[3] = np.c_[t, 0.5 * t]; x2[3] = np.c_[t + 3.0, 0.5 * t + 1.0]        # all points on one line in both images
+    x1[4] = 0.0; x2[4] = 0.0                                                # everything at the principal point
+    cams = np.zeros(6, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 900.0
+    for kind in (_capi.RELPOSE_5PT, _capi.FUNDAMENTAL_7PT):
+        ro = _capi.ransac_opt_from_dict({"max_iterations": 600, "min_iterations": 300, "max_epipolar_error": 1.5})
+        res, mask = h.estimate_batch(kind, x1, x2, None, None, ro, _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None,
+                                     cams if kind == _capi.RELPOSE_5PT else None, cams if kind == _capi.RELPOSE_5PT else None)
+        assert (res["iterations"] >= 301).all() and (res["iterations"] <= 600).all(), res["iterations"]
+        assert (res["num_inliers"] <= 300).all()
+        assert int(res[5]["num_inliers"]) > 150   # the clean pair next to them is unaffected
+
+
+@pytest.mark.parametrize("kind", [3, 5])
+def test_stress_grid_follows_the_oracle(kind):
+    """shapes x outlier rates x thresholds x dynamic / fixed stopping, 6 pairs each: every pair on the sequential oracle's trajectory"""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    off = total = 0
+    for gi, (n, outl, thr, its, min_its) in enumerate([(80, 0.2, 1.0, 400, 400), (600, 0.6, 2.0, 1500, 50), (1500, 0.4, 0.75, 700, 700),
+                                                       (250, 0.0, 1.5, 300, 20), (2500, 0.5, 1.0, 1200, 1200)]):
+        pairs = [synth.make_pair(8900 + 31 * gi + k, n, f1=1000.0, f2=1000.0, pp=(640.0, 480.0), noise_px=0.5, outlier_frac=outl) for k in range(6)]
+        ro = {"max_iterations": its, "min_iterations": min_its, "max_epipolar_error": thr, "seed": gi}
+        bo = {"loss_type": "TRUNCATED_CAUCHY", "loss_scale": thr}
+        cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [1000.0, 640.0, 480.0]}
+        x1, x2 = np.stack([p["x1"] for p in pairs]), np.stack([p["x2"] for p in pairs])
+        if kind == 3:
+            models, infos = poselib.estimate_relative_pose_batch(x1, x2, cam, cam, ro, bo)
+            models = [np.r_[m.q, m.t] for m in models]
+        else:
+            models, infos = poselib.estimate_fundamental_batch(x1, x2, ro, bo)
+        c = po.cam_flat(0, [1000.0, 640.0, 480.0])
+        for k, p in enumerate(pairs):
+            m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], po.ransac_opt(max_iterations=its, min_iterations=min_its, max_epipolar_error=thr, seed=gi),
+                                              po.bundle_opt(loss_type=4, loss_scale=thr), c, c)
+            info = infos[k]
+            total += 1
+            same = (info["refinements"], info["iterations"], info["num_inliers"]) == (st.refinements, st.iterations, st.num_inliers) and \
+                np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask)
+            if not same:
+                off += 1
+                continue
+            d = pose_diff(models[k], m) if kind == 3 else fund_diff(np.asarray(models[k]).reshape(-1), m)
+            assert d < 1e-6, (gi, k, d)
+    assert off == 0, (off, total)
