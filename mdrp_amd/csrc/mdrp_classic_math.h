@@ -398,15 +398,20 @@ __device__ int g_5pt_stage = 99; // experiment: stop after stage k (tools/stage_
 // its time waiting for them); on the host they are plain local arrays.
 struct Solve5Store { double *C; int cs; RootStack rs; };
 MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9], const Solve5Store &store) {
-    double N[36];
-    epipolar_columns<5>(x1h, x2h, store.C, store.cs); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
-    fullpiv_nullspace<5>(store.C, store.cs, N);
-    MDRP_5PT_STOP(1, N[0] + N[35])
-    // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]
+    // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]: the only copy of the null space that is kept
     double El[3][3][4];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-            for (int k = 0; k < 4; ++k) El[i][j][k] = N[k * 9 + 3 * j + i];
+    {
+        double N[36];
+        epipolar_columns<5>(x1h, x2h, store.C, store.cs); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
+        fullpiv_nullspace<5>(store.C, store.cs, N);
+        MDRP_5PT_STOP(1, N[0] + N[35])
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) El[i][j][k] = N[k * 9 + 3 * j + i];
+    }
     // The ten cubic constraints split into  L m_left + R m_right = 0  (ten eliminated monomials | [x y 1] (x) powers of z).  Only rows
     // 4..9 of X = L^-1 R are needed:  X_i = w_i R  with  L' w_i = e_i.  L' lives in the caller's strided storage (LDS on the
     // device: LU with partial pivoting needs dynamic row indices), R stays in registers (statically indexed: it is never permuted).
@@ -415,15 +420,23 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
 #define M5(r, k) M[(10 * (r) + (k)) * cs]
     double R[10][10];
     {
-        double EEt[3][3][10], tr[10];
+        double EEs[6][10], tr[10]; // E E' is symmetric: entry (i, j) at sym(i, j)
+#define SYM3(i, j) ((i) <= (j) ? (i) * 3 - (i) * ((i) - 1) / 2 + (j) - (i) : (j) * 3 - (j) * ((j) - 1) / 2 + (i) - (j))
+#pragma unroll
         for (int k = 0; k < 10; ++k) tr[k] = 0.0;
+#pragma unroll
         for (int i = 0; i < 3; ++i)
+#pragma unroll
             for (int j = i; j < 3; ++j) {
-                for (int k = 0; k < 10; ++k) EEt[i][j][k] = 0.0;
-                for (int k = 0; k < 3; ++k) lin_mul_add(El[i][k], El[j][k], 1.0, EEt[i][j]);
-                if (j != i) for (int k = 0; k < 10; ++k) EEt[j][i][k] = EEt[i][j][k];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) EEs[SYM3(i, j)][k] = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) lin_mul_add(El[i][k], El[j][k], 1.0, EEs[SYM3(i, j)]);
             }
-        for (int i = 0; i < 3; ++i) for (int k = 0; k < 10; ++k) tr[k] += EEt[i][i][k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 10; ++k) tr[k] += EEs[SYM3(i, i)][k];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -432,7 +445,7 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
 #pragma unroll
                 for (int k = 0; k < 20; ++k) row[k] = 0.0;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) quad_lin_mul_add(EEt[i][k], El[k][j], 2.0, row);
+                for (int k = 0; k < 3; ++k) quad_lin_mul_add(EEs[SYM3(i, k)], El[k][j], 2.0, row);
                 quad_lin_mul_add(tr, El[i][j], -1.0, row);
 #pragma unroll
                 for (int k = 0; k < 10; ++k) { M5(k, 3 * i + j) = row[k]; R[3 * i + j][k] = row[10 + k]; }
@@ -448,6 +461,7 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
         lin_mul_add(El[1][0], El[2][1], 1.0, m); lin_mul_add(El[1][1], El[2][0], -1.0, m); quad_lin_mul_add(m, El[0][2], 1.0, det);
 #pragma unroll
         for (int k = 0; k < 10; ++k) { M5(k, 9) = det[k]; R[9][k] = det[10 + k]; }
+#undef SYM3
     }
     MDRP_5PT_STOP(2, M5(0, 0) + M5(9, 9) + R[4][7])
     // P M = Lo Up, partial pivoting; the multipliers stay in the eliminated positions; perm[i] = original row now at position i
@@ -485,43 +499,44 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
             for (int k = 0; k < 10; ++k) if (k > col) M5(r, k) -= f * prow[k];
         }
     }
-    // rows 4..9 of X: forward / back substitution of e_t, then w R
-    double X[6][10];
-#pragma unroll
-    for (int t = 0; t < 6; ++t) {
-        double y[10];
-#pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            double v = (perm[i] == 4 + t) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < 10; ++k) if (k < i) v -= M5(i, k) * y[k];
-            y[i] = v;
-        }
-#pragma unroll
-        for (int i = 9; i >= 0; --i) {
-            double v = y[i];
-#pragma unroll
-            for (int k = 0; k < 10; ++k) if (k > i) v -= M5(i, k) * y[k];
-            y[i] = v / M5(i, i);
-        }
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            double a = 0.0;
-#pragma unroll
-            for (int r = 0; r < 10; ++r) a += y[r] * R[r][k];
-            X[t][k] = a;
-        }
-    }
-#undef M5
-    // rows (4,5), (6,7), (8,9): <x2 z> - z <x2>, <xyz> - z <xy>, <y2 z> - z <y2>  ->  B(z) [x y 1]' = 0
+    // rows 4..9 of X, two at a time: forward / back substitution of e_t, then w R; each pair (<x2 z>, <x2>), (<xyz>, <xy>),
+    // (<y2 z>, <y2>) gives one row  u - z v  of  B(z) [x y 1]' = 0
     double bx[3][4], by[3][4], b1[3][5];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double *u = X[2 * i], *v = X[2 * i + 1];
+        double uv[2][10];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int t = 4 + 2 * i + h;
+            double y[10];
+#pragma unroll
+            for (int a = 0; a < 10; ++a) {
+                double v = (perm[a] == t) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) if (k < a) v -= M5(a, k) * y[k];
+                y[a] = v;
+            }
+#pragma unroll
+            for (int a = 9; a >= 0; --a) {
+                double v = y[a];
+#pragma unroll
+                for (int k = 0; k < 10; ++k) if (k > a) v -= M5(a, k) * y[k];
+                y[a] = v / M5(a, a);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int r = 0; r < 10; ++r) acc += y[r] * R[r][k];
+                uv[h][k] = acc;
+            }
+        }
+        const double *u = uv[0], *v = uv[1];
         bx[i][3] = -v[0]; bx[i][2] = u[0] - v[1]; bx[i][1] = u[1] - v[2]; bx[i][0] = u[2];
         by[i][3] = -v[3]; by[i][2] = u[3] - v[4]; by[i][1] = u[4] - v[5]; by[i][0] = u[5];
         b1[i][4] = -v[6]; b1[i][3] = u[6] - v[7]; b1[i][2] = u[7] - v[8]; b1[i][1] = u[8] - v[9]; b1[i][0] = u[9];
     }
+#undef M5
     double c[11];
     for (int k = 0; k < 11; ++k) c[k] = 0.0;
     constexpr int PERM[6][4] = {{0, 1, 2, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {2, 1, 0, -1}};
@@ -558,9 +573,13 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
         const double x = (-B[r0][2] * B[r1][1] + B[r0][1] * B[r1][2]) / det;
         const double y = (-B[r0][0] * B[r1][2] + B[r0][2] * B[r1][0]) / det;
         double e[9], nrm = 0.0;
-        for (int k = 0; k < 9; ++k) { e[k] = x * N[k] + y * N[9 + k] + z * N[18 + k] + N[27 + k]; nrm += e[k] * e[k]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { e[3 * i + j] = x * El[i][j][0] + y * El[i][j][1] + z * El[i][j][2] + El[i][j][3]; nrm += e[3 * i + j] * e[3 * i + j]; }
         nrm = 1.0 / sqrt(nrm);
-        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Es[n_out][3 * i + j] = e[3 * j + i] * nrm;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) Es[n_out][k] = e[k] * nrm;
         ++n_out;
     }
     return n_out;
