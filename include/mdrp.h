@@ -109,8 +109,8 @@ int mdrp_create(int device, void *stream, mdrp_handle **out);
 int mdrp_create_on_stream(int device, void *stream, mdrp_handle **out);
 void mdrp_destroy(mdrp_handle *h);
 const char *mdrp_last_error(void);
-/* "mdrp-hip <ver> (gfx950) MDRP_SRC_HASH=<16 hex digits>": the hash covers mdrp_capi.hip, mdrp_kernels.h, mdrp_math.h and
- * this header as they were when the library was built (mdrp_amd/build.py source_hash()) */
+/* "mdrp-hip <ver> (gfx950) MDRP_SRC_HASH=<16 hex digits>": the hash covers mdrp_capi.hip, mdrp_kernels.h, mdrp_math.h,
+ * mdrp_classic.h, mdrp_classic_math.h and this header as they were when the library was built (mdrp_amd/build.py source_hash()) */
 const char *mdrp_version(void);
 /* block the calling thread until all work queued on the handle's stream is done */
 int mdrp_synchronize(mdrp_handle *h);
