@@ -297,6 +297,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     for (int i = 0; i < batch; ++i) sum_n += n_host[i] >= 3 ? n_host[i] : 0;
     (void)sum_n;
 
+#ifdef MDRP_LO_TRACE
+    if (getenv("MDRP_LO_TRACE_FILE")) {
+        static unsigned long long *trace_buf = nullptr;
+        if (!trace_buf) HIPCHK(hipMalloc(&trace_buf, 64ull << 20));
+        const unsigned int zero = 0;
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace), &trace_buf, sizeof trace_buf));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace_n), &zero, sizeof zero));
+    }
+#endif
     uint64_t it0 = 0;
     // iterations that certainly run: the reference cannot stop before min_iterations + 1 (or max_iterations)
     const uint64_t certain = ro->max_iterations == 0 ? 1 : std::min<uint64_t>(ro->max_iterations, ro->min_iterations + 1);
@@ -530,6 +539,21 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     (unsigned long long)it0, (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->evals_mfma,
                     h->progress_host->evals_bound, h->progress_host->evals_sweep, 100.0 * (double)h->progress_host->evals_sweep / (double)std::max<unsigned long long>(1, h->progress_host->evals),
                     h->progress_host->n_active, h->progress_host->max_needed);
+#ifdef MDRP_LO_TRACE
+        if (const char *path = getenv("MDRP_LO_TRACE_FILE")) {
+            unsigned int n_ev = 0;
+            unsigned long long *buf = nullptr;
+            HIPCHK(hipMemcpyFromSymbol(&n_ev, HIP_SYMBOL(g_lo_trace_n), sizeof n_ev));
+            HIPCHK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_lo_trace), sizeof buf));
+            if (buf && n_ev) {
+                std::vector<unsigned long long> host(8ull * n_ev);
+                HIPCHK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
+                if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+            }
+            n_ev = 0;
+            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace_n), &n_ev, sizeof n_ev));
+        }
+#endif
         it0 += super_len;
         if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
         max_needed = h->progress_host->max_needed;

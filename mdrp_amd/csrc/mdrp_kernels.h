@@ -1753,6 +1753,10 @@ __global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__re
     if (lane == 0) { prefix[batch] = run; plan[3 * (size_t)batch + 1] = run; }
 }
 
+#ifdef MDRP_LO_TRACE // experiment: per-problem timing of the LO kernels (tools/lo_trace.py)
+__device__ unsigned long long *g_lo_trace = nullptr; // 8 x u64 per problem
+__device__ unsigned int g_lo_trace_n = 0;
+#endif
 template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
@@ -1782,11 +1786,22 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
         o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
         const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
         const double *dd = dep + (size_t)pair * rp.n_max * 2;
+#ifdef MDRP_LO_TRACE
+        const unsigned long long t_start = wall_clock64();
+#endif
         lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
         double sc;
         int cn;
         block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
         if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
+#ifdef MDRP_LO_TRACE
+        if (threadIdx.x == 0 && g_lo_trace) {
+            const unsigned int k = atomicAdd(&g_lo_trace_n, 1u);
+            unsigned long long *e = g_lo_trace + 8ull * k;
+            e[0] = (unsigned long long)pair; e[1] = (unsigned long long)pos; e[2] = (unsigned long long)tr.cnt_ref; e[3] = (unsigned long long)cn;
+            e[4] = t_start; e[5] = wall_clock64(); e[6] = (unsigned long long)tr.iter + rp.chunk_start; e[7] = (unsigned long long)rp.chunk_off;
+        }
+#endif
     }
 }
 
