@@ -102,7 +102,6 @@ struct mdrp_handle {
     DevBuf rfrag;              // MFMA A fragments of the correspondences (k_prep): [pair][ceil(n_max/16)][64] x 16 B
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
-    DevBuf lo_ctl, lo_queue, lo_saved; // time-sliced LO (k_lo_sliced): queue counters per chunk, continuation queue, saved LM states
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
@@ -292,12 +291,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
     const size_t lo_mask_rows = (size_t)h->num_cu * 8;
     if (kind == MDRP_RELPOSE_5PT && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
-    // time-sliced LO: LM state per problem (up to 64 per pair and chunk; more -> the kernel runs whole problems) and a queue
-    const bool lo_slice = !classic && env_int("MDRP_LO_SLICE", 0) != 0;
-    const int lo_saved_cap = batch * 64, lo_queue_cap = lo_saved_cap * 7;
-    if (lo_slice && ((rc = h->lo_ctl.ensure(sizeof(int32_t) * LOQ_INTS * mdrp_handle::NC_MAX)) || (rc = h->lo_queue.ensure(sizeof(uint32_t) * (size_t)lo_queue_cap)) ||
-                     (rc = h->lo_saved.ensure(sizeof(LoSaved<MAX_NP>) * (size_t)lo_saved_cap))))
-        return rc;
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = SCORE_TILE_BYTES;
     int64_t sum_n = 0;
@@ -361,7 +354,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         for (int c = 0; c < n_chunks; ++c) super_len += lens[c];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
         HIPCHK(hipMemsetAsync(h->counters.p, 0, COUNTERS_BYTES, s));
-        if (lo_slice) HIPCHK(hipMemsetAsync(h->lo_ctl.p, 0, sizeof(int32_t) * LOQ_INTS * mdrp_handle::NC_MAX, s));
         // Three-stream pipeline over the chunks of a super-chunk (the benchmark shape: 512 | 9488 iterations):
         //   main:  solve 0 | score 0, scan 0 | score 1, scan 1 | ... | walk
         //   aux :            solve 1         | solve 2 ...
@@ -514,21 +506,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                              h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max);
                     return MDRP_OK;
                 }
-                if (lo_slice && lo_threads_c == 64) {
-                    int32_t *ctl = h->lo_ctl.as<int32_t>() + LOQ_INTS * c;
-                    HIPCHK(hipMemsetAsync(h->lo_queue.p, 0, sizeof(uint32_t) * (size_t)lo_queue_cap, aux2)); // LO launches are serial on this stream
-#define MDRP_LO_SLICED_LAUNCH(K, S)                                                                                                    \
-    hipLaunchKernelGGL((k_lo_sliced<K, S>), dim3(lo_blocks), dim3(64), lm_list_bytes(n_max), aux2, rp_lo, h->st.as<PairState>(),       \
-                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, ctl, \
-                       h->lo_queue.as<uint32_t>(), lo_queue_cap, reinterpret_cast<LoSaved<LmTraits<K, S>::NP> *>(h->lo_saved.p), lo_saved_cap, \
-                       lm_list_stride(n_max))
-                    if (kind == 0 && est_shift) MDRP_LO_SLICED_LAUNCH(0, true);
-                    else if (kind == 0) MDRP_LO_SLICED_LAUNCH(0, false);
-                    else if (kind == 1) MDRP_LO_SLICED_LAUNCH(1, false);
-                    else MDRP_LO_SLICED_LAUNCH(2, false);
-#undef MDRP_LO_SLICED_LAUNCH
-                    return MDRP_OK;
-                }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
                                  h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
                                  trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max));
@@ -544,12 +521,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // progress record: pairs still iterating, iterations they still need, evaluations swept (sum over pairs of models * n)
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (lo_slice) {
-            int32_t ctl_host[LOQ_INTS * mdrp_handle::NC_MAX];
-            HIPCHK(hipMemcpy(ctl_host, h->lo_ctl.p, sizeof ctl_host, hipMemcpyDeviceToHost));
-            for (int c = 0; c < n_chunks; ++c)
-                if (ctl_host[LOQ_INTS * c + LOQ_ERROR]) { g_err = "k_lo_sliced: queue wait exhausted (internal error)"; return MDRP_ERR_HIP; }
-        }
         h->sweep_evals += (int64_t)h->progress_host->evals;
         h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
         h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
@@ -732,7 +703,7 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask, &h->lo_ctl, &h->lo_queue, &h->lo_saved};
+                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);

@@ -1805,194 +1805,6 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
     }
 }
 
-// ------------------------------------------------------------------------------------------------ LO, time-sliced
-// The same refinements in slices of LO_SLICE LM iterations with a requeue.  k_lo ends when its last LONG problem does: problems
-// take 4 to 25 LM iterations (0.1 - 1.6 ms on one wavefront), nothing known beforehand predicts which (tools/lo_trace.py), and a
-// 25-iteration problem popped late runs alone on its SIMD while the rest of the chip idles (makespan 1.9 ms for 1.2 ms of work
-// per wavefront).  Here a wavefront runs at most LO_SLICE iterations of a problem, saves its LM state (model, lambda, cost, the
-// normal equations of the last accepted step) and appends the problem to the queue; whoever pops it later rebuilds the work list
-// with one cost sweep (deterministic: the same cost, the same list) and carries on.  The arithmetic of every LM is unchanged —
-// results are bit-identical to k_lo — only the tail shrinks to one slice.
-// Queue: items 0 .. total-1 are the problems themselves (implicit); continuations are appended to `queue` (zeroed before the
-// launch; entry = problem + 1).  A consumer that holds an index past the tail polls ITS OWN slot (s_sleep) until the item arrives
-// or every problem is done (a global in-order commit counter serialised the pushes at ~1 us each: 7 ms per launch); polling is
-// bounded, an exhausted bound raises ctl[LOQ_ERROR] (the host fails loudly).
-#ifndef MDRP_LO_SLICE_ITS
-#define MDRP_LO_SLICE_ITS 4
-#endif
-constexpr int LO_SLICE = MDRP_LO_SLICE_ITS;
-enum { LOQ_HEAD = 0, LOQ_TAIL_RES = 1, LOQ_TAIL_COMMIT = 2, LOQ_DONE = 3, LOQ_ERROR = 4, LOQ_INTS = 8 };
-template <int NP>
-struct LoSaved {
-    Model m;
-    double cost, lambda, mu;
-    int32_t it, recompute;
-    double A[NP * (NP + 1) / 2], g[NP];
-};
-
-template <int KIND, bool SHIFT>
-__global__ __launch_bounds__(64, MDRP_LM_MINWAVES) void k_lo_sliced(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
-                                                            const double *__restrict__ dep, const Model *__restrict__ models,
-                                                            Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan,
-                                                            int32_t *__restrict__ ctl /*LOQ_INTS, zeroed*/, uint32_t *__restrict__ queue, int queue_cap,
-                                                            LoSaved<LmTraits<KIND, SHIFT>::NP> *__restrict__ saved, int saved_cap, int list_stride) {
-    constexpr int T = 64, NP = LmTraits<KIND, SHIFT>::NP, NT = NP * (NP + 1) / 2;
-    extern __shared__ uint16_t lm_dyn_list[];
-    __shared__ LmShared sh;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
-    __syncthreads();
-    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
-    const int total = plan[3 * (size_t)rp.batch + 1];
-    // slicing needs a state record per problem and room for every continuation; otherwise whole problems (one slice of 25)
-    const bool sliced = total <= saved_cap && (long long)total * ((25 + LO_SLICE - 1) / LO_SLICE) <= (long long)queue_cap;
-    const int slice = sliced ? LO_SLICE : 1 << 20;
-    for (;;) {
-        int item = -1;
-        if (threadIdx.x == 0) {
-            const int idx = atomicAdd(&ctl[LOQ_HEAD], 1);
-            if (idx < total) item = idx;
-            else if (sliced) {
-                const int want = idx - total;
-                // relaxed polls (an acquire load invalidates the CU's L1 on every poll and starves the wavefronts that work)
-                for (int spin = 0;; ++spin) { // each waiter polls its own slot (the queue is zeroed before the launch: 0 = not there yet)
-                    const uint32_t q = __hip_atomic_load(&queue[want], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (q != 0u) { item = (int)(q - 1u); break; }
-                    if (__hip_atomic_load(&ctl[LOQ_DONE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) break;
-                    if (spin > (1 << 21)) { atomicExch(&ctl[LOQ_ERROR], 1); break; }
-                    __builtin_amdgcn_s_sleep(64);
-                }
-                if (item >= 0) item |= 1 << 30; // a continuation: its LM state is in `saved`
-            }
-        }
-        item = __shfl(item, 0, 64);
-        if (item < 0) break;
-        const bool fresh = (item & (1 << 30)) == 0;
-        const int w = item & ~(1 << 30);
-        const int pair = plan_find(prefix, rp.batch, w);
-        const int pos = begin[pair] + (w - prefix[pair]);
-        const PairState &ps = st[pair];
-        Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
-        const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
-        const double *dd = dep + (size_t)pair * rp.n_max * 2;
-        LmOpt o;
-        o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
-        o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-        const double sqrt_sr = sqrt(ps.scale_reproj), ws = rp.weight_sampson;
-        // ---- state: fresh from the triggering minimal model, or the saved one
-        Model m;
-        double cost, lambda, A[NP * NP], g[NP];
-        int it;
-        bool recompute;
-        LoSaved<NP> *sv = sliced ? saved + w : nullptr;
-        // Saved states are written and read with agent-scope relaxed atomics, word by word: they bypass the per-XCD L2, so no cache
-        // write-back / invalidate is needed around the queue (release / acquire FENCES at agent scope flush and invalidate the
-        // whole L2 of the XCD: measured 2.7x on the step).  Program order + s_waitcnt orders them with the queue commit.
-        if (fresh) {
-            const size_t slot_base = (size_t)pair * rp.slot_stride;
-            m = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_ref];
-            o.mu = 0.5; lambda = o.lambda0; it = 0; recompute = true;
-            cost = lm_cost<KIND, T>(m, pp, dd, ps.n, nullptr, sqrt_sr, ws, o, sh, 0);
-        } else {
-            constexpr int NW = (int)(sizeof(LoSaved<NP>) / 8);
-            static_assert(sizeof(LoSaved<NP>) % 8 == 0, "saved state is a whole number of 8-byte words");
-            LoSaved<NP> loc;
-            unsigned long long *dst = reinterpret_cast<unsigned long long *>(&loc);
-            unsigned long long *src = reinterpret_cast<unsigned long long *>(sv);
-#pragma unroll
-            for (int q = 0; q < NW; ++q) dst[q] = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            m = loc.m; lambda = loc.lambda; o.mu = loc.mu; it = loc.it; recompute = loc.recompute != 0;
-            int idx = 0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b) A[a * NP + b] = loc.A[idx++];
-#pragma unroll
-            for (int a = 0; a < NP; ++a) g[a] = loc.g[a];
-            cost = lm_cost<KIND, T>(m, pp, dd, ps.n, nullptr, sqrt_sr, ws, o, sh, 0); // rebuilds the work list; the value equals sv->cost
-        }
-        int cur = 0;
-        bool finished = false;
-        const int it_end = min(o.max_it, it + slice);
-        double acc[NT + NP], sol[NP];
-        for (; it < it_end; ++it) { // lm_refine's loop body, verbatim
-            if (recompute) {
-                lm_accumulate<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, sqrt_sr, ws, o, acc, sh, cur);
-                double gn = 0;
-                int idx = 0;
-#pragma unroll
-                for (int a = 0; a < NP; ++a) {
-#pragma unroll
-                    for (int b = 0; b <= a; ++b) A[a * NP + b] = acc[idx++];
-                }
-#pragma unroll
-                for (int a = 0; a < NP; ++a) { g[a] = acc[NT + a]; gn += g[a] * g[a]; }
-                if (sqrt(gn) < o.grad_tol) { finished = true; break; }
-            }
-            double Ad[NP * NP];
-#pragma unroll
-            for (int a = 0; a < NP; ++a)
-#pragma unroll
-                for (int b = 0; b <= a; ++b) Ad[a * NP + b] = A[a * NP + b] + (a == b ? lambda : 0.0);
-            chol_solve<NP>(Ad, g, sol);
-            double sn = 0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a) { sol[a] = -sol[a]; sn += sol[a] * sol[a]; }
-            if (sqrt(sn) < o.step_tol) { finished = true; break; }
-            double full[LM_NPAR];
-#pragma unroll
-            for (int q = 0; q < LM_NPAR; ++q) full[q] = 0;
-#pragma unroll
-            for (int q = 0; q < NP; ++q) full[lm_col<KIND, SHIFT>(q)] = sol[q];
-            if (KIND == 1) full[10] = full[9];
-            Model cand;
-            lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
-            const double cost_new = lm_cost<KIND, T>(cand, pp, dd, ps.n, nullptr, sqrt_sr, ws, o, sh, cur ^ 1);
-            if (cost_new < cost) {
-                m = cand;
-                cur ^= 1;
-                lambda = fmax(o.lambda_min, lambda / 10.0);
-                cost = cost_new;
-                recompute = true;
-            } else {
-                lambda = fmin(o.lambda_max, lambda * 10.0);
-                recompute = false;
-            }
-            o.mu *= 1.5;
-        }
-        if (it >= o.max_it) finished = true;
-        if (finished) {
-            double sc;
-            int cn;
-            block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
-            if (threadIdx.x == 0) {
-                tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn;
-                __hip_atomic_fetch_add(&ctl[LOQ_DONE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            if (threadIdx.x == 0) {
-                constexpr int NW = (int)(sizeof(LoSaved<NP>) / 8);
-                LoSaved<NP> loc;
-                loc.m = m; loc.cost = cost; loc.lambda = lambda; loc.mu = o.mu; loc.it = it; loc.recompute = recompute ? 1 : 0;
-                int idx = 0;
-#pragma unroll
-                for (int a = 0; a < NP; ++a)
-#pragma unroll
-                    for (int b = 0; b <= a; ++b) loc.A[idx++] = A[a * NP + b];
-#pragma unroll
-                for (int a = 0; a < NP; ++a) loc.g[a] = g[a];
-                const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&loc);
-                unsigned long long *dst = reinterpret_cast<unsigned long long *>(sv);
-#pragma unroll
-                for (int q = 0; q < NW; ++q) __hip_atomic_store(dst + q, src[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // s_waitcnt: the state is at the coherence point before the queue says so
-                const int slot = atomicAdd(&ctl[LOQ_TAIL_RES], 1);
-                __hip_atomic_store(&queue[slot], (uint32_t)w + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ walk
 // One lane per pair replays score_models<> / ransac<> bookkeeping (@0x22ebc0, @0x22f030) over the ordered triggers
 // and applies the dynamic stopping rule.
