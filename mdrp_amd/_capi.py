@@ -150,6 +150,38 @@ def library_source_hash():
     return v.split("MDRP_SRC_HASH=", 1)[1][:16] if "MDRP_SRC_HASH=" in v else None
 
 
+_torch_runtime_done = False
+
+
+def _torch_runtime_first():
+    """PyTorch-ROCm wheels bundle their own HIP / HSA runtime (torch/lib/libamdhip64.so, no SONAME), libmdrp_hip.so links the
+    system one (/opt/rocm/lib/libamdhip64.so.7): two runtimes in one process.  That works when torch's initialises first; the
+    other way round torch.cuda later fails with "No HIP GPUs are available".  So before the first handle exists: if the process
+    has imported torch, torch.cuda is initialised; if torch is merely installed, its bundled runtime library is loaded and
+    hipInit()ed (the later `import torch` finds it loaded) — without importing torch.  MDRP_NO_TORCH_PRELOAD=1 skips this."""
+    global _torch_runtime_done
+    if _torch_runtime_done or os.environ.get("MDRP_NO_TORCH_PRELOAD"):
+        return
+    _torch_runtime_done = True
+    import sys
+    torch = sys.modules.get("torch")
+    try:
+        if torch is not None:
+            if torch.cuda.is_available() and not torch.cuda.is_initialized():
+                torch.cuda.init()
+            return
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            rt = C.CDLL(path, mode=C.RTLD_GLOBAL)
+            rt.hipInit(0)
+    except Exception:
+        pass
+
+
 class Handle:
     """One handle = one HIP device + one stream + its scratch buffers.  Calls on one handle are serialised inside the
     library; use one handle per host thread for concurrency (default_handle() does).
@@ -158,6 +190,7 @@ class Handle:
     0 is the device's legacy default stream (torch.cuda.current_stream().cuda_stream is 0 on torch's default stream)."""
 
     def __init__(self, device=0, stream=None):
+        _torch_runtime_first()
         self._lib = load_library()
         h = C.c_void_p()
         if stream is None:

@@ -152,3 +152,18 @@ def test_initial_pose_and_score_initial_model_vs_reference_golden(golden):
         if flag or not deg:
             assert model_diff(m, ref_m) < 1e-6, (i, m, ref_m)
         assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), g[f"mask_{i}"])
+
+
+def test_handle_before_torch_cuda_init_in_a_fresh_process():
+    """torch imported, CUDA not yet initialised, an mdrp handle created first: torch.cuda must still come up (the wheel bundles
+    its own HIP runtime; _capi brings it up before ours)"""
+    import subprocess
+    import sys
+    code = ("import torch, numpy as np\n"
+            "from mdrp_amd import _capi\n"
+            "h = _capi.Handle(0)\n"
+            "x = torch.ones(8, device='cuda')\n"
+            "print('ok', float(x.sum()))\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    assert out.returncode == 0 and "ok 8.0" in out.stdout, out.stderr[-2000:]
