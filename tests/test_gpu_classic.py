@@ -228,3 +228,35 @@ def test_stress_grid_follows_the_oracle(kind):
             d = pose_diff(models[k], m) if kind == 3 else fund_diff(np.asarray(models[k]).reshape(-1), m)
             assert d < 1e-6, (gi, k, d)
     assert off == 0, (off, total)
+
+
+@pytest.mark.parametrize("kind", [3, 5])
+def test_large_batch_one_wavefront_per_lo_problem(kind):
+    """>= 128 pairs switch the LO kernels to one wavefront per LM problem (T = 64): same trajectories as the sequential oracle"""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    B = 136
+    pairs = [synth.make_pair(9100 + k, 100 + (k % 5) * 20, f1=850.0, f2=850.0, pp=(640.0, 480.0), noise_px=0.6, outlier_frac=0.35) for k in range(B)]
+    ro = {"max_iterations": 250, "min_iterations": 60, "max_epipolar_error": 1.5, "seed": 4}
+    bo = {"loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.5}
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [850.0, 640.0, 480.0]}
+    x1, x2 = [p["x1"] for p in pairs], [p["x2"] for p in pairs]
+    if kind == 3:
+        models, infos = poselib.estimate_relative_pose_batch(x1, x2, cam, cam, ro, bo)
+        models = [np.r_[m.q, m.t] for m in models]
+    else:
+        models, infos = poselib.estimate_fundamental_batch(x1, x2, ro, bo)
+    c = po.cam_flat(0, [850.0, 640.0, 480.0])
+    off = 0
+    for k, p in enumerate(pairs):
+        m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], po.ransac_opt(max_iterations=250, min_iterations=60, max_epipolar_error=1.5, seed=4),
+                                          po.bundle_opt(loss_type=4, loss_scale=1.5), c, c)
+        info = infos[k]
+        same = (info["refinements"], info["iterations"], info["num_inliers"]) == (st.refinements, st.iterations, st.num_inliers) and \
+            np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask)
+        if not same:
+            off += 1
+            continue
+        d = pose_diff(models[k], m) if kind == 3 else fund_diff(np.asarray(models[k]).reshape(-1), m)
+        assert d < 1e-6, (k, d)
+    assert off == 0, off
