@@ -395,8 +395,18 @@ def _stack2(points1, points2):
     return x1, x2, ns
 
 
+def _check_baseline_options(ransac_opt):
+    """options of upstream RansacOptions that change what the baseline estimators do and are not built here"""
+    ro = ransac_opt or {}
+    if ro.get("progressive_sampling"):
+        raise NotImplementedError("progressive_sampling (PROSAC) is not built (DESIGN.md 9)")
+    if ro.get("real_focal_check"):
+        raise NotImplementedError("real_focal_check (FundamentalEstimator drops models without real focal lengths) is not built")
+
+
 def estimate_relative_pose_batch(points2D_1, points2D_2, cameras1, cameras2, ransac_opt=None, bundle_opt=None, device=0):
     """B calibrated pairs through the 5-point estimator.  Returns (list[CameraPose], list[info dict])."""
+    _check_baseline_options(ransac_opt)
     x1, x2, ns = _stack2(points2D_1, points2D_2)
     B = len(ns)
 
@@ -412,6 +422,7 @@ def estimate_relative_pose_batch(points2D_1, points2D_2, cameras1, cameras2, ran
 
 def estimate_fundamental_batch(points2D_1, points2D_2, ransac_opt=None, bundle_opt=None, device=0):
     """B pairs through the 7-point estimator.  Returns (list[3 x 3 ndarray], list[info dict])."""
+    _check_baseline_options(ransac_opt)
     x1, x2, ns = _stack2(points2D_1, points2D_2)
     h = _capi.default_handle(device)
     res, mask = h.estimate_batch(_capi.FUNDAMENTAL_7PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),

@@ -166,6 +166,18 @@ def test_evaluate_focal_end_to_end_gpu(shared):
     assert row[1] < 1.0 and row[2] < 0.02 and row[3] > 0.85 and row[4] > 0.85, row
 
 
+def test_baseline_options_that_are_not_built_raise():
+    import mdrp_amd.poselib as poselib
+    x = np.zeros((10, 2))
+    with pytest.raises(NotImplementedError):
+        poselib.estimate_fundamental(x, x, {"real_focal_check": True}, {})
+    with pytest.raises(NotImplementedError):
+        poselib.estimate_relative_pose(x, x, {"model": "SIMPLE_PINHOLE", "width": 1, "height": 1, "params": [1.0, 0, 0]}, {"model": "SIMPLE_PINHOLE", "width": 1, "height": 1, "params": [1.0, 0, 0]},
+                                       {"progressive_sampling": True}, {})
+    with pytest.raises(NotImplementedError):
+        poselib.estimate_shared_focal_relative_pose(x, x, {}, {})
+
+
 def test_fork_flag_table_covers_every_experiment_name():
     """Every experiment family of the reference's lists (utils/data.py:86-200 get_experiments, eval.py:212-239) goes through
     the option builders and mdrp_amd.poselib._map_fork_options: the ones that ARE the released PR-152 estimators map, with the
