@@ -78,6 +78,7 @@ def load_library():
             return _lib
         if not os.path.exists(LIB_PATH):
             raise MdrpError(f"{LIB_PATH} is not built (run __graft_entry__.build()); mdrp_amd has no CPU fallback")
+        _torch_runtime_first()  # before OUR runtime is even loaded: its static constructors already touch the device
         lib = C.CDLL(LIB_PATH)
         vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
         lib.mdrp_last_error.restype = C.c_char_p
