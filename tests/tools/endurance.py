@@ -23,3 +23,17 @@ for it in range(400):                     # same handle, alternating shapes
     res, mask = h.estimate_batch(0, b["x1"][:n], b["x2"][:n], b["d1"][:n], b["d2"][:n], ro, bo, None, cams[:n], cams[:n])
     if n == 64: assert (res.tobytes(), mask.tobytes()) == ref, it
 print("400 calls ok, %.1f s" % (time.time() - t0), "free delta MB", (free0 - torch.cuda.mem_get_info()[0]) / 2**20)
+# the non-monodepth baselines interleaved with the monodepth estimator on one handle: determinism and no growth
+refs = {}
+t0 = time.time()
+for it in range(300):
+    kind = (3, 5, 0)[it % 3]
+    n = (64, 17, 40)[it % 3]
+    if kind == 0:
+        res, mask = h.estimate_batch(0, b["x1"][:n], b["x2"][:n], b["d1"][:n], b["d2"][:n], ro, bo, None, cams[:n], cams[:n])
+    else:
+        res, mask = h.estimate_batch(kind, b["x1"][:n], b["x2"][:n], None, None, ro, bo, None, cams[:n] if kind == 3 else None, cams[:n] if kind == 3 else None)
+    key = (kind, n)
+    if key not in refs: refs[key] = (res.tobytes(), mask.tobytes())
+    assert (res.tobytes(), mask.tobytes()) == refs[key], (it, key)
+print("300 interleaved baseline / monodepth calls ok, %.1f s" % (time.time() - t0), "free delta MB", (free0 - torch.cuda.mem_get_info()[0]) / 2**20)
