@@ -139,6 +139,8 @@ def main():
                          "e.g. --total-pairs 100000 --gpus 8, or --total-pairs 12500 --gpus 1 for one rank's share")
     ap.add_argument("--workload", default="calib_p3p_n2000_i10k", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-pairs", type=int, default=96, help="pairs timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--inflight", type=int, default=2, help="extra measurement at N = 1: the same steps with this many in flight "
+                                                              "(one handle + host thread each, mdrp_amd.pipeline); 1 = skip.  Never `value`.")
     ap.add_argument("--host-steps", type=int, default=2, help="extra steps through the host-buffer (PCIe-inclusive) entry point, N = 1 only (0 = skip)")
     args = ap.parse_args()
 
@@ -237,6 +239,33 @@ def main():
             h.estimate_batch(kind, *xs, ro, bo, None, cams if with_cams else None, cams if with_cams else None)
         host_rate = B * args.host_steps / (time.perf_counter() - th)
 
+    pipelined = None
+    if world == 1 and args.inflight > 1 and B > 0:  # consecutive steps with several in flight: an EXTRA key, `value` stays sequential
+        import threading
+        L = args.inflight
+        hs = [_capi.Handle(local_rank) for _ in range(L)]
+        masks = [torch.zeros((B, n), dtype=torch.uint8, device=dev) for _ in range(L)]
+
+        def lane(i, steps_):
+            for _ in range(steps_):
+                hs[i].estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), 0 if classic else d1.data_ptr(), 0 if classic else d2.data_ptr(), B, n, ro, bo,
+                                            None, cams if with_cams else None, cams if with_cams else None, masks[i].data_ptr())
+                hs[i].fetch_results(B)
+        for i in range(L):
+            lane(i, 1)
+        per_lane = max(1, args.steps // L)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        th = [threading.Thread(target=lane, args=(i, per_lane)) for i in range(L)]
+        [t.start() for t in th]; [t.join() for t in th]
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - tp
+        pipelined = {"in_flight": L, "steps": per_lane * L, "value": B * per_lane * L / dtp, "unit": "image-pairs/s", "ms_per_step": 1e3 * dtp / (per_lane * L),
+                     "note": "the same steps, this many in flight at a time (one handle, stream set and host thread each: mdrp_amd.pipeline.BatchPipeline); "
+                             "the next step's solver and sweeps fill the SIMDs the LM phases leave idle.  Not `value`."}
+        for hh in hs:
+            hh.close()
+
     if rank == 0:
         pairs = total * args.steps
         value = pairs / dt
@@ -281,6 +310,8 @@ def main():
             "quality": {"median_rotation_error_deg_first64": R_err,
                         "mean_inlier_ratio": float(np.mean(res["num_inliers"] / n)) if len(res) else None},
         }
+        if pipelined is not None:
+            line["pipelined"] = pipelined
         if host_rate is not None:
             line["host_buffers"] = {"value": host_rate, "unit": "image-pairs/s", "ratio_to_resident": host_rate / value,
                                     "note": "mdrp_estimate_batch with MDRP_MEM_HOST: pageable numpy buffers, H2D of 48 B per correspondence and D2H of "

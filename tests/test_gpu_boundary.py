@@ -167,3 +167,28 @@ def test_handle_before_torch_cuda_init_in_a_fresh_process():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                          cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
     assert out.returncode == 0 and "ok 8.0" in out.stdout, out.stderr[-2000:]
+
+
+def test_batch_pipeline_equals_sequential_calls():
+    """two batches in flight (two handles, two host threads): same records and masks, in submission order, as one call after
+    the other — for a monodepth estimator and for a baseline"""
+    from mdrp_amd import _capi, synth
+    from mdrp_amd.pipeline import BatchPipeline
+    batches = [synth.make_batch(6800 + 40 * k, 20 + 3 * k, 400, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4) for k in range(6)]
+    ro = {"max_iterations": 2000, "min_iterations": 2000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0}
+    bo = {"loss_type": "TRUNCATED_CAUCHY"}
+    h = _capi.Handle(0)
+    rop, bop = _capi.ransac_opt_from_dict(ro), _capi.bundle_opt_from_dict(bo)
+    for kind in (_capi.CALIB, _capi.RELPOSE_5PT):
+        def cams(b):
+            c = np.zeros(len(b["x1"]), dtype=_capi.CAMERA_DTYPE); c["params"][:, 0] = 800.0
+            return c
+        seq = [h.estimate_batch(kind, b["x1"], b["x2"], b["d1"] if kind == 0 else None, b["d2"] if kind == 0 else None, rop, bop, None, cams(b), cams(b))
+               for b in batches]
+        with BatchPipeline(depth=2) as pipe:
+            futs = [pipe.submit(kind, b["x1"], b["x2"], b["d1"] if kind == 0 else None, b["d2"] if kind == 0 else None, ro, bo, None, cams(b), cams(b))
+                    for b in batches]
+            got = [f.result() for f in futs]
+        for (r0, m0), (r1, m1) in zip(seq, got):
+            assert r0.tobytes() == r1.tobytes() and np.array_equal(m0, m1)
+    h.close()
