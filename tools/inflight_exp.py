@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from mdrp_amd import _capi, synth
 
-B, n, iters, K = 1024, 2000, 10000, 24
+B, n, iters, K = int(os.environ.get("B", 1024)), 2000, 10000, int(os.environ.get("K", 24))
 b = synth.make_batch(0, B, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
 dev = torch.device("cuda", 0)
 x1 = torch.from_numpy(b["x1"]).to(dev); x2 = torch.from_numpy(b["x2"]).to(dev)
