@@ -215,8 +215,6 @@ def test_estimate_vs_reference_golden(handle, capi, golden):
             ok = (int(res["num_inliers"]) == int(ref_st[2]) and int(res["refinements"]) == int(ref_st[0])
                   and (mask == ref_mask).all() and model_diff(m, ref_m) < 1e-6)
             same_traj += ok
-            # statistically equivalent even when a rounding-level tie sends RANSAC down another branch
-            assert abs(int(res["num_inliers"]) - int(ref_st[2])) <= max(3, 0.02 * ref_st[2]), case
     assert same_traj == noisy, (same_traj, noisy)  # every noisy golden case lands on the reference's exact trajectory
 
 
@@ -398,7 +396,7 @@ def test_dynamic_stopping_chunks(handle, capi, po):
                                 po.ransac_opt(max_epipolar_error=2.0, max_reproj_error=16.0, min_iterations=100 if of else 1000),
                                 po.bundle_opt(loss_type=4), po.cam_flat(0, [800.0, 0, 0]), po.cam_flat(0, [800.0, 0, 0]))
         assert int(res["iterations"]) == st.iterations, (of, int(res["iterations"]), st.iterations)
-        assert abs(int(res["num_inliers"]) - st.num_inliers) <= 2
+        assert int(res["num_inliers"]) == st.num_inliers and int(res["refinements"]) == st.refinements and (mask == mk).all(), of
 
 
 def test_poselib_signatures(po):
@@ -485,9 +483,11 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
     for env in ({"MDRP_CHUNKS": "512"}, {"MDRP_CHUNKS": "256,1024"}, {"MDRP_CHUNKS": "512", "MDRP_LO_OVERLAP": "0"},
                 {"MDRP_CHUNKS": "128,256,512", "MDRP_LO_OVERLAP_WAVES": "4", "MDRP_LO_AFTER_SOLVE": "0", "MDRP_LO_AFTER_COUNT": "0"},
                 {"MDRP_CHUNKS": "128", "MDRP_BOUND": "0"}, {"MDRP_CHUNKS": "64,128", "MDRP_LO_AFTER_COUNT": "0"},
-                {"MDRP_CHUNKS": "512", "MDRP_LO_THREADS": "256", "MDRP_FINAL_THREADS": "64"}):
+                {"MDRP_CHUNKS": "512", "MDRP_LO_THREADS": "256", "MDRP_FINAL_THREADS": "64"},
+                {"MDRP_CHUNKS": "128", "MDRP_LO_THREADS": "64"}, {"MDRP_CHUNKS": "128", "MDRP_FINAL_THREADS": "64"},
+                {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "0"}, {"MDRP_CHUNKS": "128,1024", "MDRP_LM_ENGINE": "1"}):
         for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_AFTER_COUNT", "MDRP_BOUND",
-                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS"):
+                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -496,7 +496,7 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
             assert np.array_equal(res[f], ref[f]), (env, f)
         assert np.array_equal(mask, ref_mask), env
         # thread-count variants reduce in a different order: models agree to rounding, not bitwise
-        tol = 1e-9 if "MDRP_LO_THREADS" in env else 0.0
+        tol = 1e-9 if ("MDRP_LO_THREADS" in env or "MDRP_FINAL_THREADS" in env or "MDRP_LM_ENGINE" in env) else 0.0
         def flat(m):
             return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
         assert np.allclose(flat(res["model"]), flat(ref["model"]), rtol=tol, atol=tol), env

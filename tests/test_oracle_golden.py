@@ -151,3 +151,37 @@ def test_initial_model_and_score_initial_match_reference(golden):
         assert abs(st.model_score - ref_st[4]) <= 1e-9 * ref_st[4]
         assert model_diff(m, ref_m) < 1e-6, i
         assert (mask == g[f"mask_{i}"]).all()
+
+
+def test_wide_full_size_pin_subsample(golden):
+    """tests/golden/estimate_wide.npz (32 reference-binary runs per estimator at BASELINE's full shapes, seeds + outputs
+    only): the stored input digests match what mdrp_amd.synth generates today for ALL 128 pairs, the stored port results
+    were result-identical to the reference on all of them, and the oracle reproduces four pairs per estimator now
+    (the GPU suite checks all 128 against the same file)."""
+    import hashlib
+    from mdrp_amd import synth
+    g = golden("estimate_wide")
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
+    deviations = 0
+    for j, name in enumerate(g["names"]):
+        kind, es, n = (int(v) for v in g["cases"][j])
+        of = float(g["outlier_frac"][j])
+        assert g[f"{name}_oracle_same"].all()
+        deviations += int((g[f"{name}_oracle_refinements"] != g[f"{name}_stats"][:, 0].astype(int)).sum())
+        for k, index in enumerate(g["indices"]):
+            p = synth.make_pair(int(index), n, noise_px=0.5, depth_noise=0.02, outlier_frac=of, random_focal=[None, "shared", "varying"][kind],
+                                shift1=0.2 if es and kind == 0 else 0.0, shift2=-0.1 if es and kind == 0 else 0.0)
+            h = hashlib.sha256()
+            for key in ("x1", "x2", "d1", "d2"):
+                h.update(np.ascontiguousarray(p[key], dtype=np.float64).tobytes())
+            assert np.frombuffer(h.digest()[:8], dtype=np.uint64)[0] == g[f"{name}_digest"][k], (name, index)
+            if k % 8 != 3:
+                continue
+            ro = po.ransac_opt(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0, max_reproj_error=16.0, estimate_shift=bool(es))
+            m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, po.bundle_opt(loss_type=4),
+                                      cam if kind == 0 else None, cam if kind == 0 else None)
+            ref_st = g[f"{name}_stats"][k]
+            assert st.iterations == int(ref_st[1]) and st.num_inliers == int(ref_st[2]), (name, index)
+            assert (mask == np.unpackbits(g[f"{name}_mask"][k])[:n]).all() and model_diff(m, g[f"{name}_model"][k]) < 1e-6, (name, index)
+            assert st.refinements == int(g[f"{name}_oracle_refinements"][k]), (name, index)
+    assert deviations == 3  # 3 of 128 pairs differ from the reference in the LO COUNT only (DESIGN.md §5): 2.3 %
