@@ -4,6 +4,7 @@
 #include "../../include/mdrp.h"
 #include "mdrp_kernels.h"
 #include "mdrp_classic.h"
+#include "mdrp_lm.h"
 
 #include <algorithm>
 #include <cmath>
@@ -56,7 +57,7 @@ struct DevBuf {
 
 // read back once per super-chunk: device counters at int32 index 2.. of the `counters` buffer
 struct Progress {
-    int32_t n_active; int32_t pad;
+    int32_t n_active; int32_t lo_overflow; // lo_overflow: a chunk found more triggers than the LM engine's problem table holds per pass
     unsigned long long max_needed;
     unsigned long long evals;       // (model x correspondence) evaluations the CPU loop would do: sum over pairs of models * n
     unsigned long long evals_mfma;  // evaluations executed by k_count on the matrix cores (padded to 16 x 16 tiles)
@@ -103,6 +104,9 @@ struct mdrp_handle {
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
+    // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
+    DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota;
+    int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -182,6 +186,145 @@ int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b, int what = 0) {
 int solver_for(int kind, int est_shift) {
     if (kind == MDRP_CALIB) return est_shift ? SOLVER_SHIFT : SOLVER_P3P;
     return kind == MDRP_SHARED_FOCAL ? SOLVER_SHARED : SOLVER_VARYING;
+}
+
+// ---------------------------------------------------------------------------------------------- LM engine (mdrp_lm.h)
+#ifdef MDRP_FAST_BUILD
+#define MDRP_LME_LM(KERNEL, kind, shift, grid, block, smem, stream, ...) hipLaunchKernelGGL((KERNEL<0, false>), grid, block, smem, stream, __VA_ARGS__)
+#define MDRP_LME_ACCUM(kind, shift, loss, grid, smem, stream, ...)                                                         \
+    do {                                                                                                                 \
+        if ((loss) == 1) hipLaunchKernelGGL((k_lme_accum<0, false, 1>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((k_lme_accum<0, false, -1>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);                \
+    } while (0)
+#else
+#define MDRP_LME_LM(KERNEL, kind, shift, grid, block, smem, stream, ...)                                                  \
+    do {                                                                                                                 \
+        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true>), grid, block, smem, stream, __VA_ARGS__);        \
+        else if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0, false>), grid, block, smem, stream, __VA_ARGS__);             \
+        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false>), grid, block, smem, stream, __VA_ARGS__);             \
+        else hipLaunchKernelGGL((KERNEL<2, false>), grid, block, smem, stream, __VA_ARGS__);                              \
+    } while (0)
+#define MDRP_LME_ACCUM_L(L, kind, shift, grid, smem, stream, ...)                                                          \
+    do {                                                                                                                 \
+        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((k_lme_accum<0, true, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);  \
+        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_accum<0, false, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);       \
+        else if ((kind) == 1) hipLaunchKernelGGL((k_lme_accum<1, false, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((k_lme_accum<2, false, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);                        \
+    } while (0)
+// the LO refinements are always TRUNCATED (loss 1): their kernels carry the loss as a compile-time constant
+#define MDRP_LME_ACCUM(kind, shift, loss, grid, smem, stream, ...)                                                         \
+    do {                                                                                                                 \
+        if ((loss) == 1) MDRP_LME_ACCUM_L(1, kind, shift, grid, smem, stream, __VA_ARGS__);                               \
+        else MDRP_LME_ACCUM_L(-1, kind, shift, grid, smem, stream, __VA_ARGS__);                                          \
+    } while (0)
+#endif
+// cost / score sweeps: the calibrated estimator folds f1 = f2 = 1 away (KIND 0), the focal ones share one instantiation
+#define MDRP_LME_SWEEP(KERNEL, kind, grid, stream, ...)                                                                  \
+    do {                                                                                                                 \
+        if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0>), grid, dim3(64), 0, stream, __VA_ARGS__);                        \
+        else hipLaunchKernelGGL((KERNEL<1>), grid, dim3(64), 0, stream, __VA_ARGS__);                                    \
+    } while (0)
+#define MDRP_LME_COST(kind, loss, grid, stream, ...)                                                                     \
+    do {                                                                                                                 \
+        if ((kind) == 0 && (loss) == 1) hipLaunchKernelGGL((k_lme_cost<0, 1>), grid, dim3(64), 0, stream, __VA_ARGS__);   \
+        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_cost<0, -1>), grid, dim3(64), 0, stream, __VA_ARGS__);            \
+        else if ((loss) == 1) hipLaunchKernelGGL((k_lme_cost<1, 1>), grid, dim3(64), 0, stream, __VA_ARGS__);             \
+        else hipLaunchKernelGGL((k_lme_cost<1, -1>), grid, dim3(64), 0, stream, __VA_ARGS__);                             \
+    } while (0)
+
+constexpr int LME_CTL_INTS = LME_RING + 8; // live ring | total | pad
+int lme_nseg(int n_max) { return std::max(1, (n_max + LME_SEG - 1) / LME_SEG); }
+size_t lme_bytes_per_problem(int n_max) {
+    const size_t nseg = (size_t)lme_nseg(n_max);
+    return sizeof(LmProb) + nseg * (sizeof(double) + sizeof(int32_t)) + 2 * nseg * LME_SEG + 2 * nseg * sizeof(uint16_t) + 16;
+}
+
+int lme_ensure(mdrp_handle *h, int cap, int batch, int n_max) {
+    const size_t nseg = (size_t)lme_nseg(n_max), c = (size_t)std::max(cap, 1);
+    int rc;
+    if ((rc = h->lme_probs.ensure(sizeof(LmProb) * c)) || (rc = h->lme_part.ensure(sizeof(double) * c * nseg)) ||
+        (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (rc = h->lme_list.ensure(c * 2 * nseg * LME_SEG)) ||
+        (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c * 2 * nseg)) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
+        (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))))
+        return rc;
+    return MDRP_OK;
+}
+
+LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, const int32_t *total, int first, int cap, const uint8_t *mask) {
+    LmePhase ph;
+    ph.probs = h->lme_probs.as<LmProb>(); ph.part = h->lme_part.as<double>(); ph.ipart = h->lme_ipart.as<int32_t>();
+    ph.list = h->lme_list.as<uint8_t>(); ph.list_cnt = h->lme_cnt.as<uint16_t>();
+    ph.pfx = pfx; ph.total = total;
+    ph.live = h->lme_ctl.as<int32_t>();
+    ph.first = first; ph.cap = cap; ph.batch = batch; ph.n_max = n_max; ph.nseg = lme_nseg(n_max);
+    ph.mask = mask;
+    return ph;
+}
+
+// The rounds of one phase on `stream`: cost of the initial models, then (accept + normal equations, solve, cost) per LM
+// iteration.  max_it <= 25 (the LO refinements) is launched blind; an open-ended phase (the user's BundleOptions) reads the live
+// counter back every `poll_every` rounds from round `poll_from` on and stops when nothing iterates any more.
+int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, int est_shift, int loss, int max_it, int accum_blocks, int problems_bound,
+            int poll_from, int poll_every) {
+    HIPCHK(hipMemsetAsync(ph.live, 0, sizeof(int32_t) * LME_RING, stream));
+    const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
+    const int dense_cap = ph.n_max <= LM_LIST_MAX_N ? ((ph.n_max + 63) / 64) * 64 : 0;
+    const size_t smem = sizeof(int32_t) * ((size_t)ph.nseg + 1) + sizeof(uint16_t) * (size_t)dense_cap + 8;
+    const dim3 solve_grid((unsigned)(std::max(problems_bound, 1) + 63) / 64);
+    MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>());
+    for (int r = 0; r <= max_it; ++r) {
+        MDRP_LME_ACCUM(kind, est_shift, loss, dim3((unsigned)std::max(accum_blocks, 1)), smem, stream, ph, h->pts.as<double>(),
+                       h->dep.as<double>(), r, dense_cap);
+        if (r == max_it) break;
+        MDRP_LME_LM(k_lme_solve, kind, est_shift, solve_grid, dim3(64), 0, stream, ph, r);
+        if (poll_every > 0 && r >= poll_from && (r - poll_from) % poll_every == 0) {
+            HIPCHK(hipMemcpyAsync(h->lme_live_host, ph.live + (r & (LME_RING - 1)), sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            if (*h->lme_live_host == 0) break;
+        }
+        MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>());
+    }
+    HIPCHK(hipGetLastError());
+    return MDRP_OK;
+}
+
+// LO of one chunk's triggers (refine_model @0x4fa550 / @0x4fad60 / @0x4fb0a0 + score_model of the refined model)
+int lme_lo(mdrp_handle *h, hipStream_t stream, const RunParams &rp, int kind, int est_shift, const int32_t *lo_plan, int trig_cap, int first, int cap) {
+    const int32_t *total = lo_plan + 3 * (size_t)rp.batch + 1;
+    const LmePhase ph = lme_phase(h, rp.batch, rp.n_max, lo_plan /*prefix*/, total, first, cap, nullptr);
+    hipLaunchKernelGGL(k_lme_lo_init, dim3((cap + 255) / 256), dim3(256), 0, stream, ph, rp, h->st.as<PairState>(), h->models.as<Model>(),
+                       h->triggers.as<Trigger>(), trig_cap, lo_plan);
+    int rc = lme_run(h, stream, ph, kind, est_shift, 1, 25, h->num_cu * 8, cap, 0, 0);
+    if (rc) return rc;
+    const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
+    MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
+    hipLaunchKernelGGL(k_lme_lo_finish, dim3((cap + 255) / 256), dim3(256), 0, stream, ph, rp, h->st.as<PairState>(), h->triggers.as<Trigger>(),
+                       trig_cap, lo_plan);
+    HIPCHK(hipGetLastError());
+    return MDRP_OK;
+}
+
+// ransac<> tail, inlier mask, inlier-only refinement, result records: one problem per pair
+int lme_final(mdrp_handle *h, hipStream_t s, const RunParams &rp, int kind, int est_shift, uint8_t *mask_dev, ResultDev *results_dev) {
+    const int batch = rp.batch;
+    int32_t *iota = h->lme_iota.as<int32_t>(), *total = h->lme_ctl.as<int32_t>() + LME_RING;
+    hipLaunchKernelGGL(k_lme_iota, dim3((batch + 1 + 255) / 256), dim3(256), 0, s, iota, batch + 1, total, batch, -1);
+    LmePhase ph = lme_phase(h, batch, rp.n_max, iota, total, 0, batch, nullptr);
+    const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)batch), pair_grid((unsigned)(batch + 255) / 256);
+    hipLaunchKernelGGL(k_lme_fin_init, dim3(batch), dim3(64), 0, s, ph, rp, h->st.as<PairState>(), mask_dev, results_dev);
+    const int step_blocks = std::min(batch, h->num_cu * 8);
+    int rc = lme_run(h, s, ph, kind, est_shift, 1, 25, step_blocks, batch, env_int("MDRP_LME_POLL_FROM", 3), env_int("MDRP_LME_POLL_EVERY", 4));
+    if (rc) return rc;
+    MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, s, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
+    hipLaunchKernelGGL(k_lme_fin_select, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
+    MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, s, ph, h->st.as<PairState>(), h->pts.as<double>(), mask_dev);
+    hipLaunchKernelGGL(k_lme_fin_init2, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
+    ph.mask = mask_dev;
+    rc = lme_run(h, s, ph, kind, est_shift, rp.final_loss, rp.final_max_it, step_blocks, batch, env_int("MDRP_LME_POLL_FROM2", 8), env_int("MDRP_LME_POLL_EVERY", 4));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_lme_fin_write, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
+    HIPCHK(hipGetLastError());
+    return MDRP_OK;
 }
 
 // one pass = a contiguous range of pairs that fits the scratch budget
@@ -288,6 +431,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
+    // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
+    // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)
+    const bool use_lme = !classic && env_int("MDRP_LM_ENGINE", 1) != 0;
+    const int lme_cap = std::max(batch, env_int("MDRP_LME_CAP", batch * 48 + 2048));
+    if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
     const size_t lo_mask_rows = (size_t)h->num_cu * 8;
     if (kind == MDRP_RELPOSE_5PT && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
@@ -500,6 +648,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
             const RunParams rp_lo = rp;
             auto launch_lo = [=]() -> int {
+                if (use_lme) return lme_lo(h, aux2, rp_lo, kind, est_shift, lo_plan, trig_cap, 0, lme_cap);
                 if (classic) {
                     MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), 0, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
                                              h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c,
@@ -516,11 +665,27 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         }
         if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
         hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
-                           h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4));
+                           h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
+                           h->work_pair.as<int32_t>(), use_lme ? n_chunks : 0, (int)lo_plan_ints, lme_cap);
         HIPCHK(hipGetLastError());
         // progress record: pairs still iterating, iterations they still need, evaluations swept (sum over pairs of models * n)
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
+        if (use_lme && h->progress_host->lo_overflow) {
+            // a chunk found more triggers than one pass of the LM engine holds: refine the rest, pass by pass, then replay
+            std::vector<int32_t> totals(n_chunks);
+            for (int c = 0; c < n_chunks; ++c)
+                HIPCHK(hipMemcpy(&totals[c], h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints + 3 * (size_t)batch + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int c = 0; c < n_chunks; ++c)
+                for (int first = lme_cap; first < totals[c]; first += lme_cap)
+                    if ((rc = lme_lo(h, s, rp, kind, est_shift, h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints, trig_cap, first, lme_cap))) return rc;
+            HIPCHK(hipMemsetAsync(cnt + 3, 0, sizeof(int32_t), s));
+            hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
+                               h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
+                               (const int32_t *)nullptr, 0, 0, 0);
+            HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+        }
         h->sweep_evals += (int64_t)h->progress_host->evals;
         h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
         h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
@@ -559,7 +724,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         max_needed = h->progress_host->max_needed;
     }
 
-    if (classic)
+    if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
+    else if (classic)
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev);
     else
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
@@ -598,8 +764,10 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
+    const size_t per_pair_all = per_pair + (kind <= 2 ? 49 * lme_bytes_per_problem(n_max) : 0) /*LM engine: 48 problems per pair and pass*/ +
+                                (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
-    int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair));
+    int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
     for (int p0 = 0; p0 < batch; p0 += per_pass) {
         const int nb = std::min(per_pass, batch - p0);
@@ -666,6 +834,7 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     HIPCHK(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->lme_live_host, sizeof(int32_t), hipHostMallocDefault));
     {   // high priority: the few long LO wavefronts should be placed first, the sweep fills the remaining slots
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -703,10 +872,12 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask};
+                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
+                      &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
+    if (h->lme_live_host) (void)hipHostFree(h->lme_live_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
@@ -1021,6 +1192,20 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
     o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
+    if (env_int("MDRP_LM_ENGINE", 1) != 0) {
+        // the phase-batched engine with all `count` problems on one pair (pair 0 = the packed records)
+        if ((rc = lme_ensure(h, count, 1, nn)) || (rc = h->st.ensure(sizeof(PairState)))) return rc;
+        PairState ps;
+        std::memset(&ps, 0, sizeof ps);
+        ps.n = n;
+        HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
+        int32_t *iota = h->lme_iota.as<int32_t>(), *total = h->lme_ctl.as<int32_t>() + LME_RING;
+        hipLaunchKernelGGL(k_lme_iota, dim3(1), dim3(64), 0, s, iota, 2, total, count, count);
+        const LmePhase ph = lme_phase(h, 1, nn, iota, total, 0, count, nullptr);
+        hipLaunchKernelGGL(k_lme_unit_init, dim3((count + 255) / 256), dim3(256), 0, s, ph, count, h->unit_e.as<Model>(), kind, n, scale_reproj, weight_sampson, o);
+        if ((rc = lme_run(h, s, ph, kind, (kind == MDRP_CALIB && estimate_shift) ? 1 : 0, o.loss, o.max_it, std::min(count, h->num_cu * 8), count, 8, 8))) return rc;
+        hipLaunchKernelGGL(k_lme_unit_finish, dim3((count + 255) / 256), dim3(256), 0, s, ph, count, h->unit_e.as<Model>(), h->unit_a.as<double>());
+    } else
     MDRP_LM_DISPATCH(k_refine_unit, (count >= 2048 ? 64 : 256), kind, (kind == MDRP_CALIB && estimate_shift), dim3(count), lm_list_bytes(n), s,
                      count, h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
                      h->unit_a.as<double>(), lm_list_stride(n));

@@ -1808,10 +1808,19 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
 // ------------------------------------------------------------------------------------------------ walk
 // One lane per pair replays score_models<> / ransac<> bookkeeping (@0x22ebc0, @0x22f030) over the ordered triggers
 // and applies the dynamic stopping rule.
+// lo_plans / n_plans / lo_cap: the LM engine refines at most lo_cap triggers of a chunk per pass (its problem table is sized
+// before anyone knows how many triggers the scans will find); if a chunk found more, nothing is replayed yet — the flag
+// n_active[1] tells the host to run the remaining passes and launch the walk again.
 __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__restrict__ models, const Trigger *__restrict__ triggers,
-                       int trig_cap, int32_t *__restrict__ n_active, unsigned long long *__restrict__ max_needed) {
+                       int trig_cap, int32_t *__restrict__ n_active, unsigned long long *__restrict__ max_needed,
+                       const int32_t *__restrict__ lo_plans, int n_plans, int plan_stride, int lo_cap) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= rp.batch) return;
+    for (int c = 0; c < n_plans; ++c)
+        if (lo_plans[(size_t)c * plan_stride + 3 * (size_t)rp.batch + 1] > lo_cap) {
+            if (pair == 0) n_active[1] = 1;
+            return;
+        }
     PairState &ps = st[pair];
     if (!ps.active) return;
     const size_t slot_base = (size_t)pair * rp.slot_stride;

@@ -1,0 +1,660 @@
+// mdrp_lm.h — phase-batched Levenberg-Marquardt engine for the LO / final refinements of the monodepth estimators
+// (refine_monodepth_relpose @0x261030, ..._shared_focal_relpose @0x2592e0, ..._varying_focal_relpose @0x260fa0 + lm_impl<>).
+//
+// The reference runs one LM loop per refinement, start to end.  Rounds 1-2 mapped that loop onto one wavefront (or one
+// workgroup) per problem: every problem dragged its own serial part (Cholesky, step, accept / reject) and its own sweeps
+// through one wavefront, a launch ended with its longest problem (mean residency 1.15 wavefronts per SIMD of 2), and every
+// LM iteration of every problem re-streamed its pair's records (55x re-fetch).  Here the LOOP is turned inside
+// out: all problems of a phase advance together, one LM iteration per ROUND, and a round is three kernels
+//
+//   k_lme_cost   one wavefront per (pair, segment of correspondences): the records are loaded ONCE into registers and
+//                evaluated against the candidate model of every problem of that pair that is still iterating (4-12 LO
+//                problems share a pair; their expanded states are staged through LDS in one go): cost partial per
+//                (problem, segment) and the segment's work list (correspondences with a non-zero IRLS weight, ballot-compacted);
+//   k_lme_accum  one workgroup per problem: accept / reject of the candidate (cost partials summed in segment order), then
+//                J'J | J'r over the work list of the accepted model — the dense list is rebuilt in LDS from the segment
+//                lists, four wavefronts take every fourth trip of 64 entries, and the 35-54 accumulators are reduced across
+//                lanes with the gfx950 half-/quarter-wave swaps (v_permlane32_swap / v_permlane16_swap: one add reduces two
+//                accumulators) instead of 6 shuffles each;
+//   k_lme_solve  one LANE per problem: gradient test, damped Cholesky solve, step test, next candidate and its expanded
+//                state — the serial part of lm_impl<>, paid once per problem instead of once per wavefront.
+//
+// Everything a problem carries between rounds (model, candidate, lambda, J'J, lists) lives in HBM (about 1 KB + 2 n bytes);
+// problems that converge simply stop taking part, so a round costs what its live problems cost and the chip is refilled
+// every few microseconds instead of waiting for stragglers.  Summation orders are fixed by record index and list position
+// alone, so results do not depend on the batch, the grid or the schedule.  The LM arithmetic itself (residuals, Jacobians,
+// losses, Cholesky recurrences, step) is mdrp_math.h's, unchanged.
+#pragma once
+#include "mdrp_kernels.h"
+
+namespace mdrp {
+
+#ifndef MDRP_LME_RPT
+#define MDRP_LME_RPT 4
+#endif
+constexpr int LME_RPT = MDRP_LME_RPT;  // records per lane in the cost sweep
+constexpr int LME_SEG = 64 * LME_RPT;  // correspondences per cost-sweep segment (one wavefront)
+constexpr int LME_T = 256;             // threads per problem in k_lme_accum
+constexpr int LME_NW = LME_T / 64;
+constexpr int LME_RING = 64;           // live counters of the rounds live in a ring (a round clears the slot 32 rounds ahead)
+constexpr int LME_STAGE = 16;          // problem states staged in LDS per pass of the cost sweep
+constexpr int LME_HEAD = 48;           // leading doubles of LmProb the cost sweep needs (state, loss parameters, flags)
+
+struct alignas(64) LmProb {
+    // --- read by the cost sweep: the first LME_HEAD doubles
+    LmState cs;             // the model under evaluation, expanded (R, t, s, u, v, f1, f2, E, F): 35 doubles
+    double sqrt_sr, ws, loss_scale, mu;
+    int32_t status;         // 1 = iterating, 0 = finished (m is the result) or unused
+    int32_t has_cand;       // 0 nothing to evaluate, 1 candidate step, 2 the initial model (its cost starts the loop)
+    int32_t loss, cur;      // cur: list buffer that belongs to the current model m
+    int32_t pair, n, it, max_it, recompute, pad_;
+    double pad2_[4];
+    // --- LM state
+    double cost, lambda, grad_tol, step_tol, lambda_min, lambda_max;
+    Model m, cand;
+    double acc[MAX_ACC];    // J'J (lower triangle, row major) | J'r of the current model (kept for rejected steps)
+};
+static_assert(offsetof(LmProb, cost) == LME_HEAD * sizeof(double), "cost-sweep header of LmProb");
+
+struct LmePhase {
+    LmProb *probs;          // [cap]
+    double *part;           // [cap][nseg] per (problem, segment): cost partial; squared-residual sum in the closing score sweep
+    int32_t *ipart;         // [cap][nseg] inlier counts of the closing score sweep
+    uint8_t *list;          // [cap][2][nseg][LME_SEG] work lists: segment-relative record indices, ascending
+    uint16_t *list_cnt;     // [cap][2][nseg]
+    const int32_t *pfx;     // [batch + 1] dense problem indices of pair p: [pfx[p], pfx[p + 1])
+    const int32_t *total;   // number of problems of the phase (device side: only the scan knows how many triggers there are)
+    int32_t *live;          // [LME_RING] problems still iterating after the round
+    int first, cap;         // this pass handles the dense problems [first, first + cap)
+    int batch, n_max, nseg;
+    const uint8_t *mask;    // [batch][n_max] record mask (the inlier-only final refinement) or null
+};
+
+__device__ __forceinline__ int lme_count(const LmePhase &ph) {
+    const int t = *ph.total - ph.first;
+    return t < 0 ? 0 : (t < ph.cap ? t : ph.cap);
+}
+
+// ------------------------------------------------------------------------------------------------ cross-lane sums (gfx950)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// every lane of a row of 16 gets the row's sum (row_ror 8, 4, 2, 1)
+__device__ __forceinline__ double row_sum16(double s) {
+    s += dpp_f64<0x128>(s);
+    s += dpp_f64<0x124>(s);
+    s += dpp_f64<0x122>(s);
+    s += dpp_f64<0x121>(s);
+    return s;
+}
+typedef unsigned int lme_u2 __attribute__((ext_vector_type(2)));
+// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b;  v_permlane16_swap: odd rows (of 16 lanes) of a <-> even rows of b
+__device__ __forceinline__ void swap32(double &a, double &b) {
+    const lme_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const lme_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void swap16(double &a, double &b) {
+    const lme_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const lme_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ void swap32i(int &a, int &b) {
+    const lme_u2 r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    a = (int)r.x; b = (int)r.y;
+}
+__device__ __forceinline__ void swap16i(int &a, int &b) {
+    const lme_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
+    a = (int)r.x; b = (int)r.y;
+}
+// sum over the wavefront, every lane gets it: two swap levels + the row rotations, no LDS round trips
+__device__ __forceinline__ double wave_sum_swap(double v) {
+    double b = v;
+    swap32(v, b); v += b;
+    b = v;
+    swap16(v, b); v += b;
+    return row_sum16(v);
+}
+__device__ __forceinline__ int wave_sum_swap_i(int v) {
+    int b = v;
+    swap32i(v, b); v += b;
+    b = v;
+    swap16i(v, b); v += b;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
+    return v;
+}
+// Reduce-scatter of NA per-lane accumulators over the wavefront.  Level 1 pairs accumulators (2i, 2i+1): after the half swap one
+// add leaves accumulator 2i in lanes 0-31 and 2i+1 in lanes 32-63; level 2 pairs those sums the same way over the rows of 16;
+// the row rotations finish.  A tag travels through the same swaps, so the write-out index is whatever the hardware moved where.
+template <int NA>
+__device__ __forceinline__ void wave_reduce_scatter(const double *acc, double *out /*LDS or global, [NA]*/) {
+    constexpr int M1 = (NA + 1) / 2, M2 = (M1 + 1) / 2;
+    double w[M1];
+    int t1[M1];
+#pragma unroll
+    for (int i = 0; i < M1; ++i) {
+        double a = acc[2 * i], b = (2 * i + 1 < NA) ? acc[2 * i + 1] : 0.0;
+        int ta = 2 * i, tb = (2 * i + 1 < NA) ? 2 * i + 1 : -1;
+        swap32(a, b);
+        swap32i(ta, tb);
+        w[i] = a + b; t1[i] = ta;
+    }
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < M2; ++i) {
+        double c = w[2 * i], d = (2 * i + 1 < M1) ? w[2 * i + 1] : 0.0;
+        int tc = t1[2 * i], td = (2 * i + 1 < M1) ? t1[2 * i + 1] : -1;
+        swap16(c, d);
+        swap16i(tc, td);
+        const double x = row_sum16(c + d);
+        if ((lane & 15) == 0 && tc >= 0) out[tc] = x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ cost sweep
+// grid (nseg, batch), 64 threads.  Record i of the segment sits in lane i & 63, slot i >> 6.
+// LOSS: the phase's loss type when it is known at compile time (1 = TRUNCATED: every LO refinement), -1 = read per problem
+template <int KIND, int LOSS>
+__global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                 const double *__restrict__ dep) {
+    __shared__ double s_state[LME_STAGE][LME_HEAD];
+    __shared__ int s_idx[LME_STAGE];
+    const int pair = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+    const int n = st[pair].n;
+    if (seg * LME_SEG >= n) return;
+    const int cnt = lme_count(ph);
+    const int j0 = max(ph.pfx[pair] - ph.first, 0), j1 = min(ph.pfx[pair + 1] - ph.first, cnt);
+    if (j0 >= j1) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    bool loaded = false;
+    double ra[LME_RPT], rb[LME_RPT], rc[LME_RPT], rd[LME_RPT], e1[LME_RPT], e2[LME_RPT];
+    bool ok[LME_RPT];
+    for (int base = j0; base < j1; base += LME_STAGE) {
+        // which of the next LME_STAGE problems of this pair have a model waiting for its cost?  (lane l looks at problem base + l)
+        const int jl = base + lane;
+        bool live = false;
+        if (lane < LME_STAGE && jl < j1) { const LmProb *P = ph.probs + jl; live = P->status != 0 && P->has_cand != 0; }
+        const unsigned long long lb = __ballot(live);
+        const int k = __popcll(lb);
+        if (k == 0) continue;
+        __syncthreads(); // previous pass done with the stage
+        if (live) s_idx[__popcll(lb & lt)] = jl;
+        __syncthreads();
+        for (int e = lane; e < k * LME_HEAD; e += 64) {
+            const int r = e / LME_HEAD, f = e - r * LME_HEAD;
+            s_state[r][f] = reinterpret_cast<const double *>(ph.probs + s_idx[r])[f];
+        }
+        if (!loaded) { // the records, once, while the states are in flight
+            loaded = true;
+            const double *pp = pts + (size_t)pair * ph.n_max * PT_STRIDE;
+            const double *dd = dep + (size_t)pair * ph.n_max * 2;
+            const uint8_t *mk = ph.mask ? ph.mask + (size_t)pair * ph.n_max : nullptr;
+#pragma unroll
+            for (int r = 0; r < LME_RPT; ++r) {
+                const int i = seg * LME_SEG + r * 64 + lane;
+                ok[r] = i < n && (!mk || mk[i]);
+                ra[r] = rb[r] = rc[r] = rd[r] = 0; e1[r] = e2[r] = 1;
+                if (ok[r]) {
+                    const double2 *P = reinterpret_cast<const double2 *>(pp + (size_t)i * PT_STRIDE);
+                    const double2 p01 = P[0], p23 = P[1];
+                    const double2 d12 = *reinterpret_cast<const double2 *>(dd + 2 * (size_t)i);
+                    ra[r] = p01.x; rb[r] = p01.y; rc[r] = p23.x; rd[r] = p23.y; e1[r] = d12.x; e2[r] = d12.y;
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = 0; q < k; ++q) {
+            const int j = s_idx[q];
+            const double *S = s_state[q];
+            LmState stt;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { stt.R[i] = S[i]; stt.E[i] = S[17 + i]; stt.F[i] = S[26 + i]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) stt.t[i] = S[9 + i];
+            stt.s = S[12]; stt.u = S[13]; stt.v = S[14]; stt.f1 = S[15]; stt.f2 = S[16];
+            lm_state_uniform(stt);
+            const double sqrt_sr = uniform_f64(S[35]), ws = uniform_f64(S[36]), lsc = uniform_f64(S[37]), mu = uniform_f64(S[38]);
+            const int2 lc = *reinterpret_cast<const int2 *>(S + 40); // loss, cur
+            const int loss = LOSS >= 0 ? LOSS : __builtin_amdgcn_readfirstlane(lc.x), buf = __builtin_amdgcn_readfirstlane(lc.y) ^ 1;
+            double cost = 0;
+            bool contrib[LME_RPT];
+            // straight-line over the lane's records (padding lanes hold a harmless record and are masked by selects): the
+            // RPT residual chains are independent, so the scheduler interleaves them — a branch per record serialised them
+#pragma unroll
+            for (int r = 0; r < LME_RPT; ++r) {
+                double res[5], zf, zb;
+                point_residuals<false, KIND != 0>(stt, sqrt_sr, ra[r], rb[r], rc[r], rd[r], e1[r], e2[r], res, zf, zb, nullptr);
+                const double rs = res[0] * res[0], rf = res[1] * res[1] + res[2] * res[2], rbk = res[3] * res[3] + res[4] * res[4];
+                const bool fwd = !(zf < 0), bwd = !(zb < 0);
+                double c = ws * loss_value(loss, lsc, rs);
+                c += fwd ? loss_value(loss, lsc, rf) : 0.0;
+                c += bwd ? loss_value(loss, lsc, rbk) : 0.0;
+                cost += ok[r] ? c : 0.0;
+                contrib[r] = ok[r] && ((ws * loss_weight(loss, lsc, rs, mu) != 0.0) || (fwd && loss_weight(loss, lsc, rf, mu) != 0.0) ||
+                                       (bwd && loss_weight(loss, lsc, rbk, mu) != 0.0));
+            }
+            cost = wave_sum_swap(cost);
+            uint8_t *L = ph.list + (((size_t)j * 2 + buf) * ph.nseg + seg) * LME_SEG;
+            int fill = 0;
+#pragma unroll
+            for (int r = 0; r < LME_RPT; ++r) {
+                const unsigned long long ball = __ballot(contrib[r]);
+                if (contrib[r]) L[fill + __popcll(ball & lt)] = (uint8_t)(r * 64 + lane);
+                fill += __popcll(ball);
+            }
+            if (lane == 0) {
+                ph.part[(size_t)j * ph.nseg + seg] = cost;
+                ph.list_cnt[((size_t)j * 2 + buf) * ph.nseg + seg] = (uint16_t)fill;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ accept / reject + J'J
+// J'J | J'r of model m over the work list `buf` of problem j; the totals land in scratch[0 .. NA).
+// LDS: int32 pre[nseg + 1] | u16 dense[] (n <= dense_cap), scratch[LME_NW][MAX_ACC].
+template <int KIND, bool SHIFT>
+__device__ void lme_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+                               const LmePhase &ph, int j, int buf, double sqrt_sr, double ws, const LmOpt &o, double (*scratch)[MAX_ACC],
+                               int32_t *pre, uint16_t *dense, bool use_dense) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NA = NP * (NP + 1) / 2 + NP;
+    LmState stt;
+    lm_state_from_model(m, KIND != 0, stt);
+    lm_state_uniform(stt);
+    double acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = (n + LME_SEG - 1) / LME_SEG;
+    const uint16_t *cnt = ph.list_cnt + ((size_t)j * 2 + buf) * ph.nseg;
+    const uint8_t *lst = ph.list + ((size_t)j * 2 + buf) * ph.nseg * LME_SEG;
+    if (use_dense) {
+        // exclusive prefix of the segment counts (wave 0: lane l owns K consecutive segments), then the dense list
+        if (wave == 0) {
+            const int K = (nseg + 63) / 64;
+            int own = 0;
+            for (int k = 0; k < K; ++k) { const int s = lane * K + k; if (s < nseg) own += cnt[s]; }
+            int inc = own;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(inc, d, 64); if (lane >= d) inc += v; }
+            int run = inc - own;
+            for (int k = 0; k < K; ++k) { const int s = lane * K + k; if (s < nseg) { pre[s] = run; run += cnt[s]; } }
+            if (lane == 63) pre[nseg] = inc;
+        }
+        __syncthreads();
+        for (int s = wave; s < nseg; s += LME_NW) {
+            const int c = cnt[s], p0 = pre[s];
+            for (int e = lane; e < c; e += 64) dense[p0 + e] = (uint16_t)(s * LME_SEG + lst[(size_t)s * LME_SEG + e]);
+        }
+        __syncthreads();
+        const int total = pre[nseg];
+        // trips of 64 list entries; wavefront w takes trips w, w + 4, ...; software-pipelined by one trip
+        double2 n01 = make_double2(0, 0), n23 = n01, ndd = n01;
+        auto fetch = [&](int k) {
+            if (k < total) {
+                const size_t i = (size_t)dense[k];
+                const double2 *P = reinterpret_cast<const double2 *>(pts + i * PT_STRIDE);
+                n01 = P[0]; n23 = P[1];
+                ndd = *reinterpret_cast<const double2 *>(dep + 2 * i);
+            }
+        };
+        fetch(wave * 64 + lane);
+        for (int k = wave * 64 + lane; k < total; k += 64 * LME_NW) {
+            const double2 c01 = n01, c23 = n23, cdd = ndd;
+            fetch(k + 64 * LME_NW);
+            lm_accumulate_point<KIND, SHIFT>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
+        }
+    } else {
+        // large pairs: walk the segment lists directly (wavefront w takes segments w, w + 4, ...)
+        for (int s = wave; s < nseg; s += LME_NW) {
+            const int c = cnt[s];
+            for (int e = lane; e < c; e += 64) {
+                const size_t i = (size_t)s * LME_SEG + lst[(size_t)s * LME_SEG + e];
+                const double2 *P = reinterpret_cast<const double2 *>(pts + i * PT_STRIDE);
+                lm_accumulate_point<KIND, SHIFT>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * i), sqrt_sr, ws, o, acc);
+            }
+        }
+    }
+    wave_reduce_scatter<NA>(acc, scratch[wave]);
+    __syncthreads();
+    if (threadIdx.x < NA) {
+        double s = scratch[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < LME_NW; ++w) s += scratch[w][threadIdx.x];
+        scratch[0][threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// lm_impl<>'s loop body from "the cost of the candidate is known" to "the normal equations of the current model are known"
+// (upstream PoseLib convention, as lm_refine of round 2).  Workgroups stride over the problems of the pass.
+template <int KIND, bool SHIFT, int LOSS>
+__global__ __launch_bounds__(LME_T, MDRP_LM_MINWAVES) void k_lme_accum(LmePhase ph, const double *__restrict__ pts, const double *__restrict__ dep,
+                                                                       int round, int dense_cap) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NA = NP * (NP + 1) / 2 + NP;
+    extern __shared__ int32_t lme_dyn[];
+    __shared__ double scratch[LME_NW][MAX_ACC];
+    int32_t *pre = lme_dyn;
+    uint16_t *dense = reinterpret_cast<uint16_t *>(lme_dyn + ph.nseg + 1);
+    const int count = lme_count(ph);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ph.live[(round + LME_RING / 2) & (LME_RING - 1)] = 0; // free: every earlier round has ended
+    for (int j = blockIdx.x; j < count; j += gridDim.x) {
+        LmProb *P = ph.probs + j;
+        if (P->status == 0) continue;
+        // ---- local copy of the loop state (uniform)
+        Model m = P->m;
+        double cost = P->cost, lambda = P->lambda, mu = P->mu;
+        int it = P->it, cur = P->cur, recompute = 0;
+        const int has_cand = P->has_cand, n = P->n, pair = P->pair, max_it = P->max_it;
+        const double lambda_min = P->lambda_min, lambda_max = P->lambda_max;
+        __syncthreads(); // every wavefront holds its copy before thread 0 writes anything back; LDS of the previous problem is free
+        if (has_cand == 0) continue; // (a problem that is live always has a model waiting)
+        // ---- accept / reject the candidate whose cost the sweep just produced
+        {
+            const int nseg = (n + LME_SEG - 1) / LME_SEG;
+            double cost_new = 0;
+            for (int s = 0; s < nseg; ++s) cost_new += ph.part[(size_t)j * ph.nseg + s];
+            if (has_cand == 2) { cost = cost_new; cur ^= 1; recompute = 1; }
+            else {
+                if (cost_new < cost) { m = P->cand; cur ^= 1; lambda = fmax(lambda_min, lambda / 10.0); cost = cost_new; recompute = 1; }
+                else { lambda = fmin(lambda_max, lambda * 10.0); }
+                mu *= 1.5; // TRUNCATED_LE_ZACH: the reference's per-iteration callback
+                ++it;
+            }
+        }
+        const bool done = it >= max_it;
+        if (!done && recompute) {
+            LmOpt o;
+            o.max_it = max_it; o.loss = LOSS >= 0 ? LOSS : P->loss; o.loss_scale = P->loss_scale; o.mu = mu;
+            const double *pp = pts + (size_t)pair * ph.n_max * PT_STRIDE;
+            const double *dd = dep + (size_t)pair * ph.n_max * 2;
+            lme_accumulate<KIND, SHIFT>(m, pp, dd, n, ph, j, cur, P->sqrt_sr, P->ws, o, scratch, pre, dense, n <= dense_cap);
+            if (threadIdx.x < NA) P->acc[threadIdx.x] = scratch[0][threadIdx.x];
+        }
+        if (threadIdx.x == 0) {
+            P->m = m; P->cost = cost; P->lambda = lambda; P->mu = mu; P->it = it; P->cur = cur; P->recompute = recompute;
+            P->has_cand = 0;
+            if (done) P->status = 0;
+        }
+    }
+}
+
+// Cholesky solve of the damped normal equations, packed lower triangle (row major) in place: the recurrences and their
+// summation order are chol_solve<>'s (mdrp_math.h), only the storage differs (one lane per problem: registers matter)
+template <int N>
+__device__ __forceinline__ void chol_solve_packed(double *L /*in: A + lambda I, out: factor*/, const double *b, double *x) {
+#define LME_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = L[LME_TRI(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[LME_TRI(i, k)] * L[LME_TRI(j, k)];
+            if (i == j) L[LME_TRI(i, i)] = sqrt(s);
+            else L[LME_TRI(i, j)] = s / L[LME_TRI(j, j)];
+        }
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[LME_TRI(i, k)] * y[k];
+        y[i] = s / L[LME_TRI(i, i)];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= L[LME_TRI(k, i)] * x[k];
+        x[i] = s / L[LME_TRI(i, i)];
+    }
+#undef LME_TRI
+}
+
+// one lane per problem: gradient test, damped solve, step test, next candidate
+template <int KIND, bool SHIFT>
+__global__ __launch_bounds__(64) void k_lme_solve(LmePhase ph, int round) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NT = NP * (NP + 1) / 2;
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    bool alive = false;
+    if (j < lme_count(ph)) {
+        LmProb *P = ph.probs + j;
+        if (P->status != 0) {
+            bool done = false;
+            double L[NT], g[NP], sol[NP];
+#pragma unroll
+            for (int a = 0; a < NP; ++a) g[a] = P->acc[NT + a];
+            if (P->recompute) {
+                double gn = 0;
+#pragma unroll
+                for (int a = 0; a < NP; ++a) gn += g[a] * g[a];
+                if (sqrt(gn) < P->grad_tol) done = true;
+            }
+            if (!done) {
+                const double lambda = P->lambda;
+                int idx = 0;
+#pragma unroll
+                for (int a = 0; a < NP; ++a) {
+#pragma unroll
+                    for (int b = 0; b <= a; ++b, ++idx) L[idx] = P->acc[idx] + (a == b ? lambda : 0.0);
+                }
+                chol_solve_packed<NP>(L, g, sol);
+                double sn = 0;
+#pragma unroll
+                for (int a = 0; a < NP; ++a) { sol[a] = -sol[a]; sn += sol[a] * sol[a]; }
+                if (sqrt(sn) < P->step_tol) done = true;
+            }
+            if (done) { P->status = 0; P->has_cand = 0; }
+            else {
+                double full[LM_NPAR];
+#pragma unroll
+                for (int q = 0; q < LM_NPAR; ++q) full[q] = 0;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) full[lm_col<KIND, SHIFT>(q)] = sol[q];
+                if (KIND == 1) full[10] = full[9];
+                const Model m = P->m;
+                Model cand;
+                lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
+                P->cand = cand;
+                LmState cs;
+                lm_state_from_model(cand, KIND != 0, cs);
+                P->cs = cs;
+                P->has_cand = 1;
+                alive = true;
+            }
+            P->recompute = 0;
+        }
+    }
+    const unsigned long long lb = __ballot(alive);
+    if (threadIdx.x == 0 && lb) atomicAdd(ph.live + (round & (LME_RING - 1)), __popcll(lb));
+}
+
+// ------------------------------------------------------------------------------------------------ closing score sweep
+// exact MSAC score (score_model of the estimators) of the current model of every problem, per (problem, segment);
+// mask_out: get_inliers mask of the model (the final phase has one problem per pair)
+template <int KIND>
+__global__ __launch_bounds__(64) void k_lme_score(LmePhase ph, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                  uint8_t *__restrict__ mask_out) {
+    const int pair = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+    const PairState &ps = st[pair];
+    const int n = ps.n;
+    if (seg * LME_SEG >= n) return;
+    const int cnt = lme_count(ph);
+    const int j0 = max(ph.pfx[pair] - ph.first, 0), j1 = min(ph.pfx[pair + 1] - ph.first, cnt);
+    const double *pp = pts + (size_t)pair * ph.n_max * PT_STRIDE;
+    const double thr = ps.sq_thr;
+    for (int j = j0; j < j1; ++j) {
+        const Model m = ph.probs[j].m;
+        double R[9], E[9], Em[9];
+        quat_to_R(m.q, R);
+        essential_from_Rt(R, m.t, Em);
+        if (KIND == 0) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) E[i] = Em[i];
+        } else fundamental_from_E(Em, m.f1, m.f2, E);
+        double score = 0;
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < LME_RPT; ++r) {
+            const int i = seg * LME_SEG + r * 64 + lane;
+            if (i < n) {
+                double s1 = 0;
+                int c1 = 0;
+                score_point<KIND == 0>(pp + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
+                score += s1; c += c1;
+                if (mask_out) mask_out[(size_t)pair * ph.n_max + i] = (uint8_t)c1;
+            }
+        }
+        score = wave_sum_swap(score);
+        c = wave_sum_swap_i(c);
+        if (lane == 0) { ph.part[(size_t)j * ph.nseg + seg] = score; ph.ipart[(size_t)j * ph.nseg + seg] = c; }
+    }
+}
+
+__device__ __forceinline__ void lme_score_total(const LmePhase &ph, int j, int n, double thr, double &score, int &cnt) {
+    const int nseg = (n + LME_SEG - 1) / LME_SEG;
+    double s = 0;
+    int c = 0;
+    for (int k = 0; k < nseg; ++k) { s += ph.part[(size_t)j * ph.nseg + k]; c += ph.ipart[(size_t)j * ph.nseg + k]; }
+    cnt = c;
+    score = s + thr * (double)(n - c);
+}
+
+__device__ __forceinline__ void lme_start(LmProb &P, const Model &m0, bool focal, int pair, int n, double scale_reproj, double ws,
+                                          const LmOpt &o) {
+    P.m = m0; P.cand = m0;
+    lm_state_from_model(m0, focal, P.cs);
+    P.sqrt_sr = sqrt(scale_reproj); P.ws = ws; P.loss_scale = o.loss_scale; P.mu = 0.5;
+    P.status = 1; P.has_cand = 2; P.loss = o.loss; P.cur = 0;
+    P.pair = pair; P.n = n; P.it = 0; P.max_it = o.max_it; P.recompute = 0; P.pad_ = 0;
+    P.cost = 0; P.lambda = o.lambda0; P.grad_tol = o.grad_tol; P.step_tol = o.step_tol; P.lambda_min = o.lambda_min; P.lambda_max = o.lambda_max;
+}
+
+// ------------------------------------------------------------------------------------------------ LO phase (refine_model)
+// one thread per trigger of the chunk's frozen plan (k_lo_plan): 25 iterations, TRUNCATED at the epipolar threshold
+__global__ void k_lme_lo_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const Model *__restrict__ models,
+                              const Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lme_count(ph)) return;
+    const int w = ph.first + j;
+    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
+    const int pair = plan_find(prefix, rp.batch, w);
+    const int pos = begin[pair] + (w - prefix[pair]);
+    const PairState &ps = st[pair];
+    const Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+    const Model m0 = models[(size_t)pair * rp.slot_stride + (size_t)tr.iter * rp.mps + tr.k_ref];
+    LmOpt o;
+    o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+    o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+    lme_start(ph.probs[j], m0, rp.kind != 0, pair, ps.n, ps.scale_reproj, rp.weight_sampson, o);
+}
+
+__global__ void k_lme_lo_finish(LmePhase ph, RunParams rp, const PairState *__restrict__ st, Trigger *__restrict__ triggers, int trig_cap,
+                                const int32_t *__restrict__ plan) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lme_count(ph)) return;
+    const int w = ph.first + j;
+    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
+    const int pair = plan_find(prefix, rp.batch, w);
+    const int pos = begin[pair] + (w - prefix[pair]);
+    const PairState &ps = st[pair];
+    Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+    double sc;
+    int cn;
+    lme_score_total(ph, j, ps.n, ps.sq_thr, sc, cn);
+    tr.refined = ph.probs[j].m; tr.ref_score = sc; tr.ref_cnt = cn;
+}
+
+// ------------------------------------------------------------------------------------------------ final phase
+// ransac<> tail (@0x22f1d0-0x22f295) + get_inliers (@0x4f7a10/@0x4f77f0) + the estimator's inlier-only refinement
+// (@0x2247c3 / @0x223815) + focal un-normalisation, one problem per pair.
+// stage 0: result header, mask rows of short pairs, LO from the best model (one wavefront per pair)
+__global__ __launch_bounds__(64) void k_lme_fin_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, uint8_t *__restrict__ mask_all,
+                                                     ResultDev *__restrict__ results) {
+    const int pair = blockIdx.x;
+    const PairState &ps = st[pair];
+    uint8_t *mask = mask_all + (size_t)pair * rp.n_max;
+    for (int i = (ps.n < 3 ? 0 : ps.n) + threadIdx.x; i < rp.n_max; i += 64) mask[i] = 0;
+    if (threadIdx.x != 0) return;
+    ResultDev res;
+    res.model = ps.best;
+    res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
+    res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
+    results[pair] = res;
+    LmProb &P = ph.probs[pair];
+    if (ps.n < 3) { P.status = 0; P.has_cand = 0; P.n = 0; P.pair = pair; P.m = ps.best; return; }
+    LmOpt o;
+    o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+    o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+    lme_start(P, ps.best, rp.kind != 0, pair, ps.n, ps.scale_reproj, rp.weight_sampson, o);
+}
+
+// stage 1 (after the LO and its score sweep): adopt the refined model if it scores better; the model whose inliers the
+// mask sweep then marks is left in P.m
+__global__ void k_lme_fin_select(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= rp.batch) return;
+    const PairState &ps = st[pair];
+    if (ps.n < 3) return;
+    LmProb &P = ph.probs[pair];
+    double sc;
+    int cn;
+    lme_score_total(ph, pair, ps.n, ps.sq_thr, sc, cn);
+    results[pair].refinements = ps.refinements + 1;
+    if (sc < ps.model_score) results[pair].num_inliers = (uint64_t)cn; // score / ratio NOT updated (reference)
+    else P.m = ps.best;
+}
+
+// stage 2 (after the mask sweep): the inlier-only refinement with the user's bundle options
+__global__ void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const ResultDev *__restrict__ results) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= rp.batch) return;
+    const PairState &ps = st[pair];
+    if (ps.n < 3 || !(results[pair].num_inliers > 3)) return;
+    LmOpt f;
+    f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
+    f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
+    const Model m0 = ph.probs[pair].m;
+    lme_start(ph.probs[pair], m0, rp.kind != 0, pair, ps.n, ps.scale_reproj, rp.weight_sampson, f);
+}
+
+__global__ void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= rp.batch) return;
+    const PairState &ps = st[pair];
+    if (ps.n < 3) return;
+    Model best = ph.probs[pair].m;
+    if (rp.kind != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
+    results[pair].model = best;
+}
+
+// ------------------------------------------------------------------------------------------------ unit path (mdrp_refine_models)
+__global__ void k_lme_unit_init(LmePhase ph, int count, const Model *__restrict__ models, int kind, int n, double scale_reproj, double ws, LmOpt o) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    lme_start(ph.probs[j], models[j], kind != 0, 0, n, scale_reproj, ws, o);
+}
+__global__ void k_lme_unit_finish(LmePhase ph, int count, Model *__restrict__ models, double *__restrict__ final_cost) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    models[j] = ph.probs[j].m;
+    if (final_cost) final_cost[j] = ph.probs[j].cost;
+}
+// pfx = 0, 1, 2, ... (one problem per pair) or 0, count (all problems on pair 0); total
+__global__ void k_lme_iota(int32_t *pfx, int entries, int32_t *total, int total_value, int unit_count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries) pfx[i] = unit_count >= 0 ? (i == 0 ? 0 : unit_count) : i;
+    if (i == 0) *total = total_value;
+}
+
+} // namespace mdrp

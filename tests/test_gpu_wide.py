@@ -53,8 +53,9 @@ def wide_pair(kind, es, n, of, index):
 
 def check_against_reference(capi, g, name, n, res, mask, rows):
     """res / mask rows `rows` of a batch against the reference binary's outputs for the 32 pinned pairs: result identity
-    (iterations, inlier count, mask, model <= 1e-6, score) on EVERY pair; the LO count equals the CPU port's, which differs
-    from the reference's only where gen_golden_wide.py measured it"""
+    (iterations, inlier count, mask, model <= 1e-6, score) on EVERY pair; the LO count equals the reference's or, on the few
+    pairs where gen_golden_wide.py measured a solver-level deviation of the CPU port, the port's; returns
+    the number of pairs whose LO count differs from the reference's"""
     ref_m, ref_st, ref_mask = g[f"{name}_model"], g[f"{name}_stats"], g[f"{name}_mask"]
     port_lo = g[f"{name}_oracle_refinements"]
     lo_dev = 0
@@ -66,8 +67,8 @@ def check_against_reference(capi, g, name, n, res, mask, rows):
         assert model_diff(capi.model_to_array(res[r]["model"]), ref_m[j]) < 1e-6, (where, model_diff(capi.model_to_array(res[r]["model"]), ref_m[j]))
         assert res[r]["model_score"] == pytest.approx(ref_st[j][4], rel=1e-9), where
         assert res[r]["inlier_ratio"] == pytest.approx(ref_st[j][3], rel=1e-12), where
-        assert int(res[r]["refinements"]) == int(port_lo[j]), (where, int(res[r]["refinements"]), int(port_lo[j]), int(ref_st[j][0]))
-        lo_dev += int(port_lo[j]) != int(ref_st[j][0])
+        assert int(res[r]["refinements"]) in (int(ref_st[j][0]), int(port_lo[j])), (where, int(res[r]["refinements"]), int(port_lo[j]), int(ref_st[j][0]))
+        lo_dev += int(res[r]["refinements"]) != int(ref_st[j][0])
     return lo_dev
 
 
@@ -87,7 +88,7 @@ def test_headline_batch_vs_reference_binary(handle, capi, golden):
     res, mask = handle.estimate_batch(capi.CALIB, b["x1"], b["x2"], b["d1"], b["d2"], capi.ransac_opt_from_dict(ro),
                                       capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None, cams, cams)
     lo_dev = check_against_reference(capi, g, "calib_p3p", n, res, mask, rows)
-    assert lo_dev <= 4  # the reference's NaN-pose / missed-root cases: ~2 % of pairs
+    assert lo_dev <= 1  # the reference's NaN-pose / missed-root cases: pair 957 in the port's run
     # every pair of the batch ran all iterations and found the planted geometry (50 % outliers of 2000)
     assert (res["iterations"] == 10000).all() and int(res["num_inliers"].min()) > 700
 
@@ -110,14 +111,17 @@ def test_full_size_wide_vs_reference_binary(handle, capi, golden, name):
     res, mask = handle.estimate_batch(kind, x1, x2, d1, d2, capi.ransac_opt_from_dict(ro), capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}),
                                       None, cams if kind == 0 else None, cams if kind == 0 else None)
     lo_dev = check_against_reference(capi, g, name, n, res, mask, list(range(B)))
-    assert lo_dev <= 4
+    assert lo_dev <= 1
 
 
 @pytest.mark.parametrize("kind,es,rf", [(0, False, None), (0, True, None), (1, False, "shared"), (2, False, "varying")])
-def test_large_ragged_batch_vs_oracle(handle, capi, po, kind, es, rf):
+def test_large_ragged_batch_vs_oracle(handle, capi, po, golden, kind, es, rf):
     """B = 136 ragged pairs (N = 40 ... 300, 0-50 % outliers) of every monodepth estimator in ONE call — above every batch-size
-    switch of the host schedule — against the sequential CPU oracle: every pair on the oracle's exact trajectory."""
+    switch of the host schedule — against the sequential CPU oracle: every pair on the oracle's exact trajectory.  The LO
+    count may equal the reference binary's instead (tests/golden/ragged_lo.npz) on the pairs where oracle and reference
+    differ by one through a solver-level deviation: the HIP solvers side with one or the other."""
     from mdrp_amd import synth
+    ref = golden("ragged_lo")[f"k{kind}_s{int(es)}"]
     B = 136
     rng = np.random.default_rng(77 + kind + int(es))
     ns = rng.integers(40, 301, B)
@@ -140,6 +144,7 @@ def test_large_ragged_batch_vs_oracle(handle, capi, po, kind, es, rf):
         m, st, mk = po.estimate(kind, x1[i, :n], x2[i, :n], d1[i, :n], d2[i, :n], oro, po.bundle_opt(loss_type=4),
                                 cam if kind == 0 else None, cam if kind == 0 else None)
         where = (kind, es, i, n)
-        assert int(res[i]["iterations"]) == st.iterations == 700 and int(res[i]["refinements"]) == st.refinements, where
-        assert int(res[i]["num_inliers"]) == st.num_inliers and (mask[i, :n] == mk).all() and mask[i, n:].sum() == 0, where
+        assert int(res[i]["iterations"]) == st.iterations == 700, where
+        assert int(res[i]["refinements"]) in (st.refinements, int(ref[i][0])), (where, int(res[i]["refinements"]), st.refinements, int(ref[i][0]))
+        assert int(res[i]["num_inliers"]) == st.num_inliers == int(ref[i][1]) and (mask[i, :n] == mk).all() and mask[i, n:].sum() == 0, where
         assert model_diff(capi.model_to_array(res[i]["model"]), m) < 2e-6, (where, model_diff(capi.model_to_array(res[i]["model"]), m))

@@ -11,7 +11,7 @@ O=$R/gpurun_out/${TAG}_$W
 mkdir -p $O $R/profiles
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --host-steps 0 --workload $W --batch $B > $O/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --workload $W --batch $B > $O/bench_prof.log 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 python3 $R/tools/rocpd_summary.py "$DB" > $O/kernel_stats.txt
 python3 $R/tools/rocpd_timeline.py "$DB" 40 > $O/timeline.txt
@@ -20,7 +20,7 @@ for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
          "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$i -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --workload $W --batch $B > $O/pmc_$i.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$i -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --workload $W --batch $B > $O/pmc_$i.log 2>&1
   F=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$F" ]; then grep -E "Counter_Name|mdrp::" "$F" > $O/pmc_$i.csv; else echo "pass $i: no counters"; tail -3 $O/pmc_$i.log; fi
 done
