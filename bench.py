@@ -126,6 +126,11 @@ def pmc_profile(workload, batch, kernel):
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s; 512 MAC per cycle and SIMD)
 FLOP_PER_MFMA_EVAL = 64.0       # one (model x correspondence) evaluation in k_count = 32 bf16 MACs of the K = 32 contraction
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md: fp64 vector peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+# fp64 flop per correspondence of the LM sweeps, (cost sweep: residuals | normal-equation sweep: residuals + Jacobians + J'J),
+# read off the ISA of this build by tools/lm_flops.py (FMA-class instructions 2 flop, every other fp64 VALU instruction 1);
+# keyed by (estimator kind, monodepth_estimate_shift on the calibrated estimator)
+LM_FLOP = {(0, False): (179.0, 711.0), (0, True): (179.0, 821.0), (1, False): (187.0, 875.0), (2, False): (187.0, 973.0)}
 
 
 def main():
@@ -190,6 +195,7 @@ def main():
     h = _capi.Handle(local_rank)  # its own stream; k_count / k_score are timed with HIP events recorded on that stream
     rec_local = torch.zeros((per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev)  # this rank's block of the gather
     rec_all = torch.empty((world * per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
+    torch.cuda.synchronize(dev)  # the inputs were written on torch's stream, the handle runs on its own: order them once
 
     with_cams = kind in (0, 3)
     classic = kind >= 3
@@ -245,6 +251,7 @@ def main():
         L = args.inflight
         hs = [_capi.Handle(local_rank) for _ in range(L)]
         masks = [torch.zeros((B, n), dtype=torch.uint8, device=dev) for _ in range(L)]
+        torch.cuda.synchronize(dev)
 
         def lane(i, steps_):
             for _ in range(steps_):
@@ -272,14 +279,51 @@ def main():
         from mdrp_amd import synth
         from mdrp_amd.poselib import _quat_to_R
         R_err = None if kind == 5 else float(np.median([synth.rotation_error_deg(g["R"], _quat_to_R(r["model"]["q"])) for r, g in zip(res[:64], b["gt"][:64])]))
-        # ---- roofline of the dominant scoring kernel, k_count: executed MFMA work / its own launch durations (HIP events)
-        cl = max(acc.get("count_launches", 0), 1)
-        count_s = acc.get("count_ms", 0.0) / 1e3
+        # ---- per-kernel time of the step (HIP events around every launch, on the stream it runs on) and the roofline of the
+        # kernel with the largest share.  k_count: executed MFMA work (64 flop per evaluation, 16 x 16 tiles, padding included,
+        # counted on the device) against the dense bf16 MFMA peak.  The LM kernels (k_lo, k_final): fp64 flop = correspondences
+        # their sweeps evaluated (counted on the device) x the flop per correspondence of LM_FLOP, against the fp64 vector peak.
+        steps = max(args.steps, 1)
+        kern = {"k_count": acc.get("count_ms", 0.0), "k_score": acc.get("sweep_ms", 0.0), "k_bound": acc.get("bound_ms", 0.0),
+                "k_solve": acc.get("solve_ms", 0.0), "k_lo": acc.get("lo_ms", 0.0), "k_final": acc.get("final_ms", 0.0)}
+        launches = {"k_count": acc.get("count_launches", 0), "k_score": acc.get("sweep_launches", 0), "k_bound": acc.get("bound_launches", 0),
+                    "k_solve": acc.get("solve_launches", 0), "k_lo": acc.get("lo_launches", 0), "k_final": acc.get("final_launches", 0)}
+        lm_key = (kind, bool(es) and kind == 0)
+        rooflines = {}
+        cl = max(launches["k_count"], 1)
+        count_s = kern["k_count"] / 1e3
         flop = FLOP_PER_MFMA_EVAL * acc.get("evals_mfma", 0)
         achieved = flop / count_s / 1e12 if count_s > 0 else 0.0
         prof = pmc_profile(args.workload, B, "k_count")
         hbm = prof.get("hbm_bytes_corrected")
         avg_launch_s = count_s / cl
+        rooflines["k_count"] = {
+            "bound": "mfma", "kernel": "k_count (v_mfma_f32_16x16x32_bf16)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": hbm, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+            "traffic_source": prof.get("source"), "avg_launch_ms": 1e3 * avg_launch_s, "launches_per_step": cl / steps,
+            "executed_evals_per_step": acc.get("evals_mfma", 0) / steps, "share_of_step": count_s / dt,
+            "hbm_GBs": (hbm / avg_launch_s / 1e9) if (hbm and avg_launch_s > 0) else None,
+            "hbm_frac": (hbm / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (hbm and avg_launch_s > 0) else None,
+            "mfma_busy_frac_pmc": prof.get("mfma_busy_frac"), "valu_active_per_simd_cycle_pmc": prof.get("valu_active_per_simd_cycle")}
+        if lm_key in LM_FLOP:
+            fc, fa = LM_FLOP[lm_key]
+            for name, ce, ae in (("k_lo", "lm_cost_evals", "lm_accum_evals"), ("k_final", "final_cost_evals", "final_accum_evals")):
+                ksec, nl = kern[name] / 1e3, max(launches[name], 1)
+                fl = fc * acc.get(ce, 0) + fa * acc.get(ae, 0)
+                ach = fl / ksec / 1e12 if ksec > 0 else 0.0
+                pr = pmc_profile(args.workload, B, name)
+                hb = pr.get("hbm_bytes_corrected")
+                rooflines[name] = {
+                    "bound": "fp64", "kernel": f"{name} (LM refinements: v_fma_f64)", "achieved": ach, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / FP64_VALU_PEAK_TFLOPS, "traffic": hb, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
+                    "traffic_source": pr.get("source"), "avg_launch_ms": 1e3 * ksec / nl, "launches_per_step": nl / steps, "share_of_step": ksec / dt,
+                    "fp64_flop_per_step": fl / steps, "flop_per_correspondence": {"cost_sweep": fc, "normal_equations": fa},
+                    "correspondences_per_step": {"cost_sweep": acc.get(ce, 0) / steps, "normal_equations": acc.get(ae, 0) / steps},
+                    "hbm_GBs": (hb / (ksec / nl) / 1e9) if (hb and ksec > 0) else None,
+                    "hbm_frac": (hb / (ksec / nl) / 1e9 / HBM_PEAK_GBS) if (hb and ksec > 0) else None,
+                    "valu_active_per_simd_cycle_pmc": pr.get("valu_active_per_simd_cycle"), "mean_waves_per_simd_pmc": pr.get("mean_waves_per_simd")}
+        dominant = max((k for k in kern if k in rooflines), key=lambda k: kern[k]) if any(kern.values()) else "k_count"
+        top = max(kern, key=lambda k: kern[k])
         line = {
             "metric": "image-pairs/sec (2000 corrs, 10k RANSAC iters)", "value": value, "unit": "image-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -288,17 +332,11 @@ def main():
                        "outlier_fraction": of, "estimator": ["calibrated", "shared_focal", "varying_focal", "relative_pose_5pt", "shared_focal_6pt", "fundamental_7pt"][kind],
                        "monodepth_estimate_shift": es,
                        "parallelism": f"{'ceil(P/G) contiguous pairs per rank' if strong else 'fixed pairs per rank'} x{world}, device-side all_gather of the 136-B records"},
-            # bound: the matrix pipe.  achieved = 64 flop x the (model x correspondence) evaluations k_count EXECUTED (16 x 16 tiles,
-            # padding included, counted on the device) / the summed duration of its launches -> a fraction of the dense bf16
-            # MFMA peak that is <= 1 by construction.  traffic: HBM-side bytes of one launch (PMC), from profiles/.
-            "roofline": {"bound": "mfma", "kernel": "k_count (v_mfma_f32_16x16x32_bf16)", "achieved": achieved, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS, "traffic": hbm, "traffic_unit": "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE)",
-                         "traffic_source": prof.get("source"), "avg_launch_ms": 1e3 * avg_launch_s, "launches_per_step": cl / args.steps,
-                         "executed_evals_per_step": acc.get("evals_mfma", 0) / args.steps,
-                         "share_of_step": count_s / dt,
-                         "hbm_GBs": (hbm / avg_launch_s / 1e9) if (hbm and avg_launch_s > 0) else None,
-                         "hbm_frac": (hbm / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (hbm and avg_launch_s > 0) else None,
-                         "mfma_busy_frac_pmc": prof.get("mfma_busy_frac"), "valu_active_per_simd_cycle_pmc": prof.get("valu_active_per_simd_cycle")},
+            # the kernel with the largest event-timed share of the step; the MFMA figure of k_count stays beside it
+            "roofline": rooflines[dominant],
+            "roofline_count": rooflines["k_count"],
+            "kernel_ms_per_step": {k: v / steps for k, v in kern.items()},
+            "top_kernel_by_event_time": top,
             # what the CPU loop would do vs what runs: SURVEY.md 8(d)'s 32 B per evaluation is an ALGORITHMIC figure (kept as an
             # extra key: the correspondences stay in LDS / L2, HBM is not the bound), next to the evaluations actually executed
             "work": {"evals_algorithmic_per_step": acc.get("evals_algorithmic", 0) / args.steps, "algorithmic_bytes_per_eval": BYTES_PER_EVAL,
@@ -306,7 +344,8 @@ def main():
                      "evals_mfma_count_per_step": acc.get("evals_mfma", 0) / args.steps,
                      "evals_fp32_bound_per_step": acc.get("evals_bound", 0) / args.steps,
                      "evals_fp64_sweep_per_step": acc.get("evals_fp64", 0) / args.steps,
-                     "k_count_ms_per_step": acc.get("count_ms", 0.0) / args.steps, "k_score_ms_per_step": acc.get("sweep_ms", 0.0) / args.steps},
+                     "k_count_ms_per_step": acc.get("count_ms", 0.0) / args.steps, "k_score_ms_per_step": acc.get("sweep_ms", 0.0) / args.steps,
+                     "lm_fp64_flop_per_step": sum(r.get("fp64_flop_per_step", 0.0) for r in rooflines.values())},
             "quality": {"median_rotation_error_deg_first64": R_err,
                         "mean_inlier_ratio": float(np.mean(res["num_inliers"] / n)) if len(res) else None},
         }

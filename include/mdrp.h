@@ -189,6 +189,20 @@ typedef struct {
     int64_t evals_mfma;        /* evaluations executed by k_count (16 x 16 tiles, padding included) */
     int64_t evals_fp64;        /* evaluations handed to k_score (survivors * n) */
     int64_t evals_bound;       /* evaluations executed by k_bound in fp32 (k_count's survivors * n) */
+    /* LM refinements (refine_monodepth_*relpose @0x261030 / @0x2592e0 / @0x260fa0): HIP events around every launch of the LO
+     * kernel (on the stream it runs on) and of the final-refinement kernel, and the correspondences their sweeps evaluated */
+    double lo_ms;              /* total time in k_lo (or the LM engine's LO phases) */
+    int64_t lo_launches;
+    double final_ms;           /* total time in k_final (or the LM engine's final phase) */
+    int64_t final_launches;
+    double bound_ms;           /* total time in k_bound */
+    int64_t bound_launches;
+    double solve_ms;           /* total time in the minimal-solver kernel */
+    int64_t solve_launches;
+    int64_t lm_cost_evals;     /* LO kernel: correspondences evaluated by its cost sweeps (residuals only) */
+    int64_t lm_accum_evals;    /* LO kernel: correspondences evaluated by its normal-equation sweeps (residuals + Jacobians + J'J) */
+    int64_t final_cost_evals;  /* the same two counters of the final-refinement kernel */
+    int64_t final_accum_evals;
 } mdrp_stats;
 int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out);
 

@@ -48,7 +48,10 @@ class Camera(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("count_ms", C.c_double), ("count_launches", C.c_int64), ("sweep_ms", C.c_double), ("sweep_launches", C.c_int64),
-                ("evals_algorithmic", C.c_int64), ("evals_mfma", C.c_int64), ("evals_fp64", C.c_int64), ("evals_bound", C.c_int64)]
+                ("evals_algorithmic", C.c_int64), ("evals_mfma", C.c_int64), ("evals_fp64", C.c_int64), ("evals_bound", C.c_int64),
+                ("lo_ms", C.c_double), ("lo_launches", C.c_int64), ("final_ms", C.c_double), ("final_launches", C.c_int64),
+                ("bound_ms", C.c_double), ("bound_launches", C.c_int64), ("solve_ms", C.c_double), ("solve_launches", C.c_int64),
+                ("lm_cost_evals", C.c_int64), ("lm_accum_evals", C.c_int64), ("final_cost_evals", C.c_int64), ("final_accum_evals", C.c_int64)]
 
 
 class Result(C.Structure):

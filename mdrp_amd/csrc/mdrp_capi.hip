@@ -107,14 +107,19 @@ struct mdrp_handle {
     // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
     DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota;
     int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
+    DevBuf lm_stats;                  // four u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel
+    unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
     // sweep timing
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    std::vector<int> ev_what; // 0 = k_score (fp64 sweep), 1 = k_count (MFMA)
+    std::vector<int> ev_what; // 0 = k_score (fp64 sweep), 1 = k_count (MFMA), 2 = LO, 3 = final refinement, 4 = k_bound, 5 = minimal solver
     size_t ev_used = 0;
     double sweep_ms = 0.0, count_ms = 0.0;
+    double kind_ms[6] = {0, 0, 0, 0, 0, 0};
+    int64_t kind_launches[6] = {0, 0, 0, 0, 0, 0};
+    int64_t lm_cost_evals = 0, lm_accum_evals = 0, fin_cost_evals = 0, fin_accum_evals = 0;
     int64_t count_launches = 0;
     int64_t sweep_launches = 0, sweep_evals = 0, mfma_evals = 0, fp64_evals = 0, bound_evals = 0;
     int last_batch = 0;
@@ -433,11 +438,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
     // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
     // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)
-    const bool use_lme = !classic && env_int("MDRP_LM_ENGINE", 1) != 0;
+    // Default: on for the varying-focal estimator only.  Its LO leaves loss_scale at 1.0 (reference quirk), nothing is
+    // truncated, every sweep of every problem covers all N correspondences — long, uniform sweeps, where the round structure costs
+    // little and the shared cost sweep pays (N = 5000: 53.5 vs 57.1 ms per 1024 pairs).  On the calibrated / shared-focal shapes the
+    // persistent one-wavefront-per-problem kernels are faster (11.7 vs 14.5 ms): their problems are short and many, and a round's
+    // three kernel boundaries cost more than the stragglers they remove (DESIGN.md §4 "LM engine").
+    const bool use_lme = !classic && env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 1 : 0) != 0;
     const int lme_cap = std::max(batch, env_int("MDRP_LME_CAP", batch * 48 + 2048));
     if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
-    const size_t lo_mask_rows = (size_t)h->num_cu * 8;
+    const size_t lo_mask_rows = (size_t)h->num_cu * (size_t)std::max(lo_overlap_waves, 8); // kc_lo launches num_cu * max(overlap waves, 8 | 2) workgroups
     if (kind == MDRP_RELPOSE_5PT && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = SCORE_TILE_BYTES;
@@ -540,6 +550,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
             if (c < 2 && presampled[c]) HIPCHK(hipStreamWaitEvent(st_, h->ev_sampled[c], 0));
             else launch_samples(st_, r.chunk_len, smp);
+            hipEvent_t v0, v1;
+            int rc_;
+            if ((rc_ = get_events(h, &v0, &v1, 5))) return rc_;
+            HIPCHK(hipEventRecord(v0, st_));
+            struct Stop { hipEvent_t e; hipStream_t s; ~Stop() { (void)hipEventRecord(e, s); } } stop_{v1, st_}; // after the solver launch below
             if (classic) {
                 const dim3 sgrid((r.chunk_len + 63) / 64, batch);
                 if (kind == MDRP_RELPOSE_5PT)
@@ -612,9 +627,13 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                        BND_THREADS, h->cplan.as<int32_t>());
                     const dim3 bgrid((unsigned)batch * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
                     unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
+                    hipEvent_t b0, b1;
+                    if ((rc = get_events(h, &b0, &b1, 4))) return rc;
+                    HIPCHK(hipEventRecord(b0, s));
                     MDRP_SWEEP_DISPATCH(k_bound, kind, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
                                         h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
                                         tags_b, h->surv2_count.as<int32_t>(), bstats);
+                    HIPCHK(hipEventRecord(b1, s));
                     surv_tags = tags_b; surv_cnt = h->surv2_count.as<int32_t>();
                 }
                 hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, surv_cnt, surv_tags, tags_sc);
@@ -647,7 +666,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int lo_threads_c = (c + 1 == n_chunks) ? lo_threads_last : lo_threads;
             const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
             const RunParams rp_lo = rp;
-            auto launch_lo = [=]() -> int {
+            unsigned long long *lm_stats = h->lm_stats.as<unsigned long long>();
+            auto launch_lo_kernels = [=]() -> int {
                 if (use_lme) return lme_lo(h, aux2, rp_lo, kind, est_shift, lo_plan, trig_cap, 0, lme_cap);
                 if (classic) {
                     MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), 0, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
@@ -657,7 +677,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
                                  h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max));
+                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max), lm_stats);
+                return MDRP_OK;
+            };
+            auto launch_lo = [=]() -> int { // bracketed by HIP events on the stream the LO runs on (mdrp_stats::lo_ms)
+                hipEvent_t l0, l1;
+                int rc_;
+                if ((rc_ = get_events(h, &l0, &l1, 2))) return rc_;
+                HIPCHK(hipEventRecord(l0, aux2));
+                if ((rc_ = launch_lo_kernels())) return rc_;
+                HIPCHK(hipEventRecord(l1, aux2));
                 return MDRP_OK;
             };
             if (piped && lo_after_count && c + 1 < n_chunks) pending_lo = launch_lo;
@@ -724,12 +753,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         max_needed = h->progress_host->max_needed;
     }
 
+    hipEvent_t f0, f1;
+    if ((rc = get_events(h, &f0, &f1, 3))) return rc;
+    HIPCHK(hipEventRecord(f0, s));
     if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
     else if (classic)
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev);
-    else
+    else {
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
-                         h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max));
+                         h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+                         h->lm_stats.as<unsigned long long>() + 2);
+    }
+    HIPCHK(hipEventRecord(f1, s));
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -742,9 +777,11 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     if ((kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT) && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
     if (kind <= 2 && batch > 0 && n_max > 0 && (!d1 || !d2)) { g_err = "monodepth estimator needs depths"; return MDRP_ERR_INVALID; }
     const int mps = kind == MDRP_RELPOSE_5PT ? 12 : 4;
-    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch;
+    h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch; h->lm_cost_evals = 0; h->lm_accum_evals = 0;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
+    if ((rc = h->lm_stats.ensure(32))) return rc;
+    HIPCHK(hipMemsetAsync(h->lm_stats.p, 0, 32, h->stream));
     if (batch == 0) return MDRP_OK;
     std::vector<int32_t> n_host(batch);
     for (int i = 0; i < batch; ++i) {
@@ -781,14 +818,18 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
 }
 
 int finish_timing(mdrp_handle *h) {
+    if (h->lm_stats.p) HIPCHK(hipMemcpyAsync(h->lm_stats_host, h->lm_stats.p, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    double ms[2] = {0, 0};
+    h->lm_cost_evals = (int64_t)h->lm_stats_host[0]; h->lm_accum_evals = (int64_t)h->lm_stats_host[1];
+    h->fin_cost_evals = (int64_t)h->lm_stats_host[2]; h->fin_accum_evals = (int64_t)h->lm_stats_host[3];
+    for (int k = 0; k < 6; ++k) { h->kind_ms[k] = 0; h->kind_launches[k] = 0; }
     for (size_t i = 0; i < h->ev_used; ++i) {
         float t = 0;
         HIPCHK(hipEventElapsedTime(&t, h->ev_pool[i].first, h->ev_pool[i].second));
-        ms[h->ev_what[i] & 1] += t;
+        const int k = std::min(std::max(h->ev_what[i], 0), 5);
+        h->kind_ms[k] += t; h->kind_launches[k]++;
     }
-    h->sweep_ms = ms[0]; h->count_ms = ms[1];
+    h->sweep_ms = h->kind_ms[0]; h->count_ms = h->kind_ms[1];
     return MDRP_OK;
 }
 
@@ -835,6 +876,8 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->lme_live_host, sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->lm_stats_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+    std::memset(h->lm_stats_host, 0, 4 * sizeof(unsigned long long));
     {   // high priority: the few long LO wavefronts should be placed first, the sweep fills the remaining slots
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -873,11 +916,12 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
                       &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
-                      &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota};
+                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
     if (h->lme_live_host) (void)hipHostFree(h->lme_live_host);
+    if (h->lm_stats_host) (void)hipHostFree(h->lm_stats_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
@@ -971,6 +1015,10 @@ int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out) {
     out->count_ms = h->count_ms; out->count_launches = h->count_launches;
     out->sweep_ms = h->sweep_ms; out->sweep_launches = h->sweep_launches;
     out->evals_algorithmic = h->sweep_evals; out->evals_mfma = h->mfma_evals; out->evals_fp64 = h->fp64_evals; out->evals_bound = h->bound_evals;
+    out->lo_ms = h->kind_ms[2]; out->lo_launches = h->kind_launches[2]; out->final_ms = h->kind_ms[3]; out->final_launches = h->kind_launches[3];
+    out->bound_ms = h->kind_ms[4]; out->bound_launches = h->kind_launches[4]; out->solve_ms = h->kind_ms[5]; out->solve_launches = h->kind_launches[5];
+    out->lm_cost_evals = h->lm_cost_evals; out->lm_accum_evals = h->lm_accum_evals;
+    out->final_cost_evals = h->fin_cost_evals; out->final_accum_evals = h->fin_accum_evals;
     return MDRP_OK;
 }
 
@@ -1192,7 +1240,7 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
     o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
-    if (env_int("MDRP_LM_ENGINE", 1) != 0) {
+    if (env_int("MDRP_LM_ENGINE", 0) != 0) {
         // the phase-batched engine with all `count` problems on one pair (pair 0 = the packed records)
         if ((rc = lme_ensure(h, count, 1, nn)) || (rc = h->st.ensure(sizeof(PairState)))) return rc;
         PairState ps;

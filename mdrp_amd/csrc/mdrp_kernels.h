@@ -1005,8 +1005,36 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
 // true record candidates and near-ties, and only those reach the fp64 sweep.  Branch-free: ~23 fp32 instructions per
 // evaluation against ~12 (mostly fp64, divergent) of the exact sweep's survivors, and no second phase.
 constexpr int BND_THREADS = 256;
-constexpr int BND_TILE = 1024; // correspondences per LDS tile (16 B each, fp32)
+#ifndef MDRP_BND_TILE
+#define MDRP_BND_TILE 256
+#endif
+constexpr int BND_TILE = MDRP_BND_TILE; // correspondences per LDS tile (16 B each, fp32); early-exit test and compaction per tile
 
+// E (or F) of a model as the scoring sweeps see it
+template <bool POSE, bool RAWF>
+__device__ __forceinline__ void model_matrix(const Model &m, double E[9]) {
+    if (RAWF) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) E[q] = reinterpret_cast<const double *>(&m)[q];
+    } else {
+        double R[9], Em[9];
+        quat_to_R(m.q, R);
+        essential_from_Rt(R, m.t, Em);
+        if (POSE) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) E[q] = Em[q];
+        } else fundamental_from_E(Em, m.f1, m.f2, E);
+    }
+}
+
+// Both proofs are monotone in the records seen so far (the terms of the score bound are >= 0; unseen records can add at most
+// their number to the inlier bound), so after every tile a model whose partial sums already prove it irrelevant leaves; the
+// workgroup then packs the models that are still open into as few wavefronts as they need (their state moves through LDS), so
+// a wavefront never idles along beside one open lane, and wavefronts without open models only help load tiles.  Outlier-free
+// pairs, where every model is good and the bound has to see a large part of the sum: 8.4 -> 5.9 ms per 1024 pairs at 512
+// records per tile, 5.6 at 256.  (Measured and dropped: walking the records in the order of their residual under the best
+// minimal model so far, largest first — residuals of minimal models are dominated by each model's own error, not by the
+// record's noise, so one model's order says little about another's: -6 % on k_bound for a 0.18 ms sort.)
 template <bool POSE, bool RAWF = false>
 __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags_in,
@@ -1014,6 +1042,9 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
                                                           int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_out,
                                                           int32_t *__restrict__ cnt_out, unsigned long long *__restrict__ stats) {
     __shared__ float4 s_rec[BND_TILE];
+    struct Open { uint32_t tag; int32_t sane; float Ef[9], eC, eD, thr_dn, c0, c1; double lb; }; // a model's state while it is still open
+    __shared__ Open s_open[BND_THREADS];
+    __shared__ int s_wave_open[BND_THREADS / 64];
     const int total = plan[rp.batch];
     const int w = blockIdx.x;
     if (w >= total) return;
@@ -1021,9 +1052,9 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
     const int blk = w - plan[pair];
     const PairState &ps = st[pair];
     const int n = ps.n, cnt = cnt_in[pair];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blk * BND_THREADS + tid;
-    const bool live = i < cnt;
+    bool open = i < cnt; // this lane holds a model that is neither retired nor passed on yet
     const size_t slot_base = (size_t)pair * rp.slot_stride;
     const double thr = ps.sq_thr;
     uint32_t tag = 0;
@@ -1031,21 +1062,11 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
     bool sane = false;
 #pragma unroll
     for (int q = 0; q < 9; ++q) Ef[q] = 0.f;
-    if (live) {
+    if (open) {
         tag = tags_in[slot_base + i];
         const Model m = models[slot_base + (tag & 0xFFFFFFu)];
-        double R[9], Em[9], E[9];
-        if (RAWF) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) E[q] = reinterpret_cast<const double *>(&m)[q];
-        } else {
-            quat_to_R(m.q, R);
-            essential_from_Rt(R, m.t, Em);
-            if (POSE) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) E[q] = Em[q];
-            } else fundamental_from_E(Em, m.f1, m.f2, E);
-        }
+        double E[9];
+        model_matrix<POSE, RAWF>(m, E);
         sane = bound_setup32(E, ps.box, thr, Ef, eC, eD, thr_dn);
     }
     // Two correspondences per step in packed fp32 (every VALU instruction costs 4 cycles per wavefront; v_pk_* carry two
@@ -1056,10 +1077,8 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
     const float thr_cnt = (float)(thr * (1.0 + 1e-5)) * (1.0f + 1e-6f); // q may exceed r^2 by its own roundings (<= 8u)
     const float BIG = 1.2089258e24f; // 2^80
     const f32x2 nbig = {-BIG, -BIG}, kcnt = {thr_cnt * BIG, thr_cnt * BIG};
-    f32x2 Ev[9];
-#pragma unroll
-    for (int q = 0; q < 9; ++q) Ev[q] = (f32x2){Ef[q], Ef[q]};
-    const f32x2 eDv = {eD, eD};
+    const long long rec_cnt = (long long)ps.best_min_cnt;
+    const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
     float4 *s_pair = s_rec; // two correspondences per 32 B, component-major: (a0 a1 b0 b1)(c0 c1 d0 d1)
     const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     for (int t0 = 0; t0 < n; t0 += BND_TILE) {
@@ -1071,44 +1090,79 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
             store_rec32(s_pair, j, p0.x, p0.y, p1.x, p1.y);
         }
         __syncthreads();
-        const int npairs = npts >> 1;
-        for (int j0 = 0; j0 < npairs; j0 += 32) { // partial sums of <= 64 terms in fp32, then fp64
-            const int je = min(32, npairs - j0);
-            f32x2 part = {0.f, 0.f};
+        if (__ballot(open)) { // wavefronts without an open model only helped load the tile
+            f32x2 Ev[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) Ev[q] = (f32x2){Ef[q], Ef[q]};
+            const f32x2 eDv = {eD, eD};
+            const int npairs = npts >> 1;
+            for (int j0 = 0; j0 < npairs; j0 += 32) { // partial sums of <= 64 terms in fp32, then fp64
+                const int je = min(32, npairs - j0);
+                f32x2 part = {0.f, 0.f};
 #pragma unroll 2
-            for (int j = 0; j < je; ++j) {
-                const float4 ab = s_pair[2 * (j0 + j)], cd = s_pair[2 * (j0 + j) + 1];
-                const f32x2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, c = {cd.x, cd.y}, d = {cd.z, cd.w};
-                const f32x2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
-                const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
-                const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
-                const f32x2 g0 = __builtin_elementwise_fma(Ev[0], c, __builtin_elementwise_fma(Ev[3], d, Ev[6]));
-                const f32x2 g1 = __builtin_elementwise_fma(Ev[1], c, __builtin_elementwise_fma(Ev[4], d, Ev[7]));
-                const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
-                const f32x2 den = __builtin_elementwise_fma(e0, e0, __builtin_elementwise_fma(e1, e1, __builtin_elementwise_fma(g0, g0, __builtin_elementwise_fma(g1, g1, eDv))));
-                const f32x2 t = {fmaxf(fabsf(C.x) - eC, 0.0f), fmaxf(fabsf(C.y) - eC, 0.0f)};
-                const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)}; // v_rcp_f32: 1 ulp, inside BOUND_SLACK
-                const f32x2 q = (t * t) * rc;
-                const f32x2 term = {__builtin_fminf(q.x, thr_dn), __builtin_fminf(q.y, thr_dn)}; // v_min_f32: NaN -> thr, like the reference's `r2 < thr`
-                part += term;
-                f32x2 o;
-                asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(q), "v"(nbig), "v"(kcnt));
-                cnt2 += o;
+                for (int j = 0; j < je; ++j) {
+                    const float4 ab = s_pair[2 * (j0 + j)], cd = s_pair[2 * (j0 + j) + 1];
+                    const f32x2 a = {ab.x, ab.y}, b = {ab.z, ab.w}, c = {cd.x, cd.y}, d = {cd.z, cd.w};
+                    const f32x2 e0 = __builtin_elementwise_fma(Ev[0], a, __builtin_elementwise_fma(Ev[1], b, Ev[2]));
+                    const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
+                    const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
+                    const f32x2 g0 = __builtin_elementwise_fma(Ev[0], c, __builtin_elementwise_fma(Ev[3], d, Ev[6]));
+                    const f32x2 g1 = __builtin_elementwise_fma(Ev[1], c, __builtin_elementwise_fma(Ev[4], d, Ev[7]));
+                    const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
+                    const f32x2 den = __builtin_elementwise_fma(e0, e0, __builtin_elementwise_fma(e1, e1, __builtin_elementwise_fma(g0, g0, __builtin_elementwise_fma(g1, g1, eDv))));
+                    const f32x2 t = {fmaxf(fabsf(C.x) - eC, 0.0f), fmaxf(fabsf(C.y) - eC, 0.0f)};
+                    const f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)}; // v_rcp_f32: 1 ulp, inside BOUND_SLACK
+                    const f32x2 q = (t * t) * rc;
+                    const f32x2 term = {__builtin_fminf(q.x, thr_dn), __builtin_fminf(q.y, thr_dn)}; // v_min_f32: NaN -> thr, like the reference's `r2 < thr`
+                    part += term;
+                    f32x2 o;
+                    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(o) : "v"(q), "v"(nbig), "v"(kcnt));
+                    cnt2 += o;
+                }
+                total_lb += (double)part.x + (double)part.y;
             }
-            total_lb += (double)part.x + (double)part.y;
+            if (npts & 1) { // odd tail of the last tile
+                const float *fl = reinterpret_cast<const float *>(s_pair) + (npts >> 1) * 8;
+                const float q = bound_r2_32(Ef, eC, eD, fl[0], fl[2], fl[4], fl[6]);
+                total_lb += (double)__builtin_fminf(q, thr_dn);
+                cnt2.x += (q < thr_cnt) ? 1.0f : 0.0f;
+            }
         }
-        if (npts & 1) { // odd tail of the last tile
-            const float *fl = reinterpret_cast<const float *>(s_pair) + (npts >> 1) * 8;
-            const float q = bound_r2_32(Ef, eC, eD, fl[0], fl[2], fl[4], fl[6]);
-            total_lb += (double)__builtin_fminf(q, thr_dn);
-            cnt2.x += (q < thr_cnt) ? 1.0f : 0.0f;
+        // Monotone exit: unseen records can only add inliers (at most their number) and can only raise the score bound; after the
+        // last tile this IS the full test.  A model outside the fp32 range (`sane` false) is never retired.
+        const int seen = t0 + npts;
+        if (open && sane) {
+            const long long cnt_ub = (long long)(cnt2.x + cnt2.y) + 1 + (long long)(n - seen); // + 1: the clamped sum may carry a fraction
+            if (cnt_ub <= rec_cnt && total_lb * (1.0 - BOUND_SLACK) >= rec_score) open = false; // its slot keeps k_solve's -2
+        }
+        if (seen >= n) break;
+        // pack the open models into as few wavefronts as they need
+        const unsigned long long ob = __ballot(open);
+        if (lane == 0) s_wave_open[wave] = __popcll(ob);
+        __syncthreads();
+        int tot = 0, before = 0, waves_used = 0;
+#pragma unroll
+        for (int v = 0; v < BND_THREADS / 64; ++v) { const int c = s_wave_open[v]; if (v < wave) before += c; tot += c; waves_used += c > 0; }
+        if (tot == 0) break; // (uniform) every model of this workgroup is decided
+        if ((tot + 63) / 64 < waves_used) {
+            if (open) {
+                Open &o = s_open[before + __popcll(ob & ((1ull << lane) - 1ull))];
+                o.tag = tag; o.sane = sane; o.eC = eC; o.eD = eD; o.thr_dn = thr_dn; o.c0 = cnt2.x; o.c1 = cnt2.y; o.lb = total_lb;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) o.Ef[q] = Ef[q];
+            }
+            __syncthreads();
+            open = tid < tot;
+            if (open) {
+                const Open &o = s_open[tid];
+                tag = o.tag; sane = o.sane != 0; eC = o.eC; eD = o.eD; thr_dn = o.thr_dn; cnt2.x = o.c0; cnt2.y = o.c1; total_lb = o.lb;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) Ef[q] = o.Ef[q];
+            }
         }
     }
-    const int cnt_ub = (int)(cnt2.x + cnt2.y) + 1; // + 1: the sum of the clamped values may carry a fraction
-    const long long rec_cnt = (long long)ps.best_min_cnt;
-    const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
-    const bool dead = live && sane && (long long)cnt_ub <= rec_cnt && total_lb * (1.0 - BOUND_SLACK) >= rec_score; // its slot keeps k_solve's -2
-    const bool surv = live && !dead;
+    // what is still marked open here has seen every record without being retired: on to the exact sweep
+    const bool surv = open;
     const unsigned long long ball = __ballot(surv);
     if (ball) {
         int base = 0;
@@ -1465,7 +1519,17 @@ struct LmShared {
     int count[2][4];
     uint16_t *list;  // dynamic LDS, 2 * stride entries
     int stride;
+    unsigned long long *stats; // [0] correspondences evaluated by cost sweeps, [1] by accumulate sweeps (or null): bench.py's fp64 roofline
+    unsigned long long ev[2];  // ... collected here per problem, flushed by lm_flush_stats
 };
+// one pair of global atomics per LM problem (thread 0, after the problem's last barrier)
+__device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
+    if (sh.stats) {
+        if (sh.ev[0]) atomicAdd(sh.stats, sh.ev[0]);
+        if (sh.ev[1]) atomicAdd(sh.stats + 1, sh.ev[1]);
+    }
+    sh.ev[0] = 0; sh.ev[1] = 0;
+}
 
 template <int KIND, int T>
 __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
@@ -1496,10 +1560,12 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         return r;
     };
     Rec nxt = fetch(lo);
+    int evaluated = 0;
     for (int base = lo; base < hi; base += 64) {
         const Rec cur = nxt;
         if (base + 64 < hi) nxt = fetch(base + 64);
         const int i = base + lane;
+        evaluated += __popcll(__ballot(cur.ok));
         bool contrib = false;
         if (cur.ok) {
             double r[5], zf, zb;
@@ -1518,6 +1584,7 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         }
     }
     if (use_list && lane == 0) sh.count[buf][wave] = cnt;
+    if (sh.stats && lane == 0 && evaluated) atomicAdd(&sh.ev[0], (unsigned long long)evaluated);
     double v[1] = {cost};
     block_sum<1, T>(v, sh.scratch);
     return v[0];
@@ -1617,6 +1684,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
             fetch(k + 64);
             lm_accumulate_point<KIND, SHIFT>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
         }
+        if (sh.stats && lane == 0 && cnt) atomicAdd(&sh.ev[1], (unsigned long long)cnt);
     } else {
         const int hi = min(n, lo + seg);
         for (int i = lo + lane; i < hi; i += 64)
@@ -1761,11 +1829,11 @@ template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
                                                    Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan,
-                                                   int32_t *__restrict__ head /*zeroed*/, int list_stride) {
+                                                   int32_t *__restrict__ head /*zeroed*/, int list_stride, unsigned long long *__restrict__ lm_stats) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
     __syncthreads();
     const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
     const int total = plan[3 * (size_t)rp.batch + 1];
@@ -1793,7 +1861,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
         double sc;
         int cn;
         block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
-        if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
+        if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; lm_flush_stats(sh); }
 #ifdef MDRP_LO_TRACE
         if (threadIdx.x == 0 && g_lo_trace) {
             const unsigned int k = atomicAdd(&g_lo_trace_n, 1u);
@@ -1895,10 +1963,10 @@ struct ResultDev {
 template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
-                                                      ResultDev *__restrict__ results, int list_stride) {
+                                                      ResultDev *__restrict__ results, int list_stride, unsigned long long *__restrict__ lm_stats) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
     __syncthreads();
     double *scratch = sh.scratch;
     const int pair = blockIdx.x;
@@ -1937,7 +2005,8 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     }
     if (KIND != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
     res.model = best;
-    if (threadIdx.x == 0) results[pair] = res;
+    __syncthreads();
+    if (threadIdx.x == 0) { results[pair] = res; lm_flush_stats(sh); }
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels
@@ -2010,7 +2079,7 @@ __global__ __launch_bounds__(T) void k_refine_unit(int count, Model *__restrict_
                                                             double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost, int list_stride) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; }
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = nullptr; sh.ev[0] = 0; sh.ev[1] = 0; }
     __syncthreads();
     const int i = blockIdx.x;
     if (i >= count) return;

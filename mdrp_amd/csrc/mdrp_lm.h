@@ -32,6 +32,9 @@ namespace mdrp {
 #ifndef MDRP_LME_RPT
 #define MDRP_LME_RPT 4
 #endif
+#ifndef MDRP_LME_MINWAVES
+#define MDRP_LME_MINWAVES 2 // workgroups of k_lme_accum per CU (2 = 256 VGPRs per lane)
+#endif
 constexpr int LME_RPT = MDRP_LME_RPT;  // records per lane in the cost sweep
 constexpr int LME_SEG = 64 * LME_RPT;  // correspondences per cost-sweep segment (one wavefront)
 constexpr int LME_T = 256;             // threads per problem in k_lme_accum
@@ -336,7 +339,7 @@ __device__ void lme_accumulate(const Model &m, const double *__restrict__ pts, c
 // lm_impl<>'s loop body from "the cost of the candidate is known" to "the normal equations of the current model are known"
 // (upstream PoseLib convention, as lm_refine of round 2).  Workgroups stride over the problems of the pass.
 template <int KIND, bool SHIFT, int LOSS>
-__global__ __launch_bounds__(LME_T, MDRP_LM_MINWAVES) void k_lme_accum(LmePhase ph, const double *__restrict__ pts, const double *__restrict__ dep,
+__global__ __launch_bounds__(LME_T, MDRP_LME_MINWAVES) void k_lme_accum(LmePhase ph, const double *__restrict__ pts, const double *__restrict__ dep,
                                                                        int round, int dense_cap) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NA = NP * (NP + 1) / 2 + NP;

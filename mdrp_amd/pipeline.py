@@ -46,6 +46,9 @@ class BatchPipeline:
     def submit_device(self, kind, x1_ptr, x2_ptr, d1_ptr, d2_ptr, batch, n_max, ropt, bopt, n_per_pair=None, cam1=None, cam2=None,
                       mask_ptr=None):
         """device pointers (e.g. torch tensors' data_ptr()); returns a Future of the result records (numpy)"""
+        ropt = _capi.ransac_opt_from_dict(ropt) if isinstance(ropt, dict) else ropt  # as submit() does
+        bopt = _capi.bundle_opt_from_dict(bopt) if isinstance(bopt, dict) else bopt
+
         def run():
             h = self._handle()
             h.estimate_batch_device(kind, x1_ptr, x2_ptr, d1_ptr, d2_ptr, batch, n_max, ropt, bopt, n_per_pair, cam1, cam2, mask_ptr)
