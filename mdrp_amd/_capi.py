@@ -81,7 +81,7 @@ def load_library():
             return _lib
         if not os.path.exists(LIB_PATH):
             raise MdrpError(f"{LIB_PATH} is not built (run __graft_entry__.build()); mdrp_amd has no CPU fallback")
-        _torch_runtime_first()  # before OUR runtime is even loaded: its static constructors already touch the device
+        _ensure_hip_runtime()  # the library binds its hip* symbols to the process's one runtime when it is loaded
         lib = C.CDLL(LIB_PATH)
         vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
         lib.mdrp_last_error.restype = C.c_char_p
@@ -154,36 +154,43 @@ def library_source_hash():
     return v.split("MDRP_SRC_HASH=", 1)[1][:16] if "MDRP_SRC_HASH=" in v else None
 
 
-_torch_runtime_done = False
+_hip_runtime = None
 
 
-def _torch_runtime_first():
-    """PyTorch-ROCm wheels bundle their own HIP / HSA runtime (torch/lib/libamdhip64.so, no SONAME), libmdrp_hip.so links the
-    system one (/opt/rocm/lib/libamdhip64.so.7): two runtimes in one process.  That works when torch's initialises first; the
-    other way round torch.cuda later fails with "No HIP GPUs are available".  So before the first handle exists: if the process
-    has imported torch, torch.cuda is initialised; if torch is merely installed, its bundled runtime library is loaded and
-    hipInit()ed (the later `import torch` finds it loaded) — without importing torch.  MDRP_NO_TORCH_PRELOAD=1 skips this."""
-    global _torch_runtime_done
-    if _torch_runtime_done or os.environ.get("MDRP_NO_TORCH_PRELOAD"):
-        return
-    _torch_runtime_done = True
+def _ensure_hip_runtime():
+    """libmdrp_hip.so is linked WITHOUT a HIP runtime of its own (build.py: -no-hip-rt): its hip* symbols bind to whatever runtime
+    the process has, so that there is exactly one — streams, events and device pointers of the host framework are then valid
+    inside the library by construction.  PyTorch-ROCm wheels bundle a runtime (torch/lib/libamdhip64.so, no SONAME): if torch is
+    imported or merely installed, THAT file is (re)opened with RTLD_GLOBAL (dlopen of an already loaded library only widens its
+    scope); otherwise the system runtime is.  MDRP_HIP_RUNTIME=/path/to/libamdhip64.so overrides the choice."""
+    global _hip_runtime
+    if _hip_runtime is not None:
+        return _hip_runtime
     import sys
-    torch = sys.modules.get("torch")
+    cands = []
+    if os.environ.get("MDRP_HIP_RUNTIME"):
+        cands.append(os.environ["MDRP_HIP_RUNTIME"])
     try:
+        torch = sys.modules.get("torch")
         if torch is not None:
-            if torch.cuda.is_available() and not torch.cuda.is_initialized():
-                torch.cuda.init()
-            return
-        import importlib.util
-        spec = importlib.util.find_spec("torch")
-        if spec is None or not spec.submodule_search_locations:
-            return
-        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(path):
-            rt = C.CDLL(path, mode=C.RTLD_GLOBAL)
-            rt.hipInit(0)
+            tdir = os.path.dirname(torch.__file__)
+        else:
+            import importlib.util
+            spec = importlib.util.find_spec("torch")
+            tdir = list(spec.submodule_search_locations)[0] if spec is not None and spec.submodule_search_locations else None
+        if tdir and os.path.exists(os.path.join(tdir, "lib", "libamdhip64.so")):
+            cands.append(os.path.join(tdir, "lib", "libamdhip64.so"))
     except Exception:
         pass
+    cands += ["libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"]
+    errs = []
+    for c in cands:
+        try:
+            _hip_runtime = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return _hip_runtime
+        except OSError as e:
+            errs.append(f"{c}: {e}")
+    raise MdrpError("no HIP runtime (libamdhip64) could be loaded: " + "; ".join(errs))
 
 
 class Handle:
@@ -194,7 +201,6 @@ class Handle:
     0 is the device's legacy default stream (torch.cuda.current_stream().cuda_stream is 0 on torch's default stream)."""
 
     def __init__(self, device=0, stream=None):
-        _torch_runtime_first()
         self._lib = load_library()
         h = C.c_void_p()
         if stream is None:

@@ -17,6 +17,7 @@ DEPS = [SRC, os.path.join(HERE, "csrc", "mdrp_kernels.h"), os.path.join(HERE, "c
         os.path.join(HERE, "..", "include", "mdrp.h")]
 OUT = os.path.join(HERE, "libmdrp_hip.so")
 _MARK = b"MDRP_SRC_HASH="
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=fast", "-no-hip-rt"]
 
 
 def hipcc():
@@ -29,6 +30,7 @@ def hipcc():
 def source_hash():
     """sha256 over the source files (name + content), first 16 hex digits"""
     h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())  # a change of the compile / link flags is a change of the binary
     for d in DEPS:
         h.update(os.path.basename(d).encode() + b"\0")
         with open(d, "rb") as f:
@@ -53,7 +55,11 @@ def up_to_date():
 def build(force=False, verbose=False, defines=(), out=OUT):
     if not force and not defines and out == OUT and up_to_date():
         return out
-    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=fast",
+    # -no-hip-rt: no DT_NEEDED on a particular libamdhip64.  The hip* symbols stay undefined and bind, when the library is loaded,
+    # to the ONE HIP runtime the host process already has (PyTorch-ROCm wheels bundle their own; a second runtime instance in the
+    # same process cannot share streams or device memory with it).  mdrp_amd/_capi.py makes a runtime globally visible first;
+    # a C / C++ host links -lamdhip64 itself.
+    cmd = [hipcc(), *FLAGS,
            f'-DMDRP_SRC_HASH="{source_hash()}"', *[f"-D{d}" for d in defines], SRC, "-o", out + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

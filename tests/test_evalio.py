@@ -114,6 +114,37 @@ def test_evaluate_calibrated_end_to_end_gpu():
     rows = evalio.summarize(exps, res)
     for exp, med, maa, ms, inl in rows:
         assert med < 0.5 and maa > 0.9 and ms > 0 and 0.5 < inl <= 1.0, rows
+    # every per-pair record against the CPU oracle run on the same pair with the options eval.py would build
+    # (eval.py:93-160): pose, stats and both error metrics (the 5-point rows: direction of t, its norm is a gauge)
+    from oracle import pyorc as po
+    pairs = [evalio.load_pair(h5, a, b, depth=10) for a, b in evalio.list_pairs(h5)]
+    pairs = [p for p in pairs if len(p["kp1"]) >= 5]
+    assert len(pairs) == 7
+    for e, exp in enumerate(exps):
+        ro, bo = evalio.experiment_options(exp, iters=1000, threshold=2.0)
+        for j, p in enumerate(pairs):
+            rec = res[e * 7 + j]
+            c1 = po.cam_flat(1, [p["K1"][0, 0], p["K1"][1, 1], p["K1"][0, 2], p["K1"][1, 2]])
+            c2 = po.cam_flat(1, [p["K2"][0, 0], p["K2"][1, 1], p["K2"][0, 2], p["K2"][1, 2]])
+            oro = po.ransac_opt(max_iterations=1000, min_iterations=1000, max_epipolar_error=2.0, max_reproj_error=16.0,
+                                estimate_shift=exp.startswith("3p_ours_shift"))
+            obo = po.bundle_opt(loss_type={"TRUNCATED": 1, "TRUNCATED_CAUCHY": 4, "CAUCHY": 3}[bo["loss_type"]], loss_scale=bo.get("loss_scale", 1.0))
+            if exp.startswith("5p"):
+                m, st, mk = po.estimate_classic(3, p["kp1"], p["kp2"], oro, obo, c1, c2)
+            else:
+                m, st, mk = po.estimate(po.CALIB, p["kp1"], p["kp2"], p["d"][:, 0], p["d"][:, 1], oro, obo, c1, c2)
+            Ro = po.quat_to_rotmat(m[:4])
+            where = (exp, j)
+            assert rec["info"]["num_inliers"] == st.num_inliers and rec["info"]["iterations"] == st.iterations == 1000, where
+            assert rec["info"]["refinements"] == st.refinements, where
+            assert np.abs(np.array(rec["R"]) - Ro).max() < 1e-6, where
+            to, tg = m[4:7], np.array(rec["t"])
+            if exp.startswith("5p"):
+                assert np.abs(tg / np.linalg.norm(tg) - to / np.linalg.norm(to)).max() < 1e-6, where
+            else:
+                assert np.abs(tg - to).max() < 1e-6 * (1 + np.abs(to).max()), where
+            assert rec["R_err"] == pytest.approx(evalio.rotation_error_deg(p["R_gt"], Ro), abs=1e-6)
+            assert rec["t_err"] == pytest.approx(evalio.translation_error_deg(p["t_gt"], to), abs=1e-5)
 
 
 def fake_h5_focal(n_pairs=6, n=400, depth=12, seed=0, varying=False):
@@ -164,6 +195,21 @@ def test_evaluate_focal_end_to_end_gpu(shared):
     assert len(res) == 7 and {"f1", "f2", "f_err", "f1_gt"} <= set(res[0])
     (row,) = evalio.summarize_focal(exps, res)
     assert row[1] < 1.0 and row[2] < 0.02 and row[3] > 0.85 and row[4] > 0.85, row
+    # every per-pair record (R, t, focals, stats) against the CPU oracle on the same centred pixels (eval_shared_f.py:111-183)
+    from oracle import pyorc as po
+    pairs = [evalio.load_pair_focal(h5, a, b, depth=12, shared=shared) for a, b in evalio.list_pairs(h5)]
+    pairs = [p for p in pairs if len(p["kp1"]) >= (6 if shared else 7)]
+    assert len(pairs) == len(res)
+    ro, bo = evalio.focal_options(exps[0], iters=1000, threshold=2.0, varying=not shared)
+    oro = po.ransac_opt(max_iterations=1000, min_iterations=1000, max_epipolar_error=2.0, max_reproj_error=16.0)
+    obo = po.bundle_opt(loss_type={"TRUNCATED": 1, "TRUNCATED_CAUCHY": 4, "CAUCHY": 3}[bo["loss_type"]], loss_scale=bo.get("loss_scale", 1.0))
+    for j, p in enumerate(pairs):
+        m, st, mk = po.estimate(po.SHARED if shared else po.VARYING, p["kp1"], p["kp2"], p["d"][:, 0], p["d"][:, 1], oro, obo)
+        rec = res[j]
+        assert rec["info"]["num_inliers"] == st.num_inliers and rec["info"]["iterations"] == st.iterations and rec["info"]["refinements"] == st.refinements, j
+        assert np.abs(np.array(rec["R"]) - po.quat_to_rotmat(m[:4])).max() < 1e-6, j
+        assert np.abs(np.array(rec["t"]) - m[4:7]).max() < 1e-6 * (1 + np.abs(m[4:7]).max()), j
+        assert rec["f1"] == pytest.approx(m[10], rel=1e-6) and rec["f2"] == pytest.approx(m[11], rel=1e-6), j
 
 
 def test_baseline_options_that_are_not_built_raise():

@@ -7,7 +7,7 @@ cd $R
 mkdir -p gpurun_out/variants
 for v in "$@"; do
   name=${v%%:*}; flags=${v#*:}
-  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=fast $flags mdrp_amd/csrc/mdrp_capi.hip -o mdrp_amd/libmdrp_hip.so 2> gpurun_out/variants/$name.build.log || { echo "$name: BUILD FAILED"; tail -5 gpurun_out/variants/$name.build.log; continue; }
+  hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared -ffp-contract=fast -no-hip-rt $flags mdrp_amd/csrc/mdrp_capi.hip -o mdrp_amd/libmdrp_hip.so 2> gpurun_out/variants/$name.build.log || { echo "$name: BUILD FAILED"; tail -5 gpurun_out/variants/$name.build.log; continue; }
   timeout 600 python bench.py --batch ${BATCH:-512} --steps ${STEPS:-3} --warmup 1 --cpu-pairs 0 --workload ${WORKLOAD:-calib_p3p_n2000_i10k} > gpurun_out/variants/$name.json 2> gpurun_out/variants/$name.err || { echo "$name: RUN FAILED"; tail -3 gpurun_out/variants/$name.err; continue; }
   python3 - "$name" <<'PY'
 import json, sys
