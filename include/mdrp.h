@@ -29,7 +29,11 @@ enum { MDRP_CALIB = 0, MDRP_SHARED_FOCAL = 1, MDRP_VARYING_FOCAL = 2,
         * estimate_relative_pose (wheel _core.pyi:504-529; 5-point, cameras as for MDRP_CALIB; model: q, t) and
         * estimate_fundamental (_core.pyi:309-323; 7-point; model: F row-major in the first nine doubles of mdrp_model).
         * 4 is reserved for estimate_shared_focal_relative_pose (6-point), not built. */
-       MDRP_RELPOSE_5PT = 3, MDRP_FUNDAMENTAL_7PT = 5 };
+       MDRP_RELPOSE_5PT = 3, MDRP_FUNDAMENTAL_7PT = 5,
+       /* estimate_shared_focal_relative_pose (wheel _core.pyi: 6-point, one unknown focal length shared by both images;
+        * /root/reference/eval_shared_f.py:161).  Pixels relative to nothing: the principal point travels in cam1[i].params[0..1]
+        * (cam2 unused); model: q, t, f1 = f2 = f in pixels */
+       MDRP_SHARED_6PT = 4 };
 
 enum { /* return codes */
     MDRP_OK = 0,

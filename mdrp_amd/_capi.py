@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDRP_LIB") or os.path.join(_HERE, "libmdrp_hip.so")  # MDRP_LIB: experiment builds (tools/)
 
 CALIB, SHARED_FOCAL, VARYING_FOCAL = 0, 1, 2
-RELPOSE_5PT, FUNDAMENTAL_7PT = 3, 5  # non-monodepth baselines (d1 = d2 = None)
+RELPOSE_5PT, SHARED_6PT, FUNDAMENTAL_7PT = 3, 4, 5  # non-monodepth baselines (d1 = d2 = None)
 MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
@@ -294,9 +294,10 @@ class Handle:
         return out, n_out
 
     def classic_solver_batch(self, kind, x1h, x2h):
-        """relpose_5pt (kind 3: x1h, x2h (count, 5, 3) unit bearings -> up to 10 poses) / relpose_7pt (kind 5: (count, 7, 3) ->
-        up to 3 fundamental matrices in the models' first nine doubles)"""
-        K, M = (5, 10) if kind == RELPOSE_5PT else (7, 3)
+        """relpose_5pt (kind 3: x1h, x2h (count, 5, 3) unit bearings -> up to 10 poses) / relpose_6pt_shared_focal (kind 4:
+        (count, 6, 3) -> up to 15 poses with f1 = f2 = f, by ascending f) / relpose_7pt (kind 5: (count, 7, 3) -> up to 3
+        fundamental matrices in the models' first nine doubles)"""
+        K, M = {RELPOSE_5PT: (5, 10), SHARED_6PT: (6, 15), FUNDAMENTAL_7PT: (7, 3)}[kind]
         x1h = np.ascontiguousarray(x1h, dtype=np.float64).reshape(-1, K, 3)
         x2h = np.ascontiguousarray(x2h, dtype=np.float64).reshape(-1, K, 3)
         count = len(x1h)

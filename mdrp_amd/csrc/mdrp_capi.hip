@@ -105,7 +105,7 @@ struct mdrp_handle {
     DevBuf surv2_count;        // survivors of k_bound per pair
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
     // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
-    DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota;
+    DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live;
     int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
     DevBuf lm_stats;                  // four u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
@@ -160,6 +160,8 @@ namespace {
     do {                                                                                                                        \
         if ((kind) == MDRP_RELPOSE_5PT && (threads) == 64) hipLaunchKernelGGL((KERNEL<CLASSIC_RELPOSE, 64>), grid, dim3(64), smem, stream, __VA_ARGS__); \
         else if ((kind) == MDRP_RELPOSE_5PT) hipLaunchKernelGGL((KERNEL<CLASSIC_RELPOSE, 256>), grid, dim3(256), smem, stream, __VA_ARGS__); \
+        else if ((kind) == MDRP_SHARED_6PT && (threads) == 64) hipLaunchKernelGGL((KERNEL<CLASSIC_SHARED, 64>), grid, dim3(64), smem, stream, __VA_ARGS__); \
+        else if ((kind) == MDRP_SHARED_6PT) hipLaunchKernelGGL((KERNEL<CLASSIC_SHARED, 256>), grid, dim3(256), smem, stream, __VA_ARGS__); \
         else if ((threads) == 64) hipLaunchKernelGGL((KERNEL<CLASSIC_FUND, 64>), grid, dim3(64), smem, stream, __VA_ARGS__);      \
         else hipLaunchKernelGGL((KERNEL<CLASSIC_FUND, 256>), grid, dim3(256), smem, stream, __VA_ARGS__);                        \
     } while (0)
@@ -250,7 +252,7 @@ int lme_ensure(mdrp_handle *h, int cap, int batch, int n_max) {
     if ((rc = h->lme_probs.ensure(sizeof(LmProb) * c)) || (rc = h->lme_part.ensure(sizeof(double) * c * nseg)) ||
         (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (rc = h->lme_list.ensure(c * 2 * nseg * LME_SEG)) ||
         (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c * 2 * nseg)) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
-        (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))))
+        (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))) || (rc = h->lme_pair_live.ensure(sizeof(int32_t) * 2 * (size_t)std::max(batch, 1))))
         return rc;
     return MDRP_OK;
 }
@@ -260,7 +262,7 @@ LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, con
     ph.probs = h->lme_probs.as<LmProb>(); ph.part = h->lme_part.as<double>(); ph.ipart = h->lme_ipart.as<int32_t>();
     ph.list = h->lme_list.as<uint8_t>(); ph.list_cnt = h->lme_cnt.as<uint16_t>();
     ph.pfx = pfx; ph.total = total;
-    ph.live = h->lme_ctl.as<int32_t>();
+    ph.live = h->lme_ctl.as<int32_t>(); ph.pair_live = h->lme_pair_live.as<int32_t>();
     ph.first = first; ph.cap = cap; ph.batch = batch; ph.n_max = n_max; ph.nseg = lme_nseg(n_max);
     ph.mask = mask;
     return ph;
@@ -272,11 +274,12 @@ LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, con
 int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, int est_shift, int loss, int max_it, int accum_blocks, int problems_bound,
             int poll_from, int poll_every) {
     HIPCHK(hipMemsetAsync(ph.live, 0, sizeof(int32_t) * LME_RING, stream));
+    HIPCHK(hipMemsetAsync(ph.pair_live, 0, sizeof(int32_t) * 2 * (size_t)std::max(ph.batch, 1), stream));
     const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
     const int dense_cap = ph.n_max <= LM_LIST_MAX_N ? ((ph.n_max + 63) / 64) * 64 : 0;
     const size_t smem = sizeof(int32_t) * ((size_t)ph.nseg + 1) + sizeof(uint16_t) * (size_t)dense_cap + 8;
     const dim3 solve_grid((unsigned)(std::max(problems_bound, 1) + 63) / 64);
-    MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>());
+    MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
     for (int r = 0; r <= max_it; ++r) {
         MDRP_LME_ACCUM(kind, est_shift, loss, dim3((unsigned)std::max(accum_blocks, 1)), smem, stream, ph, h->pts.as<double>(),
                        h->dep.as<double>(), r, dense_cap);
@@ -287,7 +290,7 @@ int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, in
             HIPCHK(hipStreamSynchronize(stream));
             if (*h->lme_live_host == 0) break;
         }
-        MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>());
+        MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
     }
     HIPCHK(hipGetLastError());
     return MDRP_OK;
@@ -339,8 +342,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     hipStream_t s = h->stream;
     const int est_shift = (kind == MDRP_CALIB && ro->monodepth_estimate_shift) ? 1 : 0;
     const bool classic = kind >= MDRP_RELPOSE_5PT;              // non-monodepth baselines (mdrp_classic.h)
-    const int mps = kind == MDRP_RELPOSE_5PT ? 12 : 4;          // model slots per sample
-    const int ssz = kind == MDRP_RELPOSE_5PT ? 5 : (kind == MDRP_FUNDAMENTAL_7PT ? 7 : 3); // sample size
+    const int mps = kind == MDRP_RELPOSE_5PT ? 12 : (kind == MDRP_SHARED_6PT ? 16 : 4); // model slots per sample
+    const int ssz = kind == MDRP_RELPOSE_5PT ? 5 : (kind == MDRP_SHARED_6PT ? 6 : (kind == MDRP_FUNDAMENTAL_7PT ? 7 : 3)); // sample size
 
     // ---- group pairs by correspondence count: one sample table per distinct N
     std::vector<int32_t> table_of(batch), tab_n;
@@ -394,7 +397,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     HIPCHK(hipMemcpyAsync(h->table_of_pair.p, table_of.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->nper.p, n_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
     HIPCHK(hipEventRecord(h->ev_tables, s)); // sample tables can be drawn from here on
-    if (kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT) {
+    if (kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) {
         HIPCHK(hipMemcpyAsync(h->cams1.p, cam1, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(h->cams2.p, cam2, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
     }
@@ -448,7 +451,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
     const size_t lo_mask_rows = (size_t)h->num_cu * (size_t)std::max(lo_overlap_waves, 8); // kc_lo launches num_cu * max(overlap waves, 8 | 2) workgroups
-    if (kind == MDRP_RELPOSE_5PT && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
+    if ((kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = SCORE_TILE_BYTES;
     int64_t sum_n = 0;
@@ -527,7 +530,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // The sample tables of the first two chunks do not depend on anything but (seed, N): they are drawn on the (still idle)
         // LO stream while k_prep runs, so the one-wavefront-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
         auto launch_samples = [&](hipStream_t st_, int len_, uint32_t *smp_) {
-            if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            if (ssz == 6) hipLaunchKernelGGL(kc_samples<6>, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            else if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
             else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
             else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(64), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
         };
@@ -557,7 +561,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             struct Stop { hipEvent_t e; hipStream_t s; ~Stop() { (void)hipEventRecord(e, s); } } stop_{v1, st_}; // after the solver launch below
             if (classic) {
                 const dim3 sgrid((r.chunk_len + 63) / 64, batch);
-                if (kind == MDRP_RELPOSE_5PT)
+                if (kind == MDRP_SHARED_6PT)
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_SHARED>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
+                                       h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+                else if (kind == MDRP_RELPOSE_5PT)
                     hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
                                        h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
                 else
@@ -647,7 +654,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 HIPCHK(hipEventRecord(e1, s));
                 h->sweep_launches++;
             }
-            if (mps == 12)
+            if (mps == 16)
+                hipLaunchKernelGGL(k_scan<16>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
+                                   h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
+                                   reinterpret_cast<unsigned long long *>(cnt + 10));
+            else if (mps == 12)
                 hipLaunchKernelGGL(k_scan<12>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
                                    h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
                                    reinterpret_cast<unsigned long long *>(cnt + 10));
@@ -772,11 +783,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
 int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
                     int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1, const mdrp_camera *cam2,
                     const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
-    const bool known_kind = (kind >= 0 && kind <= 2) || kind == MDRP_RELPOSE_5PT || kind == MDRP_FUNDAMENTAL_7PT;
+    const bool known_kind = kind >= 0 && kind <= 5;
     if (!h || batch < 0 || n_max < 0 || !known_kind || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (kind == MDRP_SHARED_6PT && batch > 0 && !cam1) { g_err = "the 6-point estimator needs the principal point in cam1"; return MDRP_ERR_INVALID; }
     if ((kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT) && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
     if (kind <= 2 && batch > 0 && n_max > 0 && (!d1 || !d2)) { g_err = "monodepth estimator needs depths"; return MDRP_ERR_INVALID; }
-    const int mps = kind == MDRP_RELPOSE_5PT ? 12 : 4;
+    const int mps = kind == MDRP_RELPOSE_5PT ? 12 : (kind == MDRP_SHARED_6PT ? 16 : 4);
     h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch; h->lm_cost_evals = 0; h->lm_accum_evals = 0;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
@@ -916,7 +928,7 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
                       &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
-                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota};
+                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota, &h->lme_pair_live};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -1048,10 +1060,10 @@ int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const doubl
 }
 
 int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const double *x2h, int count, mdrp_model *out, int32_t *n_out) {
-    if (!h || count < 0 || (kind != MDRP_RELPOSE_5PT && kind != MDRP_FUNDAMENTAL_7PT) || !out || !n_out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || count < 0 || kind < MDRP_RELPOSE_5PT || kind > MDRP_FUNDAMENTAL_7PT || !out || !n_out) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (count == 0) return MDRP_OK;
     MDRP_ENTER(h);
-    const int K = kind == MDRP_RELPOSE_5PT ? 5 : 7, M = kind == MDRP_RELPOSE_5PT ? MAX_MODELS_5PT : 3;
+    const int K = kind == MDRP_RELPOSE_5PT ? 5 : (kind == MDRP_SHARED_6PT ? 6 : 7), M = kind == MDRP_RELPOSE_5PT ? MAX_MODELS_5PT : (kind == MDRP_SHARED_6PT ? MAX_MODELS_6PT : 3);
     int rc;
     if ((rc = h->unit_a.ensure(sizeof(double) * 3 * K * count)) || (rc = h->unit_b.ensure(sizeof(double) * 3 * K * count)) ||
         (rc = h->unit_e.ensure(sizeof(Model) * M * count)) || (rc = h->unit_f.ensure(sizeof(int32_t) * count)))
@@ -1064,7 +1076,10 @@ int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const
     { const int stage = env_int("MDRP_5PT_STAGE", 99); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_5pt_stage), &stage, sizeof(int))); }
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, s));
 #endif
-    if (kind == MDRP_RELPOSE_5PT)
+    if (kind == MDRP_SHARED_6PT)
+        hipLaunchKernelGGL(kc_solver_unit<CLASSIC_SHARED>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
+                           h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
+    else if (kind == MDRP_RELPOSE_5PT)
         hipLaunchKernelGGL(kc_solver_unit<CLASSIC_RELPOSE>, dim3((count + 63) / 64), dim3(64), SOLVE5_LDS_BYTES, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
     else
@@ -1083,7 +1098,7 @@ int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const
 
 int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model *models, int num_models, const double *x1,
                       const double *x2, int n, double sq_threshold, double *scores, int32_t *counts) {
-    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || kind == 4 || !scores || !counts) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || !scores || !counts) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (num_models == 0) return MDRP_OK;
     MDRP_ENTER(h);
     hipStream_t s = h->stream;
@@ -1146,7 +1161,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
 
 int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1, const double *x2,
                           int n, double sq_threshold, int32_t *candidates) {
-    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || kind == 4 || !candidates || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || !candidates || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (num_models == 0) return MDRP_OK;
     MDRP_ENTER(h);
     hipStream_t s = h->stream;
@@ -1196,7 +1211,7 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
 int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, const double *x1, const double *x2,
                        const double *d1, const double *d2, int n, double scale_reproj, double weight_sampson,
                        const mdrp_bundle_opt *opt, int estimate_shift, double *final_cost) {
-    if (!h || count < 0 || n < 0 || kind < 0 || kind > 5 || kind == 4 || !opt || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (!h || count < 0 || n < 0 || kind < 0 || kind > 5 || !opt || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (count == 0) return MDRP_OK;
     MDRP_ENTER(h);
     hipStream_t s = h->stream;

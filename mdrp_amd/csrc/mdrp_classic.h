@@ -14,10 +14,12 @@ namespace mdrp {
 
 template <int CK> struct ClassicTraits;
 template <> struct ClassicTraits<CLASSIC_RELPOSE> { static constexpr int K = 5, MPS = 12, MAXM = MAX_MODELS_5PT, NP = 5; static constexpr bool POSE = true; };
+template <> struct ClassicTraits<CLASSIC_SHARED> { static constexpr int K = 6, MPS = 16, MAXM = MAX_MODELS_6PT, NP = 6; static constexpr bool POSE = false; };
 template <> struct ClassicTraits<CLASSIC_FUND> { static constexpr int K = 7, MPS = 4, MAXM = 3, NP = 7; static constexpr bool POSE = false; };
 
 // ------------------------------------------------------------------------------------------------ prep
 // kind 3: Camera::unproject, threshold * (1/f1 + 1/f2) / 2 (estimate_relative_pose @0x21f800)
+// kind 4: x <- (x - pp) / s with the same shared scale s (estimate_shared_focal_relative_pose @0x2205a0; pp in cam1[pair].p[0..1])
 // kind 5: normalize_points(normalize_scale, normalize_centroid, shared_scale) @0x4f6ae0: x <- (x - centroid) / s,
 //         s = sum(|x1 - c1| + |x2 - c2|) / (sqrt2 N); thresholds / s (estimate_fundamental @0x221a00)
 __global__ __launch_bounds__(256) void kc_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
@@ -47,6 +49,10 @@ __global__ __launch_bounds__(256) void kc_prep(RunParams rp, const double *__res
         const double inv_n = 1.0 / (double)(n > 0 ? n : 1);
         cx1 = (red[0][0] + red[1][0] + red[2][0] + red[3][0]) * inv_n; cy1 = (red[0][1] + red[1][1] + red[2][1] + red[3][1]) * inv_n;
         cx2 = (red[0][2] + red[1][2] + red[2][2] + red[3][2]) * inv_n; cy2 = (red[0][3] + red[1][3] + red[2][3] + red[3][3]) * inv_n;
+        if (rp.kind == CLASSIC_SHARED) { // estimate_shared_focal_relative_pose: the caller's principal point instead of the centroids
+            const CamDev a = cam1[pair];
+            cx1 = cx2 = a.p[0]; cy1 = cy2 = a.p[1];
+        }
         double acc = 0;
         for (int i = tid; i < n; i += 256) {
             const double a = x1[2 * (base + i)] - cx1, b = x1[2 * (base + i) + 1] - cy1, c = x2[2 * (base + i)] - cx2, d = x2[2 * (base + i) + 1] - cy2;
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(256) void kc_prep(RunParams rp, const double *__res
         s.inlier_ratio = 0.0; s.model_score = DBL_MAX;
         model_identity(s.best);
         if (rp.kind == CLASSIC_FUND) { double *F = model_F(s.best); for (int q = 0; q < 9; ++q) F[q] = (q % 4 == 0) ? 1.0 : 0.0; }
-        if (rp.score_initial && ok && rp.kind == CLASSIC_RELPOSE) { // the reset identity pose has E = 0: no inliers, score N eps^2, one LO
+        if (rp.score_initial && ok && rp.kind != CLASSIC_FUND) { // the reset identity pose has E = 0: no inliers, score N eps^2, one LO
             s.best_min_score = s.sq_thr * (double)n;
             s.model_score = s.best_min_score;
             s.refinements = 1;
@@ -189,7 +195,8 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
     if (!ps.active) return;
     const bool live = it < rp.chunk_len;
     int n = 0;
-    Model out[MAXM];
+    Model out[CK == CLASSIC_FUND ? MAXM : 1]; // the 5- and 6-point solvers write their poses straight into their slots
+    const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * MPS;
     if (live) {
         const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it) * K;
         double x1h[K][3], x2h[K][3];
@@ -201,7 +208,8 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
             x1h[k][0] = p01.x * p45.x; x1h[k][1] = p01.y * p45.x; x1h[k][2] = p45.x;
             x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
         }
-        if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt(x1h, x2h, out, lds_solve5_store());
+        if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt_emit(x1h, x2h, lds_solve5_store(), [&](const Model &m, int k) { models[slot0 + k] = m; });
+        else if (CK == CLASSIC_SHARED) n = solver_relpose_6pt_emit(x1h, x2h, [&](const Model &m, int k) { models[slot0 + k] = m; });
         else { extern __shared__ double solve5_lds[]; n = solver_fundamental_7pt(x1h, x2h, out, solve5_lds + (threadIdx.x & 63), 64); }
     }
     const int lane = threadIdx.x & 63;
@@ -216,7 +224,6 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
     if (lane == 63 && tot > 0) base = atomicAdd(&model_count[2 * pair], tot);
     base = __shfl(base, 63, 64);
     if (!live) return;
-    const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * MPS;
     int pos = base + pre - n;
     const size_t tag_base = (size_t)pair * rp.slot_stride;
 #pragma unroll
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
         *reinterpret_cast<int4 *>(slot_inl + slot0 + 4 * g) =
             make_int4(n > 4 * g ? -2 : -1, n > 4 * g + 1 ? -2 : -1, n > 4 * g + 2 ? -2 : -1, n > 4 * g + 3 ? -2 : -1);
     for (int k = 0; k < n; ++k) {
-        models[slot0 + k] = out[k];
+        if (CK == CLASSIC_FUND) models[slot0 + k] = out[k];
         tags[tag_base + pos] = (uint32_t)((rp.chunk_off + it) * MPS + k);
         ++pos;
     }
@@ -674,6 +681,7 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
 #pragma unroll
         for (int i = 0; i < 9; ++i) F[i] = O[i] * nrm;
     }
+    if (CK == CLASSIC_SHARED) { best.f1 *= ps.norm; best.f2 *= ps.norm; } // back to pixels
     res.model = best;
     if (threadIdx.x == 0) results[pair] = res;
 }
@@ -690,7 +698,8 @@ __global__ __launch_bounds__(64) void kc_solver_unit(int count, const double *__
         for (int c = 0; c < 3; ++c) { a[k][c] = x1h[(size_t)3 * K * i + 3 * k + c]; b[k][c] = x2h[(size_t)3 * K * i + 3 * k + c]; }
     Model m[MAXM];
     extern __shared__ double solve5_lds[];
-    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m, lds_solve5_store()) : solver_fundamental_7pt(a, b, m, solve5_lds + (threadIdx.x & 63), 64);
+    const int n = (CK == CLASSIC_RELPOSE) ? solver_relpose_5pt(a, b, m, lds_solve5_store())
+                  : (CK == CLASSIC_SHARED ? solver_relpose_6pt(a, b, m) : solver_fundamental_7pt(a, b, m, solve5_lds + (threadIdx.x & 63), 64));
     n_out[i] = n;
     for (int k = 0; k < n; ++k) out[(size_t)MAXM * i + k] = m[k];
 }

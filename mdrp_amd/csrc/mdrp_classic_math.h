@@ -397,7 +397,12 @@ __device__ int g_5pt_stage = 99; // experiment: stop after stage k (tools/stage_
 // may alias).  On the device both live in LDS, one column of 64 lanes per element (in scratch memory the solver spent 90 % of
 // its time waiting for them); on the host they are plain local arrays.
 struct Solve5Store { double *C; int cs; RootStack rs; };
-MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9], const Solve5Store &store) {
+// emit(const double E[9]) is called for every essential matrix, in the order of the roots: the device solver hands each one straight
+// on to motion_from_essential and to the model slots (ten matrices and ten poses held in arrays cost the kernel 420 registers)
+template <class Emit>
+MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Emit &&emit) {
+    double Es[1][9]; // (only the experiment hooks below write here)
+    (void)Es;
     // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]: the only copy of the null space that is kept
     double El[3][3][4];
     {
@@ -579,10 +584,15 @@ MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double
             for (int j = 0; j < 3; ++j) { e[3 * i + j] = x * El[i][j][0] + y * El[i][j][1] + z * El[i][j][2] + El[i][j][3]; nrm += e[3 * i + j] * e[3 * i + j]; }
         nrm = 1.0 / sqrt(nrm);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) Es[n_out][k] = e[k] * nrm;
+        for (int k = 0; k < 9; ++k) e[k] *= nrm;
+        emit(e);
         ++n_out;
     }
     return n_out;
+}
+MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9], const Solve5Store &store) {
+    int n = 0;
+    return relpose_5pt_emit(x1h, x2h, store, [&](const double *e) { for (int k = 0; k < 9; ++k) Es[n][k] = e[k]; ++n; });
 }
 
 // ---------------------------------------------------------------- E -> poses (motion_from_essential @0x1dd540)
@@ -595,7 +605,8 @@ MDRP_HD bool cheirality_bearing(const double R[9], const double t[3], const doub
     const double b2 = x2[0] * t[0] + x2[1] * t[1] + x2[2] * t[2];
     return (b1 - a * b2) > 0.0 && (-a * b1 + b2) > 0.0;
 }
-MDRP_HD int motion_from_essential(const double E[9], const double (*x1h)[3], const double (*x2h)[3], int npts, Model *out) {
+template <class Emit>
+MDRP_HD int motion_from_essential_emit(const double E[9], const double (*x1h)[3], const double (*x2h)[3], int npts, Emit &&emit) {
     const double c0[3] = {E[0], E[3], E[6]}, c1[3] = {E[1], E[4], E[7]}, c2[3] = {E[2], E[5], E[8]};
     double u12[3], u13[3], u23[3];
     cross3(c0, c1, u12); cross3(c0, c2, u13); cross3(c1, c2, u23);
@@ -635,7 +646,8 @@ MDRP_HD int motion_from_essential(const double E[9], const double (*x1h)[3], con
                 model_identity(m);
                 R_to_quat(R, m.q);
                 m.t[0] = t[0]; m.t[1] = t[1]; m.t[2] = t[2];
-                out[n_out++] = m;
+                emit(m);
+                ++n_out;
             }
             for (int k = 0; k < 3; ++k) t[k] = -t[k];
         }
@@ -645,17 +657,351 @@ MDRP_HD int motion_from_essential(const double E[9], const double (*x1h)[3], con
     return n_out;
 }
 
-constexpr int MAX_MODELS_5PT = 10; // one pose per essential matrix passes the cheirality of all five points (generic data)
-MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_5PT]*/, const Solve5Store &store) {
-    double Es[10][9];
-    const int ne = relpose_5pt_E(x1h, x2h, Es, store);
+MDRP_HD int motion_from_essential(const double E[9], const double (*x1h)[3], const double (*x2h)[3], int npts, Model *out) {
     int n = 0;
-    for (int i = 0; i < ne && n < MAX_MODELS_5PT; ++i) {
-        Model tmp[4];
-        const int k = motion_from_essential(Es[i], x1h, x2h, 5, tmp);
-        for (int j = 0; j < k && n < MAX_MODELS_5PT; ++j) out[n++] = tmp[j];
-    }
+    return motion_from_essential_emit(E, x1h, x2h, npts, [&](const Model &m) { out[n++] = m; });
+}
+
+constexpr int MAX_MODELS_5PT = 10; // one pose per essential matrix passes the cheirality of all five points (generic data)
+// emit(const Model &, int k) for the k-th pose of the sample (k < MAX_MODELS_5PT), in the reference's order
+template <class Emit>
+MDRP_HD int solver_relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Emit &&emit) {
+    int n = 0;
+    relpose_5pt_emit(x1h, x2h, store, [&](const double *e) {
+        if (n < MAX_MODELS_5PT) motion_from_essential_emit(e, x1h, x2h, 5, [&](const Model &m) { if (n < MAX_MODELS_5PT) { emit(m, n); ++n; } });
+    });
     return n;
+}
+MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_5PT]*/, const Solve5Store &store) {
+    return solver_relpose_5pt_emit(x1h, x2h, store, [&](const Model &m, int k) { out[k] = m; });
+}
+
+// ---------------------------------------------------------------- 6-point, one shared unknown focal length
+// relpose_6pt_shared_focal of the reference (SharedFocalRelativePoseEstimator::generate_models; estimate_shared_focal_relative_pose,
+// /root/reference/eval_shared_f.py:161).  The binary uses a generated elimination template and a 15 x 15 action matrix; the solution
+// SET belongs to the polynomial system, and this restates the published formulation (Stewenius et al. 2005; as a polynomial
+// eigenvalue problem Kukelova, Bujnak, Pajdla 2008):  F = x N0 + y N1 + N2 on the null space of the six epipolar constraints,
+// Q = diag(1, 1, w), w = 1 / f^2:  2 F Q F' Q F - tr(F Q F' Q) F = 0 and det F = 0 are ten cubics in (x, y), quadratic in w:
+// (M0 + w M1 + w^2 M2) v = 0, v = (x3, x2y, xy2, y3, x2, xy, y2, x, y, 1).  In u = 1 / w = f^2 the leading matrix M0 is regular:
+// the eigenvalues of the 20 x 20 companion matrix [[0, I], [-M0^-1 M2, -M0^-1 M1]] (Hessenberg reduction + shifted QR, below), five of
+// them the spurious u = 0.  Real u > 0 -> f, null vector of M(w) -> (x, y) -> F -> E = diag(1,1,1/f) F diag(1,1,1/f) -> poses with the
+// cheirality of all six points.  Solutions come out by ascending focal length (the binary's order is the order of Eigen's
+// eigenvalues; pinned: the sets, and the estimator's trajectory — 48 / 48 identical results without that order).
+// One lane per sample; the matrices (about 1100 doubles) are dynamically indexed and live in the lane's scratch memory.
+MDRP_HD double sgn_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
+// real and imaginary parts of the eigenvalues of a (n x n, row-major, destroyed); false if the QR iteration did not converge
+MDRP_HD bool hessenberg_qr_eigenvalues(double *a, int n, double *wr, double *wi) {
+#define HA(i, j) a[(i) * n + (j)]
+    for (int m = 1; m < n - 1; ++m) {
+        double x = 0.0;
+        int piv = m;
+        for (int j = m; j < n; ++j)
+            if (fabs(HA(j, m - 1)) > fabs(x)) { x = HA(j, m - 1); piv = j; }
+        if (piv != m) {
+            for (int j = m - 1; j < n; ++j) { const double t = HA(piv, j); HA(piv, j) = HA(m, j); HA(m, j) = t; }
+            for (int j = 0; j < n; ++j) { const double t = HA(j, piv); HA(j, piv) = HA(j, m); HA(j, m) = t; }
+        }
+        if (x != 0.0)
+            for (int i = m + 1; i < n; ++i) {
+                double y = HA(i, m - 1);
+                if (y != 0.0) {
+                    y /= x;
+                    HA(i, m - 1) = y;
+                    for (int j = m; j < n; ++j) HA(i, j) -= y * HA(m, j);
+                    for (int j = 0; j < n; ++j) HA(j, m) += y * HA(j, i);
+                }
+            }
+    }
+    for (int i = 2; i < n; ++i)
+        for (int j = 0; j < i - 1; ++j) HA(i, j) = 0.0;
+    int nn = n - 1, its = 0;
+    double t = 0.0, anorm = 0.0, p = 0, q = 0, r = 0, s, w, x, y, z;
+    for (int i = 0; i < n; ++i)
+        for (int j = (i > 0 ? i - 1 : 0); j < n; ++j) anorm += fabs(HA(i, j));
+    while (nn >= 0) {
+        int l;
+        for (l = nn; l >= 1; --l) {
+            s = fabs(HA(l - 1, l - 1)) + fabs(HA(l, l));
+            if (s == 0.0) s = anorm;
+            if (fabs(HA(l, l - 1)) + s == s) { HA(l, l - 1) = 0.0; break; }
+        }
+        x = HA(nn, nn);
+        if (l == nn) { wr[nn] = x + t; wi[nn] = 0.0; --nn; its = 0; continue; }
+        y = HA(nn - 1, nn - 1);
+        w = HA(nn, nn - 1) * HA(nn - 1, nn);
+        if (l == nn - 1) {
+            p = 0.5 * (y - x);
+            q = p * p + w;
+            z = sqrt(fabs(q));
+            x += t;
+            if (q >= 0.0) {
+                z = p + sgn_of(z, p);
+                wr[nn - 1] = wr[nn] = x + z;
+                if (z != 0.0) wr[nn] = x - w / z;
+                wi[nn - 1] = wi[nn] = 0.0;
+            } else {
+                wr[nn - 1] = wr[nn] = x + p;
+                wi[nn - 1] = z; wi[nn] = -z;
+            }
+            nn -= 2; its = 0;
+            continue;
+        }
+        if (its == 60) return false;
+        if (its == 10 || its == 20 || its == 30 || its == 40) { // exceptional shift
+            t += x;
+            for (int i = 0; i <= nn; ++i) HA(i, i) -= x;
+            s = fabs(HA(nn, nn - 1)) + fabs(HA(nn - 1, nn - 2));
+            y = x = 0.75 * s;
+            w = -0.4375 * s * s;
+        }
+        ++its;
+        int m;
+        for (m = nn - 2; m >= l; --m) {
+            z = HA(m, m);
+            r = x - z; s = y - z;
+            p = (r * s - w) / HA(m + 1, m) + HA(m, m + 1);
+            q = HA(m + 1, m + 1) - z - r - s;
+            r = HA(m + 2, m + 1);
+            s = fabs(p) + fabs(q) + fabs(r);
+            p /= s; q /= s; r /= s;
+            if (m == l) break;
+            const double u = fabs(HA(m, m - 1)) * (fabs(q) + fabs(r));
+            const double v = fabs(p) * (fabs(HA(m - 1, m - 1)) + fabs(z) + fabs(HA(m + 1, m + 1)));
+            if (u + v == v) break;
+        }
+        for (int i = m + 2; i <= nn; ++i) { HA(i, i - 2) = 0.0; if (i != m + 2) HA(i, i - 3) = 0.0; }
+        for (int k = m; k <= nn - 1; ++k) {
+            if (k != m) {
+                p = HA(k, k - 1); q = HA(k + 1, k - 1); r = 0.0;
+                if (k != nn - 1) r = HA(k + 2, k - 1);
+                if ((x = fabs(p) + fabs(q) + fabs(r)) != 0.0) { p /= x; q /= x; r /= x; }
+            }
+            if ((s = sgn_of(sqrt(p * p + q * q + r * r), p)) != 0.0) {
+                if (k == m) { if (l != m) HA(k, k - 1) = -HA(k, k - 1); }
+                else HA(k, k - 1) = -s * x;
+                p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
+                for (int j = k; j <= nn; ++j) {
+                    p = HA(k, j) + q * HA(k + 1, j);
+                    if (k != nn - 1) { p += r * HA(k + 2, j); HA(k + 2, j) -= p * z; }
+                    HA(k + 1, j) -= p * y; HA(k, j) -= p * x;
+                }
+                const int mmin = nn < k + 3 ? nn : k + 3;
+                for (int i = l; i <= mmin; ++i) {
+                    p = x * HA(i, k) + y * HA(i, k + 1);
+                    if (k != nn - 1) { p += z * HA(i, k + 2); HA(i, k + 2) -= p * r; }
+                    HA(i, k + 1) -= p * q; HA(i, k) -= p;
+                }
+            }
+        }
+    }
+    return true;
+#undef HA
+}
+
+// polynomials in (x, y) of degree <= 3 as 10 coefficients in the order x3, x2y, xy2, y3, x2, xy, y2, x, y, 1
+MDRP_HD constexpr int six_exp_x(int i) { return i == 0 ? 3 : (i == 1 || i == 4) ? 2 : (i == 2 || i == 5 || i == 7) ? 1 : 0; }
+MDRP_HD constexpr int six_exp_y(int i) { return i == 3 ? 3 : (i == 2 || i == 6) ? 2 : (i == 1 || i == 5 || i == 8) ? 1 : 0; }
+MDRP_HD constexpr int six_index(int a, int b) { return a + b == 3 ? 3 - a : (a + b == 2 ? 6 - a : (a + b == 1 ? 8 - a : 9)); }
+MDRP_HD void six_mul_add(const double *a, const double *b, double s, double *out) { // out += s a b (degrees above 3 do not occur)
+    for (int i = 0; i < 10; ++i) {
+        if (a[i] == 0.0) continue;
+        for (int j = 0; j < 10; ++j) {
+            if (b[j] == 0.0) continue;
+            const int ex = six_exp_x(i) + six_exp_x(j), ey = six_exp_y(i) + six_exp_y(j);
+            if (ex + ey <= 3) out[six_index(ex, ey)] += s * a[i] * b[j];
+        }
+    }
+}
+// null vector of a 10 x 10 matrix (row-major, destroyed) by complete pivoting; returns |last pivot| / |first pivot|
+MDRP_HD double six_null_vector(double *M, double *v) {
+    int cp[10];
+    for (int i = 0; i < 10; ++i) cp[i] = i;
+    double first = 0.0, last = 0.0;
+    for (int k = 0; k < 10; ++k) {
+        int pr = k, pc = k;
+        double best = -1.0;
+        for (int i = k; i < 10; ++i)
+            for (int j = k; j < 10; ++j)
+                if (fabs(M[i * 10 + j]) > best) { best = fabs(M[i * 10 + j]); pr = i; pc = j; }
+        if (k == 0) first = best;
+        if (k == 9) { last = best; break; }
+        if (pr != k) for (int j = 0; j < 10; ++j) { const double t = M[pr * 10 + j]; M[pr * 10 + j] = M[k * 10 + j]; M[k * 10 + j] = t; }
+        if (pc != k) {
+            for (int i = 0; i < 10; ++i) { const double t = M[i * 10 + pc]; M[i * 10 + pc] = M[i * 10 + k]; M[i * 10 + k] = t; }
+            const int t = cp[pc]; cp[pc] = cp[k]; cp[k] = t;
+        }
+        const double piv = M[k * 10 + k];
+        if (piv == 0.0) break;
+        for (int i = k + 1; i < 10; ++i) {
+            const double f = M[i * 10 + k] / piv;
+            if (f != 0.0) for (int j = k; j < 10; ++j) M[i * 10 + j] -= f * M[k * 10 + j];
+        }
+    }
+    double y[10];
+    y[9] = 1.0;
+    for (int i = 8; i >= 0; --i) {
+        double s = 0.0;
+        for (int j = i + 1; j < 10; ++j) s += M[i * 10 + j] * y[j];
+        y[i] = M[i * 10 + i] != 0.0 ? -s / M[i * 10 + i] : 0.0;
+    }
+    for (int i = 0; i < 10; ++i) v[cp[i]] = y[i];
+    return first > 0.0 ? last / first : 1.0;
+}
+
+// Gauss-Newton on the ten equations in (x, y, w): three steps bring the residual of an eigenpair to rounding level
+MDRP_HD double six_pow(double x, int a) { return a == 0 ? 1.0 : (a == 1 ? x : (a == 2 ? x * x : x * x * x)); }
+MDRP_HD void six_polish(const double *M0, const double *M1, const double *M2, double &px, double &py, double &pw) {
+    for (int it = 0; it < 3; ++it) {
+        const double x = px, y = py, w = pw;
+        double mono[10], dmx[10], dmy[10];
+        for (int e = 0; e < 10; ++e) {
+            const int a = six_exp_x(e), b = six_exp_y(e);
+            mono[e] = six_pow(x, a) * six_pow(y, b);
+            dmx[e] = a > 0 ? a * six_pow(x, a - 1) * six_pow(y, b) : 0.0;
+            dmy[e] = b > 0 ? b * six_pow(x, a) * six_pow(y, b - 1) : 0.0;
+        }
+        double JtJ[9], Jtr[3] = {0, 0, 0};
+        for (int a = 0; a < 9; ++a) JtJ[a] = 0.0;
+        for (int r = 0; r < 10; ++r) {
+            double g = 0, gx = 0, gy = 0, gw = 0;
+            for (int e = 0; e < 10; ++e) {
+                const double c = M0[r * 10 + e] + w * (M1[r * 10 + e] + w * M2[r * 10 + e]);
+                g += c * mono[e]; gx += c * dmx[e]; gy += c * dmy[e];
+                gw += (M1[r * 10 + e] + 2.0 * w * M2[r * 10 + e]) * mono[e];
+            }
+            const double J[3] = {gx, gy, gw};
+            for (int a = 0; a < 3; ++a) { Jtr[a] += J[a] * g; for (int b = 0; b < 3; ++b) JtJ[3 * a + b] += J[a] * J[b]; }
+        }
+        double d[3];
+        if (!solve3x3(JtJ, Jtr, d)) return;
+        px = x - d[0]; py = y - d[1]; pw = w - d[2];
+    }
+}
+
+constexpr int MAX_MODELS_6PT = 15;
+constexpr double SIX_MIN_U = 1e-5; // the defective cluster of the five spurious u = 0 spreads to ~1e-7 on scale-normalised points; f < 0.003 is no camera
+// emit(const Model &, int k) for the k-th model (pose, f1 = f2 = f) of the sample, k < MAX_MODELS_6PT
+template <class Emit>
+MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[3], Emit &&emit) {
+    double Nq[27]; // three null vectors, each the column-major vec of a 3 x 3 matrix: F(i, j) = N[3 j + i]
+    {
+        double A[54];
+        epipolar_columns<6>(x1h, x2h, A, 1);
+        fullpiv_nullspace<6>(A, 1, Nq);
+    }
+    double F[3][3][10];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            for (int e = 0; e < 10; ++e) F[i][j][e] = 0.0;
+            F[i][j][7] = Nq[3 * j + i]; F[i][j][8] = Nq[9 + 3 * j + i]; F[i][j][9] = Nq[18 + 3 * j + i];
+        }
+    double S0[3][3][10], S1[3][3][10], tr0[10], tr1[10], tr2[10];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            for (int e = 0; e < 10; ++e) { S0[i][k][e] = 0.0; S1[i][k][e] = 0.0; }
+            six_mul_add(F[i][0], F[k][0], 1.0, S0[i][k]); six_mul_add(F[i][1], F[k][1], 1.0, S0[i][k]);
+            six_mul_add(F[i][2], F[k][2], 1.0, S1[i][k]);
+        }
+    for (int e = 0; e < 10; ++e) {
+        tr0[e] = S0[0][0][e] + S0[1][1][e];
+        tr1[e] = S1[0][0][e] + S1[1][1][e] + S0[2][2][e];
+        tr2[e] = S1[2][2][e];
+    }
+    double M0[100], M1[100], M2[100];
+    for (int e = 0; e < 100; ++e) { M0[e] = 0.0; M1[e] = 0.0; M2[e] = 0.0; }
+    for (int i = 0; i < 3; ++i)
+        for (int l = 0; l < 3; ++l) {
+            double *t0 = M0 + (3 * i + l) * 10, *t1 = M1 + (3 * i + l) * 10, *t2 = M2 + (3 * i + l) * 10;
+            six_mul_add(S0[i][0], F[0][l], 2.0, t0); six_mul_add(S0[i][1], F[1][l], 2.0, t0); six_mul_add(tr0, F[i][l], -1.0, t0);
+            six_mul_add(S1[i][0], F[0][l], 2.0, t1); six_mul_add(S1[i][1], F[1][l], 2.0, t1); six_mul_add(S0[i][2], F[2][l], 2.0, t1);
+            six_mul_add(tr1, F[i][l], -1.0, t1);
+            six_mul_add(S1[i][2], F[2][l], 2.0, t2); six_mul_add(tr2, F[i][l], -1.0, t2);
+        }
+    { // det F
+        double m[10], *d = M0 + 90;
+        for (int e = 0; e < 10; ++e) m[e] = 0.0;
+        six_mul_add(F[1][1], F[2][2], 1.0, m); six_mul_add(F[1][2], F[2][1], -1.0, m); six_mul_add(m, F[0][0], 1.0, d);
+        for (int e = 0; e < 10; ++e) m[e] = 0.0;
+        six_mul_add(F[1][0], F[2][2], 1.0, m); six_mul_add(F[1][2], F[2][0], -1.0, m); six_mul_add(m, F[0][1], -1.0, d);
+        for (int e = 0; e < 10; ++e) m[e] = 0.0;
+        six_mul_add(F[1][0], F[2][1], 1.0, m); six_mul_add(F[1][1], F[2][0], -1.0, m); six_mul_add(m, F[0][2], 1.0, d);
+    }
+    // X = M0^-1 [M2 | M1]: LU with partial pivoting on a copy of M0, 20 right-hand sides; then the companion matrix
+    double C[400], wr[20], wi[20];
+    {
+        double L[100], B[200];
+        for (int e = 0; e < 100; ++e) L[e] = M0[e];
+        for (int i = 0; i < 10; ++i)
+            for (int j = 0; j < 10; ++j) { B[i * 20 + j] = M2[i * 10 + j]; B[i * 20 + 10 + j] = M1[i * 10 + j]; }
+        for (int k = 0; k < 10; ++k) {
+            int piv = k;
+            for (int i = k + 1; i < 10; ++i) if (fabs(L[i * 10 + k]) > fabs(L[piv * 10 + k])) piv = i;
+            if (L[piv * 10 + k] == 0.0) return 0;
+            if (piv != k) {
+                for (int j = 0; j < 10; ++j) { const double t = L[piv * 10 + j]; L[piv * 10 + j] = L[k * 10 + j]; L[k * 10 + j] = t; }
+                for (int j = 0; j < 20; ++j) { const double t = B[piv * 20 + j]; B[piv * 20 + j] = B[k * 20 + j]; B[k * 20 + j] = t; }
+            }
+            for (int i = k + 1; i < 10; ++i) {
+                const double f = L[i * 10 + k] / L[k * 10 + k];
+                if (f == 0.0) continue;
+                for (int j = k; j < 10; ++j) L[i * 10 + j] -= f * L[k * 10 + j];
+                for (int j = 0; j < 20; ++j) B[i * 20 + j] -= f * B[k * 20 + j];
+            }
+        }
+        for (int i = 9; i >= 0; --i)
+            for (int j = 0; j < 20; ++j) {
+                double s = B[i * 20 + j];
+                for (int k = i + 1; k < 10; ++k) s -= L[i * 10 + k] * B[k * 20 + j];
+                B[i * 20 + j] = s / L[i * 10 + i];
+            }
+        for (int e = 0; e < 400; ++e) C[e] = 0.0;
+        for (int i = 0; i < 10; ++i) {
+            C[i * 20 + 10 + i] = 1.0;
+            for (int j = 0; j < 20; ++j) C[(10 + i) * 20 + j] = -B[i * 20 + j];
+        }
+    }
+    if (!hessenberg_qr_eigenvalues(C, 20, wr, wi)) return 0;
+    double us[20];
+    int nu = 0;
+    for (int i = 0; i < 20; ++i)
+        if (fabs(wi[i]) <= 1e-9 * (fabs(wr[i]) + 1e-300) && wr[i] > SIX_MIN_U) us[nu++] = wr[i];
+    for (int i = 1; i < nu; ++i) { const double t = us[i]; int j = i - 1; while (j >= 0 && us[j] > t) { us[j + 1] = us[j]; --j; } us[j + 1] = t; }
+    int n_out = 0;
+    for (int s = 0; s < nu && n_out < MAX_MODELS_6PT; ++s) {
+        const double w = 1.0 / us[s];
+        double *Mw = C, v[10]; // the companion matrix is dead: reuse its storage
+        for (int e = 0; e < 100; ++e) Mw[e] = M0[e] + w * (M1[e] + w * M2[e]);
+        const double res = six_null_vector(Mw, v);
+        if (!(res < 1e-6) || !(fabs(v[9]) > 0.0)) continue;
+        double x = v[7] / v[9], y = v[8] / v[9], wv = w;
+        six_polish(M0, M1, M2, x, y, wv);
+        if (!(wv > 0.0)) continue;
+        const double f = sqrt(1.0 / wv), invf = 1.0 / f;
+        double E[9], nrm = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                const double Fij = x * Nq[3 * j + i] + y * Nq[9 + 3 * j + i] + Nq[18 + 3 * j + i];
+                E[3 * i + j] = Fij * (i == 2 ? invf : 1.0) * (j == 2 ? invf : 1.0);
+                nrm += E[3 * i + j] * E[3 * i + j];
+            }
+        nrm = 1.0 / sqrt(nrm);
+        for (int e = 0; e < 9; ++e) E[e] *= nrm;
+        double b1[6][3], b2[6][3]; // bearings K^-1 x, unit length
+        for (int p = 0; p < 6; ++p) {
+            const double a0 = x1h[p][0] * invf, a1 = x1h[p][1] * invf, a2 = x1h[p][2];
+            const double c0 = x2h[p][0] * invf, c1 = x2h[p][1] * invf, c2 = x2h[p][2];
+            const double na = 1.0 / sqrt(a0 * a0 + a1 * a1 + a2 * a2), nb = 1.0 / sqrt(c0 * c0 + c1 * c1 + c2 * c2);
+            b1[p][0] = a0 * na; b1[p][1] = a1 * na; b1[p][2] = a2 * na;
+            b2[p][0] = c0 * nb; b2[p][1] = c1 * nb; b2[p][2] = c2 * nb;
+        }
+        motion_from_essential_emit(E, b1, b2, 6, [&](const Model &m) {
+            if (n_out < MAX_MODELS_6PT) { Model o = m; o.f1 = f; o.f2 = f; emit(o, n_out); ++n_out; }
+        });
+    }
+    return n_out;
+}
+MDRP_HD int solver_relpose_6pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_6PT]*/) {
+    return solver_relpose_6pt_emit(x1h, x2h, [&](const Model &m, int k) { out[k] = m; });
 }
 
 // plain local storage (host tests; not for the device: these arrays would land in scratch memory)

@@ -68,6 +68,8 @@ struct LmePhase {
     const int32_t *pfx;     // [batch + 1] dense problem indices of pair p: [pfx[p], pfx[p + 1])
     const int32_t *total;   // number of problems of the phase (device side: only the scan knows how many triggers there are)
     int32_t *live;          // [LME_RING] problems still iterating after the round
+    int32_t *pair_live;     // [2][batch] live problems per pair after round r in half r & 1 (k_lme_solve); lets the cost sweep of a
+                            // pair without live problems leave after its first round trip
     int first, cap;         // this pass handles the dense problems [first, first + cap)
     int batch, n_max, nseg;
     const uint8_t *mask;    // [batch][n_max] record mask (the inlier-only final refinement) or null
@@ -165,12 +167,13 @@ __device__ __forceinline__ void wave_reduce_scatter(const double *acc, double *o
 // LOSS: the phase's loss type when it is known at compile time (1 = TRUNCATED: every LO refinement), -1 = read per problem
 template <int KIND, int LOSS>
 __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *__restrict__ st, const double *__restrict__ pts,
-                                                 const double *__restrict__ dep) {
+                                                 const double *__restrict__ dep, int live_half /*-1: the initial sweep, every problem is live*/) {
     __shared__ double s_state[LME_STAGE][LME_HEAD];
     __shared__ int s_idx[LME_STAGE];
     const int pair = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
     const int n = st[pair].n;
-    if (seg * LME_SEG >= n) return;
+    const int pl = live_half >= 0 ? ph.pair_live[(size_t)live_half * ph.batch + pair] : 1;
+    if (seg * LME_SEG >= n || pl == 0) return;
     const int cnt = lme_count(ph);
     const int j0 = max(ph.pfx[pair] - ph.first, 0), j1 = min(ph.pfx[pair + 1] - ph.first, cnt);
     if (j0 >= j1) return;
@@ -179,21 +182,16 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
     double ra[LME_RPT], rb[LME_RPT], rc[LME_RPT], rd[LME_RPT], e1[LME_RPT], e2[LME_RPT];
     bool ok[LME_RPT];
     for (int base = j0; base < j1; base += LME_STAGE) {
-        // which of the next LME_STAGE problems of this pair have a model waiting for its cost?  (lane l looks at problem base + l)
-        const int jl = base + lane;
-        bool live = false;
-        if (lane < LME_STAGE && jl < j1) { const LmProb *P = ph.probs + jl; live = P->status != 0 && P->has_cand != 0; }
-        const unsigned long long lb = __ballot(live);
-        const int k = __popcll(lb);
-        if (k == 0) continue;
+        // One round trip: the headers (expanded state, loss parameters, flags) of the next LME_STAGE problems of this pair go to
+        // LDS whether they are live or not — their addresses depend on the pair alone — together with the records; which of them
+        // have a model waiting for its cost is read from the staged flags afterwards.
+        const int kk = min(LME_STAGE, j1 - base);
         __syncthreads(); // previous pass done with the stage
-        if (live) s_idx[__popcll(lb & lt)] = jl;
-        __syncthreads();
-        for (int e = lane; e < k * LME_HEAD; e += 64) {
+        for (int e = lane; e < kk * LME_HEAD; e += 64) {
             const int r = e / LME_HEAD, f = e - r * LME_HEAD;
-            s_state[r][f] = reinterpret_cast<const double *>(ph.probs + s_idx[r])[f];
+            s_state[r][f] = reinterpret_cast<const double *>(ph.probs + base + r)[f];
         }
-        if (!loaded) { // the records, once, while the states are in flight
+        if (!loaded) { // the records, once, while the headers are in flight
             loaded = true;
             const double *pp = pts + (size_t)pair * ph.n_max * PT_STRIDE;
             const double *dd = dep + (size_t)pair * ph.n_max * 2;
@@ -212,9 +210,16 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
             }
         }
         __syncthreads();
+        bool live = false;
+        if (lane < kk) { const int2 fl = *reinterpret_cast<const int2 *>(&s_state[lane][39]); live = fl.x != 0 && fl.y != 0; } // status, has_cand
+        const unsigned long long lb = __ballot(live);
+        const int k = __popcll(lb);
+        if (k == 0) continue;
+        if (live) s_idx[__popcll(lb & lt)] = lane;
+        __syncthreads();
         for (int q = 0; q < k; ++q) {
-            const int j = s_idx[q];
-            const double *S = s_state[q];
+            const int sl = s_idx[q], j = base + sl;
+            const double *S = s_state[sl];
             LmState stt;
 #pragma unroll
             for (int i = 0; i < 9; ++i) { stt.R[i] = S[i]; stt.E[i] = S[17 + i]; stt.F[i] = S[26 + i]; }
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(64) void k_lme_solve(LmePhase ph, int round) {
     constexpr int NT = NP * (NP + 1) / 2;
     const int j = blockIdx.x * 64 + threadIdx.x;
     bool alive = false;
+    if (j < ph.batch) ph.pair_live[(size_t)((round + 1) & 1) * ph.batch + j] = 0; // the half the NEXT round counts into (its reader, the cost sweep two kernels back, is done)
     if (j < lme_count(ph)) {
         LmProb *P = ph.probs + j;
         if (P->status != 0) {
@@ -474,6 +480,7 @@ __global__ __launch_bounds__(64) void k_lme_solve(LmePhase ph, int round) {
                 P->cs = cs;
                 P->has_cand = 1;
                 alive = true;
+                atomicAdd(ph.pair_live + (size_t)(round & 1) * ph.batch + P->pair, 1);
             }
             P->recompute = 0;
         }

@@ -465,8 +465,66 @@ def relpose_7pt(x1, x2):
     return [_capi.model_to_fundamental(m) for m in out[0][:n[0]]]
 
 
+class ImagePair:
+    """(_core.pyi:164-169): pose and the two cameras of the 6-point shared-focal estimator"""
+
+    def __init__(self, pose=None, camera1=None, camera2=None):
+        self.pose = pose if pose is not None else CameraPose()
+        self.camera1 = camera1 if camera1 is not None else Camera()
+        self.camera2 = camera2 if camera2 is not None else Camera()
+
+    def __repr__(self):
+        return f"ImagePair(pose={self.pose!r}, f1={self.camera1.focal():.6g}, f2={self.camera2.focal():.6g})"
+
+
+def _pp_records(pp, B):
+    """principal point(s) as the camera records the C ABI carries them in (MDRP_SHARED_6PT: cam1[i].params[0..1])"""
+    pp = np.zeros(2) if pp is None else np.asarray(pp, dtype=np.float64)
+    pp = np.broadcast_to(pp.reshape(-1, 2) if pp.size != 2 else pp.reshape(1, 2), (B, 2))
+    rec = np.zeros(B, dtype=_capi.CAMERA_DTYPE)
+    rec["params"][:, 0] = pp[:, 0]; rec["params"][:, 1] = pp[:, 1]
+    return rec, pp
+
+
+def estimate_shared_focal_relative_pose_batch(points2D_1, points2D_2, pp=None, ransac_opt=None, bundle_opt=None, device=0):
+    """B pairs through the 6-point shared-focal estimator.  pp: one principal point for all pairs or (B, 2).
+    Returns (list[ImagePair], list[info dict])."""
+    _check_baseline_options(ransac_opt)
+    x1, x2, ns = _stack2(points2D_1, points2D_2)
+    B = len(ns)
+    rec, ppb = _pp_records(pp, B)
+    h = _capi.default_handle(device)
+    res, mask = h.estimate_batch(_capi.SHARED_6PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
+                                 _capi.bundle_opt_from_dict(bundle_opt), ns, rec, rec)
+    out = []
+    for i, r in enumerate(res):
+        f = float(r["model"]["f1"])
+        cam = Camera("SIMPLE_PINHOLE", [f, float(ppb[i, 0]), float(ppb[i, 1])])
+        out.append(ImagePair(CameraPose(r["model"]["q"].copy(), r["model"]["t"].copy()), cam, Camera("SIMPLE_PINHOLE", [f, float(ppb[i, 0]), float(ppb[i, 1])])))
+    return out, [_info(res[i], mask[i], ns[i]) for i in range(B)]
+
+
+def estimate_shared_focal_relative_pose(points2D_1, points2D_2, pp=None, ransac_opt={}, bundle_opt={}, initial_image_pair=None):
+    """Relative pose with one unknown focal length shared by both images, 6-point solver + non-linear refinement
+    (_core.pyi:531-543; /root/reference/eval_shared_f.py:161, where the fork's signature has no `pp` and the points are
+    already centred: a dict in the third position is taken as ransac_opt).  An initial image pair only sets
+    score_initial_model, like the initial pose of the other estimators."""
+    if isinstance(pp, dict):  # fork call shape: (kp1, kp2, ransac_dict, bundle_dict)
+        pp, ransac_opt, bundle_opt = None, pp, (ransac_opt if ransac_opt else bundle_opt)
+    pairs, infos = estimate_shared_focal_relative_pose_batch([_as_points(points2D_1)], [_as_points(points2D_2)], pp,
+                                                             _with_initial(initial_image_pair, ransac_opt), bundle_opt)
+    return pairs[0], infos[0]
+
+
+def relpose_6pt_shared_focal(x1, x2):
+    """six homogeneous image points per view -> list[ImagePair], by ascending focal length (the reference's order is the
+    order of its eigenvalue solver and is not reproduced)"""
+    out, n = _capi.default_handle(0).classic_solver_batch(_capi.SHARED_6PT, _bearings(x1)[None], _bearings(x2)[None])
+    return [ImagePair(CameraPose(m["q"].copy(), m["t"].copy()), Camera("SIMPLE_PINHOLE", [float(m["f1"]), 0.0, 0.0]),
+                      Camera("SIMPLE_PINHOLE", [float(m["f2"]), 0.0, 0.0])) for m in out[0][:n[0]]]
+
+
 # names the reference scripts also reach for: present so that a swapped import fails with a clear message at the call
-estimate_shared_focal_relative_pose = _not_on_path("estimate_shared_focal_relative_pose", "6-point baseline, eval_shared_f.py:161")
 estimate_relative_pose_w_relative_depth = _not_on_path("estimate_relative_pose_w_relative_depth", "fork-only variant, eval.py:140 (commented out upstream)")
 
 

@@ -94,6 +94,9 @@ int orc_relpose_5pt_E(const double *x1h, const double *x2h, double *E_out /*<=10
 int orc_relpose_5pt(const double *x1h, const double *x2h, orc_model *out /*<=40*/);
 int orc_motion_from_essential(const double *E /*row-major*/, const double *x1h, const double *x2h, int npts, orc_model *out /*<=4*/);
 int orc_relpose_7pt(const double *x1h, const double *x2h, double *F_out /*<=3 x 9 row-major*/);
+/* 6-point relative pose with one shared unknown focal length (orc_sixpt.c): models with f1 = f2 = f, by ascending f */
+int orc_relpose_6pt(const double *x1h, const double *x2h, orc_model *out /*<=60*/);
+int orc_eigenvalues(double *a /*n x n row-major, destroyed*/, int n, double *wr, double *wi);
 /* kind 3 = relative pose (blob: q, t), 4 = shared focal (q, t, f1 = f2 = f), 5 = fundamental (F row-major in the first 9 doubles) */
 enum { ORC_RELPOSE = 3, ORC_SHARED_RELPOSE = 4, ORC_FUNDAMENTAL = 5 };
 orc_bundle_stats orc_refine_classic(int kind, const double *x1, const double *x2, int n, orc_model *blob, const orc_bundle_opt *opt,

@@ -724,7 +724,7 @@ orc_bundle_stats orc_refine_classic(int kind, const double *x1, const double *x2
  * steps; estimate_relative_pose @0x21f800, estimate_fundamental @0x221a00. */
 #include <stdio.h>
 #include <stdlib.h>
-#define CMAX_MODELS 40
+#define CMAX_MODELS 64
 
 typedef struct {
     int kind, n, sample_sz;
@@ -767,6 +767,7 @@ static int c_generate_models(cestimator *e, orc_model *out) {
         for (int i = 0; i < n; ++i) { memset(&out[i], 0, sizeof out[i]); memcpy(&out[i], Fs + 9 * i, 9 * sizeof(double)); }
         return n;
     }
+    if (e->kind == 4) return orc_relpose_6pt(x1h, x2h, out);
     return 0;
 }
 

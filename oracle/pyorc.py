@@ -234,6 +234,22 @@ def relpose_7pt(x1h, x2h):
     return out[:n].reshape(-1, 3, 3)
 
 
+def relpose_6pt(x1h, x2h):
+    """6-point shared-focal solver: rows of the 12-wide model blob (q, t, ..., f1 = f2 = f), by ascending focal length"""
+    x1h, x2h = f64(x1h), f64(x2h)
+    out = np.zeros((60, MODEL_W))
+    n = lib().orc_relpose_6pt(_p(x1h), _p(x2h), _p(out))
+    return out[:n]
+
+
+def eigenvalues(a):
+    a = f64(a).copy()
+    n = a.shape[0]
+    wr, wi = np.zeros(n), np.zeros(n)
+    rc = lib().orc_eigenvalues(_p(a), C.c_int(n), _p(wr), _p(wi))
+    return rc, wr + 1j * wi
+
+
 def classic_blob(kind, model=None):
     m = np.zeros(MODEL_W)
     if model is None:

@@ -220,8 +220,6 @@ def test_baseline_options_that_are_not_built_raise():
     with pytest.raises(NotImplementedError):
         poselib.estimate_relative_pose(x, x, {"model": "SIMPLE_PINHOLE", "width": 1, "height": 1, "params": [1.0, 0, 0]}, {"model": "SIMPLE_PINHOLE", "width": 1, "height": 1, "params": [1.0, 0, 0]},
                                        {"progressive_sampling": True}, {})
-    with pytest.raises(NotImplementedError):
-        poselib.estimate_shared_focal_relative_pose(x, x, {}, {})
 
 
 def test_fork_flag_table_covers_every_experiment_name():

@@ -260,3 +260,98 @@ def test_large_batch_one_wavefront_per_lo_problem(kind):
         d = pose_diff(models[k], m) if kind == 3 else fund_diff(np.asarray(models[k]).reshape(-1), m)
         assert d < 1e-6, (k, d)
     assert off == 0, off
+
+
+# ---------------------------------------------------------------------------------------------- 6-point, shared focal
+def _six_rows(out, n):
+    return [np.r_[m["q"], m["t"], m["f1"]] for m in out[:n]]
+
+
+def test_sixpt_solver_equals_oracle_and_reference(golden):
+    """relpose_6pt_shared_focal on the device: on the 96 fixtures of tests/golden/sixpt.npz the same sets as the oracle (1e-6),
+    hence every accurate solution of the reference binary (test_oracle_classic.py::test_sixpt_solution_sets_equal_reference);
+    on 2000 random samples the same sets as the oracle up to eigenvalues at the edge of being real."""
+    from mdrp_amd import _capi
+    from test_oracle_classic import _same_sixpt, _sixpt_residual
+    h = _capi.default_handle(0)
+    g = golden("sixpt")
+    out, n = h.classic_solver_batch(_capi.SHARED_6PT, g["solver_x1"], g["solver_x2"])
+    for i in range(len(n)):
+        mine = _six_rows(out[i], n[i])
+        ref = [np.r_[m[:7], m[10]] for m in po.relpose_6pt(g["solver_x1"][i], g["solver_x2"][i])]
+        assert len(mine) == len(ref), (i, len(mine), len(ref))
+        for u, v in zip(mine, ref):  # both ascending in f
+            assert _same_sixpt(u, v, 1e-6) and _sixpt_residual(u, g["solver_x1"][i], g["solver_x2"][i]) < 1e-8, (i, u[7], v[7])
+    rng = np.random.default_rng(5)
+
+    def unit(x):
+        hh = np.concatenate([x, np.ones(x.shape[:-1] + (1,))], axis=-1)
+        return np.ascontiguousarray(hh / np.linalg.norm(hh, axis=-1, keepdims=True))
+
+    x1 = rng.uniform(-1, 1, (2000, 6, 2))
+    x2 = x1 + rng.normal(size=x1.shape) * np.where(np.arange(2000) % 2, 0.1, 1.0)[:, None, None]
+    a, b = unit(x1), unit(x2)
+    out, n = h.classic_solver_batch(_capi.SHARED_6PT, a, b)
+    bad = loose = 0
+    for i in range(2000):
+        ref = [np.r_[m[:7], m[10]] for m in po.relpose_6pt(a[i], b[i])]
+        mine = _six_rows(out[i], n[i])
+        if len(ref) != len(mine):
+            bad += 1
+            continue
+        loose += sum(not _same_sixpt(u, v, 1e-6) for u, v in zip(mine, ref))
+    assert bad <= 20 and loose <= 20, (bad, loose)
+
+
+def test_sixpt_estimator_equals_reference_golden(golden):
+    """estimate_shared_focal_relative_pose through the drop-in signature: the 24 small reference-binary runs one by one (every
+    loss type, fixed and dynamic stopping, with and without a principal point) and the 8 full-size ones (N = 2000, 10^4 iterations,
+    50 % outliers) as one batch: iterations, inlier count, mask, pose, focal length; the LO count within one of the
+    reference's (its solver's solution ORDER is not reproduced)."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    g = golden("sixpt")
+    names = {0: "TRIVIAL", 1: "TRUNCATED", 2: "HUBER", 3: "CAUCHY", 4: "TRUNCATED_CAUCHY", 5: "TRUNCATED_LE_ZACH"}
+    lo_dev = 0
+
+    def check(pair, info, ref_m, ref_st, ref_mask, where):
+        nonlocal lo_dev
+        assert info["iterations"] == int(ref_st[1]) and info["num_inliers"] == int(ref_st[2]), (where, info["iterations"], info["num_inliers"], ref_st)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), ref_mask), where
+        assert np.abs(pair.pose.R - po.quat_to_rotmat(ref_m[:4])).max() < 1e-6, where
+        t, tr = pair.pose.t / np.linalg.norm(pair.pose.t), ref_m[4:7] / np.linalg.norm(ref_m[4:7])
+        assert np.abs(t - tr).max() < 1e-6 and pair.camera1.focal() == pytest.approx(ref_m[7], rel=1e-6) and pair.camera2.focal() == pair.camera1.focal(), where
+        assert abs(info["refinements"] - int(ref_st[0])) <= 1, (where, info["refinements"], ref_st[0])
+        lo_dev += info["refinements"] != int(ref_st[0])
+
+    for case in g["est_cases"]:
+        k, n, its, min_its, loss, thr, seed = int(case[0]), int(case[1]), int(case[2]), int(case[3]), int(case[4]), float(case[5]), int(case[6])
+        pp = np.array([float(case[7]), float(case[8])])
+        ro = {"max_iterations": its, "min_iterations": min_its, "max_epipolar_error": thr, "seed": seed}
+        pair, info = poselib.estimate_shared_focal_relative_pose(g[f"est_x1_{k}"], g[f"est_x2_{k}"], pp, ro, {"loss_type": names[loss], "loss_scale": thr})
+        check(pair, info, g[f"est_model_{k}"], g[f"est_stats_{k}"], g[f"est_mask_{k}"], ("small", k))
+    prs = [synth.make_pair(int(ix), 2000, noise_px=0.5, outlier_frac=0.5, random_focal="shared", pp=(0.0, 0.0)) for ix in g["full_indices"]]
+    pairs, infos = poselib.estimate_shared_focal_relative_pose_batch(np.stack([p["x1"] for p in prs]), np.stack([p["x2"] for p in prs]), None,
+                                                                     {"max_iterations": 10000, "min_iterations": 10000, "max_epipolar_error": 2.0},
+                                                                     {"loss_type": "TRUNCATED_CAUCHY"})
+    for j in range(len(prs)):
+        check(pairs[j], infos[j], g["full_model"][j], g["full_stats"][j], np.unpackbits(g["full_mask"][j])[:2000], ("full", int(g["full_indices"][j])))
+    assert lo_dev <= 4, lo_dev
+
+
+def test_sixpt_batch_follows_the_oracle_trajectory():
+    """24 ragged noisy pairs with outliers in one call: every pair on the sequential oracle's exact trajectory"""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    pairs = [synth.make_pair(8900 + 7 * k, [200, 350, 120, 500][k % 4], pp=(0.0, 0.0), noise_px=0.7, outlier_frac=[0.3, 0.5, 0.15, 0.4][k % 4],
+                             random_focal="shared") for k in range(24)]
+    ro = {"max_iterations": 800, "min_iterations": 100, "max_epipolar_error": 1.5, "seed": 2}
+    bo = {"loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.5}
+    out, infos = poselib.estimate_shared_focal_relative_pose_batch([p["x1"] for p in pairs], [p["x2"] for p in pairs], None, ro, bo)
+    oro = po.ransac_opt(max_iterations=800, min_iterations=100, max_epipolar_error=1.5, seed=2)
+    for k, p in enumerate(pairs):
+        m, st, mask = po.estimate_classic(4, p["x1"], p["x2"], oro, po.bundle_opt(loss_type=4, loss_scale=1.5), pp=(0.0, 0.0))
+        info = infos[k]
+        assert (info["refinements"], info["iterations"], info["num_inliers"]) == (st.refinements, st.iterations, st.num_inliers), (k, info["refinements"], st.refinements)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask), k
+        assert np.abs(out[k].pose.R - po.quat_to_rotmat(m[:4])).max() < 1e-6 and out[k].camera1.focal() == pytest.approx(m[10], rel=1e-6), k
