@@ -38,6 +38,7 @@ WORKLOADS = {
     # non-monodepth baselines on the same kernels: 5-point relative pose, 7-point fundamental matrix
     "relpose_5pt_n2000_i10k": (3, 2000, 10000, 0.5, False, None),
     "fundamental_7pt_n2000_i10k": (5, 2000, 10000, 0.5, False, None),
+    "shared_6pt_n2000_i10k": (4, 2000, 10000, 0.5, False, "shared"),
 }
 
 
@@ -72,7 +73,7 @@ def _cpu_worker(args):
     t0 = time.perf_counter()
     for i in range(count):
         if kind >= 3:
-            po.estimate_classic(kind, b["x1"][i], b["x2"][i], ro, bo, cam, cam)
+            po.estimate_classic(kind, b["x1"][i], b["x2"][i], ro, bo, cam, cam, pp=(0.0, 0.0))
         else:
             po.estimate(kind, b["x1"][i], b["x2"][i], b["d1"][i], b["d2"][i], ro, bo, cam if kind == 0 else None, cam if kind == 0 else None)
     return time.perf_counter() - t0
@@ -189,6 +190,8 @@ def main():
     mask = torch.zeros((max(B, 1), n), dtype=torch.uint8, device=dev)
     cams = np.zeros(max(B, 1), dtype=_capi.CAMERA_DTYPE)
     cams["params"][:, 0] = 800.0
+    if kind == 4:
+        cams["params"][:] = 0.0  # MDRP_SHARED_6PT: cam1 carries the principal point; the synthetic pixels are centred
     ro = _capi.ransac_opt_from_dict({"max_iterations": iters, "min_iterations": iters, "max_epipolar_error": 2.0,
                                      "max_reproj_error": 16.0, "monodepth_estimate_shift": es})
     bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
@@ -197,7 +200,7 @@ def main():
     rec_all = torch.empty((world * per, mdist.RECORD_BYTES), dtype=torch.uint8, device=dev) if world > 1 else None
     torch.cuda.synchronize(dev)  # the inputs were written on torch's stream, the handle runs on its own: order them once
 
-    with_cams = kind in (0, 3)
+    with_cams = kind in (0, 3, 4)  # kind 4: the principal point travels in cam1 (0, 0 here: the synthetic pixels are centred)
     classic = kind >= 3
 
     def step():

@@ -266,13 +266,19 @@ def evaluate_focal(h5, experiments, shared=True, iters=None, threshold=1.0, repr
     for experiment in experiments:
         depth = int(experiment.split("+")[1]) if "+" in experiment else None
         ro, bo = focal_options(experiment, iters, threshold, reproj_threshold, varying=not shared)
-        ro = poselib._map_fork_options(ro, _capi.SHARED_FOCAL if shared else _capi.VARYING_FOCAL)
+        six_point = shared and "6p" in experiment  # eval_shared_f.py:159-162: the non-monodepth 6-point row
+        ro = {k: v for k, v in ro.items() if k in CORE_RANSAC_KEYS} if six_point else \
+            poselib._map_fork_options(ro, _capi.SHARED_FOCAL if shared else _capi.VARYING_FOCAL)
         loaded = [p for p in (load_pair_focal(h5, a, b, depth, shared) for a, b in pairs) if len(p["kp1"]) >= min_n]
         for s in range(0, len(loaded), batch):
             chunk = loaded[s:s + batch]
             t0 = time.perf_counter()
-            out, infos = estimate_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [p["d"][:, 0] for p in chunk],
-                                        [p["d"][:, 1] for p in chunk], ro, bo)
+            if six_point:
+                out, infos = poselib.estimate_shared_focal_relative_pose_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], None, ro, bo,
+                                                                               device=device)
+            else:
+                out, infos = estimate_batch([p["kp1"] for p in chunk], [p["kp2"] for p in chunk], [p["d"][:, 0] for p in chunk],
+                                            [p["d"][:, 1] for p in chunk], ro, bo)
             ms = 1000.0 * (time.perf_counter() - t0) / max(len(chunk), 1)
             for p, ip, info in zip(chunk, out, infos):
                 info = dict(info)

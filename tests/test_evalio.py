@@ -210,6 +210,15 @@ def test_evaluate_focal_end_to_end_gpu(shared):
         assert np.abs(np.array(rec["R"]) - po.quat_to_rotmat(m[:4])).max() < 1e-6, j
         assert np.abs(np.array(rec["t"]) - m[4:7]).max() < 1e-6 * (1 + np.abs(m[4:7]).max()), j
         assert rec["f1"] == pytest.approx(m[10], rel=1e-6) and rec["f2"] == pytest.approx(m[11], rel=1e-6), j
+    if shared:  # the 6-point row of the shared-focal tables (eval_shared_f.py:159-162): no depths, upstream RansacOptions keys only
+        res6 = evalio.evaluate_focal(h5, ["6p"], shared=True, iters=1000, threshold=2.0)
+        assert len(res6) == len(pairs)
+        for j, p in enumerate(pairs):
+            m, st, mk = po.estimate_classic(4, p["kp1"], p["kp2"], oro, po.bundle_opt(loss_type=3), pp=(0.0, 0.0))
+            rec = res6[j]
+            assert rec["info"]["num_inliers"] == st.num_inliers and rec["info"]["iterations"] == st.iterations, j
+            assert np.abs(np.array(rec["R"]) - po.quat_to_rotmat(m[:4])).max() < 1e-6 and rec["f1"] == pytest.approx(m[10], rel=1e-6), j
+        assert np.median([r["R_err"] for r in res6]) < 1.0 and np.median([r["f_err"] for r in res6]) < 0.05
 
 
 def test_baseline_options_that_are_not_built_raise():
