@@ -91,6 +91,7 @@ struct mdrp_handle {
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
     hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
+    DevBuf fuse;                       // fused tail: control words (64 B) | done_cnt[batch] | ready[batch]
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
     hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
@@ -307,7 +308,7 @@ int lme_lo(mdrp_handle *h, hipStream_t stream, const RunParams &rp, int kind, in
     const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
     MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
     hipLaunchKernelGGL(k_lme_lo_finish, dim3((cap + 255) / 256), dim3(256), 0, stream, ph, rp, h->st.as<PairState>(), h->triggers.as<Trigger>(),
-                       trig_cap, lo_plan);
+                       trig_cap, lo_plan, h->lm_stats.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -330,7 +331,8 @@ int lme_final(mdrp_handle *h, hipStream_t s, const RunParams &rp, int kind, int 
     ph.mask = mask_dev;
     rc = lme_run(h, s, ph, kind, est_shift, rp.final_loss, rp.final_max_it, step_blocks, batch, env_int("MDRP_LME_POLL_FROM2", 8), env_int("MDRP_LME_POLL_EVERY", 4));
     if (rc) return rc;
-    hipLaunchKernelGGL(k_lme_fin_write, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
+    hipLaunchKernelGGL(k_lme_fin_write, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev,
+                       h->lm_stats.as<unsigned long long>() + 2);
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -439,6 +441,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
     const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
+    // Fused tail (mdrp_kernels.h FuseTail): when the end of the run is known on the host (the super-chunk reaches max_iterations), the
+    // last LO launch replays each pair as its last trigger is refined (no k_walk launch), and k_final starts - on the main stream,
+    // behind k_gate - as soon as the LO queue is empty, taking pairs in the order they became ready: the final refinements fill
+    // the wavefront slots the LO's stragglers leave free, instead of LO | k_walk | k_final one after the other.
+    const bool fuse_env = env_int("MDRP_FUSE_TAIL", 1) != 0;
+    bool final_done = false;
     // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
     // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)
     // Default: on for the varying-focal estimator only.  Its LO leaves loss_scale at 1.0 (reference quirk), nothing is
@@ -524,6 +532,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // swept, and chunk c's triggers are refined while chunk c + 1 is swept.  Chunks alternate between two sets of tag
         // lists / model counters / sample tables; slots, triggers and LO plans of different chunks are disjoint.
         const bool piped = n_chunks > 1 && lo_overlap;
+        const bool fuse_tail = fuse_env && piped && !use_lme && !classic && it0 + super_len >= ro->max_iterations;
+        int32_t *fz_ctl = nullptr, *fz_done = nullptr, *fz_ready = nullptr;
+        if (fuse_tail) {
+            if ((rc = h->fuse.ensure(64 + 2 * sizeof(int32_t) * (size_t)batch))) return rc;
+            fz_ctl = h->fuse.as<int32_t>(); fz_done = fz_ctl + 16; fz_ready = fz_done + batch;
+        }
         hipStream_t aux = piped ? h->aux_stream : s, aux2 = piped ? h->aux_stream2 : s;
         int offs[mdrp_handle::NC_MAX] = {0};
         for (int c = 1; c < n_chunks; ++c) offs[c] = offs[c - 1] + (int)lens[c - 1];
@@ -670,12 +684,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
             const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
             hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
+            const bool fuse_here = fuse_tail && c + 1 == n_chunks;
+            if (fuse_here) {
+                HIPCHK(hipMemsetAsync(fz_ctl, 0, 64 + sizeof(int32_t) * (size_t)batch, s));
+                HIPCHK(hipMemsetAsync(fz_ready, 0xFF, sizeof(int32_t) * (size_t)batch, s));
+            }
             if (piped) { HIPCHK(hipEventRecord(h->ev_scanned[c], s)); HIPCHK(hipStreamWaitEvent(aux2, h->ev_scanned[c], 0)); }
             // LO beside the solver wastes both (two latency-bound kernels share a SIMD); LO beside the sweep does not
             if (piped && lo_after_solve && c + 1 < n_chunks) HIPCHK(hipStreamWaitEvent(aux2, h->ev_solved[c + 1], 0));
             const int lo_waves_c = (piped && c + 1 < n_chunks) ? lo_overlap_waves : 8; // the last chunk's LO has the chip to itself
             const int lo_threads_c = (c + 1 == n_chunks) ? lo_threads_last : lo_threads;
             const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
+            const FuseTail fz = fuse_here ? FuseTail{fz_done, fz_ready, fz_ctl, h->st.as<PairState>()} : FuseTail{nullptr, nullptr, nullptr, nullptr};
             const RunParams rp_lo = rp;
             unsigned long long *lm_stats = h->lm_stats.as<unsigned long long>();
             auto launch_lo_kernels = [=]() -> int {
@@ -688,7 +708,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
                                  h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max), lm_stats);
+                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max), lm_stats, fz);
                 return MDRP_OK;
             };
             auto launch_lo = [=]() -> int { // bracketed by HIP events on the stream the LO runs on (mdrp_stats::lo_ms)
@@ -703,10 +723,26 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (piped && lo_after_count && c + 1 < n_chunks) pending_lo = launch_lo;
             else if ((rc = launch_lo())) return rc;
         }
+        if (fuse_tail) { // final refinements on the main stream, released when the last LO launch's queue is empty
+            const int cl = n_chunks - 1;
+            const int32_t *plan_l = h->work_pair.as<int32_t>() + (size_t)cl * lo_plan_ints;
+            const int lo_blocks_l = h->num_cu * (lo_threads_last == 64 ? 8 : 2); // = lo_blocks of the last chunk's launch above
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const int32_t *)(cnt + CNT_LO_HEAD + cl), plan_l + 3 * (size_t)batch + 1,
+                               (const int32_t *)fz_ctl, lo_blocks_l);
+            hipEvent_t g0, g1;
+            if ((rc = get_events(h, &g0, &g1, 3))) return rc;
+            HIPCHK(hipEventRecord(g0, s));
+            MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
+                             h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+                             h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready);
+            HIPCHK(hipEventRecord(g1, s));
+            final_done = true;
+        }
         if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
-        hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
-                           h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
-                           h->work_pair.as<int32_t>(), use_lme ? n_chunks : 0, (int)lo_plan_ints, lme_cap);
+        if (!fuse_tail)
+            hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
+                               h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
+                               h->work_pair.as<int32_t>(), use_lme ? n_chunks : 0, (int)lo_plan_ints, lme_cap);
         HIPCHK(hipGetLastError());
         // progress record: pairs still iterating, iterations they still need, evaluations swept (sum over pairs of models * n)
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
@@ -764,6 +800,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         max_needed = h->progress_host->max_needed;
     }
 
+    if (final_done) return MDRP_OK; // fused tail: the final refinements ran beside the last LO launch
     hipEvent_t f0, f1;
     if ((rc = get_events(h, &f0, &f1, 3))) return rc;
     HIPCHK(hipEventRecord(f0, s));
@@ -773,7 +810,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     else {
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                          h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                         h->lm_stats.as<unsigned long long>() + 2);
+                         h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr);
     }
     HIPCHK(hipEventRecord(f1, s));
     HIPCHK(hipGetLastError());

@@ -1821,77 +1821,17 @@ __global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__re
     if (lane == 0) { prefix[batch] = run; plan[3 * (size_t)batch + 1] = run; }
 }
 
-#ifdef MDRP_LO_TRACE // experiment: per-problem timing of the LO kernels (tools/lo_trace.py)
-__device__ unsigned long long *g_lo_trace = nullptr; // 8 x u64 per problem
-__device__ unsigned int g_lo_trace_n = 0;
-#endif
-template <int KIND, bool SHIFT, int T>
-__global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
-                                                   const double *__restrict__ dep, const Model *__restrict__ models,
-                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan,
-                                                   int32_t *__restrict__ head /*zeroed*/, int list_stride, unsigned long long *__restrict__ lm_stats) {
-    extern __shared__ uint16_t lm_dyn_list[];
-    __shared__ LmShared sh;
-    __shared__ int s_item;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
-    __syncthreads();
-    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
-    const int total = plan[3 * (size_t)rp.batch + 1];
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
-        __syncthreads();
-        const int w = s_item;
-        if (w >= total) break;
-        const int pair = plan_find(prefix, rp.batch, w);
-        const int pos = begin[pair] + (w - prefix[pair]);
-        const PairState &ps = st[pair];
-        Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
-        const size_t slot_base = (size_t)pair * rp.slot_stride;
-        Model m = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_ref];
-        LmOpt o;
-        o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
-        o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-        const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
-        const double *dd = dep + (size_t)pair * rp.n_max * 2;
-#ifdef MDRP_LO_TRACE
-        const unsigned long long t_start = wall_clock64();
-#endif
-        lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
-        double sc;
-        int cn;
-        block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
-        if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; lm_flush_stats(sh); }
-#ifdef MDRP_LO_TRACE
-        if (threadIdx.x == 0 && g_lo_trace) {
-            const unsigned int k = atomicAdd(&g_lo_trace_n, 1u);
-            unsigned long long *e = g_lo_trace + 8ull * k;
-            e[0] = (unsigned long long)pair; e[1] = (unsigned long long)pos; e[2] = (unsigned long long)tr.cnt_ref; e[3] = (unsigned long long)cn;
-            e[4] = t_start; e[5] = wall_clock64(); e[6] = (unsigned long long)tr.iter + rp.chunk_start; e[7] = (unsigned long long)rp.chunk_off;
-        }
-#endif
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ walk
 // One lane per pair replays score_models<> / ransac<> bookkeeping (@0x22ebc0, @0x22f030) over the ordered triggers
 // and applies the dynamic stopping rule.
 // lo_plans / n_plans / lo_cap: the LM engine refines at most lo_cap triggers of a chunk per pass (its problem table is sized
 // before anyone knows how many triggers the scans will find); if a chunk found more, nothing is replayed yet — the flag
 // n_active[1] tells the host to run the remaining passes and launch the walk again.
-__global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__restrict__ models, const Trigger *__restrict__ triggers,
-                       int trig_cap, int32_t *__restrict__ n_active, unsigned long long *__restrict__ max_needed,
-                       const int32_t *__restrict__ lo_plans, int n_plans, int plan_stride, int lo_cap) {
-    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= rp.batch) return;
-    for (int c = 0; c < n_plans; ++c)
-        if (lo_plans[(size_t)c * plan_stride + 3 * (size_t)rp.batch + 1] > lo_cap) {
-            if (pair == 0) n_active[1] = 1;
-            return;
-        }
-    PairState &ps = st[pair];
-    if (!ps.active) return;
-    const size_t slot_base = (size_t)pair * rp.slot_stride;
+// Replay of one pair (one lane).  Returns true if the pair has stopped; otherwise `need` = iterations it still certainly needs.
+__device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__restrict__ models, const Trigger *__restrict__ trig /*of this pair*/,
+                          size_t slot_base, uint64_t &need) {
+    need = 0;
+    if (!ps.active) return true;
     const uint64_t c0 = rp.chunk_start, c1 = rp.chunk_start + (uint64_t)rp.super_len;
     uint64_t it = c0; // iterations completed so far
     bool stopped = false;
@@ -1905,7 +1845,7 @@ __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__
         return s;
     };
     for (int k = 0; k < ps.n_triggers && !stopped; ++k) {
-        const Trigger &tr = triggers[(size_t)pair * trig_cap + k];
+        const Trigger &tr = trig[k];
         const uint64_t ti = c0 + tr.iter; // absolute index of the triggering iteration
         // iterations it .. ti-1 complete without bookkeeping changes; would the loop stop at a value in (it, ti] ?
         if (ti > it) {
@@ -1943,11 +1883,131 @@ __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__
         }
     }
     ps.iterations = it;
-    if (stopped) ps.active = 0;
-    else {
+    if (stopped) { ps.active = 0; return true; }
+    need = first_stop(it + 1) - it; // iterations still certainly needed with the current dyn_max_iter
+    return false;
+}
+
+__global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__restrict__ models, const Trigger *__restrict__ triggers,
+                       int trig_cap, int32_t *__restrict__ n_active, unsigned long long *__restrict__ max_needed,
+                       const int32_t *__restrict__ lo_plans, int n_plans, int plan_stride, int lo_cap) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= rp.batch) return;
+    for (int c = 0; c < n_plans; ++c)
+        if (lo_plans[(size_t)c * plan_stride + 3 * (size_t)rp.batch + 1] > lo_cap) {
+            if (pair == 0) n_active[1] = 1;
+            return;
+        }
+    PairState &ps = st[pair];
+    if (!ps.active) return;
+    uint64_t need;
+    if (!walk_pair(rp, ps, models, triggers + (size_t)pair * trig_cap, (size_t)pair * rp.slot_stride, need)) {
         atomicAdd(n_active, 1);
-        uint64_t need = first_stop(it + 1) - it; // iterations still certainly needed with the current dyn_max_iter
         atomicMax(max_needed, (unsigned long long)need);
+    }
+}
+
+// Fused tail (the LAST LO launch of a run whose end is known): the workgroup that refines the last open trigger of a
+// pair replays the pair (walk_pair, instead of a k_walk launch) and appends it to `ready`.  When the LO queue is empty - its last
+// problems are in flight, most wavefront slots are already free - k_gate lets the final refinements start on another stream:
+// workgroup i of k_final takes the i-th ready pair.  The few whose pair is not ready yet wait for problems that resident LO
+// workgroups hold (nobody needs their slots: the queue is empty), so the wait cannot block anything.
+struct FuseTail {
+    int32_t *done_cnt;   // [batch] refined triggers of this launch per pair (zeroed)
+    int32_t *ready;      // [batch] pairs in the order they became ready (-1 = not yet)
+    int32_t *ctl;        // [0] entries of `ready`, [1] LO workgroups that have started (their trigger-less pairs are published)   (zeroed)
+    PairState *st;       // mutable alias of the pair states (only the walking lane writes)
+};
+// one lane: returns when every workgroup of the LO launch has started and every problem has been taken from its queue - from then
+// on whatever a final refinement may wait for is in the hands of a resident workgroup
+__global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks) {
+    const int total = *plan_total;
+    while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lo_blocks ||
+           __hip_atomic_load(lo_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total)
+        __builtin_amdgcn_s_sleep(64);
+}
+__device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams &rp, int pair, const Model *__restrict__ models,
+                                             const Trigger *__restrict__ triggers, int trig_cap) {
+    uint64_t need;
+    walk_pair(rp, fz.st[pair], models, triggers + (size_t)pair * trig_cap, (size_t)pair * rp.slot_stride, need);
+    __threadfence();
+    const int t = atomicAdd(fz.ctl, 1);
+    __hip_atomic_store(fz.ready + t, pair, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#ifdef MDRP_LO_TRACE // experiment: per-problem timing of the LO kernels (tools/lo_trace.py)
+__device__ unsigned long long *g_lo_trace = nullptr; // 8 x u64 per problem
+__device__ unsigned int g_lo_trace_n = 0;
+#endif
+// LO of item w of the launch's plan (refine_model + score_model of the refined model), by the whole workgroup
+template <int KIND, bool SHIFT, int T>
+__device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st, const double *__restrict__ pts, const double *__restrict__ dep,
+                           const Model *__restrict__ models, Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan, int w,
+                           LmShared &sh, const FuseTail &fz) {
+    const int32_t *prefix = plan, *begin = plan + rp.batch + 1, *end = begin + rp.batch;
+    const int pair = plan_find(prefix, rp.batch, w);
+    const int pos = begin[pair] + (w - prefix[pair]);
+    const PairState &ps = st[pair];
+    Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+    const size_t slot_base = (size_t)pair * rp.slot_stride;
+    Model m = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_ref];
+    LmOpt o;
+    o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+    o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+    const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    const double *dd = dep + (size_t)pair * rp.n_max * 2;
+#ifdef MDRP_LO_TRACE
+    const unsigned long long t_start = wall_clock64();
+#endif
+    lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
+    double sc;
+    int cn;
+    block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
+    if (threadIdx.x == 0) {
+        tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; lm_flush_stats(sh);
+        if (fz.ready) {
+            __threadfence(); // this trigger's results before the count
+            if (atomicAdd(fz.done_cnt + pair, 1) + 1 == end[pair] - begin[pair]) {
+                __threadfence(); // the other triggers' results (written on other CUs / XCDs) before the replay reads them
+                fuse_publish(fz, rp, pair, models, triggers, trig_cap);
+            }
+        }
+    }
+#ifdef MDRP_LO_TRACE
+    if (threadIdx.x == 0 && g_lo_trace) {
+        const unsigned int k = atomicAdd(&g_lo_trace_n, 1u);
+        unsigned long long *e = g_lo_trace + 8ull * k;
+        e[0] = (unsigned long long)pair; e[1] = (unsigned long long)pos; e[2] = (unsigned long long)tr.cnt_ref; e[3] = (unsigned long long)cn;
+        e[4] = t_start; e[5] = wall_clock64(); e[6] = (unsigned long long)tr.iter + rp.chunk_start; e[7] = (unsigned long long)rp.chunk_off;
+    }
+#endif
+}
+
+template <int KIND, bool SHIFT, int T>
+__global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                   const double *__restrict__ dep, const Model *__restrict__ models,
+                                                   Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan,
+                                                   int32_t *__restrict__ head /*zeroed*/, int list_stride, unsigned long long *__restrict__ lm_stats,
+                                                   FuseTail fz /*ready == null: off*/) {
+    extern __shared__ uint16_t lm_dyn_list[];
+    __shared__ LmShared sh;
+    __shared__ int s_item;
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
+    __syncthreads();
+    const int total = plan[3 * (size_t)rp.batch + 1];
+    if (fz.ready && threadIdx.x == 0) { // pairs without a trigger in this launch are ready as they are (earlier LO launches have ended: stream order)
+        const int32_t *begin = plan + rp.batch + 1, *end = begin + rp.batch;
+        for (int p = blockIdx.x; p < rp.batch; p += gridDim.x)
+            if (end[p] == begin[p]) fuse_publish(fz, rp, p, models, triggers, trig_cap);
+        atomicAdd(fz.ctl + 1, 1);
+    }
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
+        __syncthreads();
+        const int w = s_item;
+        if (w >= total) break;
+        lo_problem<KIND, SHIFT, T>(rp, st, pts, dep, models, triggers, trig_cap, plan, w, sh, fz);
     }
 }
 
@@ -1961,15 +2021,9 @@ struct ResultDev {
 };
 
 template <int KIND, bool SHIFT, int T>
-__global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
-                                                      const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
-                                                      ResultDev *__restrict__ results, int list_stride, unsigned long long *__restrict__ lm_stats) {
-    extern __shared__ uint16_t lm_dyn_list[];
-    __shared__ LmShared sh;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
-    __syncthreads();
+__device__ void final_pair(const RunParams &rp, PairState *__restrict__ st, const double *__restrict__ pts, const double *__restrict__ dep,
+                           uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results, int pair, LmShared &sh) {
     double *scratch = sh.scratch;
-    const int pair = blockIdx.x;
     PairState &ps = st[pair];
     ResultDev res;
     res.model = ps.best;
@@ -2007,6 +2061,27 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     res.model = best;
     __syncthreads();
     if (threadIdx.x == 0) { results[pair] = res; lm_flush_stats(sh); }
+}
+
+template <int KIND, bool SHIFT, int T>
+__global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
+                                                      const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
+                                                      ResultDev *__restrict__ results, int list_stride, unsigned long long *__restrict__ lm_stats,
+                                                      const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/) {
+    extern __shared__ uint16_t lm_dyn_list[];
+    __shared__ LmShared sh;
+    __shared__ int s_pair;
+    if (threadIdx.x == 0) {
+        sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0;
+        int p = blockIdx.x;
+        if (ready) { // fused tail: the blockIdx-th pair to become ready
+            while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+            __threadfence(); // the replayed pair state (written on another CU / XCD) before anyone of this workgroup reads it
+        }
+        s_pair = p;
+    }
+    __syncthreads();
+    final_pair<KIND, SHIFT, T>(rp, st, pts, dep, mask_all, results, s_pair, sh);
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels

@@ -51,7 +51,8 @@ struct alignas(64) LmProb {
     int32_t has_cand;       // 0 nothing to evaluate, 1 candidate step, 2 the initial model (its cost starts the loop)
     int32_t loss, cur;      // cur: list buffer that belongs to the current model m
     int32_t pair, n, it, max_it, recompute, pad_;
-    double pad2_[4];
+    unsigned long long ev_cost, ev_acc; // correspondences evaluated by the cost sweeps / the normal-equation sweeps of this problem (mdrp_stats)
+    double pad2_[2];
     // --- LM state
     double cost, lambda, grad_tol, step_tol, lambda_min, lambda_max;
     Model m, cand;
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(LME_T, MDRP_LME_MINWAVES) void k_lme_accum(LmePhase
             const int nseg = (n + LME_SEG - 1) / LME_SEG;
             double cost_new = 0;
             for (int s = 0; s < nseg; ++s) cost_new += ph.part[(size_t)j * ph.nseg + s];
+            if (threadIdx.x == 0) P->ev_cost += (unsigned long long)n;
             if (has_cand == 2) { cost = cost_new; cur ^= 1; recompute = 1; }
             else {
                 if (cost_new < cost) { m = P->cand; cur ^= 1; lambda = fmax(lambda_min, lambda / 10.0); cost = cost_new; recompute = 1; }
@@ -386,6 +388,12 @@ __global__ __launch_bounds__(LME_T, MDRP_LME_MINWAVES) void k_lme_accum(LmePhase
             const double *dd = dep + (size_t)pair * ph.n_max * 2;
             lme_accumulate<KIND, SHIFT>(m, pp, dd, n, ph, j, cur, P->sqrt_sr, P->ws, o, scratch, pre, dense, n <= dense_cap);
             if (threadIdx.x < NA) P->acc[threadIdx.x] = scratch[0][threadIdx.x];
+            if (threadIdx.x == LME_T - 1) {
+                const uint16_t *lc = ph.list_cnt + ((size_t)j * 2 + cur) * ph.nseg;
+                unsigned long long tot = 0;
+                for (int s_ = 0; s_ < (n + LME_SEG - 1) / LME_SEG; ++s_) tot += lc[s_];
+                P->ev_acc += tot;
+            }
         }
         if (threadIdx.x == 0) {
             P->m = m; P->cost = cost; P->lambda = lambda; P->mu = mu; P->it = it; P->cur = cur; P->recompute = recompute;
@@ -550,6 +558,15 @@ __device__ __forceinline__ void lme_start(LmProb &P, const Model &m0, bool focal
     P.cost = 0; P.lambda = o.lambda0; P.grad_tol = o.grad_tol; P.step_tol = o.step_tol; P.lambda_min = o.lambda_min; P.lambda_max = o.lambda_max;
 }
 
+// the evaluation counters of a problem go into stats[0 .. 1] (one atomic per wavefront)
+__device__ __forceinline__ void lme_flush_evals(const LmProb *P /*or null*/, unsigned long long *__restrict__ stats) {
+    if (!stats) return;
+    unsigned long long a = P ? P->ev_cost : 0ull, b = P ? P->ev_acc : 0ull;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd(stats, a); if (b) atomicAdd(stats + 1, b); }
+}
+
 // ------------------------------------------------------------------------------------------------ LO phase (refine_model)
 // one thread per trigger of the chunk's frozen plan (k_lo_plan): 25 iterations, TRUNCATED at the epipolar threshold
 __global__ void k_lme_lo_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const Model *__restrict__ models,
@@ -567,12 +584,15 @@ __global__ void k_lme_lo_init(LmePhase ph, RunParams rp, const PairState *__rest
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
     o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
     lme_start(ph.probs[j], m0, rp.kind != 0, pair, ps.n, ps.scale_reproj, rp.weight_sampson, o);
+    ph.probs[j].ev_cost = 0; ph.probs[j].ev_acc = 0;
 }
 
 __global__ void k_lme_lo_finish(LmePhase ph, RunParams rp, const PairState *__restrict__ st, Trigger *__restrict__ triggers, int trig_cap,
-                                const int32_t *__restrict__ plan) {
+                                const int32_t *__restrict__ plan, unsigned long long *__restrict__ lm_stats) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= lme_count(ph)) return;
+    const bool mine = j < lme_count(ph);
+    lme_flush_evals(mine ? ph.probs + j : nullptr, lm_stats);
+    if (!mine) return;
     const int w = ph.first + j;
     const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
     const int pair = plan_find(prefix, rp.batch, w);
@@ -602,6 +622,7 @@ __global__ __launch_bounds__(64) void k_lme_fin_init(LmePhase ph, RunParams rp, 
     res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
     results[pair] = res;
     LmProb &P = ph.probs[pair];
+    P.ev_cost = 0; P.ev_acc = 0;
     if (ps.n < 3) { P.status = 0; P.has_cand = 0; P.n = 0; P.pair = pair; P.m = ps.best; return; }
     LmOpt o;
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
@@ -638,8 +659,10 @@ __global__ void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__re
     lme_start(ph.probs[pair], m0, rp.kind != 0, pair, ps.n, ps.scale_reproj, rp.weight_sampson, f);
 }
 
-__global__ void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results) {
+__global__ void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results,
+                                unsigned long long *__restrict__ lm_stats) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    lme_flush_evals(pair < rp.batch ? ph.probs + pair : nullptr, lm_stats);
     if (pair >= rp.batch) return;
     const PairState &ps = st[pair];
     if (ps.n < 3) return;
@@ -653,6 +676,7 @@ __global__ void k_lme_unit_init(LmePhase ph, int count, const Model *__restrict_
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     lme_start(ph.probs[j], models[j], kind != 0, 0, n, scale_reproj, ws, o);
+    ph.probs[j].ev_cost = 0; ph.probs[j].ev_acc = 0;
 }
 __global__ void k_lme_unit_finish(LmePhase ph, int count, Model *__restrict__ models, double *__restrict__ final_cost) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;

@@ -155,3 +155,38 @@ def test_large_ragged_batch_vs_oracle(handle, capi, po, golden, kind, es, rf):
     # record to 1e-14 (pair 34 of the calibrated batch, iteration 264: tests/tools/diag_gpu_solver.py finds no solver difference);
     # whether `score < record` then holds is decided by the summation order.  One LO more or less, the same result.
     assert len(lo_dev) <= 2 and all(abs(d[2] - d[3]) == 1 for d in lo_dev), lo_dev
+
+
+@pytest.mark.parametrize("kind,es", [(0, False), (0, True), (1, False)])
+def test_fused_tail_is_bit_identical(capi, monkeypatch, kind, es):
+    """The fused tail (the last LO launch replays each pair itself and k_final starts from the ready list while the LO drains,
+    mdrp_capi.hip `fuse_tail`) against LO | k_walk | k_final one after the other: the same arithmetic in another order of
+    launches - records and masks bit for bit, on a ragged batch large enough for one wavefront per LO problem (with pairs
+    that have no trigger in the last chunk, pairs below the sample size, and a dynamic-stopping run, where it must stay off)."""
+    from mdrp_amd import synth
+    B, N = 160, 600
+    rf = [None, "shared", "varying"][kind]
+    pairs = [synth.make_pair(8800 + i, [N, 400, 3, 2, 150][i % 5] if i % 7 == 0 else N, noise_px=0.5, depth_noise=0.02,
+                             outlier_frac=[0.5, 0.2, 0.0][i % 3], random_focal=rf) for i in range(B)]
+    n_per = np.array([len(p["x1"]) for p in pairs], dtype=np.int32)
+    x1, x2 = np.zeros((B, N, 2)), np.zeros((B, N, 2))
+    d1, d2 = np.ones((B, N)), np.ones((B, N))
+    for i, p in enumerate(pairs):
+        x1[i, : n_per[i]], x2[i, : n_per[i]], d1[i, : n_per[i]], d2[i, : n_per[i]] = p["x1"], p["x2"], p["d1"], p["d2"]
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE)
+    cams["params"][:, 0] = 800.0
+    bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    h = capi.Handle(0)
+    try:
+        for ropt in ({"max_iterations": 3000, "min_iterations": 3000}, {"max_iterations": 3000, "min_iterations": 100}):
+            ro = capi.ransac_opt_from_dict({**ropt, "max_epipolar_error": 2.0, "max_reproj_error": 16.0, "monodepth_estimate_shift": es})
+            out = []
+            for fuse in ("0", "1"):
+                monkeypatch.setenv("MDRP_FUSE_TAIL", fuse)
+                res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, n_per, cams if kind == 0 else None, cams if kind == 0 else None)
+                out.append((res.copy(), mask.copy()))
+            (r0, m0), (r1, m1) = out
+            assert r0.tobytes() == r1.tobytes() and np.array_equal(m0, m1), ropt
+            assert int(r0["refinements"].max()) > 3
+    finally:
+        h.close()
