@@ -445,7 +445,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // last LO launch replays each pair as its last trigger is refined (no k_walk launch), and k_final starts - on the main stream,
     // behind k_gate - as soon as the LO queue is empty, taking pairs in the order they became ready: the final refinements fill
     // the wavefront slots the LO's stragglers leave free, instead of LO | k_walk | k_final one after the other.
-    const bool fuse_env = env_int("MDRP_FUSE_TAIL", 1) != 0;
+    // Measured per 1024 pairs (N = 2000, 10^4 iterations): calibrated 11.75 -> 11.2 ms, shared focal 12.5 -> 11.9, outlier-free 18.6 -> 17.4;
+    // with the shift solver's 9-parameter LM the final refinements are 1.5x the LO's tail and gain nothing (12.75 -> 12.9 ms): off there.
+    const bool fuse_env = env_int("MDRP_FUSE_TAIL", (kind == MDRP_CALIB && est_shift) ? 0 : 1) != 0;
     bool final_done = false;
     // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
     // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
             x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
         }
         if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt_emit(x1h, x2h, lds_solve5_store(), [&](const Model &m, int k) { models[slot0 + k] = m; });
-        else if (CK == CLASSIC_SHARED) n = solver_relpose_6pt_emit(x1h, x2h, [&](const Model &m, int k) { models[slot0 + k] = m; });
+        else if (CK == CLASSIC_SHARED) { PlainStore6 st6; n = solver_relpose_6pt_emit(x1h, x2h, st6, [&](const Model &m, int k) { models[slot0 + k] = m; }); }
         else { extern __shared__ double solve5_lds[]; n = solver_fundamental_7pt(x1h, x2h, out, solve5_lds + (threadIdx.x & 63), 64); }
     }
     const int lane = threadIdx.x & 63;

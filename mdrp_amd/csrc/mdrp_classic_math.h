@@ -688,39 +688,51 @@ MDRP_HD int solver_relpose_5pt(const double (*x1h)[3], const double (*x2h)[3], M
 // cheirality of all six points.  Solutions come out by ascending focal length (the binary's order is the order of Eigen's
 // eigenvalues; pinned: the sets, and the estimator's trajectory — 48 / 48 identical results without that order).
 // One lane per sample; the matrices (about 1100 doubles) are dynamically indexed and live in the lane's scratch memory.
+// The 6-point solver is ~2000 lines of loop nests over small matrices when fully unrolled: 512 registers and 763 spilled VGPRs at one
+// wavefront per SIMD.  Kept rolled it is a compact scalar program per lane whose arrays live in scratch / LDS, at full occupancy.
+#define MDRP_ROLLED _Pragma("unroll 1")
 MDRP_HD double sgn_of(double a, double b) { return b >= 0.0 ? fabs(a) : -fabs(a); }
-// real and imaginary parts of the eigenvalues of a (n x n, row-major, destroyed); false if the QR iteration did not converge
-MDRP_HD bool hessenberg_qr_eigenvalues(double *a, int n, double *wr, double *wi) {
-#define HA(i, j) a[(i) * n + (j)]
-    for (int m = 1; m < n - 1; ++m) {
+// Square matrices of the 6-point solver behind an accessor (plain row-major storage here).  Measured and dropped: one matrix per lane
+// in LDS with the lanes interleaved (element e of slot g at base[e * slots + g]).  The 20 x 20 companion matrix is 3.2 KB, a CU's LDS
+// holds 48 of them, and 48 lanes per CU with every access ~100 cycles of exposed LDS latency are slower (220-310 pairs/s) than 512
+// lanes per CU waiting for scratch memory (480 pairs/s): the sequential chain per sample is the problem, not where the matrix lives.
+struct PlainMat {
+    double *a; int n;
+    MDRP_HD double &operator()(int i, int j) const { return a[i * n + j]; }
+};
+// real and imaginary parts of the eigenvalues of a (n x n, destroyed); false if the QR iteration did not converge
+template <class Mat>
+MDRP_HD bool hessenberg_qr_eigenvalues(Mat a, int n, double *wr, double *wi) {
+#define HA(i, j) a((i), (j))
+    MDRP_ROLLED for (int m = 1; m < n - 1; ++m) {
         double x = 0.0;
         int piv = m;
-        for (int j = m; j < n; ++j)
+        MDRP_ROLLED for (int j = m; j < n; ++j)
             if (fabs(HA(j, m - 1)) > fabs(x)) { x = HA(j, m - 1); piv = j; }
         if (piv != m) {
-            for (int j = m - 1; j < n; ++j) { const double t = HA(piv, j); HA(piv, j) = HA(m, j); HA(m, j) = t; }
-            for (int j = 0; j < n; ++j) { const double t = HA(j, piv); HA(j, piv) = HA(j, m); HA(j, m) = t; }
+            MDRP_ROLLED for (int j = m - 1; j < n; ++j) { const double t = HA(piv, j); HA(piv, j) = HA(m, j); HA(m, j) = t; }
+            MDRP_ROLLED for (int j = 0; j < n; ++j) { const double t = HA(j, piv); HA(j, piv) = HA(j, m); HA(j, m) = t; }
         }
         if (x != 0.0)
-            for (int i = m + 1; i < n; ++i) {
+            MDRP_ROLLED for (int i = m + 1; i < n; ++i) {
                 double y = HA(i, m - 1);
                 if (y != 0.0) {
                     y /= x;
                     HA(i, m - 1) = y;
-                    for (int j = m; j < n; ++j) HA(i, j) -= y * HA(m, j);
-                    for (int j = 0; j < n; ++j) HA(j, m) += y * HA(j, i);
+                    MDRP_ROLLED for (int j = m; j < n; ++j) HA(i, j) -= y * HA(m, j);
+                    MDRP_ROLLED for (int j = 0; j < n; ++j) HA(j, m) += y * HA(j, i);
                 }
             }
     }
-    for (int i = 2; i < n; ++i)
-        for (int j = 0; j < i - 1; ++j) HA(i, j) = 0.0;
+    MDRP_ROLLED for (int i = 2; i < n; ++i)
+        MDRP_ROLLED for (int j = 0; j < i - 1; ++j) HA(i, j) = 0.0;
     int nn = n - 1, its = 0;
     double t = 0.0, anorm = 0.0, p = 0, q = 0, r = 0, s, w, x, y, z;
-    for (int i = 0; i < n; ++i)
-        for (int j = (i > 0 ? i - 1 : 0); j < n; ++j) anorm += fabs(HA(i, j));
+    MDRP_ROLLED for (int i = 0; i < n; ++i)
+        MDRP_ROLLED for (int j = (i > 0 ? i - 1 : 0); j < n; ++j) anorm += fabs(HA(i, j));
     while (nn >= 0) {
         int l;
-        for (l = nn; l >= 1; --l) {
+        MDRP_ROLLED for (l = nn; l >= 1; --l) {
             s = fabs(HA(l - 1, l - 1)) + fabs(HA(l, l));
             if (s == 0.0) s = anorm;
             if (fabs(HA(l, l - 1)) + s == s) { HA(l, l - 1) = 0.0; break; }
@@ -749,14 +761,14 @@ MDRP_HD bool hessenberg_qr_eigenvalues(double *a, int n, double *wr, double *wi)
         if (its == 60) return false;
         if (its == 10 || its == 20 || its == 30 || its == 40) { // exceptional shift
             t += x;
-            for (int i = 0; i <= nn; ++i) HA(i, i) -= x;
+            MDRP_ROLLED for (int i = 0; i <= nn; ++i) HA(i, i) -= x;
             s = fabs(HA(nn, nn - 1)) + fabs(HA(nn - 1, nn - 2));
             y = x = 0.75 * s;
             w = -0.4375 * s * s;
         }
         ++its;
         int m;
-        for (m = nn - 2; m >= l; --m) {
+        MDRP_ROLLED for (m = nn - 2; m >= l; --m) {
             z = HA(m, m);
             r = x - z; s = y - z;
             p = (r * s - w) / HA(m + 1, m) + HA(m, m + 1);
@@ -769,8 +781,8 @@ MDRP_HD bool hessenberg_qr_eigenvalues(double *a, int n, double *wr, double *wi)
             const double v = fabs(p) * (fabs(HA(m - 1, m - 1)) + fabs(z) + fabs(HA(m + 1, m + 1)));
             if (u + v == v) break;
         }
-        for (int i = m + 2; i <= nn; ++i) { HA(i, i - 2) = 0.0; if (i != m + 2) HA(i, i - 3) = 0.0; }
-        for (int k = m; k <= nn - 1; ++k) {
+        MDRP_ROLLED for (int i = m + 2; i <= nn; ++i) { HA(i, i - 2) = 0.0; if (i != m + 2) HA(i, i - 3) = 0.0; }
+        MDRP_ROLLED for (int k = m; k <= nn - 1; ++k) {
             if (k != m) {
                 p = HA(k, k - 1); q = HA(k + 1, k - 1); r = 0.0;
                 if (k != nn - 1) r = HA(k + 2, k - 1);
@@ -780,13 +792,13 @@ MDRP_HD bool hessenberg_qr_eigenvalues(double *a, int n, double *wr, double *wi)
                 if (k == m) { if (l != m) HA(k, k - 1) = -HA(k, k - 1); }
                 else HA(k, k - 1) = -s * x;
                 p += s; x = p / s; y = q / s; z = r / s; q /= p; r /= p;
-                for (int j = k; j <= nn; ++j) {
+                MDRP_ROLLED for (int j = k; j <= nn; ++j) {
                     p = HA(k, j) + q * HA(k + 1, j);
                     if (k != nn - 1) { p += r * HA(k + 2, j); HA(k + 2, j) -= p * z; }
                     HA(k + 1, j) -= p * y; HA(k, j) -= p * x;
                 }
                 const int mmin = nn < k + 3 ? nn : k + 3;
-                for (int i = l; i <= mmin; ++i) {
+                MDRP_ROLLED for (int i = l; i <= mmin; ++i) {
                     p = x * HA(i, k) + y * HA(i, k + 1);
                     if (k != nn - 1) { p += z * HA(i, k + 2); HA(i, k + 2) -= p * r; }
                     HA(i, k + 1) -= p * q; HA(i, k) -= p;
@@ -803,9 +815,9 @@ MDRP_HD constexpr int six_exp_x(int i) { return i == 0 ? 3 : (i == 1 || i == 4) 
 MDRP_HD constexpr int six_exp_y(int i) { return i == 3 ? 3 : (i == 2 || i == 6) ? 2 : (i == 1 || i == 5 || i == 8) ? 1 : 0; }
 MDRP_HD constexpr int six_index(int a, int b) { return a + b == 3 ? 3 - a : (a + b == 2 ? 6 - a : (a + b == 1 ? 8 - a : 9)); }
 MDRP_HD void six_mul_add(const double *a, const double *b, double s, double *out) { // out += s a b (degrees above 3 do not occur)
-    for (int i = 0; i < 10; ++i) {
+    MDRP_ROLLED for (int i = 0; i < 10; ++i) {
         if (a[i] == 0.0) continue;
-        for (int j = 0; j < 10; ++j) {
+        MDRP_ROLLED for (int j = 0; j < 10; ++j) {
             if (b[j] == 0.0) continue;
             const int ex = six_exp_x(i) + six_exp_x(j), ey = six_exp_y(i) + six_exp_y(j);
             if (ex + ey <= 3) out[six_index(ex, ey)] += s * a[i] * b[j];
@@ -813,64 +825,65 @@ MDRP_HD void six_mul_add(const double *a, const double *b, double s, double *out
     }
 }
 // null vector of a 10 x 10 matrix (row-major, destroyed) by complete pivoting; returns |last pivot| / |first pivot|
-MDRP_HD double six_null_vector(double *M, double *v) {
+template <class Mat>
+MDRP_HD double six_null_vector(Mat Mm, double *v) {
     int cp[10];
-    for (int i = 0; i < 10; ++i) cp[i] = i;
+    MDRP_ROLLED for (int i = 0; i < 10; ++i) cp[i] = i;
     double first = 0.0, last = 0.0;
-    for (int k = 0; k < 10; ++k) {
+    MDRP_ROLLED for (int k = 0; k < 10; ++k) {
         int pr = k, pc = k;
         double best = -1.0;
-        for (int i = k; i < 10; ++i)
-            for (int j = k; j < 10; ++j)
-                if (fabs(M[i * 10 + j]) > best) { best = fabs(M[i * 10 + j]); pr = i; pc = j; }
+        MDRP_ROLLED for (int i = k; i < 10; ++i)
+            MDRP_ROLLED for (int j = k; j < 10; ++j)
+                if (fabs(Mm(i, j)) > best) { best = fabs(Mm(i, j)); pr = i; pc = j; }
         if (k == 0) first = best;
         if (k == 9) { last = best; break; }
-        if (pr != k) for (int j = 0; j < 10; ++j) { const double t = M[pr * 10 + j]; M[pr * 10 + j] = M[k * 10 + j]; M[k * 10 + j] = t; }
+        if (pr != k) MDRP_ROLLED for (int j = 0; j < 10; ++j) { const double t = Mm(pr, j); Mm(pr, j) = Mm(k, j); Mm(k, j) = t; }
         if (pc != k) {
-            for (int i = 0; i < 10; ++i) { const double t = M[i * 10 + pc]; M[i * 10 + pc] = M[i * 10 + k]; M[i * 10 + k] = t; }
+            MDRP_ROLLED for (int i = 0; i < 10; ++i) { const double t = Mm(i, pc); Mm(i, pc) = Mm(i, k); Mm(i, k) = t; }
             const int t = cp[pc]; cp[pc] = cp[k]; cp[k] = t;
         }
-        const double piv = M[k * 10 + k];
+        const double piv = Mm(k, k);
         if (piv == 0.0) break;
-        for (int i = k + 1; i < 10; ++i) {
-            const double f = M[i * 10 + k] / piv;
-            if (f != 0.0) for (int j = k; j < 10; ++j) M[i * 10 + j] -= f * M[k * 10 + j];
+        MDRP_ROLLED for (int i = k + 1; i < 10; ++i) {
+            const double f = Mm(i, k) / piv;
+            if (f != 0.0) MDRP_ROLLED for (int j = k; j < 10; ++j) Mm(i, j) -= f * Mm(k, j);
         }
     }
     double y[10];
     y[9] = 1.0;
-    for (int i = 8; i >= 0; --i) {
+    MDRP_ROLLED for (int i = 8; i >= 0; --i) {
         double s = 0.0;
-        for (int j = i + 1; j < 10; ++j) s += M[i * 10 + j] * y[j];
-        y[i] = M[i * 10 + i] != 0.0 ? -s / M[i * 10 + i] : 0.0;
+        MDRP_ROLLED for (int j = i + 1; j < 10; ++j) s += Mm(i, j) * y[j];
+        y[i] = Mm(i, i) != 0.0 ? -s / Mm(i, i) : 0.0;
     }
-    for (int i = 0; i < 10; ++i) v[cp[i]] = y[i];
+    MDRP_ROLLED for (int i = 0; i < 10; ++i) v[cp[i]] = y[i];
     return first > 0.0 ? last / first : 1.0;
 }
 
 // Gauss-Newton on the ten equations in (x, y, w): three steps bring the residual of an eigenpair to rounding level
 MDRP_HD double six_pow(double x, int a) { return a == 0 ? 1.0 : (a == 1 ? x : (a == 2 ? x * x : x * x * x)); }
 MDRP_HD void six_polish(const double *M0, const double *M1, const double *M2, double &px, double &py, double &pw) {
-    for (int it = 0; it < 3; ++it) {
+    MDRP_ROLLED for (int it = 0; it < 3; ++it) {
         const double x = px, y = py, w = pw;
         double mono[10], dmx[10], dmy[10];
-        for (int e = 0; e < 10; ++e) {
+        MDRP_ROLLED for (int e = 0; e < 10; ++e) {
             const int a = six_exp_x(e), b = six_exp_y(e);
             mono[e] = six_pow(x, a) * six_pow(y, b);
             dmx[e] = a > 0 ? a * six_pow(x, a - 1) * six_pow(y, b) : 0.0;
             dmy[e] = b > 0 ? b * six_pow(x, a) * six_pow(y, b - 1) : 0.0;
         }
         double JtJ[9], Jtr[3] = {0, 0, 0};
-        for (int a = 0; a < 9; ++a) JtJ[a] = 0.0;
-        for (int r = 0; r < 10; ++r) {
+        MDRP_ROLLED for (int a = 0; a < 9; ++a) JtJ[a] = 0.0;
+        MDRP_ROLLED for (int r = 0; r < 10; ++r) {
             double g = 0, gx = 0, gy = 0, gw = 0;
-            for (int e = 0; e < 10; ++e) {
+            MDRP_ROLLED for (int e = 0; e < 10; ++e) {
                 const double c = M0[r * 10 + e] + w * (M1[r * 10 + e] + w * M2[r * 10 + e]);
                 g += c * mono[e]; gx += c * dmx[e]; gy += c * dmy[e];
                 gw += (M1[r * 10 + e] + 2.0 * w * M2[r * 10 + e]) * mono[e];
             }
             const double J[3] = {gx, gy, gw};
-            for (int a = 0; a < 3; ++a) { Jtr[a] += J[a] * g; for (int b = 0; b < 3; ++b) JtJ[3 * a + b] += J[a] * J[b]; }
+            MDRP_ROLLED for (int a = 0; a < 3; ++a) { Jtr[a] += J[a] * g; MDRP_ROLLED for (int b = 0; b < 3; ++b) JtJ[3 * a + b] += J[a] * J[b]; }
         }
         double d[3];
         if (!solve3x3(JtJ, Jtr, d)) return;
@@ -881,8 +894,14 @@ MDRP_HD void six_polish(const double *M0, const double *M1, const double *M2, do
 constexpr int MAX_MODELS_6PT = 15;
 constexpr double SIX_MIN_U = 1e-5; // the defective cluster of the five spurious u = 0 spreads to ~1e-7 on scale-normalised points; f < 0.003 is no camera
 // emit(const Model &, int k) for the k-th model (pose, f1 = f2 = f) of the sample, k < MAX_MODELS_6PT
-template <class Emit>
-MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[3], Emit &&emit) {
+// storage of the companion matrix (and, once that is dead, of M(w) for the null vectors)
+struct PlainStore6 {
+    double c[400];
+    MDRP_HD PlainMat mat20() { return PlainMat{c, 20}; }
+    MDRP_HD PlainMat mat10() { return PlainMat{c, 10}; }
+};
+template <class Store, class Emit>
+MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[3], Store &&store, Emit &&emit) {
     double Nq[27]; // three null vectors, each the column-major vec of a 3 x 3 matrix: F(i, j) = N[3 j + i]
     {
         double A[54];
@@ -890,27 +909,27 @@ MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[
         fullpiv_nullspace<6>(A, 1, Nq);
     }
     double F[3][3][10];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) {
-            for (int e = 0; e < 10; ++e) F[i][j][e] = 0.0;
+    MDRP_ROLLED for (int i = 0; i < 3; ++i)
+        MDRP_ROLLED for (int j = 0; j < 3; ++j) {
+            MDRP_ROLLED for (int e = 0; e < 10; ++e) F[i][j][e] = 0.0;
             F[i][j][7] = Nq[3 * j + i]; F[i][j][8] = Nq[9 + 3 * j + i]; F[i][j][9] = Nq[18 + 3 * j + i];
         }
     double S0[3][3][10], S1[3][3][10], tr0[10], tr1[10], tr2[10];
-    for (int i = 0; i < 3; ++i)
-        for (int k = 0; k < 3; ++k) {
-            for (int e = 0; e < 10; ++e) { S0[i][k][e] = 0.0; S1[i][k][e] = 0.0; }
+    MDRP_ROLLED for (int i = 0; i < 3; ++i)
+        MDRP_ROLLED for (int k = 0; k < 3; ++k) {
+            MDRP_ROLLED for (int e = 0; e < 10; ++e) { S0[i][k][e] = 0.0; S1[i][k][e] = 0.0; }
             six_mul_add(F[i][0], F[k][0], 1.0, S0[i][k]); six_mul_add(F[i][1], F[k][1], 1.0, S0[i][k]);
             six_mul_add(F[i][2], F[k][2], 1.0, S1[i][k]);
         }
-    for (int e = 0; e < 10; ++e) {
+    MDRP_ROLLED for (int e = 0; e < 10; ++e) {
         tr0[e] = S0[0][0][e] + S0[1][1][e];
         tr1[e] = S1[0][0][e] + S1[1][1][e] + S0[2][2][e];
         tr2[e] = S1[2][2][e];
     }
     double M0[100], M1[100], M2[100];
-    for (int e = 0; e < 100; ++e) { M0[e] = 0.0; M1[e] = 0.0; M2[e] = 0.0; }
-    for (int i = 0; i < 3; ++i)
-        for (int l = 0; l < 3; ++l) {
+    MDRP_ROLLED for (int e = 0; e < 100; ++e) { M0[e] = 0.0; M1[e] = 0.0; M2[e] = 0.0; }
+    MDRP_ROLLED for (int i = 0; i < 3; ++i)
+        MDRP_ROLLED for (int l = 0; l < 3; ++l) {
             double *t0 = M0 + (3 * i + l) * 10, *t1 = M1 + (3 * i + l) * 10, *t2 = M2 + (3 * i + l) * 10;
             six_mul_add(S0[i][0], F[0][l], 2.0, t0); six_mul_add(S0[i][1], F[1][l], 2.0, t0); six_mul_add(tr0, F[i][l], -1.0, t0);
             six_mul_add(S1[i][0], F[0][l], 2.0, t1); six_mul_add(S1[i][1], F[1][l], 2.0, t1); six_mul_add(S0[i][2], F[2][l], 2.0, t1);
@@ -919,58 +938,59 @@ MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[
         }
     { // det F
         double m[10], *d = M0 + 90;
-        for (int e = 0; e < 10; ++e) m[e] = 0.0;
+        MDRP_ROLLED for (int e = 0; e < 10; ++e) m[e] = 0.0;
         six_mul_add(F[1][1], F[2][2], 1.0, m); six_mul_add(F[1][2], F[2][1], -1.0, m); six_mul_add(m, F[0][0], 1.0, d);
-        for (int e = 0; e < 10; ++e) m[e] = 0.0;
+        MDRP_ROLLED for (int e = 0; e < 10; ++e) m[e] = 0.0;
         six_mul_add(F[1][0], F[2][2], 1.0, m); six_mul_add(F[1][2], F[2][0], -1.0, m); six_mul_add(m, F[0][1], -1.0, d);
-        for (int e = 0; e < 10; ++e) m[e] = 0.0;
+        MDRP_ROLLED for (int e = 0; e < 10; ++e) m[e] = 0.0;
         six_mul_add(F[1][0], F[2][1], 1.0, m); six_mul_add(F[1][1], F[2][0], -1.0, m); six_mul_add(m, F[0][2], 1.0, d);
     }
     // X = M0^-1 [M2 | M1]: LU with partial pivoting on a copy of M0, 20 right-hand sides; then the companion matrix
-    double C[400], wr[20], wi[20];
+    auto C = store.mat20();
+    double wr[20], wi[20];
     {
         double L[100], B[200];
-        for (int e = 0; e < 100; ++e) L[e] = M0[e];
-        for (int i = 0; i < 10; ++i)
-            for (int j = 0; j < 10; ++j) { B[i * 20 + j] = M2[i * 10 + j]; B[i * 20 + 10 + j] = M1[i * 10 + j]; }
-        for (int k = 0; k < 10; ++k) {
+        MDRP_ROLLED for (int e = 0; e < 100; ++e) L[e] = M0[e];
+        MDRP_ROLLED for (int i = 0; i < 10; ++i)
+            MDRP_ROLLED for (int j = 0; j < 10; ++j) { B[i * 20 + j] = M2[i * 10 + j]; B[i * 20 + 10 + j] = M1[i * 10 + j]; }
+        MDRP_ROLLED for (int k = 0; k < 10; ++k) {
             int piv = k;
-            for (int i = k + 1; i < 10; ++i) if (fabs(L[i * 10 + k]) > fabs(L[piv * 10 + k])) piv = i;
+            MDRP_ROLLED for (int i = k + 1; i < 10; ++i) if (fabs(L[i * 10 + k]) > fabs(L[piv * 10 + k])) piv = i;
             if (L[piv * 10 + k] == 0.0) return 0;
             if (piv != k) {
-                for (int j = 0; j < 10; ++j) { const double t = L[piv * 10 + j]; L[piv * 10 + j] = L[k * 10 + j]; L[k * 10 + j] = t; }
-                for (int j = 0; j < 20; ++j) { const double t = B[piv * 20 + j]; B[piv * 20 + j] = B[k * 20 + j]; B[k * 20 + j] = t; }
+                MDRP_ROLLED for (int j = 0; j < 10; ++j) { const double t = L[piv * 10 + j]; L[piv * 10 + j] = L[k * 10 + j]; L[k * 10 + j] = t; }
+                MDRP_ROLLED for (int j = 0; j < 20; ++j) { const double t = B[piv * 20 + j]; B[piv * 20 + j] = B[k * 20 + j]; B[k * 20 + j] = t; }
             }
-            for (int i = k + 1; i < 10; ++i) {
+            MDRP_ROLLED for (int i = k + 1; i < 10; ++i) {
                 const double f = L[i * 10 + k] / L[k * 10 + k];
                 if (f == 0.0) continue;
-                for (int j = k; j < 10; ++j) L[i * 10 + j] -= f * L[k * 10 + j];
-                for (int j = 0; j < 20; ++j) B[i * 20 + j] -= f * B[k * 20 + j];
+                MDRP_ROLLED for (int j = k; j < 10; ++j) L[i * 10 + j] -= f * L[k * 10 + j];
+                MDRP_ROLLED for (int j = 0; j < 20; ++j) B[i * 20 + j] -= f * B[k * 20 + j];
             }
         }
-        for (int i = 9; i >= 0; --i)
-            for (int j = 0; j < 20; ++j) {
+        MDRP_ROLLED for (int i = 9; i >= 0; --i)
+            MDRP_ROLLED for (int j = 0; j < 20; ++j) {
                 double s = B[i * 20 + j];
-                for (int k = i + 1; k < 10; ++k) s -= L[i * 10 + k] * B[k * 20 + j];
+                MDRP_ROLLED for (int k = i + 1; k < 10; ++k) s -= L[i * 10 + k] * B[k * 20 + j];
                 B[i * 20 + j] = s / L[i * 10 + i];
             }
-        for (int e = 0; e < 400; ++e) C[e] = 0.0;
-        for (int i = 0; i < 10; ++i) {
-            C[i * 20 + 10 + i] = 1.0;
-            for (int j = 0; j < 20; ++j) C[(10 + i) * 20 + j] = -B[i * 20 + j];
+        MDRP_ROLLED for (int i = 0; i < 10; ++i) {
+            MDRP_ROLLED for (int j = 0; j < 20; ++j) { C(i, j) = j == 10 + i ? 1.0 : 0.0; C(10 + i, j) = -B[i * 20 + j]; }
         }
     }
     if (!hessenberg_qr_eigenvalues(C, 20, wr, wi)) return 0;
     double us[20];
     int nu = 0;
-    for (int i = 0; i < 20; ++i)
+    MDRP_ROLLED for (int i = 0; i < 20; ++i)
         if (fabs(wi[i]) <= 1e-9 * (fabs(wr[i]) + 1e-300) && wr[i] > SIX_MIN_U) us[nu++] = wr[i];
-    for (int i = 1; i < nu; ++i) { const double t = us[i]; int j = i - 1; while (j >= 0 && us[j] > t) { us[j + 1] = us[j]; --j; } us[j + 1] = t; }
+    MDRP_ROLLED for (int i = 1; i < nu; ++i) { const double t = us[i]; int j = i - 1; while (j >= 0 && us[j] > t) { us[j + 1] = us[j]; --j; } us[j + 1] = t; }
     int n_out = 0;
-    for (int s = 0; s < nu && n_out < MAX_MODELS_6PT; ++s) {
+    MDRP_ROLLED for (int s = 0; s < nu && n_out < MAX_MODELS_6PT; ++s) {
         const double w = 1.0 / us[s];
-        double *Mw = C, v[10]; // the companion matrix is dead: reuse its storage
-        for (int e = 0; e < 100; ++e) Mw[e] = M0[e] + w * (M1[e] + w * M2[e]);
+        auto Mw = store.mat10(); // the companion matrix is dead: reuse its storage
+        double v[10];
+        MDRP_ROLLED for (int i = 0; i < 10; ++i)
+            MDRP_ROLLED for (int j = 0; j < 10; ++j) Mw(i, j) = M0[i * 10 + j] + w * (M1[i * 10 + j] + w * M2[i * 10 + j]);
         const double res = six_null_vector(Mw, v);
         if (!(res < 1e-6) || !(fabs(v[9]) > 0.0)) continue;
         double x = v[7] / v[9], y = v[8] / v[9], wv = w;
@@ -978,16 +998,16 @@ MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[
         if (!(wv > 0.0)) continue;
         const double f = sqrt(1.0 / wv), invf = 1.0 / f;
         double E[9], nrm = 0.0;
-        for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) {
+        MDRP_ROLLED for (int i = 0; i < 3; ++i)
+            MDRP_ROLLED for (int j = 0; j < 3; ++j) {
                 const double Fij = x * Nq[3 * j + i] + y * Nq[9 + 3 * j + i] + Nq[18 + 3 * j + i];
                 E[3 * i + j] = Fij * (i == 2 ? invf : 1.0) * (j == 2 ? invf : 1.0);
                 nrm += E[3 * i + j] * E[3 * i + j];
             }
         nrm = 1.0 / sqrt(nrm);
-        for (int e = 0; e < 9; ++e) E[e] *= nrm;
+        MDRP_ROLLED for (int e = 0; e < 9; ++e) E[e] *= nrm;
         double b1[6][3], b2[6][3]; // bearings K^-1 x, unit length
-        for (int p = 0; p < 6; ++p) {
+        MDRP_ROLLED for (int p = 0; p < 6; ++p) {
             const double a0 = x1h[p][0] * invf, a1 = x1h[p][1] * invf, a2 = x1h[p][2];
             const double c0 = x2h[p][0] * invf, c1 = x2h[p][1] * invf, c2 = x2h[p][2];
             const double na = 1.0 / sqrt(a0 * a0 + a1 * a1 + a2 * a2), nb = 1.0 / sqrt(c0 * c0 + c1 * c1 + c2 * c2);
@@ -1001,9 +1021,11 @@ MDRP_HD int solver_relpose_6pt_emit(const double (*x1h)[3], const double (*x2h)[
     return n_out;
 }
 MDRP_HD int solver_relpose_6pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[MAX_MODELS_6PT]*/) {
-    return solver_relpose_6pt_emit(x1h, x2h, [&](const Model &m, int k) { out[k] = m; });
+    PlainStore6 st;
+    return solver_relpose_6pt_emit(x1h, x2h, st, [&](const Model &m, int k) { out[k] = m; });
 }
 
+#undef MDRP_ROLLED
 // plain local storage (host tests; not for the device: these arrays would land in scratch memory)
 struct Solve5Local {
     double C[100], lo[12], hi[12], ilo[10], ihi[10];
