@@ -136,33 +136,16 @@ __device__ __forceinline__ void draw_sample_k(uint64_t n, uint64_t &state, uint3
     }
 }
 template <int K>
-__global__ __launch_bounds__(64) void kc_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
-                                                 int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][K]*/) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(SAMP_THREADS) void kc_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
+                                                           int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][K]*/) {
+    const int t = blockIdx.x;
     if (t >= n_tables) return;
     const uint64_t n = (uint64_t)table_n[t];
     if (n < (uint64_t)K) return;
-    const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
     uint64_t state = table_state[t];
-    uint32_t *out = samples + (size_t)t * chunk_len * K;
-    int done = 0;
-    while (done < chunk_len) {
-        uint64_t s = state + (uint64_t)(K * lane) * GAMMA;
-        const uint64_t s0 = s;
-        uint32_t smp[K];
-        draw_sample_k<K>(n, s, smp);
-        const bool rejected = (s - s0) != (uint64_t)K * GAMMA;
-        const unsigned long long ball = __ballot(rejected);
-        const int first = ball ? (__ffsll((long long)ball) - 1) : 63;
-        const int nvalid = min(first + 1, chunk_len - done);
-        if (lane < nvalid) {
-#pragma unroll
-            for (int k = 0; k < K; ++k) out[(size_t)K * (done + lane) + k] = smp[k];
-        }
-        state = __shfl(s, nvalid - 1, 64);
-        done += nvalid;
-    }
-    if (lane == 0) table_state[t] = state;
+    __syncthreads(); // every thread holds the state before thread 0 advances it
+    samples_block<K>(n, state, chunk_len, samples + (size_t)t * chunk_len * K, [](uint64_t n_, uint64_t &s_, uint32_t *o) { draw_sample_k<K>(n_, s_, o); });
+    if (threadIdx.x == 0) table_state[t] = state;
 }
 
 // LDS storage of the 5-point solver: the 10 x 10 matrix of its LU factorisation, one 64-lane column per element, and — in the

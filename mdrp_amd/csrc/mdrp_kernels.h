@@ -280,37 +280,56 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
 }
 
 // ------------------------------------------------------------------------------------------------ samples
-// One wavefront per distinct N.  The sample sequence is a pure function of (seed, N) (RandomSampler @0x4f8970): splitmix64
-// is counter based (state after k raw draws = state + k*GAMMA), and a sample consumes 3 raw draws plus one per rejected
-// duplicate (probability ~3/N).  Lane l speculates that its sample starts 3*l draws after the wave's state; lanes up to
-// and including the first one that saw a rejection are correct, the wave commits those and continues from that lane's
-// end state.  ~N/3 samples per rejection -> a 10k-sample table takes ~170 wave steps instead of 10k serial ones.
-__global__ __launch_bounds__(64) void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
-                                                int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][3]*/) {
-    const int t = blockIdx.x, lane = threadIdx.x;
+// One workgroup per distinct N.  The sample sequence is a pure function of (seed, N) (RandomSampler @0x4f8970): splitmix64
+// is counter based (state after k raw draws = state + k*GAMMA), and a sample consumes K raw draws plus one per rejected
+// duplicate (probability ~K^2/2N).  Thread i speculates that its sample starts K*i draws after the workgroup's state; threads up
+// to and including the first one that saw a rejection are correct, the workgroup commits those and continues from that thread's
+// end state.  ~2N/K^2 samples per rejection and 1024 threads: a 10k-sample table of triples (N = 2000) takes ~25 steps instead
+// of 10k serial ones (0.18 ms with one wavefront per table, on the critical path of the run's first solver launch).
+constexpr int SAMP_THREADS = 1024;
+template <int K, class Draw>
+__device__ __forceinline__ void samples_block(uint64_t n, uint64_t &state_io, int chunk_len, uint32_t *__restrict__ out, Draw &&draw) {
+    __shared__ int s_first[SAMP_THREADS / 64];
+    __shared__ unsigned long long s_state;
+    const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t state = state_io;
+    int done = 0;
+    while (done < chunk_len) {
+        uint64_t s = state + (uint64_t)(K * tid) * GAMMA;
+        const uint64_t s0 = s;
+        uint32_t smp[K];
+        draw(n, s, smp);
+        const bool rejected = (s - s0) != (uint64_t)K * GAMMA;
+        const unsigned long long ball = __ballot(rejected);
+        if (lane == 0) s_first[wave] = ball ? wave * 64 + (__ffsll((long long)ball) - 1) : SAMP_THREADS;
+        __syncthreads();
+        int first = SAMP_THREADS - 1;
+#pragma unroll
+        for (int w = SAMP_THREADS / 64 - 1; w >= 0; --w) { const int v = s_first[w]; if (v < SAMP_THREADS) first = v; }
+        const int nvalid = min(first + 1, chunk_len - done);
+        if (tid < nvalid) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) out[(size_t)K * (done + tid) + k] = smp[k];
+        }
+        if (tid == nvalid - 1) s_state = s;
+        __syncthreads();
+        state = s_state;
+        done += nvalid;
+    }
+    state_io = state;
+}
+__global__ __launch_bounds__(SAMP_THREADS) void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
+                                                          int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][3]*/) {
+    const int t = blockIdx.x;
     if (t >= n_tables) return;
     const uint64_t n = (uint64_t)table_n[t];
     if (n < 3) return;
-    const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
     uint64_t state = table_state[t];
-    uint32_t *out = samples + (size_t)t * chunk_len * 3;
-    int done = 0;
-    while (done < chunk_len) {
-        uint64_t s = state + (uint64_t)(3 * lane) * GAMMA;
-        const uint64_t s0 = s;
-        uint32_t a, b, c;
-        draw_sample3(n, s, a, b, c);
-        const bool rejected = (s - s0) != 3 * GAMMA;
-        const unsigned long long ball = __ballot(rejected);
-        const int first = ball ? (__ffsll((long long)ball) - 1) : 63;
-        const int nvalid = min(first + 1, chunk_len - done);
-        if (lane < nvalid) {
-            out[3 * (done + lane)] = a; out[3 * (done + lane) + 1] = b; out[3 * (done + lane) + 2] = c;
-        }
-        state = __shfl(s, nvalid - 1, 64);
-        done += nvalid;
-    }
-    if (lane == 0) table_state[t] = state;
+    __syncthreads(); // every thread holds the state before thread 0 advances it
+    samples_block<3>(n, state, chunk_len, samples + (size_t)t * chunk_len * 3,
+                     [](uint64_t n_, uint64_t &s_, uint32_t *o) { draw_sample3(n_, s_, o[0], o[1], o[2]); });
+    if (threadIdx.x == 0) table_state[t] = state;
 }
 
 // ------------------------------------------------------------------------------------------------ Sampson terms
@@ -1828,7 +1847,14 @@ __global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__re
 // before anyone knows how many triggers the scans will find); if a chunk found more, nothing is replayed yet — the flag
 // n_active[1] tells the host to run the remaining passes and launch the walk again.
 // Replay of one pair (one lane).  Returns true if the pair has stopped; otherwise `need` = iterations it still certainly needs.
-__device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__restrict__ models, const Trigger *__restrict__ trig /*of this pair*/,
+// COHERENT: the LO results in the triggers were written by other workgroups of the SAME launch (fused tail): they are read with
+// agent-scope atomic loads, which neither the compiler (restrict / invariance reasoning) nor the scalar cache can serve from
+// anything older than the acquire that preceded the call.
+__device__ __forceinline__ double coherent_f64(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <bool COHERENT = false>
+__device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__restrict__ models, const Trigger *trig /*of this pair*/,
                           size_t slot_base, uint64_t &need) {
     need = 0;
     if (!ps.active) return true;
@@ -1859,10 +1885,20 @@ __device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__res
             ps.num_inliers = (uint64_t)tr.cnt_min;
         }
         ps.refinements++;
-        if (tr.ref_score < ps.model_score) {
-            ps.model_score = tr.ref_score;
-            ps.num_inliers = (uint64_t)tr.ref_cnt;
-            ps.best = tr.refined;
+        const double ref_score = COHERENT ? coherent_f64(&tr.ref_score) : tr.ref_score;
+        if (ref_score < ps.model_score) {
+            ps.model_score = ref_score;
+            if (COHERENT) {
+                ps.num_inliers = (uint64_t)__hip_atomic_load(&tr.ref_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                static_assert(sizeof(Model) % 8 == 0, "Model is copied as doubles");
+                const double *src = reinterpret_cast<const double *>(&tr.refined);
+                double *dst = reinterpret_cast<double *>(&ps.best);
+#pragma unroll
+                for (int q = 0; q < (int)(sizeof(Model) / 8); ++q) dst[q] = coherent_f64(src + q);
+            } else {
+                ps.num_inliers = (uint64_t)tr.ref_cnt;
+                ps.best = tr.refined;
+            }
         }
         ps.inlier_ratio = (double)ps.num_inliers / (double)ps.n;
         if (ps.inlier_ratio >= 0.9999) ps.dyn_max_iter = rp.min_iterations;
@@ -1901,7 +1937,7 @@ __global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__
     PairState &ps = st[pair];
     if (!ps.active) return;
     uint64_t need;
-    if (!walk_pair(rp, ps, models, triggers + (size_t)pair * trig_cap, (size_t)pair * rp.slot_stride, need)) {
+    if (!walk_pair<false>(rp, ps, models, triggers + (size_t)pair * trig_cap, (size_t)pair * rp.slot_stride, need)) {
         atomicAdd(n_active, 1);
         atomicMax(max_needed, (unsigned long long)need);
     }
@@ -1929,7 +1965,7 @@ __global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__res
 __device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams &rp, int pair, const Model *__restrict__ models,
                                              const Trigger *__restrict__ triggers, int trig_cap) {
     uint64_t need;
-    walk_pair(rp, fz.st[pair], models, triggers + (size_t)pair * trig_cap, (size_t)pair * rp.slot_stride, need);
+    walk_pair<true>(rp, fz.st[pair], models, triggers + (size_t)pair * trig_cap, (size_t)pair * rp.slot_stride, need);
     __threadfence();
     const int t = atomicAdd(fz.ctl, 1);
     __hip_atomic_store(fz.ready + t, pair, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -2021,10 +2057,9 @@ struct ResultDev {
 };
 
 template <int KIND, bool SHIFT, int T>
-__device__ void final_pair(const RunParams &rp, PairState *__restrict__ st, const double *__restrict__ pts, const double *__restrict__ dep,
+__device__ void final_pair(const RunParams &rp, const PairState &ps, const double *__restrict__ pts, const double *__restrict__ dep,
                            uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results, int pair, LmShared &sh) {
     double *scratch = sh.scratch;
-    PairState &ps = st[pair];
     ResultDev res;
     res.model = ps.best;
     res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
@@ -2071,6 +2106,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_pair;
+    __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
     if (threadIdx.x == 0) {
         sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0;
         int p = blockIdx.x;
@@ -2081,7 +2117,16 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
         s_pair = p;
     }
     __syncthreads();
-    final_pair<KIND, SHIFT, T>(rp, st, pts, dep, mask_all, results, s_pair, sh);
+    if (!ready) { final_pair<KIND, SHIFT, T>(rp, st[s_pair], pts, dep, mask_all, results, s_pair, sh); return; }
+    // The pair state was written DURING this launch (by the LO workgroup that replayed the pair).  This kernel never writes `st`, so the
+    // compiler may fetch st[pair] through the scalar cache, which an acquire does not invalidate and which can hold the cache line that
+    // the previous pair's last field shares with this pair's head from BEFORE the replay: read it once, with vector loads, into LDS.
+    {
+        const volatile unsigned int *src = reinterpret_cast<const volatile unsigned int *>(st + s_pair);
+        for (int i = threadIdx.x; i < (int)(sizeof(PairState) / 4); i += T) s_ps[i] = src[i];
+    }
+    __syncthreads();
+    final_pair<KIND, SHIFT, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, dep, mask_all, results, s_pair, sh);
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels

@@ -28,10 +28,16 @@ for mode in os.environ.get("MODES", "0,1,0,1").split(","):
     step(); step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    bad = 0
     for _ in range(reps):
         res = step()
+        if "0" in out and mode != "0":  # every step against the unfused records (stress for the cross-workgroup hand-over)
+            r0, m0 = out["0"]
+            bad += int(not (res.tobytes() == r0.tobytes() and np.array_equal(mask.cpu().numpy(), m0)))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    if bad:
+        print(f"MISMATCH in {bad} of {reps} steps", flush=True)
     m = mask.cpu().numpy()
     key = mode
     same = ""
