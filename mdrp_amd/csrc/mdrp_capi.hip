@@ -624,8 +624,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 if ((rc = get_events(h, &e0, &e1, 0)) || (rc = get_events(h, &c0, &c1, 1))) return rc;
                 // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
                 const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
-                HIPCHK(hipMemsetAsync(h->surv_count.p, 0, sizeof(int32_t) * batch, s));
-                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>());
+                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
+                                   h->surv_count.as<int32_t>()); // also clears the survivor counters k_count appends to
                 const dim3 cgrid((unsigned)batch * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                 unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
                 HIPCHK(hipEventRecord(c0, s));
@@ -645,9 +645,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 if (use_bound && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
                     // fp32 lower bound of the score for k_count's survivors; its survivors go back into the chunk's tag list
                     uint32_t *tags_b = (odd ? h->tags2 : h->tags).as<uint32_t>();
-                    HIPCHK(hipMemsetAsync(h->surv2_count.p, 0, sizeof(int32_t) * batch, s));
-                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1,
-                                       BND_THREADS, h->cplan.as<int32_t>());
+                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1,
+                                       BND_THREADS, h->cplan.as<int32_t>(), h->surv2_count.as<int32_t>());
                     const dim3 bgrid((unsigned)batch * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
                     unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
                     hipEvent_t b0, b1;
@@ -661,7 +660,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 }
                 hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, surv_cnt, surv_tags, tags_sc);
                 int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, batch, mcount_c, plan, totals);
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, mcount_c, plan, totals);
                 HIPCHK(hipEventRecord(e0, s));
                 const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
                                                         : (unsigned)batch * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
@@ -685,7 +684,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
             int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
             const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
-            hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(64), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
+            hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
             const bool fuse_here = fuse_tail && c + 1 == n_chunks;
             if (fuse_here) {
                 HIPCHK(hipMemsetAsync(fz_ctl, 0, 64 + sizeof(int32_t) * (size_t)batch, s));
@@ -1182,7 +1181,7 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
     const size_t tile_bytes = SCORE_TILE_BYTES;
     if ((rc = h->plan.ensure(sizeof(int32_t) * 8))) return rc;
     int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 4;
-    hipLaunchKernelGGL(k_plan, dim3(1), dim3(64), 0, s, 1, h->model_count.as<int32_t>(), plan, totals);
+    hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, 1, h->model_count.as<int32_t>(), plan, totals);
     const dim3 grid((unsigned)std::min(h->num_cu * 4, (num_models + SCORE_THREADS - 1) / SCORE_THREADS));
     h->ev_used = 0; h->sweep_launches = 1; h->sweep_evals = (int64_t)num_models * n;
     hipEvent_t e0, e1;
@@ -1236,7 +1235,8 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
     rp.kind = kind; rp.batch = 1; rp.n_max = nn; rp.slot_stride = num_models; rp.mps = 4; rp.sample_sz = 3;
-    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(64), 0, s, 1, h->st.as<PairState>(), h->model_count.as<int32_t>(), 2, CNT_WG_MODELS, h->cplan.as<int32_t>());
+    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, 1, h->st.as<PairState>(), h->model_count.as<int32_t>(), 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
+                       (int32_t *)nullptr);
     const dim3 grid((unsigned)((num_models + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
     MDRP_SWEEP_DISPATCH(k_count, kind, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
                         h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),

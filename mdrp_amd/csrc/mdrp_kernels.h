@@ -782,20 +782,44 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // plan[0..B] = prefix sum of workgroups per pair (ceil(counts[stride * pair] / per_wg)); one wavefront
-__global__ __launch_bounds__(64) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
-                                                   int per_wg, int32_t *__restrict__ plan) {
-    const int lane = threadIdx.x;
-    int run = 0;
-    for (int p0 = 0; p0 < batch; p0 += 64) {
-        const int p = p0 + lane;
-        const int b = (p < batch && st[p].active) ? (counts[stride * p] + per_wg - 1) / per_wg : 0;
-        int inc = b;
+// The plan kernels are prefix sums over the pairs of the batch, each between two sweeps on the critical path of the step: one
+// 1024-thread workgroup issues all its (dependent, ~2 us) loads at once where one wavefront walked the batch in 16 steps.
+constexpr int PLAN_THREADS = 1024;
+// exclusive prefix of v over the workgroup (PLAN_THREADS threads); total = sum.  s_w: PLAN_THREADS / 64 + 1 ints of LDS.
+__device__ __forceinline__ int plan_block_scan(int v, int &total, int *s_w) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-        if (p < batch) plan[p] = run + inc - b;
-        run += __shfl(inc, 63, 64);
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    __syncthreads(); // s_w of the previous call is no longer read
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const int x = lane < PLAN_THREADS / 64 ? s_w[lane] : 0;
+        int xi = x;
+#pragma unroll
+        for (int o = 1; o < PLAN_THREADS / 64; o <<= 1) { const int u = __shfl_up(xi, o, 64); if (lane >= o) xi += u; }
+        if (lane < PLAN_THREADS / 64) s_w[lane] = xi - x;
+        if (lane == PLAN_THREADS / 64 - 1) s_w[PLAN_THREADS / 64] = xi;
     }
-    if (lane == 0) plan[batch] = run;
+    __syncthreads();
+    total = s_w[PLAN_THREADS / 64];
+    return inc - v + s_w[wave];
+}
+// zero_a / zero_b: per-pair counters the next sweep accumulates into (or null) - cleared here instead of by a memset node in front
+__global__ __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
+                                                             int per_wg, int32_t *__restrict__ plan, int32_t *__restrict__ zero_a) {
+    __shared__ int s_w[PLAN_THREADS / 64 + 1];
+    int run = 0;
+    for (int p0 = 0; p0 < batch; p0 += PLAN_THREADS) {
+        const int p = p0 + threadIdx.x;
+        const int b = (p < batch && st[p].active) ? (counts[stride * p] + per_wg - 1) / per_wg : 0;
+        int tot;
+        const int ex = plan_block_scan(b, tot, s_w);
+        if (p < batch) { plan[p] = run + ex; if (zero_a) zero_a[p] = 0; }
+        run += tot;
+    }
+    if (threadIdx.x == 0) plan[batch] = run;
 }
 
 template <bool POSE, bool RAWF = false> // RAWF: the model IS a fundamental matrix (first nine doubles, row-major) — 7-point baseline
@@ -1249,31 +1273,27 @@ __global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState
 
 // Work plan of one sweep launch: the workgroups a pair needs (ceil(count / SCORE_THREADS) per density class).
 // One wavefront, 64 pairs per step.  plan[0..B] = prefix sum of blocks per pair, plan[B+1 .. 2B] = sparse blocks of the pair.
-__global__ __launch_bounds__(64) void k_plan(int batch, const int32_t *__restrict__ model_count, int32_t *__restrict__ plan,
-                                             int32_t *__restrict__ totals /*[0] dense, [1] dense + sparse, [2] queue head*/) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int batch, const int32_t *__restrict__ model_count, int32_t *__restrict__ plan,
+                                                       int32_t *__restrict__ totals /*[0] dense, [1] dense + sparse, [2] queue head*/) {
+    __shared__ int s_w[PLAN_THREADS / 64 + 1];
     int run_d = 0, run_s = 0;
     int32_t *pd = plan, *psp = plan + batch + 1;
-    for (int p0 = 0; p0 < batch; p0 += 64) {
-        const int p = p0 + lane;
+    for (int p0 = 0; p0 < batch; p0 += PLAN_THREADS) {
+        const int p = p0 + threadIdx.x;
         int bd = 0, bs = 0;
         if (p < batch) {
             bs = (model_count[2 * p] + SCORE_THREADS - 1) / SCORE_THREADS;
             bd = (model_count[2 * p + 1] + SCORE_THREADS - 1) / SCORE_THREADS;
         }
-        int id = bd, is = bs;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int vd = __shfl_up(id, o, 64), vs = __shfl_up(is, o, 64);
-            if (lane >= o) { id += vd; is += vs; }
-        }
+        int tot_d, tot_s;
+        const int ed = plan_block_scan(bd, tot_d, s_w), es = plan_block_scan(bs, tot_s, s_w);
         // pair-major order: a pair's sparse blocks then its dense blocks, pairs consecutive (dense workgroups, whose
         // phase 2 reads LDS at per-lane addresses, stay spread out in time instead of saturating every CU's LDS at once)
-        if (p < batch) { pd[p] = run_d + run_s + id + is - bd - bs; psp[p] = bs; }
-        run_d += __shfl(id, 63, 64);
-        run_s += __shfl(is, 63, 64);
+        if (p < batch) { pd[p] = run_d + run_s + ed + es; psp[p] = bs; }
+        run_d += tot_d;
+        run_s += tot_s;
     }
-    if (lane == 0) { pd[batch] = run_d + run_s; psp[batch] = 0; totals[0] = run_d; totals[1] = run_d + run_s; totals[2] = 0; }
+    if (threadIdx.x == 0) { pd[batch] = run_d + run_s; psp[batch] = 0; totals[0] = run_d; totals[1] = run_d + run_s; totals[2] = 0; }
 }
 
 // Workgroup w handles item w of the plan (grid = an upper bound, surplus workgroups at the END exit at once).  A static
@@ -1820,24 +1840,22 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 // (Measured and dropped: longest-first ordering by inlier count — no change; XCD-affine queues, pair p on XCD p mod 8 —
 // 2.8x less HBM fetch, same time: LO is bound by dependent fp64 latency at 2 waves/SIMD, not by bandwidth or order.)
 // plan layout: prefix[B+1] | begin[B] | end[B] | total
-__global__ __launch_bounds__(64) void k_lo_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ prev_plan /*or null*/,
-                                                int32_t *__restrict__ plan) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(PLAN_THREADS) void k_lo_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ prev_plan /*or null*/,
+                                                          int32_t *__restrict__ plan) {
+    __shared__ int s_w[PLAN_THREADS / 64 + 1];
     int32_t *prefix = plan, *begin = plan + batch + 1, *end = begin + batch;
     const int32_t *prev_end = prev_plan ? prev_plan + 2 * (size_t)batch + 1 : nullptr;
     int run = 0;
-    for (int p0 = 0; p0 < batch; p0 += 64) {
-        const int p = p0 + lane;
+    for (int p0 = 0; p0 < batch; p0 += PLAN_THREADS) {
+        const int p = p0 + threadIdx.x;
         int b = 0, e = 0;
         if (p < batch) { b = prev_end ? prev_end[p] : 0; e = st[p].n_triggers; if (e < b) e = b; }
-        const int c = e - b;
-        int inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if (lane >= o) inc += v; }
-        if (p < batch) { prefix[p] = run + inc - c; begin[p] = b; end[p] = e; }
-        run += __shfl(inc, 63, 64);
+        int tot;
+        const int ex = plan_block_scan(e - b, tot, s_w);
+        if (p < batch) { prefix[p] = run + ex; begin[p] = b; end[p] = e; }
+        run += tot;
     }
-    if (lane == 0) { prefix[batch] = run; plan[3 * (size_t)batch + 1] = run; }
+    if (threadIdx.x == 0) { prefix[batch] = run; plan[3 * (size_t)batch + 1] = run; }
 }
 
 // ------------------------------------------------------------------------------------------------ walk
