@@ -534,7 +534,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // swept, and chunk c's triggers are refined while chunk c + 1 is swept.  Chunks alternate between two sets of tag
         // lists / model counters / sample tables; slots, triggers and LO plans of different chunks are disjoint.
         const bool piped = n_chunks > 1 && lo_overlap;
-        const bool fuse_tail = fuse_env && piped && !use_lme && !classic && it0 + super_len >= ro->max_iterations;
+        const bool fuse_tail = fuse_env && piped && !use_lme && it0 + super_len >= ro->max_iterations;
         int32_t *fz_ctl = nullptr, *fz_done = nullptr, *fz_ready = nullptr;
         if (fuse_tail) {
             if ((rc = h->fuse.ensure(64 + 2 * sizeof(int32_t) * (size_t)batch))) return rc;
@@ -704,7 +704,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 if (classic) {
                     MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), 0, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
                                              h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c,
-                                             h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max);
+                                             h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max, fz);
                     return MDRP_OK;
                 }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
@@ -733,9 +733,13 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             hipEvent_t g0, g1;
             if ((rc = get_events(h, &g0, &g1, 3))) return rc;
             HIPCHK(hipEventRecord(g0, s));
-            MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
-                             h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                             h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready);
+            if (classic)
+                MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
+                                         (const int32_t *)fz_ready);
+            else
+                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
+                                 h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready);
             HIPCHK(hipEventRecord(g1, s));
             final_done = true;
         }
@@ -807,7 +811,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     HIPCHK(hipEventRecord(f0, s));
     if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
     else if (classic)
-        MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev);
+        MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
+                                 (const int32_t *)nullptr);
     else {
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                          h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),

@@ -584,12 +584,17 @@ template <int CK, int T>
 __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                               const Model *__restrict__ models, Trigger *__restrict__ triggers, int trig_cap,
                                               const int32_t *__restrict__ plan, int32_t *__restrict__ head /*zeroed*/,
-                                              uint8_t *__restrict__ lo_mask /*[gridDim.x][n_max]*/) {
+                                              uint8_t *__restrict__ lo_mask /*[gridDim.x][n_max]*/, FuseTail fz /*ready == null: off*/) {
     __shared__ double scratch[4 * MAX_ACC];
     __shared__ int s_item;
-    const int32_t *prefix = plan, *begin = plan + rp.batch + 1;
+    const int32_t *prefix = plan, *begin = plan + rp.batch + 1, *end = begin + rp.batch;
     const int total = plan[3 * (size_t)rp.batch + 1];
     uint8_t *wg_mask = lo_mask + (size_t)blockIdx.x * rp.n_max;
+    if (fz.ready && threadIdx.x == 0) { // fused tail (mdrp_kernels.h FuseTail): pairs without a trigger in this launch are ready as they are
+        for (int p = blockIdx.x; p < rp.batch; p += gridDim.x)
+            if (end[p] == begin[p]) fuse_publish(fz, rp, p, models, triggers, trig_cap);
+        atomicAdd(fz.ctl + 1, 1);
+    }
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
@@ -607,7 +612,16 @@ __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__r
         double sc;
         int cn;
         cblock_score<CK, T>(m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
-        if (threadIdx.x == 0) { tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn; }
+        if (threadIdx.x == 0) {
+            tr.refined = m; tr.ref_score = sc; tr.ref_cnt = cn;
+            if (fz.ready) {
+                __threadfence(); // this trigger's results before the count
+                if (atomicAdd(fz.done_cnt + pair, 1) + 1 == end[pair] - begin[pair]) {
+                    __threadfence(); // the other triggers' results (written on other CUs / XCDs) before the replay reads them
+                    fuse_publish(fz, rp, pair, models, triggers, trig_cap);
+                }
+            }
+        }
     }
 }
 
@@ -615,11 +629,8 @@ __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__r
 // ransac<> tail + get_inliers + the estimator's inlier-only refinement with the user's BundleOptions (estimate_relative_pose
 // @0x21f800: if more than 5 inliers; estimate_fundamental @0x221a00: more than 7, then F <- T2' F T1 / |.|)
 template <int CK, int T>
-__global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
-                                                 uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results) {
-    __shared__ double scratch[4 * MAX_ACC];
-    const int pair = blockIdx.x;
-    PairState &ps = st[pair];
+__device__ void cfinal_pair(const RunParams &rp, const PairState &ps, const double *__restrict__ pts, uint8_t *__restrict__ mask_all,
+                            ResultDev *__restrict__ results, int pair, double *scratch) {
     ResultDev res;
     res.model = ps.best;
     res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
@@ -667,6 +678,28 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
     if (CK == CLASSIC_SHARED) { best.f1 *= ps.norm; best.f2 *= ps.norm; } // back to pixels
     res.model = best;
     if (threadIdx.x == 0) results[pair] = res;
+}
+template <int CK, int T>
+__global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
+                                                 uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results,
+                                                 const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/) {
+    __shared__ double scratch[4 * MAX_ACC];
+    __shared__ int s_pair;
+    __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
+    if (!ready) { cfinal_pair<CK, T>(rp, st[blockIdx.x], pts, mask_all, results, blockIdx.x, scratch); return; }
+    if (threadIdx.x == 0) { // fused tail: the blockIdx-th pair to become ready (k_final, mdrp_kernels.h)
+        int p;
+        while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+        __threadfence();
+        s_pair = p;
+    }
+    __syncthreads();
+    {
+        const volatile unsigned int *src = reinterpret_cast<const volatile unsigned int *>(st + s_pair);
+        for (int i = threadIdx.x; i < (int)(sizeof(PairState) / 4); i += T) s_ps[i] = src[i];
+    }
+    __syncthreads();
+    cfinal_pair<CK, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, mask_all, results, s_pair, scratch);
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels
