@@ -91,7 +91,7 @@ struct mdrp_handle {
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
     hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
-    DevBuf fuse;                       // fused tail: control words (64 B) | done_cnt[batch] | ready[batch]
+    DevBuf fuse;                       // fused tail: control words (64 B) | done_cnt[batch] | fin_done[batch] | ready[batch]
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
     hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
@@ -535,10 +535,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // lists / model counters / sample tables; slots, triggers and LO plans of different chunks are disjoint.
         const bool piped = n_chunks > 1 && lo_overlap;
         const bool fuse_tail = fuse_env && piped && !use_lme && it0 + super_len >= ro->max_iterations;
-        int32_t *fz_ctl = nullptr, *fz_done = nullptr, *fz_ready = nullptr;
+        int32_t *fz_ctl = nullptr, *fz_done = nullptr, *fz_fin = nullptr, *fz_ready = nullptr;
         if (fuse_tail) {
-            if ((rc = h->fuse.ensure(64 + 2 * sizeof(int32_t) * (size_t)batch))) return rc;
-            fz_ctl = h->fuse.as<int32_t>(); fz_done = fz_ctl + 16; fz_ready = fz_done + batch;
+            if ((rc = h->fuse.ensure(64 + 3 * sizeof(int32_t) * (size_t)batch))) return rc;
+            fz_ctl = h->fuse.as<int32_t>(); fz_done = fz_ctl + 16; fz_fin = fz_done + batch; fz_ready = fz_fin + batch;
         }
         hipStream_t aux = piped ? h->aux_stream : s, aux2 = piped ? h->aux_stream2 : s;
         int offs[mdrp_handle::NC_MAX] = {0};
@@ -687,7 +687,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
             const bool fuse_here = fuse_tail && c + 1 == n_chunks;
             if (fuse_here) {
-                HIPCHK(hipMemsetAsync(fz_ctl, 0, 64 + sizeof(int32_t) * (size_t)batch, s));
+                HIPCHK(hipMemsetAsync(fz_ctl, 0, 64 + 2 * sizeof(int32_t) * (size_t)batch, s));
                 HIPCHK(hipMemsetAsync(fz_ready, 0xFF, sizeof(int32_t) * (size_t)batch, s));
             }
             if (piped) { HIPCHK(hipEventRecord(h->ev_scanned[c], s)); HIPCHK(hipStreamWaitEvent(aux2, h->ev_scanned[c], 0)); }
@@ -728,22 +728,34 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int cl = n_chunks - 1;
             const int32_t *plan_l = h->work_pair.as<int32_t>() + (size_t)cl * lo_plan_ints;
             const int lo_blocks_l = h->num_cu * (lo_threads_last == 64 ? 8 : 2); // = lo_blocks of the last chunk's launch above
+            // bounded waits (k_gate): far beyond anything a healthy run needs (the LO queue of 1024 pairs is empty after ~1 ms)
+            const unsigned long long gate_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_GATE_US", 50000 + 40 * batch);
+            const unsigned long long wait_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_WAIT_US", 20000 + 4 * batch);
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const int32_t *)(cnt + CNT_LO_HEAD + cl), plan_l + 3 * (size_t)batch + 1,
-                               (const int32_t *)fz_ctl, lo_blocks_l);
+                               (const int32_t *)fz_ctl, lo_blocks_l, gate_ticks);
             hipEvent_t g0, g1;
             if ((rc = get_events(h, &g0, &g1, 3))) return rc;
             HIPCHK(hipEventRecord(g0, s));
             if (classic)
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                         (const int32_t *)fz_ready);
+                                         (const int32_t *)fz_ready, fz_fin, wait_ticks);
             else
                 MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready);
+                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready, fz_fin, wait_ticks);
             HIPCHK(hipEventRecord(g1, s));
             final_done = true;
         }
         if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
+        if (fuse_tail) { // behind the LO launch: the pairs a bounded wait gave up on (none in a healthy run: 1024 workgroups that read a flag)
+            if (classic)
+                MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
+                                         (const int32_t *)nullptr, fz_fin, 0ull);
+            else
+                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
+                                 h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, fz_fin, 0ull);
+        }
         if (!fuse_tail)
             hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                                h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
@@ -812,11 +824,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
     else if (classic)
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                 (const int32_t *)nullptr);
+                                 (const int32_t *)nullptr, (int32_t *)nullptr, 0ull);
     else {
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                          h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                         h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr);
+                         h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, (int32_t *)nullptr, 0ull);
     }
     HIPCHK(hipEventRecord(f1, s));
     HIPCHK(hipGetLastError());

@@ -682,24 +682,34 @@ __device__ void cfinal_pair(const RunParams &rp, const PairState &ps, const doub
 template <int CK, int T>
 __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                  uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results,
-                                                 const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/) {
+                                                 const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/,
+                                                 int32_t *__restrict__ fin_done /*fused: set per refined pair; unfused: pairs to skip, or null*/,
+                                                 unsigned long long ticks) {
     __shared__ double scratch[4 * MAX_ACC];
     __shared__ int s_pair;
     __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
-    if (!ready) { cfinal_pair<CK, T>(rp, st[blockIdx.x], pts, mask_all, results, blockIdx.x, scratch); return; }
-    if (threadIdx.x == 0) { // fused tail: the blockIdx-th pair to become ready (k_final, mdrp_kernels.h)
+    if (!ready) {
+        if (fin_done && fin_done[blockIdx.x]) return; // (uniform) the pass behind a fused tail: only what that left undone
+        cfinal_pair<CK, T>(rp, st[blockIdx.x], pts, mask_all, results, blockIdx.x, scratch);
+        return;
+    }
+    if (threadIdx.x == 0) { // fused tail: the blockIdx-th pair to become ready, bounded wait (k_final / k_gate, mdrp_kernels.h)
         int p;
-        while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+        const unsigned long long t0 = wall_clock64();
+        while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
+            __builtin_amdgcn_s_sleep(16);
         __threadfence();
         s_pair = p;
     }
     __syncthreads();
+    if (s_pair < 0) return;
     {
         const volatile unsigned int *src = reinterpret_cast<const volatile unsigned int *>(st + s_pair);
         for (int i = threadIdx.x; i < (int)(sizeof(PairState) / 4); i += T) s_ps[i] = src[i];
     }
     __syncthreads();
     cfinal_pair<CK, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, mask_all, results, s_pair, scratch);
+    if (threadIdx.x == 0) fin_done[s_pair] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels

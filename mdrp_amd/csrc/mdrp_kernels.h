@@ -1973,11 +1973,17 @@ struct FuseTail {
     PairState *st;       // mutable alias of the pair states (only the walking lane writes)
 };
 // one lane: returns when every workgroup of the LO launch has started and every problem has been taken from its queue - from then
-// on whatever a final refinement may wait for is in the hands of a resident workgroup
-__global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks) {
+// on whatever a final refinement may wait for is in the hands of a resident workgroup.
+// Both this wait and the final refinements' wait for their pair are BOUNDED (`ticks` of the 100 MHz clock): where kernels of
+// different streams cannot run side by side (rocprofv3 --pmc serialises dispatches, debuggers do) the LO launch may be stuck behind
+// the very kernels that wait for it.  Then the gate gives up, the final workgroups give up and leave their pairs undone, the LO
+// launch runs, and the ordinary k_final pass behind it (`skip`) refines what is left: slower, never stuck.
+__global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks,
+                       unsigned long long ticks) {
     const int total = *plan_total;
-    while (__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lo_blocks ||
-           __hip_atomic_load(lo_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total)
+    const unsigned long long t0 = wall_clock64();
+    while ((__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lo_blocks ||
+            __hip_atomic_load(lo_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) && wall_clock64() - t0 < ticks)
         __builtin_amdgcn_s_sleep(64);
 }
 __device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams &rp, int pair, const Model *__restrict__ models,
@@ -2120,7 +2126,9 @@ template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
                                                       ResultDev *__restrict__ results, int list_stride, unsigned long long *__restrict__ lm_stats,
-                                                      const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/) {
+                                                      const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/,
+                                                      int32_t *__restrict__ fin_done /*fused: set per refined pair; unfused: pairs to skip, or null*/,
+                                                      unsigned long long ticks) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_pair;
@@ -2128,13 +2136,16 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     if (threadIdx.x == 0) {
         sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0;
         int p = blockIdx.x;
-        if (ready) { // fused tail: the blockIdx-th pair to become ready
-            while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(16);
+        if (ready) { // fused tail: the blockIdx-th pair to become ready (bounded wait, see k_gate)
+            const unsigned long long t0 = wall_clock64();
+            while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
+                __builtin_amdgcn_s_sleep(16);
             __threadfence(); // the replayed pair state (written on another CU / XCD) before anyone of this workgroup reads it
-        }
+        } else if (fin_done && fin_done[p]) p = -1; // the pass behind a fused tail: only what that left undone
         s_pair = p;
     }
     __syncthreads();
+    if (s_pair < 0) return;
     if (!ready) { final_pair<KIND, SHIFT, T>(rp, st[s_pair], pts, dep, mask_all, results, s_pair, sh); return; }
     // The pair state was written DURING this launch (by the LO workgroup that replayed the pair).  This kernel never writes `st`, so the
     // compiler may fetch st[pair] through the scalar cache, which an acquire does not invalidate and which can hold the cache line that
@@ -2145,6 +2156,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     }
     __syncthreads();
     final_pair<KIND, SHIFT, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, dep, mask_all, results, s_pair, sh);
+    if (threadIdx.x == 0) fin_done[s_pair] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels

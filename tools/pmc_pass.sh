@@ -8,7 +8,8 @@ for kv in "$@"; do export "$kv"; done
 mkdir -p $R/gpurun_out/pmc
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$name
-rocprofv3 --pmc $counters --output-format csv -d /tmp/pmc_$name -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --batch ${BATCH:-1024} --workload ${WORKLOAD:-calib_p3p_n2000_i10k} > $R/gpurun_out/pmc/$name.log 2>&1
+# (counter collection serialises dispatches: the fused tail cannot overlap, profile the unfused order - see tools/profile_round.sh)
+MDRP_FUSE_TAIL=${MDRP_FUSE_TAIL:-0} rocprofv3 --pmc $counters --output-format csv -d /tmp/pmc_$name -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --batch ${BATCH:-1024} --workload ${WORKLOAD:-calib_p3p_n2000_i10k} > $R/gpurun_out/pmc/$name.log 2>&1
 F=$(find /tmp/pmc_$name -name "*counter_collection.csv" | head -1)
 if [ -z "$F" ]; then echo "$name: no counter file"; tail -5 $R/gpurun_out/pmc/$name.log; exit 1; fi
 grep -E "Counter_Name|mdrp::" "$F" > $R/gpurun_out/pmc/$name.csv

@@ -20,7 +20,9 @@ for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE" \
          "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   i=$((i+1)); rm -rf /tmp/pmc_$i
-  rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$i -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --workload $W --batch $B > $O/pmc_$i.log 2>&1
+  # counter collection serialises kernel dispatches: the fused tail (last LO launch and final refinements side by side) cannot
+  # overlap then and would only show its bounded waits - the PMC passes profile the same kernels in the unfused order
+  MDRP_FUSE_TAIL=0 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$i -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --workload $W --batch $B > $O/pmc_$i.log 2>&1
   F=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$F" ]; then grep -E "Counter_Name|mdrp::" "$F" > $O/pmc_$i.csv; else echo "pass $i: no counters"; tail -3 $O/pmc_$i.log; fi
 done
