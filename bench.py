@@ -131,7 +131,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X_MICROARCH.md: fp64 vector peak (256 CUs
 # fp64 flop per correspondence of the LM sweeps, (cost sweep: residuals | normal-equation sweep: residuals + Jacobians + J'J),
 # read off the ISA of this build by tools/lm_flops.py (FMA-class instructions 2 flop, every other fp64 VALU instruction 1);
 # keyed by (estimator kind, monodepth_estimate_shift on the calibrated estimator)
-LM_FLOP = {(0, False): (179.0, 711.0), (0, True): (179.0, 821.0), (1, False): (187.0, 875.0), (2, False): (187.0, 973.0)}
+LM_FLOP = {(0, False): (179.0, 716.0), (0, True): (179.0, 826.0), (1, False): (187.0, 883.0), (2, False): (187.0, 973.0)}
 
 
 def main():

@@ -39,7 +39,12 @@ def main(path):
         inner = [l for l in loops if not any(o != l and l[0] <= o[0] and o[1] <= l[1] for o in loops)]
         stats = []
         for a, b in inner:
-            f, n = flops([x.strip() for x in body[a:b + 1]])
+            lines = [x.strip() for x in body[a:b + 1]]
+            # the sweeps read one record per trip (<= 4 loads); the replay loop of the fused tail (walk_pair: ~40 loads and stores per
+            # trigger, pow / log expansions) is not an LM sweep
+            if sum(1 for x in lines if x.startswith(("global_", "flat_", "scratch_", "buffer_"))) > 12:
+                continue
+            f, n = flops(lines)
             ballot = any("v_mbcnt" in x or "v_bcnt" in x for x in body[a:b + 1])
             stats.append((f, n, ballot, b - a))
         acc = max(stats)
