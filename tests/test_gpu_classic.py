@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import pyorc as po
-from test_oracle_classic import check_solver_lists, classic_cam, est_cases, fund_diff, pose_diff, sample_residual
+from test_oracle_classic import (WIDE_CLASSIC, check_solver_lists, classic_cam, est_cases, fund_diff, pose_diff, sample_residual,
+                                 wide_classic_digest, wide_classic_pair)
 
 pytestmark = pytest.mark.gpu
 
@@ -395,3 +396,43 @@ def test_sixpt_batch_follows_the_oracle_trajectory():
         assert (info["refinements"], info["iterations"], info["num_inliers"]) == (st.refinements, st.iterations, st.num_inliers), (k, info["refinements"], st.refinements)
         assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask), k
         assert np.abs(out[k].pose.R - po.quat_to_rotmat(m[:4])).max() < 1e-6 and out[k].camera1.focal() == pytest.approx(m[10], rel=1e-6), k
+
+
+@pytest.mark.parametrize("name,kind", WIDE_CLASSIC)
+def test_full_size_wide_vs_reference_binary(golden, name, kind):
+    """The baselines at the benchmark shape (N = 2000, 10^4 iterations, 50 % outliers) as ONE batch against the reference binary's
+    own outputs (tests/golden/classic_wide.npz: 32 / 16 / 32 pairs): iterations, inlier count, mask, model and score on every
+    pair; the LO count equals the reference's, or the CPU port's on the one 6-point pair where that differs (solution order)."""
+    import mdrp_amd.poselib as poselib
+    g = golden("classic_wide")
+    count = len(g[f"{name}_stats"])
+    pairs = [wide_classic_pair(kind, j) for j in range(count)]
+    for j, p in enumerate(pairs):
+        assert wide_classic_digest(p) == g[f"{name}_digest"][j], "mdrp_amd.synth changed: regenerate tests/golden/classic_wide.npz"
+    ro = {"max_iterations": 10000, "min_iterations": 10000, "max_epipolar_error": 2.0, "seed": 0}
+    bo = {"loss_type": "TRUNCATED_CAUCHY"}
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+    x1, x2 = [p["x1"] for p in pairs], [p["x2"] for p in pairs]
+    if kind == 3:
+        models, infos = poselib.estimate_relative_pose_batch(x1, x2, cam, cam, ro, bo)
+        rows = [np.r_[m.q, m.t] for m in models]
+    elif kind == 4:
+        models, infos = poselib.estimate_shared_focal_relative_pose_batch(x1, x2, (0.0, 0.0), ro, bo)
+        rows = [np.r_[m.pose.q, m.pose.t, m.camera1.params[0]] for m in models]
+    else:
+        models, infos = poselib.estimate_fundamental_batch(x1, x2, ro, bo)
+        rows = [np.asarray(m).reshape(-1) for m in models]
+    lo_dev = 0
+    for j in range(count):
+        ref_m, ref_st = g[f"{name}_model"][j], g[f"{name}_stats"][j]
+        info = infos[j]
+        assert (info["iterations"], info["num_inliers"]) == (int(ref_st[1]), int(ref_st[2])), (name, j)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), np.unpackbits(g[f"{name}_mask"][j])[:2000]), (name, j)
+        assert abs(info["model_score"] - ref_st[4]) <= 1e-9 * abs(ref_st[4]), (name, j)
+        d = fund_diff(rows[j], ref_m) if kind == 5 else pose_diff(rows[j], ref_m)
+        assert d < 1e-6, (name, j, d)
+        if kind == 4:
+            assert abs(rows[j][7] - ref_m[7]) < 1e-6 * ref_m[7], (name, j)
+        assert info["refinements"] in (int(ref_st[0]), int(g[f"{name}_oracle_refinements"][j])), (name, j, info["refinements"], ref_st[0])
+        lo_dev += info["refinements"] != int(ref_st[0])
+    assert lo_dev <= 1, lo_dev

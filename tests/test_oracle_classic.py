@@ -269,3 +269,53 @@ def test_sixpt_estimator_vs_reference(golden):
         assert m[10] == pytest.approx(ref_m[7], rel=1e-6), index
         lo_dev += st.refinements != int(ref_st[0])
     assert lo_dev <= 3, lo_dev
+
+
+# ---------------------------------------------------------------------------------------------- wide full-size pin (classic_wide.npz)
+WIDE_CLASSIC = (("relpose_5pt", 3), ("shared_6pt", 4), ("fundamental_7pt", 5))
+
+
+def wide_classic_pair(kind, index):
+    """the inputs of tests/tools/gen_golden_wide_classic.py (seeds only are stored)"""
+    from mdrp_amd import synth
+    if kind == 4:
+        return synth.make_pair(7000 + index, 2000, noise_px=0.5, outlier_frac=0.5, random_focal="shared", pp=(0.0, 0.0))
+    return synth.make_pair(7000 + index, 2000, f1=800.0, f2=800.0, pp=(0.0, 0.0), noise_px=0.5, outlier_frac=0.5)
+
+
+def wide_classic_digest(p):
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("x1", "x2"):
+        h.update(np.ascontiguousarray(p[k], dtype=np.float64).tobytes())
+    return np.frombuffer(h.digest()[:8], dtype=np.uint64)[0]
+
+
+def wide_classic_model_diff(kind, m, ref):
+    """m: flat model of ours (pose: q, t [, f at `fi`]; fundamental: nine entries), ref: the fixture's row (q, t, f, f | F)"""
+    if kind == 5:
+        return fund_diff(m, ref)
+    return pose_diff(m, ref)
+
+
+def test_wide_full_size_classic_pin_subsample(golden):
+    """tests/golden/classic_wide.npz: 80 full-size runs of the reference binary (N = 2000, 10^4 iterations, 50 % outliers; 32 + 16 +
+    32 pairs of the 5- / 6- / 7-point estimators) on which the oracle's RESULT equals the reference's on every pair (written by
+    the generator into `oracle_same`) and the LO count on all but one 6-point pair; three pairs per estimator are re-run here."""
+    g = golden("classic_wide")
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
+    for name, kind in WIDE_CLASSIC:
+        assert g[f"{name}_oracle_same"].all(), name
+        dev = g[f"{name}_oracle_refinements"] - g[f"{name}_stats"][:, 0].astype(int)
+        assert int(np.abs(dev).sum()) == (1 if kind == 4 else 0), (name, dev)
+        for j in (0, 5, 12):
+            p = wide_classic_pair(kind, j)
+            assert wide_classic_digest(p) == g[f"{name}_digest"][j], "mdrp_amd.synth changed: regenerate tests/golden/classic_wide.npz"
+            m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], po.ransac_opt(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0, seed=0),
+                                              po.bundle_opt(loss_type=4), cam if kind == 3 else None, cam if kind == 3 else None, pp=(0.0, 0.0))
+            ref_st = g[f"{name}_stats"][j]
+            assert (st.iterations, st.num_inliers) == (int(ref_st[1]), int(ref_st[2])) and st.refinements == int(g[f"{name}_oracle_refinements"][j])
+            assert np.array_equal(mask, np.unpackbits(g[f"{name}_mask"][j])[:2000])
+            assert wide_classic_model_diff(kind, m, g[f"{name}_model"][j]) < 1e-8
+            if kind == 4:
+                assert abs(m[10] - g[f"{name}_model"][j][7]) < 1e-8 * m[10]
