@@ -873,6 +873,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
+    per_pass = std::max(1, std::min(per_pass, env_int("MDRP_PAIRS_PER_PASS", per_pass))); // (tests: several passes on a small batch)
     for (int p0 = 0; p0 < batch; p0 += per_pass) {
         const int nb = std::min(per_pass, batch - p0);
         rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 ? d1 + (size_t)p0 * n_max : nullptr,

@@ -192,3 +192,35 @@ def test_batch_pipeline_equals_sequential_calls():
         for (r0, m0), (r1, m1) in zip(seq, got):
             assert r0.tobytes() == r1.tobytes() and np.array_equal(m0, m1)
     h.close()
+
+
+@pytest.mark.gpu
+def test_batches_larger_than_one_pass(monkeypatch):
+    """A batch that does not fit the scratch budget is processed in passes of consecutive pairs (estimate_device); forced here
+    with MDRP_PAIRS_PER_PASS on a ragged batch: records and masks equal the single-pass ones bit for bit (pairs are independent
+    and a pass only changes which launches they share), for a monodepth estimator and a baseline."""
+    from mdrp_amd import _capi, synth
+    B, N = 37, 400
+    pairs = [synth.make_pair(6600 + i, [N, 250, 2, 90][i % 4] if i % 3 == 0 else N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4) for i in range(B)]
+    n_per = np.array([len(p["x1"]) for p in pairs], dtype=np.int32)
+    x1, x2 = np.zeros((B, N, 2)), np.zeros((B, N, 2))
+    d1, d2 = np.ones((B, N)), np.ones((B, N))
+    for i, p in enumerate(pairs):
+        x1[i, : n_per[i]], x2[i, : n_per[i]], d1[i, : n_per[i]], d2[i, : n_per[i]] = p["x1"], p["x2"], p["d1"], p["d2"]
+    cams = np.zeros(B, dtype=_capi.CAMERA_DTYPE)
+    cams["params"][:, 0] = 800.0
+    ro = _capi.ransac_opt_from_dict({"max_iterations": 2000, "min_iterations": 2000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+    bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    h = _capi.Handle(0)
+    try:
+        for kind in (_capi.CALIB, _capi.FUNDAMENTAL_7PT):
+            out = []
+            for per in (None, "16", "5"):
+                monkeypatch.delenv("MDRP_PAIRS_PER_PASS", raising=False) if per is None else monkeypatch.setenv("MDRP_PAIRS_PER_PASS", per)
+                res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, n_per, cams if kind == _capi.CALIB else None, cams if kind == _capi.CALIB else None)
+                out.append((res.copy(), mask.copy()))
+            for r, m in out[1:]:
+                assert r.tobytes() == out[0][0].tobytes() and np.array_equal(m, out[0][1]), kind
+            assert int(out[0][0]["refinements"].max()) > 2
+    finally:
+        h.close()
