@@ -12,5 +12,5 @@ for f in sys.argv[1:]:
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
 for (name, ctr), (n, v) in sorted(acc.items()):
-    if name.startswith("k_"):
+    if name.startswith(("k_", "kc_")):
         print(f"{name:36s} {ctr:28s} n={n:4d} sum={v:16.0f} mean={v / n:14.1f}")
