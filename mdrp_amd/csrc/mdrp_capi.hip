@@ -545,11 +545,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         for (int c = 1; c < n_chunks; ++c) offs[c] = offs[c - 1] + (int)lens[c - 1];
         // The sample tables of the first two chunks do not depend on anything but (seed, N): they are drawn on the (still idle)
         // LO stream while k_prep runs, so the one-wavefront-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
+        const int samp_threads = env_int("MDRP_SAMPLE_THREADS", ssz == 3 ? SAMP_THREADS : (ssz == 5 ? 512 : 256)); // ~ samples between two rejections
         auto launch_samples = [&](hipStream_t st_, int len_, uint32_t *smp_) {
-            if (ssz == 6) hipLaunchKernelGGL(kc_samples<6>, dim3(n_tables), dim3(SAMP_THREADS), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
-            else if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(SAMP_THREADS), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
-            else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(SAMP_THREADS), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
-            else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(SAMP_THREADS), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            if (ssz == 6) hipLaunchKernelGGL(kc_samples<6>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            else if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
         };
         bool presampled[2] = {false, false};
         if (piped && it0 == 0) {

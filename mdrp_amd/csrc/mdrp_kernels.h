@@ -286,13 +286,14 @@ __global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__rest
 // to and including the first one that saw a rejection are correct, the workgroup commits those and continues from that thread's
 // end state.  ~2N/K^2 samples per rejection and 1024 threads: a 10k-sample table of triples (N = 2000) takes ~25 steps instead
 // of 10k serial ones (0.18 ms with one wavefront per table, on the critical path of the run's first solver launch).
-constexpr int SAMP_THREADS = 1024;
+constexpr int SAMP_THREADS = 1024; // at most; the launch picks blockDim.x by sample size (samples_threads): a step commits what lies
+                                    // before the first rejection (~2N/K^2 samples), more threads than that only lengthen the step
 template <int K, class Draw>
 __device__ __forceinline__ void samples_block(uint64_t n, uint64_t &state_io, int chunk_len, uint32_t *__restrict__ out, Draw &&draw) {
     __shared__ int s_first[SAMP_THREADS / 64];
     __shared__ unsigned long long s_state;
     const uint64_t GAMMA = 0x9e3779b97f4a7c15ULL;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nwaves = nthreads >> 6;
     uint64_t state = state_io;
     int done = 0;
     while (done < chunk_len) {
@@ -304,9 +305,8 @@ __device__ __forceinline__ void samples_block(uint64_t n, uint64_t &state_io, in
         const unsigned long long ball = __ballot(rejected);
         if (lane == 0) s_first[wave] = ball ? wave * 64 + (__ffsll((long long)ball) - 1) : SAMP_THREADS;
         __syncthreads();
-        int first = SAMP_THREADS - 1;
-#pragma unroll
-        for (int w = SAMP_THREADS / 64 - 1; w >= 0; --w) { const int v = s_first[w]; if (v < SAMP_THREADS) first = v; }
+        int first = nthreads - 1;
+        for (int w = nwaves - 1; w >= 0; --w) { const int v = s_first[w]; if (v < SAMP_THREADS) first = v; }
         const int nvalid = min(first + 1, chunk_len - done);
         if (tid < nvalid) {
 #pragma unroll
