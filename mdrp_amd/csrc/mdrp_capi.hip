@@ -96,7 +96,10 @@ struct mdrp_handle {
     hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
     // persistent device buffers
-    DevBuf pts, dep, st, samples, table_n, table_state, table_of_pair, nper, cams1, cams2;
+    DevBuf pts, dep, st, samples;
+    DevBuf params;                     // per-call parameters in ONE upload: table states | cameras | table sizes | table of pair | n per pair
+    unsigned char *params_host = nullptr; // pinned staging of the same
+    size_t params_host_cap = 0;
     DevBuf models, slot_score, slot_inl, tags, model_count, triggers, work_pair, counters, results, mask, plan;
     DevBuf tags_s, tags2_s; // survivor lists ordered by candidate density (k_sort_tags)
     DevBuf tags2, model_count2, samples2; // odd chunks of a super-chunk (chunk c + 1 is solved beside the sweep of chunk c)
@@ -366,12 +369,22 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if (!classic && (rc = h->dep.ensure(sizeof(double) * 2 * batch * n_max))) return rc;
     if ((rc = h->st.ensure(sizeof(PairState) * batch))) return rc;
     if ((rc = h->samples.ensure(sizeof(uint32_t) * ssz * (size_t)n_tables * chunk_cap))) return rc;
-    if ((rc = h->table_n.ensure(sizeof(int32_t) * n_tables))) return rc;
-    if ((rc = h->table_state.ensure(sizeof(uint64_t) * n_tables))) return rc;
-    if ((rc = h->table_of_pair.ensure(sizeof(int32_t) * batch))) return rc;
-    if ((rc = h->nper.ensure(sizeof(int32_t) * batch))) return rc;
-    if ((rc = h->cams1.ensure(sizeof(CamDev) * batch))) return rc;
-    if ((rc = h->cams2.ensure(sizeof(CamDev) * batch))) return rc;
+    // the small per-call inputs travel as one block (six pageable copies cost ~60 us of an idle GPU in front of k_prep)
+    const size_t off_state = 0, off_cam1 = off_state + sizeof(uint64_t) * (size_t)n_tables, off_cam2 = off_cam1 + sizeof(CamDev) * (size_t)batch,
+                 off_tn = off_cam2 + sizeof(CamDev) * (size_t)batch, off_tof = off_tn + sizeof(int32_t) * (size_t)n_tables,
+                 off_nper = off_tof + sizeof(int32_t) * (size_t)batch, params_bytes = off_nper + sizeof(int32_t) * (size_t)batch;
+    if ((rc = h->params.ensure(params_bytes))) return rc;
+    if (h->params_host_cap < params_bytes) {
+        if (h->params_host) (void)hipHostFree(h->params_host);
+        h->params_host = nullptr; h->params_host_cap = 0;
+        HIPCHK(hipHostMalloc((void **)&h->params_host, params_bytes + params_bytes / 2, hipHostMallocDefault));
+        h->params_host_cap = params_bytes + params_bytes / 2;
+    }
+    unsigned char *pd = h->params.as<unsigned char>();
+    uint64_t *d_table_state = reinterpret_cast<uint64_t *>(pd + off_state);
+    CamDev *d_cams1 = reinterpret_cast<CamDev *>(pd + off_cam1), *d_cams2 = reinterpret_cast<CamDev *>(pd + off_cam2);
+    int32_t *d_table_n = reinterpret_cast<int32_t *>(pd + off_tn), *d_table_of = reinterpret_cast<int32_t *>(pd + off_tof),
+            *d_nper = reinterpret_cast<int32_t *>(pd + off_nper);
     if ((rc = h->models.ensure(sizeof(Model) * slots))) return rc;
     if ((rc = h->slot_score.ensure(sizeof(double) * slots))) return rc;
     if ((rc = h->slot_inl.ensure(sizeof(int32_t) * slots))) return rc;
@@ -394,15 +407,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->counters.ensure(COUNTERS_BYTES))) return rc;
     if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4 + 16)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
 
-    HIPCHK(hipMemcpyAsync(h->table_n.p, tab_n.data(), sizeof(int32_t) * n_tables, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->table_state.p, tab_state.data(), sizeof(uint64_t) * n_tables, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->table_of_pair.p, table_of.data(), sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
-    HIPCHK(hipMemcpyAsync(h->nper.p, n_host, sizeof(int32_t) * batch, hipMemcpyHostToDevice, s));
-    HIPCHK(hipEventRecord(h->ev_tables, s)); // sample tables can be drawn from here on
-    if (kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) {
-        HIPCHK(hipMemcpyAsync(h->cams1.p, cam1, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(h->cams2.p, cam2, sizeof(CamDev) * batch, hipMemcpyHostToDevice, s));
+    {
+        unsigned char *ph = h->params_host; // free: the previous call on this handle ended with a stream synchronisation
+        std::memcpy(ph + off_state, tab_state.data(), sizeof(uint64_t) * n_tables);
+        const bool cams = kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT;
+        if (cams) { std::memcpy(ph + off_cam1, cam1, sizeof(CamDev) * batch); std::memcpy(ph + off_cam2, cam2, sizeof(CamDev) * batch); }
+        else std::memset(ph + off_cam1, 0, 2 * sizeof(CamDev) * (size_t)batch);
+        std::memcpy(ph + off_tn, tab_n.data(), sizeof(int32_t) * n_tables);
+        std::memcpy(ph + off_tof, table_of.data(), sizeof(int32_t) * batch);
+        std::memcpy(ph + off_nper, n_host, sizeof(int32_t) * batch);
+        HIPCHK(hipMemcpyAsync(pd, ph, params_bytes, hipMemcpyHostToDevice, s));
     }
+    HIPCHK(hipEventRecord(h->ev_tables, s)); // sample tables can be drawn from here on
 
     RunParams rp;
     std::memset(&rp, 0, sizeof rp);
@@ -419,12 +435,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     rp.mps = mps; rp.sample_sz = ssz;
 
     if (classic)
-        hipLaunchKernelGGL(kc_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, h->nper.as<int32_t>(), h->table_of_pair.as<int32_t>(),
-                           h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error, bo->loss_scale, h->pts.as<double>(),
+        hipLaunchKernelGGL(kc_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d_nper, d_table_of,
+                           d_cams1, d_cams2, ro->max_epipolar_error, bo->loss_scale, h->pts.as<double>(),
                            h->st.as<PairState>(), h->rfrag.as<uint4>());
     else
-        hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, h->nper.as<int32_t>(),
-                           h->table_of_pair.as<int32_t>(), h->cams1.as<CamDev>(), h->cams2.as<CamDev>(), ro->max_epipolar_error,
+        hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, d_nper,
+                           d_table_of, d_cams1, d_cams2, ro->max_epipolar_error,
                            ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>(),
                            h->rfrag.as<uint4>());
     HIPCHK(hipGetLastError());
@@ -547,10 +563,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // LO stream while k_prep runs, so the one-wavefront-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
         const int samp_threads = env_int("MDRP_SAMPLE_THREADS", ssz == 3 ? SAMP_THREADS : (ssz == 5 ? 512 : 256)); // ~ samples between two rejections
         auto launch_samples = [&](hipStream_t st_, int len_, uint32_t *smp_) {
-            if (ssz == 6) hipLaunchKernelGGL(kc_samples<6>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
-            else if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
-            else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
-            else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, h->table_n.as<int32_t>(), h->table_state.as<uint64_t>(), len_, smp_);
+            if (ssz == 6) hipLaunchKernelGGL(kc_samples<6>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
+            else if (ssz == 5) hipLaunchKernelGGL(kc_samples<5>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
+            else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
+            else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
         };
         bool presampled[2] = {false, false};
         if (piped && it0 == 0) {
@@ -980,8 +996,7 @@ void mdrp_destroy(mdrp_handle *h) {
     if (!h) return;
     DeviceGuard guard_(h->device);
     (void)hipStreamSynchronize(h->stream);
-    DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->table_n, &h->table_state, &h->table_of_pair, &h->nper, &h->cams1,
-                      &h->cams2, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
+    DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->params, &h->fuse, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
                       &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
@@ -991,6 +1006,7 @@ void mdrp_destroy(mdrp_handle *h) {
     if (h->progress_host) (void)hipHostFree(h->progress_host);
     if (h->lme_live_host) (void)hipHostFree(h->lme_live_host);
     if (h->lm_stats_host) (void)hipHostFree(h->lm_stats_host);
+    if (h->params_host) (void)hipHostFree(h->params_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
