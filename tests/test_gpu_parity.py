@@ -526,3 +526,34 @@ def test_device_resident_batch_matches_host_batch(capi):
         assert np.allclose(res[i]["model"]["q"], geoms[i].pose.q, atol=0, rtol=0)
     with pytest.raises(ValueError):
         poselib.estimate_batch_torch("calibrated", t[0].float(), t[1], t[2], t[3], cam, cam, ro, bo)
+
+
+@pytest.mark.gpu
+def test_sampler_workgroup_size_does_not_change_results(capi, monkeypatch):
+    """The sample tables are drawn speculatively by one workgroup per table (thread i assumes that no sample before its own met a
+    rejection; the threads up to the first rejection are right): the sequence must not depend on how many threads speculate.  Tiny
+    N, where almost every step ends at a rejection, for the 3-, 5- and 7-point samplers: 64 threads (one wavefront, the round-2
+    scheme) against 256 and 1024, records and masks bit for bit."""
+    from mdrp_amd import synth
+    h = capi.Handle(0)
+    try:
+        out = {}
+        for thr in ("64", "256", "1024"):
+            monkeypatch.setenv("MDRP_SAMPLE_THREADS", thr)
+            rows = []
+            for N in (3, 4, 5, 7, 9, 20):
+                for kind in (0, 3, 5):
+                    if N < {0: 3, 3: 5, 5: 7}[kind]:
+                        continue
+                    B = 6
+                    b = synth.make_batch(7000 + N, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.0)
+                    ro = capi.ransac_opt_from_dict({"max_iterations": 2000, "min_iterations": 2000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+                    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE)
+                    cams["params"][:, 0] = 800.0
+                    res, mask = h.estimate_batch(kind, b["x1"], b["x2"], b["d1"], b["d2"], ro, capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}),
+                                                 None, cams if kind in (0, 3) else None, cams if kind in (0, 3) else None)
+                    rows.append(res.tobytes() + mask.tobytes())
+            out[thr] = rows
+        assert out["64"] == out["256"] == out["1024"]
+    finally:
+        h.close()
