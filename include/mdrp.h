@@ -27,12 +27,11 @@ extern "C" {
 enum { MDRP_CALIB = 0, MDRP_SHARED_FOCAL = 1, MDRP_VARYING_FOCAL = 2,
        /* non-monodepth baselines of the same binary on the same kernels (d1 = d2 = NULL):
         * estimate_relative_pose (wheel _core.pyi:504-529; 5-point, cameras as for MDRP_CALIB; model: q, t) and
-        * estimate_fundamental (_core.pyi:309-323; 7-point; model: F row-major in the first nine doubles of mdrp_model).
-        * 4 is reserved for estimate_shared_focal_relative_pose (6-point), not built. */
+        * estimate_fundamental (_core.pyi:309-323; 7-point; model: F row-major in the first nine doubles of mdrp_model). */
        MDRP_RELPOSE_5PT = 3, MDRP_FUNDAMENTAL_7PT = 5,
        /* estimate_shared_focal_relative_pose (wheel _core.pyi: 6-point, one unknown focal length shared by both images;
         * /root/reference/eval_shared_f.py:161).  Pixels relative to nothing: the principal point travels in cam1[i].params[0..1]
-        * (cam2 unused); model: q, t, f1 = f2 = f in pixels */
+        * (cam2 is not read and may be NULL); model: q, t, f1 = f2 = f in pixels */
        MDRP_SHARED_6PT = 4 };
 
 enum { /* return codes */
@@ -116,6 +115,10 @@ const char *mdrp_last_error(void);
 /* "mdrp-hip <ver> (gfx950) MDRP_SRC_HASH=<16 hex digits>": the hash covers mdrp_capi.hip, mdrp_kernels.h, mdrp_math.h,
  * mdrp_classic.h, mdrp_classic_math.h and this header as they were when the library was built (mdrp_amd/build.py source_hash()) */
 const char *mdrp_version(void);
+/* HIP_VERSION (major * 10^7 + minor * 10^5 + patch) of the toolchain the library was compiled with.  The library carries no HIP
+ * runtime of its own (it binds to the host process's libamdhip64 when it is loaded): a host compares this with
+ * hipRuntimeGetVersion() of the runtime it links; mdrp_amd/_capi.py refuses a different major. */
+int mdrp_hip_build_version(void);
 /* block the calling thread until all work queued on the handle's stream is done */
 int mdrp_synchronize(mdrp_handle *h);
 
@@ -170,6 +173,14 @@ int mdrp_score_models(mdrp_handle *h, int kind, int mem_space, const mdrp_model 
 int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1,
                           const double *x2, int n, double sq_threshold, int32_t *candidates);
 
+/* The fp32 stage between the two (k_bound) alone: for every model a LOWER bound of its MSAC score and an UPPER bound of its
+ * inlier count against the n normalised correspondences of one pair, from packed-fp32 arithmetic with explicit error terms
+ * (DESIGN.md 4).  A hypothesis is retired without the exact fp64 sweep when these two bounds prove that it cannot break a
+ * record — the tests assert score_lb <= exact score and count_ub >= exact count on adversarial inputs.  A model whose
+ * coefficients leave the fp32 range proves nothing: it reports (0, n).  Host memory.  score_lb, count_ub: [num_models]. */
+int mdrp_bound_models(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1, const double *x2,
+                      int n, double sq_threshold, double *score_lb, int32_t *count_ub);
+
 /* Hybrid LM refinement of `count` models, each over the correspondences of ONE pair (refine_monodepth_*relpose
  * @0x261030/@0x2592e0/@0x260fa0).  Host memory.  models in/out.  For MDRP_RELPOSE_5PT / MDRP_FUNDAMENTAL_7PT: the Sampson-only
  * refine_relpose @0x258f50 / refine_fundamental @0x2590d0 (d1, d2, scale_reproj, weight_sampson, estimate_shift ignored). */
@@ -207,7 +218,19 @@ typedef struct {
     int64_t lm_accum_evals;    /* LO kernel: correspondences evaluated by its normal-equation sweeps (residuals + Jacobians + J'J) */
     int64_t final_cost_evals;  /* the same two counters of the final-refinement kernel */
     int64_t final_accum_evals;
+    /* ---- appended in ABI 0.3 (mdrp_last_stats_sized only) ----
+     * Fused tail (the last LO launch and the final refinements overlap on two streams): bounded waits that expired in the
+     * last call.  Non-zero means kernels of the handle's streams did not run side by side (serialising profiler / debugger,
+     * AMD_SERIALIZE_KERNEL, a busy shared GPU): results are unaffected, the call was slower, final_ms includes the waits, and the
+     * handle runs unfused from the next call on. */
+    int64_t fuse_gate_timeouts;
+    int64_t fuse_wait_timeouts;
 } mdrp_stats;
+/* writes min(out_size, sizeof(mdrp_stats)) bytes: pass sizeof(mdrp_stats) of the header the caller was compiled against */
+int mdrp_last_stats_sized(mdrp_handle *h, mdrp_stats *out, size_t out_size);
+/* the ABI 0.2 entry point: writes the ABI 0.2 struct (everything before fuse_gate_timeouts), never more.
+ * With the fused tail, lo_ms and final_ms are overlapping intervals on two streams and final_ms includes the final refinements' wait
+ * for their pairs: read them as one phase (lo_ms + final_ms is an upper bound of it), not as two kernel durations. */
 int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out);
 
 #ifdef __cplusplus

@@ -18,9 +18,9 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
-    "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_synchronize", "mdrp_estimate_batch",
-    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_copy_results_device", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_refine_models",
-    "mdrp_last_sweep_stats", "mdrp_last_stats", "mdrp_classic_solver_batch",
+    "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_hip_build_version", "mdrp_synchronize", "mdrp_estimate_batch",
+    "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_copy_results_device", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_bound_models", "mdrp_refine_models",
+    "mdrp_last_sweep_stats", "mdrp_last_stats", "mdrp_last_stats_sized", "mdrp_classic_solver_batch",
 )
 
 
@@ -51,7 +51,8 @@ class Stats(C.Structure):
                 ("evals_algorithmic", C.c_int64), ("evals_mfma", C.c_int64), ("evals_fp64", C.c_int64), ("evals_bound", C.c_int64),
                 ("lo_ms", C.c_double), ("lo_launches", C.c_int64), ("final_ms", C.c_double), ("final_launches", C.c_int64),
                 ("bound_ms", C.c_double), ("bound_launches", C.c_int64), ("solve_ms", C.c_double), ("solve_launches", C.c_int64),
-                ("lm_cost_evals", C.c_int64), ("lm_accum_evals", C.c_int64), ("final_cost_evals", C.c_int64), ("final_accum_evals", C.c_int64)]
+                ("lm_cost_evals", C.c_int64), ("lm_accum_evals", C.c_int64), ("final_cost_evals", C.c_int64), ("final_accum_evals", C.c_int64),
+                ("fuse_gate_timeouts", C.c_int64), ("fuse_wait_timeouts", C.c_int64)]  # ABI 0.3 (mdrp_last_stats_sized)
 
 
 class Result(C.Structure):
@@ -83,6 +84,7 @@ def load_library():
             raise MdrpError(f"{LIB_PATH} is not built (run __graft_entry__.build()); mdrp_amd has no CPU fallback")
         _ensure_hip_runtime()  # the library binds its hip* symbols to the process's one runtime when it is loaded
         lib = C.CDLL(LIB_PATH)
+        _check_hip_runtime_version(lib)
         vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
         lib.mdrp_last_error.restype = C.c_char_p
         lib.mdrp_version.restype = C.c_char_p
@@ -100,10 +102,12 @@ def load_library():
         lib.mdrp_solver_batch.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_int, vp, vp]
         lib.mdrp_score_models.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp, vp]
         lib.mdrp_count_candidates.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp]
+        lib.mdrp_bound_models.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, C.c_int, C.c_double, vp, vp]
         lib.mdrp_refine_models.argtypes = [vp, C.c_int, vp, C.c_int, dp, dp, dp, dp, C.c_int, C.c_double, C.c_double,
                                            C.POINTER(BundleOpt), C.c_int, vp]
         lib.mdrp_last_sweep_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         lib.mdrp_last_stats.argtypes = [vp, C.POINTER(Stats)]
+        lib.mdrp_last_stats_sized.argtypes = [vp, C.POINTER(Stats), C.c_size_t]
         lib.mdrp_classic_solver_batch.argtypes = [vp, C.c_int, dp, dp, C.c_int, vp, vp]
         _lib = lib
         return lib
@@ -155,6 +159,35 @@ def library_source_hash():
 
 
 _hip_runtime = None
+hip_versions = None  # {"built": HIP_VERSION of the toolchain, "runtime": hipRuntimeGetVersion()} once the library is loaded
+
+
+def _check_hip_runtime_version(lib):
+    """The library binds to whatever HIP runtime the process holds (-no-hip-rt).  Compare that runtime's version
+    (hipRuntimeGetVersion: major * 10^7 + minor * 10^5 + patch) with the HIP_VERSION hipcc compiled the library against
+    (mdrp_hip_build_version()): a different MAJOR is refused (fat-binary registration and struct layouts may differ), a different
+    minor is reported once."""
+    import warnings
+    try:
+        lib.mdrp_hip_build_version.restype = C.c_int
+        built = int(lib.mdrp_hip_build_version())
+        v = C.c_int(0)
+        rt = _hip_runtime.hipRuntimeGetVersion
+        rt.argtypes = [C.POINTER(C.c_int)]
+        if rt(C.byref(v)) != 0:
+            return
+    except (AttributeError, OSError):
+        return
+    have = int(v.value)
+    if have // 10_000_000 != built // 10_000_000:
+        raise MdrpError(f"libmdrp_hip.so was built against HIP {built // 10_000_000}.{built // 100_000 % 100} but the process's HIP runtime "
+                        f"({getattr(_hip_runtime, '_name', '?')}) is {have // 10_000_000}.{have // 100_000 % 100}: set MDRP_HIP_RUNTIME to a "
+                        "matching libamdhip64.so or rebuild (mdrp_amd/build.py)")
+    global hip_versions
+    hip_versions = {"built": built, "runtime": have}  # e.g. PyTorch-ROCm 2.10 wheels bundle HIP 7.0, this image's hipcc is 7.2: same major
+    if have // 100_000 != built // 100_000 and os.environ.get("MDRP_DEBUG"):
+        warnings.warn(f"mdrp: HIP runtime {have // 10_000_000}.{have // 100_000 % 100} in this process, library built against "
+                      f"{built // 10_000_000}.{built // 100_000 % 100} (same major: continuing)", RuntimeWarning, stacklevel=3)
 
 
 def _ensure_hip_runtime():
@@ -182,7 +215,10 @@ def _ensure_hip_runtime():
             cands.append(os.path.join(tdir, "lib", "libamdhip64.so"))
     except Exception:
         pass
-    cands += ["libamdhip64.so.7", "libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"]
+    import glob
+    # the SONAME major follows the ROCm release: whatever /opt/rocm (or ROCM_PATH) ships, newest first, then the linker's search
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += sorted(glob.glob(os.path.join(rocm, "lib", "libamdhip64.so.*")), key=len)[:1] + ["libamdhip64.so", os.path.join(rocm, "lib", "libamdhip64.so")]
     errs = []
     for c in cands:
         try:
@@ -277,8 +313,10 @@ class Handle:
     def last_stats(self):
         """dict: time and launches of k_count (MFMA) and k_score (fp64), and the evaluation counters of the last estimate call"""
         st = Stats()
-        _check(self._lib, self._lib.mdrp_last_stats(self._h, C.byref(st)))
-        return {k: getattr(st, k) for k, _ in Stats._fields_}
+        _check(self._lib, self._lib.mdrp_last_stats_sized(self._h, C.byref(st), C.sizeof(Stats)))
+        d = {k: getattr(st, k) for k, _ in Stats._fields_}
+        d["fuse_timeouts"] = d["fuse_gate_timeouts"] + d["fuse_wait_timeouts"]
+        return d
 
     # ---- unit-parity entry points
     def solver_batch(self, solver, x1h, x2h, d1, d2):
@@ -325,6 +363,17 @@ class Handle:
         _check(self._lib, self._lib.mdrp_count_candidates(self._h, int(kind), _ptr(models), len(models), _ptr(x1), _ptr(x2), len(x1),
                                                           float(sq_threshold), _ptr(cand)))
         return cand
+
+    def bound_models(self, kind, models, x1, x2, sq_threshold):
+        """k_bound alone: per model (lower bound of the MSAC score, upper bound of the inlier count) from the fp32 stage"""
+        models = np.ascontiguousarray(models, dtype=MODEL_DTYPE).reshape(-1)
+        x1 = np.ascontiguousarray(x1, dtype=np.float64)
+        x2 = np.ascontiguousarray(x2, dtype=np.float64)
+        lb = np.zeros(len(models))
+        ub = np.zeros(len(models), dtype=np.int32)
+        _check(self._lib, self._lib.mdrp_bound_models(self._h, int(kind), _ptr(models), len(models), _ptr(x1), _ptr(x2), len(x1),
+                                                      float(sq_threshold), _ptr(lb), _ptr(ub)))
+        return lb, ub
 
     def score_models_device(self, kind, models_ptr, num_models, x1_ptr, x2_ptr, n, sq_threshold, scores_ptr, counts_ptr):
         _check(self._lib, self._lib.mdrp_score_models(self._h, int(kind), MEM_DEVICE, C.c_void_p(models_ptr), int(num_models),

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -66,6 +67,7 @@ struct Progress {
 };
 constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
 constexpr size_t COUNTERS_BYTES = 128;
+constexpr size_t LM_STATS_BYTES = 6 * sizeof(unsigned long long); // mdrp_handle::lm_stats
 
 // Every entry point runs on the handle's device and puts the caller's current device back on return (the caller is
 // usually torch, which tracks its own current device).
@@ -111,8 +113,11 @@ struct mdrp_handle {
     // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
     DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live;
     int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
-    DevBuf lm_stats;                  // four u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel
+    DevBuf lm_stats;                  // six u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel |
+                                      // fused tail: gate time-outs | final-refinement wait time-outs
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
+    int64_t fuse_gate_timeouts = 0, fuse_wait_timeouts = 0; // of the last call
+    bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, stay unfused
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -411,7 +416,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         unsigned char *ph = h->params_host; // free: the previous call on this handle ended with a stream synchronisation
         std::memcpy(ph + off_state, tab_state.data(), sizeof(uint64_t) * n_tables);
         const bool cams = kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT;
-        if (cams) { std::memcpy(ph + off_cam1, cam1, sizeof(CamDev) * batch); std::memcpy(ph + off_cam2, cam2, sizeof(CamDev) * batch); }
+        // MDRP_SHARED_6PT reads the principal point from cam1 only (include/mdrp.h): cam2 may be NULL there
+        if (cams) { std::memcpy(ph + off_cam1, cam1, sizeof(CamDev) * batch); std::memcpy(ph + off_cam2, cam2 ? cam2 : cam1, sizeof(CamDev) * batch); }
         else std::memset(ph + off_cam1, 0, 2 * sizeof(CamDev) * (size_t)batch);
         std::memcpy(ph + off_tn, tab_n.data(), sizeof(int32_t) * n_tables);
         std::memcpy(ph + off_tof, table_of.data(), sizeof(int32_t) * batch);
@@ -463,7 +469,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // the wavefront slots the LO's stragglers leave free, instead of LO | k_walk | k_final one after the other.
     // Measured per 1024 pairs (N = 2000, 10^4 iterations): calibrated 11.75 -> 11.2 ms, shared focal 12.5 -> 11.9, outlier-free 18.6 -> 17.4;
     // with the shift solver's 9-parameter LM the final refinements are 1.5x the LO's tail and gain nothing (12.75 -> 12.9 ms): off there.
-    const bool fuse_env = env_int("MDRP_FUSE_TAIL", (kind == MDRP_CALIB && est_shift) ? 0 : 1) != 0;
+    // After a bounded wait expired on this handle (kernels of two streams do not run side by side here: serialising profiler,
+    // AMD_SERIALIZE_KERNEL, a busy shared GPU) the handle stays unfused, unless MDRP_FUSE_TAIL is set explicitly.
+    const bool fuse_env = env_int("MDRP_FUSE_TAIL", ((kind == MDRP_CALIB && est_shift) || h->fuse_disabled) ? 0 : 1) != 0;
     bool final_done = false;
     // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
     // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)
@@ -749,17 +757,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const unsigned long long gate_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_GATE_US", 50000 + 40 * batch);
             const unsigned long long wait_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_WAIT_US", 20000 + 4 * batch);
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const int32_t *)(cnt + CNT_LO_HEAD + cl), plan_l + 3 * (size_t)batch + 1,
-                               (const int32_t *)fz_ctl, lo_blocks_l, gate_ticks);
+                               (const int32_t *)fz_ctl, lo_blocks_l, gate_ticks, h->lm_stats.as<unsigned long long>() + 4);
             hipEvent_t g0, g1;
             if ((rc = get_events(h, &g0, &g1, 3))) return rc;
             HIPCHK(hipEventRecord(g0, s));
             if (classic)
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                         (const int32_t *)fz_ready, fz_fin, wait_ticks);
+                                         (const int32_t *)fz_ready, fz_fin, wait_ticks, h->lm_stats.as<unsigned long long>() + 5);
             else
                 MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready, fz_fin, wait_ticks);
+                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready, fz_fin, wait_ticks,
+                                 h->lm_stats.as<unsigned long long>() + 5);
             HIPCHK(hipEventRecord(g1, s));
             final_done = true;
         }
@@ -767,11 +776,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         if (fuse_tail) { // behind the LO launch: the pairs a bounded wait gave up on (none in a healthy run: 1024 workgroups that read a flag)
             if (classic)
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                         (const int32_t *)nullptr, fz_fin, 0ull);
+                                         (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr);
             else
                 MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, fz_fin, 0ull);
+                                 h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr);
         }
         if (!fuse_tail)
             hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
@@ -841,11 +850,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
     else if (classic)
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                 (const int32_t *)nullptr, (int32_t *)nullptr, 0ull);
+                                 (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
     else {
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
                          h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
-                         h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, (int32_t *)nullptr, 0ull);
+                         h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
     }
     HIPCHK(hipEventRecord(f1, s));
     HIPCHK(hipGetLastError());
@@ -864,8 +873,8 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch; h->lm_cost_evals = 0; h->lm_accum_evals = 0;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
-    if ((rc = h->lm_stats.ensure(32))) return rc;
-    HIPCHK(hipMemsetAsync(h->lm_stats.p, 0, 32, h->stream));
+    if ((rc = h->lm_stats.ensure(LM_STATS_BYTES))) return rc;
+    HIPCHK(hipMemsetAsync(h->lm_stats.p, 0, LM_STATS_BYTES, h->stream));
     if (batch == 0) return MDRP_OK;
     std::vector<int32_t> n_host(batch);
     for (int i = 0; i < batch; ++i) {
@@ -885,9 +894,13 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
-    const size_t per_pair_all = per_pair + (kind <= 2 ? 49 * lme_bytes_per_problem(n_max) : 0) /*LM engine: 48 problems per pair and pass*/ +
+    // the LM engine's problem table (lme_ensure in run_pass: max(batch, MDRP_LME_CAP or 48 per pair + 2048) problems) only where it runs
+    const bool budget_lme = kind <= 2 && env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 1 : 0) != 0;
+    const size_t lme_fixed = budget_lme ? (size_t)std::max(env_int("MDRP_LME_CAP", 0), 2048) * lme_bytes_per_problem(n_max) : 0; // per pass, not per pair
+    const size_t per_pair_all = per_pair + (budget_lme ? 49 * lme_bytes_per_problem(n_max) : 0) /*LM engine: 48 problems per pair and pass*/ +
                                 (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
+    budget = budget > lme_fixed ? budget - lme_fixed : 0;
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
     per_pass = std::max(1, std::min(per_pass, env_int("MDRP_PAIRS_PER_PASS", per_pass))); // (tests: several passes on a small batch)
@@ -903,10 +916,19 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
 }
 
 int finish_timing(mdrp_handle *h) {
-    if (h->lm_stats.p) HIPCHK(hipMemcpyAsync(h->lm_stats_host, h->lm_stats.p, 32, hipMemcpyDeviceToHost, h->stream));
+    if (h->lm_stats.p) HIPCHK(hipMemcpyAsync(h->lm_stats_host, h->lm_stats.p, LM_STATS_BYTES, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->lm_cost_evals = (int64_t)h->lm_stats_host[0]; h->lm_accum_evals = (int64_t)h->lm_stats_host[1];
     h->fin_cost_evals = (int64_t)h->lm_stats_host[2]; h->fin_accum_evals = (int64_t)h->lm_stats_host[3];
+    h->fuse_gate_timeouts = (int64_t)h->lm_stats_host[4]; h->fuse_wait_timeouts = (int64_t)h->lm_stats_host[5];
+    if ((h->fuse_gate_timeouts || h->fuse_wait_timeouts) && !h->fuse_disabled) {
+        // results are unaffected (the pass behind the LO launch refined what the waits gave up on), the call was slower than unfused
+        h->fuse_disabled = true;
+        if (!getenv("MDRP_QUIET"))
+            fprintf(stderr, "[mdrp] fused tail: %lld gate / %lld final-refinement waits timed out (kernels of two streams did not overlap: "
+                            "profiler or serialised dispatch?); this handle continues unfused\n",
+                    (long long)h->fuse_gate_timeouts, (long long)h->fuse_wait_timeouts);
+    }
     for (int k = 0; k < 6; ++k) { h->kind_ms[k] = 0; h->kind_launches[k] = 0; }
     for (size_t i = 0; i < h->ev_used; ++i) {
         float t = 0;
@@ -936,7 +958,10 @@ extern "C" {
 
 const char *mdrp_last_error(void) { return g_err.c_str(); }
 // the build embeds a hash of the source files (mdrp_amd/build.py) so that a stale prebuilt library can be told from the tree
-const char *mdrp_version(void) { return "mdrp-hip 0.2 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
+const char *mdrp_version(void) { return "mdrp-hip 0.3 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
+
+// HIP_VERSION of the toolchain this library was compiled with (the runtime is bound at load time: mdrp_amd/_capi.py compares the two)
+int mdrp_hip_build_version(void) { return HIP_VERSION; }
 
 int mdrp_create(int device, void *stream, mdrp_handle **out) { return create_handle(device, (hipStream_t)stream, stream == nullptr, out); }
 int mdrp_create_on_stream(int device, void *stream, mdrp_handle **out) { return create_handle(device, (hipStream_t)stream, false, out); }
@@ -961,8 +986,8 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->lme_live_host, sizeof(int32_t), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->lm_stats_host, 4 * sizeof(unsigned long long), hipHostMallocDefault));
-    std::memset(h->lm_stats_host, 0, 4 * sizeof(unsigned long long));
+    HIPCHK(hipHostMalloc((void **)&h->lm_stats_host, LM_STATS_BYTES, hipHostMallocDefault));
+    std::memset(h->lm_stats_host, 0, LM_STATS_BYTES);
     {   // high priority: the few long LO wavefronts should be placed first, the sweep fills the remaining slots
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
@@ -1094,9 +1119,11 @@ int mdrp_last_sweep_stats(mdrp_handle *h, double *sweep_ms, int64_t *launches, i
     return MDRP_OK;
 }
 
-int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out) {
-    if (!h || !out) return MDRP_ERR_INVALID;
+int mdrp_last_stats_sized(mdrp_handle *h, mdrp_stats *out, size_t out_size) {
+    if (!h || !out || out_size < sizeof(double)) return MDRP_ERR_INVALID;
     std::lock_guard<std::mutex> lock_(h->mu);
+    mdrp_stats full, *caller = out;
+    out = &full;
     out->count_ms = h->count_ms; out->count_launches = h->count_launches;
     out->sweep_ms = h->sweep_ms; out->sweep_launches = h->sweep_launches;
     out->evals_algorithmic = h->sweep_evals; out->evals_mfma = h->mfma_evals; out->evals_fp64 = h->fp64_evals; out->evals_bound = h->bound_evals;
@@ -1104,8 +1131,13 @@ int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out) {
     out->bound_ms = h->kind_ms[4]; out->bound_launches = h->kind_launches[4]; out->solve_ms = h->kind_ms[5]; out->solve_launches = h->kind_launches[5];
     out->lm_cost_evals = h->lm_cost_evals; out->lm_accum_evals = h->lm_accum_evals;
     out->final_cost_evals = h->fin_cost_evals; out->final_accum_evals = h->fin_accum_evals;
+    out->fuse_gate_timeouts = h->fuse_gate_timeouts; out->fuse_wait_timeouts = h->fuse_wait_timeouts;
+    std::memcpy(caller, &full, std::min(out_size, sizeof full)); // a caller compiled against an older, shorter struct gets its prefix
     return MDRP_OK;
 }
+
+// the round-3 entry point writes the round-3 struct (everything before fuse_gate_timeouts) and never more
+int mdrp_last_stats(mdrp_handle *h, mdrp_stats *out) { return mdrp_last_stats_sized(h, out, offsetof(mdrp_stats, fuse_gate_timeouts)); }
 
 int mdrp_solver_batch(mdrp_handle *h, int solver, const double *x1h, const double *x2h, const double *d1, const double *d2,
                       int count, mdrp_model *out, int32_t *n_out) {
@@ -1278,6 +1310,56 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
                         h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(candidates, h->unit_f.p, sizeof(int32_t) * num_models, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return MDRP_OK;
+}
+
+int mdrp_bound_models(mdrp_handle *h, int kind, const mdrp_model *models, int num_models, const double *x1, const double *x2,
+                      int n, double sq_threshold, double *score_lb, int32_t *count_ub) {
+    if (!h || num_models < 0 || n < 0 || kind < 0 || kind > 5 || !score_lb || !count_ub || !models) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
+    if (num_models == 0) return MDRP_OK;
+    MDRP_ENTER(h);
+    hipStream_t s = h->stream;
+    const int nn = std::max(n, 1);
+    const size_t slots = (size_t)num_models;
+    int rc;
+    if ((rc = h->pts.ensure(sizeof(double) * PT_STRIDE * nn)) || (rc = h->st.ensure(sizeof(PairState))) ||
+        (rc = h->models.ensure(sizeof(Model) * slots)) || (rc = h->slot_inl.ensure(sizeof(int32_t) * slots)) ||
+        (rc = h->tags.ensure(sizeof(uint32_t) * slots)) || (rc = h->tags_v.ensure(sizeof(uint32_t) * slots)) ||
+        (rc = h->surv_count.ensure(sizeof(int32_t))) || (rc = h->surv2_count.ensure(sizeof(int32_t))) ||
+        (rc = h->cplan.ensure(2 * sizeof(int32_t))) || (rc = h->unit_a.ensure(sizeof(double) * slots)) ||
+        (rc = h->unit_f.ensure(sizeof(int32_t) * slots)) || (rc = h->in_x1.ensure(sizeof(double) * 2 * nn)) ||
+        (rc = h->in_x2.ensure(sizeof(double) * 2 * nn)))
+        return rc;
+    HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->models.p, models, sizeof(Model) * num_models, hipMemcpyHostToDevice, s));
+    std::vector<uint32_t> tags(num_models);
+    for (int i = 0; i < num_models; ++i) tags[i] = (uint32_t)i;
+    HIPCHK(hipMemcpyAsync(h->tags_v.p, tags.data(), sizeof(uint32_t) * num_models, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(h->surv_count.p, &num_models, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync(h->unit_a.p, 0, sizeof(double) * slots, s));
+    HIPCHK(hipMemsetAsync(h->unit_f.p, 0, sizeof(int32_t) * slots, s));
+    PairState ps;
+    std::memset(&ps, 0, sizeof ps);
+    ps.n = n; ps.active = 1; ps.sq_thr = sq_threshold; ps.eps = std::sqrt(sq_threshold);
+    ps.best_min_score = DBL_MAX; // no records: nothing is retired, every model sees every correspondence
+    HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pack_unit, dim3((n + 255) / 256 + 1), dim3(256), 0, s, n, h->in_x1.as<double>(), h->in_x2.as<double>(),
+                       (const double *)nullptr, (const double *)nullptr, h->pts.as<double>(), (double *)nullptr);
+    hipLaunchKernelGGL(k_box_unit, dim3(1), dim3(256), 0, s, n, h->pts.as<double>(), h->st.as<PairState>());
+    RunParams rp;
+    std::memset(&rp, 0, sizeof rp);
+    rp.kind = kind; rp.batch = 1; rp.n_max = nn; rp.slot_stride = num_models; rp.mps = 4; rp.sample_sz = 3;
+    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, 1, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1, BND_THREADS,
+                       h->cplan.as<int32_t>(), h->surv2_count.as<int32_t>());
+    const dim3 grid((unsigned)((num_models + BND_THREADS - 1) / BND_THREADS));
+    MDRP_SWEEP_DISPATCH(k_bound, kind, grid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
+                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                        h->tags.as<uint32_t>(), h->surv2_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_a.as<double>(), h->unit_f.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(score_lb, h->unit_a.p, sizeof(double) * num_models, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(count_ub, h->unit_f.p, sizeof(int32_t) * num_models, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     return MDRP_OK;
 }

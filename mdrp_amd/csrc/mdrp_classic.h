@@ -684,7 +684,7 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
                                                  uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results,
                                                  const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/,
                                                  int32_t *__restrict__ fin_done /*fused: set per refined pair; unfused: pairs to skip, or null*/,
-                                                 unsigned long long ticks) {
+                                                 unsigned long long ticks, unsigned long long *__restrict__ timeouts /*fused: expired bounded waits*/) {
     __shared__ double scratch[4 * MAX_ACC];
     __shared__ int s_pair;
     __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
@@ -698,6 +698,7 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
         const unsigned long long t0 = wall_clock64();
         while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
             __builtin_amdgcn_s_sleep(16);
+        if (p < 0 && timeouts) atomicAdd(timeouts, 1ull); // gave up: the pass behind the LO launch refines this pair (mdrp_stats.fuse_wait_timeouts)
         __threadfence();
         s_pair = p;
     }

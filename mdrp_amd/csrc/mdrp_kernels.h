@@ -1083,7 +1083,9 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags_in,
                                                           const int32_t *__restrict__ cnt_in, const int32_t *__restrict__ plan,
                                                           int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_out,
-                                                          int32_t *__restrict__ cnt_out, unsigned long long *__restrict__ stats) {
+                                                          int32_t *__restrict__ cnt_out, unsigned long long *__restrict__ stats,
+                                                          double *__restrict__ dbg_lb = nullptr /*unit entry point: the two bounds per model*/,
+                                                          int32_t *__restrict__ dbg_cnt_ub = nullptr) {
     __shared__ float4 s_rec[BND_TILE];
     struct Open { uint32_t tag; int32_t sane; float Ef[9], eC, eD, thr_dn, c0, c1; double lb; }; // a model's state while it is still open
     __shared__ Open s_open[BND_THREADS];
@@ -1206,6 +1208,10 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
     }
     // what is still marked open here has seen every record without being retired: on to the exact sweep
     const bool surv = open;
+    if (dbg_lb && surv) { // mdrp_bound_models: no records, so every model arrives here with its full sums (a model outside the fp32 range proves nothing)
+        dbg_lb[tag & 0xFFFFFFu] = sane ? total_lb * (1.0 - BOUND_SLACK) : 0.0;
+        dbg_cnt_ub[tag & 0xFFFFFFu] = sane ? (int32_t)min((long long)n, (long long)(cnt2.x + cnt2.y) + 1) : n;
+    }
     const unsigned long long ball = __ballot(surv);
     if (ball) {
         int base = 0;
@@ -1979,12 +1985,14 @@ struct FuseTail {
 // the very kernels that wait for it.  Then the gate gives up, the final workgroups give up and leave their pairs undone, the LO
 // launch runs, and the ordinary k_final pass behind it (`skip`) refines what is left: slower, never stuck.
 __global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks,
-                       unsigned long long ticks) {
+                       unsigned long long ticks, unsigned long long *__restrict__ timeouts /*[0] gate, [1] final waits: mdrp_stats.fuse_*_timeouts*/) {
     const int total = *plan_total;
     const unsigned long long t0 = wall_clock64();
-    while ((__hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < lo_blocks ||
-            __hip_atomic_load(lo_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < total) && wall_clock64() - t0 < ticks)
+    bool open = false;
+    while (!(open = __hip_atomic_load(ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= lo_blocks &&
+                    __hip_atomic_load(lo_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) && wall_clock64() - t0 < ticks)
         __builtin_amdgcn_s_sleep(64);
+    if (!open && timeouts) atomicAdd(timeouts, 1ull);
 }
 __device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams &rp, int pair, const Model *__restrict__ models,
                                              const Trigger *__restrict__ triggers, int trig_cap) {
@@ -2128,7 +2136,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
                                                       ResultDev *__restrict__ results, int list_stride, unsigned long long *__restrict__ lm_stats,
                                                       const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/,
                                                       int32_t *__restrict__ fin_done /*fused: set per refined pair; unfused: pairs to skip, or null*/,
-                                                      unsigned long long ticks) {
+                                                      unsigned long long ticks, unsigned long long *__restrict__ timeouts /*fused: expired bounded waits*/) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_pair;
@@ -2140,6 +2148,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
             const unsigned long long t0 = wall_clock64();
             while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
                 __builtin_amdgcn_s_sleep(16);
+            if (p < 0 && timeouts) atomicAdd(timeouts, 1ull); // gave up: the pass behind the LO launch refines this pair
             __threadfence(); // the replayed pair state (written on another CU / XCD) before anyone of this workgroup reads it
         } else if (fin_done && fin_done[p]) p = -1; // the pass behind a fused tail: only what that left undone
         s_pair = p;

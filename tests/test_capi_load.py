@@ -11,7 +11,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     b.build()
     lib = _capi.load_library()  # makes the process's one HIP runtime visible first: the library carries none of its own
-    assert not [ln for ln in os.popen(f"readelf -d {_capi.LIB_PATH}").read().splitlines() if "NEEDED" in ln and "amdhip" in ln]
+    import shutil
+    import subprocess
+    readelf = shutil.which("readelf") or shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    assert os.path.exists(readelf), "no readelf: the NEEDED check below would pass vacuously"
+    dyn = subprocess.run([readelf, "-d", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "NEEDED" in dyn, dyn  # the dynamic section was really read (libstdc++, libc, ...)
+    assert not [ln for ln in dyn.splitlines() if "NEEDED" in ln and "amdhip" in ln]
     hdr = open(os.path.join(ROOT, "include", "mdrp.h")).read()
     declared = sorted(set(re.findall(r"\b(mdrp_[a-z_]+)\s*\(", hdr)))
     assert declared, "no declarations parsed"
@@ -23,6 +29,23 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Model) == 96 and C.sizeof(_capi.Camera) == 40 and C.sizeof(_capi.Result) == 136
     assert C.sizeof(_capi.RansacOpt) == 72 and C.sizeof(_capi.BundleOpt) == 64
+    # mdrp_stats: every field is 8 bytes; the binding's field list must be the header's, in order
+    hdr = open(os.path.join(ROOT, "include", "mdrp.h")).read()
+    body = hdr[hdr.index("typedef struct {", hdr.index("fp64 sweep of the hypotheses")):hdr.index("} mdrp_stats;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:double|int64_t)\s+(\w+)\s*;", body)
+    assert fields == [f for f, _ in _capi.Stats._fields_], fields
+    assert C.sizeof(_capi.Stats) == 8 * len(fields)
+
+
+def test_hip_build_version_is_exported_and_matches_the_runtime_major():
+    """the library binds to the process's HIP runtime at load time; load_library() refuses a different major (here: equal)"""
+    lib = _capi.load_library()
+    lib.mdrp_hip_build_version.restype = C.c_int
+    built = lib.mdrp_hip_build_version()
+    v = C.c_int(0)
+    assert _capi._hip_runtime.hipRuntimeGetVersion(C.byref(v)) == 0
+    assert built // 10_000_000 == v.value // 10_000_000 and built > 0
 
 
 def test_no_cpu_fallback_in_product():

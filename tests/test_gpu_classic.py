@@ -436,3 +436,20 @@ def test_full_size_wide_vs_reference_binary(golden, name, kind):
         assert info["refinements"] in (int(ref_st[0]), int(g[f"{name}_oracle_refinements"][j])), (name, j, info["refinements"], ref_st[0])
         lo_dev += info["refinements"] != int(ref_st[0])
     assert lo_dev <= 1, lo_dev
+
+
+def test_sixpt_cam2_may_be_null():
+    """include/mdrp.h: MDRP_SHARED_6PT reads the principal point from cam1 and nothing from cam2 — a C caller may pass cam2 = NULL
+    (the host side used to memcpy from it).  Same records and masks as with cam2 = cam1."""
+    from mdrp_amd import _capi, synth
+    B, N = 6, 300
+    b = synth.make_batch(9100, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3, random_focal="shared", pp=(12.0, -7.0))
+    cams = np.zeros(B, dtype=_capi.CAMERA_DTYPE)
+    cams["params"][:, 0] = 12.0; cams["params"][:, 1] = -7.0
+    ro = _capi.ransac_opt_from_dict({"max_iterations": 300, "min_iterations": 300, "max_epipolar_error": 2.0})
+    bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    h = _capi.default_handle(0)
+    r1, m1 = h.estimate_batch(_capi.SHARED_6PT, b["x1"], b["x2"], None, None, ro, bo, None, cams, cams)
+    r2, m2 = h.estimate_batch(_capi.SHARED_6PT, b["x1"], b["x2"], None, None, ro, bo, None, cams, None)
+    assert r1.tobytes() == r2.tobytes() and np.array_equal(m1, m2)
+    assert int(r1["num_inliers"].min()) > 100
