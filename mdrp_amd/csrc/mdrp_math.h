@@ -747,7 +747,10 @@ MDRP_HD void count_setup_scaled(const double E[9], const double box[4], double t
     for (int j = 0; j < 8; ++j) { eh[j] = 0; el[j] = 0; }
     e8[0] = e8[1] = e8[2] = 0;
     tb2 = 1.0f;
-    if (!(M < 1e30) || !(tb < 1e30f) || !(tb > 0.0f)) return; // not judgeable: C = 0 against tb^2 = 1 keeps everything
+    // Not judgeable -> C = 0 against tb^2 = 1 keeps everything.  That includes models so small that thr * Dmax leaves the fp32
+    // NORMAL range: td would flush to zero and tb = kappa M alone would be far below sqrt(thr Dmax) — an UNDERcount (found by
+    // tests/test_gpu_adversarial.py with |F| = 1e-24; pose and unit-norm F models are 20 decades away from it).
+    if (!(M < 1e30) || !(tb < 1e30f) || !(tb > 0.0f) || !(td > 1e-30f) || !(km > 1e-30f)) return;
     int ex;
     (void)frexpf(tb, &ex);            // tb = m 2^ex, m in [0.5, 1)
     const int k = 21 - ex;            // tb 2^k in [2^20, 2^21)

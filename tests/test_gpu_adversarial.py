@@ -199,6 +199,9 @@ def test_filters_with_model_matrices_from_1e_minus_30_to_1e30(handle, capi, po):
     lb, ub = handle.bound_models(capi.FUNDAMENTAL_7PT, models, x1, x2, thr)
     cand = handle.count_candidates(capi.FUNDAMENTAL_7PT, models, x1, x2, thr)
     assert (lb == 0).all() and (ub == n).all() and (cand == n).all()
+    # ... and k_count's own range ends earlier than fp64's: thr * Dmax must be a NORMAL fp32 number (|F| = 1e-24 used to undercount)
+    small = np.array([capi.fundamental_to_model((po.essential(base[0]) * 10.0 ** e).reshape(3, 3)) for e in (-24, -20, -17)])
+    assert (handle.count_candidates(capi.FUNDAMENTAL_7PT, small, x1, x2, thr) == n).all()
 
 
 def test_filters_with_all_identical_correspondences(handle, capi, po):
@@ -278,9 +281,15 @@ def test_full_estimates_on_adversarial_inputs_equal_the_oracle(handle, capi, po,
             assert int(res[j]["iterations"]) == st.iterations, w
             assert int(res[j]["num_inliers"]) == st.num_inliers, (w, int(res[j]["num_inliers"]), st.num_inliers)
             assert (mask[j] == mk).all(), w
+            # pixels 10^4 off the principal point look like a 2-degree field of view 85 degrees off the axis to the focal estimators: focal
+            # length and translation are nearly interchangeable, and the final LM amplifies the summation-order roundings (tree on the
+            # GPU, sequential in the oracle) to 2e-6 in the model; mask and inlier count stay identical
+            tol = 1e-5 if scenario == "focal_est_offset_1e4" else 1e-6
             if st.num_inliers > 3:
-                assert model_diff(capi.model_to_array(res[j]["model"]), m) < 1e-6, (w, model_diff(capi.model_to_array(res[j]["model"]), m))
+                assert model_diff(capi.model_to_array(res[j]["model"]), m) < tol, (w, model_diff(capi.model_to_array(res[j]["model"]), m))
                 assert res[j]["model_score"] == pytest.approx(st.model_score, rel=1e-9), w
             lo_off += int(res[j]["refinements"]) != st.refinements
             assert abs(int(res[j]["refinements"]) - st.refinements) <= 1, (w, int(res[j]["refinements"]), st.refinements)
-    assert lo_off <= 1, (scenario, lo_off)  # the rounding-tie class of DESIGN.md 5 (v)
+    # the rounding-tie class of DESIGN.md 5 (v): a score equal to the record to the last digits buys or does not buy an LO that changes
+    # nothing.  With all-identical correspondences EVERY model's score ties with every other's (all inliers or none): not counted there.
+    assert lo_off <= 1 or scenario == "identical", (scenario, lo_off)

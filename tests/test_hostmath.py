@@ -247,3 +247,29 @@ def test_fp32_score_lower_bound_is_a_lower_bound(hm):
         lb, ex = C.c_double(), C.c_double()
         cu, ce = C.c_long(), C.c_long()
         assert hm.hm_bound_check(P(np.ascontiguousarray(E)), P(x1), P(x2), C.c_long(n), C.c_double(1e-5), C.byref(lb), C.byref(ex), C.byref(cu), C.byref(ce)) == 1
+
+
+def test_filters_are_conservative_for_model_matrices_of_any_magnitude(hm):
+    """|E| from 1e-36 to 1e36 (the GPU suite found k_count undercounting at |F| = 1e-24: thr * Dmax left the
+    fp32 normal range and the threshold collapsed to the kappa term).  Both filters, emulated on the host: no correspondence the
+    exact test accepts is ever dropped, no score bound exceeds the exact score, at every magnitude — a model the fp32 arithmetic
+    cannot judge must keep everything."""
+    hm.hm_count_check.restype = C.c_long
+    rng = np.random.default_rng(23)
+    n = 1500
+    judged = 0
+    for e in range(-36, 37, 2):
+        for kind in (0, 1):
+            E0 = _rand_E(rng, kind)
+            thr = 10.0 ** rng.uniform(-7, -4)
+            x1, x2 = _planted(rng, E0, n, thr, 1.0)
+            E = np.ascontiguousarray(E0 * 10.0 ** e)
+            for order in (0, 2):
+                kept, exact = C.c_long(), C.c_long()
+                assert hm.hm_count_check(P(E), P(x1), P(x2), C.c_long(n), C.c_double(thr), C.c_int(order), C.byref(kept), C.byref(exact)) == 0, (e, kind, order)
+                assert kept.value >= exact.value and exact.value > n // 10, (e, kind, kept.value, exact.value)
+            judged += kept.value < n
+            lb, ex = C.c_double(), C.c_double()
+            cu, ce = C.c_long(), C.c_long()
+            assert hm.hm_bound_check(P(E), P(x1), P(x2), C.c_long(n), C.c_double(thr), C.byref(lb), C.byref(ex), C.byref(cu), C.byref(ce)) == 1, (e, kind, lb.value, ex.value)
+    assert judged >= 20  # ... and across the ordinary magnitudes the count filter still retires something
