@@ -111,7 +111,8 @@ struct mdrp_handle {
     DevBuf surv2_count;        // survivors of k_bound per pair
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
     // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
-    DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live;
+    DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live, lme_accpart;
+    int lme_mode = 0;                  // 1 = list engine (k_lme_accum), 2 = segment engine (dense sweeps: k_lme_decide / k_lme_accum_seg / k_lme_reduce)
     int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
     DevBuf lm_stats;                  // six u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel |
                                       // fused tail: gate time-outs | final-refinement wait time-outs
@@ -240,28 +241,57 @@ int solver_for(int kind, int est_shift) {
         if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0>), grid, dim3(64), 0, stream, __VA_ARGS__);                        \
         else hipLaunchKernelGGL((KERNEL<1>), grid, dim3(64), 0, stream, __VA_ARGS__);                                    \
     } while (0)
-#define MDRP_LME_COST(kind, loss, grid, stream, ...)                                                                     \
+#define MDRP_LME_COST_D(DENSE, kind, loss, grid, stream, ...)                                                            \
     do {                                                                                                                 \
-        if ((kind) == 0 && (loss) == 1) hipLaunchKernelGGL((k_lme_cost<0, 1>), grid, dim3(64), 0, stream, __VA_ARGS__);   \
-        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_cost<0, -1>), grid, dim3(64), 0, stream, __VA_ARGS__);            \
-        else if ((loss) == 1) hipLaunchKernelGGL((k_lme_cost<1, 1>), grid, dim3(64), 0, stream, __VA_ARGS__);             \
-        else hipLaunchKernelGGL((k_lme_cost<1, -1>), grid, dim3(64), 0, stream, __VA_ARGS__);                             \
+        if ((kind) == 0 && (loss) == 1) hipLaunchKernelGGL((k_lme_cost<0, 1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);   \
+        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_cost<0, -1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);            \
+        else if ((loss) == 1) hipLaunchKernelGGL((k_lme_cost<1, 1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);             \
+        else hipLaunchKernelGGL((k_lme_cost<1, -1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);                             \
     } while (0)
+#define MDRP_LME_COST(dense, kind, loss, grid, stream, ...)                                                              \
+    do {                                                                                                                 \
+        if (dense) MDRP_LME_COST_D(true, kind, loss, grid, stream, __VA_ARGS__);                                         \
+        else MDRP_LME_COST_D(false, kind, loss, grid, stream, __VA_ARGS__);                                              \
+    } while (0)
+// segment engine: normal equations per (pair, segment), the segments of a problem added in order
+#ifdef MDRP_FAST_BUILD
+#define MDRP_LME_ACCUM_SEG(kind, shift, loss, grid, stream, ...)                                                          \
+    do {                                                                                                                 \
+        if ((loss) == 1) hipLaunchKernelGGL((k_lme_accum_seg<0, false, 1>), grid, dim3(64), 0, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((k_lme_accum_seg<0, false, -1>), grid, dim3(64), 0, stream, __VA_ARGS__);                  \
+    } while (0)
+#else
+#define MDRP_LME_ACCUM_SEG_L(L, kind, shift, grid, stream, ...)                                                           \
+    do {                                                                                                                 \
+        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((k_lme_accum_seg<0, true, L>), grid, dim3(64), 0, stream, __VA_ARGS__);  \
+        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_accum_seg<0, false, L>), grid, dim3(64), 0, stream, __VA_ARGS__);       \
+        else if ((kind) == 1) hipLaunchKernelGGL((k_lme_accum_seg<1, false, L>), grid, dim3(64), 0, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((k_lme_accum_seg<2, false, L>), grid, dim3(64), 0, stream, __VA_ARGS__);                        \
+    } while (0)
+#define MDRP_LME_ACCUM_SEG(kind, shift, loss, grid, stream, ...)                                                          \
+    do {                                                                                                                 \
+        if ((loss) == 1) MDRP_LME_ACCUM_SEG_L(1, kind, shift, grid, stream, __VA_ARGS__);                                 \
+        else MDRP_LME_ACCUM_SEG_L(-1, kind, shift, grid, stream, __VA_ARGS__);                                            \
+    } while (0)
+#endif
 
 constexpr int LME_CTL_INTS = LME_RING + 8; // live ring | total | pad
 int lme_nseg(int n_max) { return std::max(1, (n_max + LME_SEG - 1) / LME_SEG); }
 size_t lme_bytes_per_problem(int n_max) {
     const size_t nseg = (size_t)lme_nseg(n_max);
-    return sizeof(LmProb) + nseg * (sizeof(double) + sizeof(int32_t)) + 2 * nseg * LME_SEG + 2 * nseg * sizeof(uint16_t) + 16;
+    // work lists (list engine) or normal-equation partials (segment engine), whichever is larger
+    return sizeof(LmProb) + nseg * (sizeof(double) + sizeof(int32_t)) + std::max<size_t>(2 * nseg * LME_SEG + 2 * nseg * sizeof(uint16_t), nseg * MAX_ACC * sizeof(double)) + 16;
 }
 
 int lme_ensure(mdrp_handle *h, int cap, int batch, int n_max) {
     const size_t nseg = (size_t)lme_nseg(n_max), c = (size_t)std::max(cap, 1);
+    const bool seg_engine = h->lme_mode == 2; // dense sweeps: per (problem, segment) normal-equation partials instead of work lists
     int rc;
     if ((rc = h->lme_probs.ensure(sizeof(LmProb) * c)) || (rc = h->lme_part.ensure(sizeof(double) * c * nseg)) ||
-        (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (rc = h->lme_list.ensure(c * 2 * nseg * LME_SEG)) ||
-        (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c * 2 * nseg)) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
-        (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))) || (rc = h->lme_pair_live.ensure(sizeof(int32_t) * 2 * (size_t)std::max(batch, 1))))
+        (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (!seg_engine && (rc = h->lme_list.ensure(c * 2 * nseg * LME_SEG))) ||
+        (!seg_engine && (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c * 2 * nseg))) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
+        (seg_engine && (rc = h->lme_accpart.ensure(sizeof(double) * c * nseg * MAX_ACC))) ||
+        (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))) || (rc = h->lme_pair_live.ensure(sizeof(int32_t) * 4 * (size_t)std::max(batch, 1))))
         return rc;
     return MDRP_OK;
 }
@@ -272,6 +302,7 @@ LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, con
     ph.list = h->lme_list.as<uint8_t>(); ph.list_cnt = h->lme_cnt.as<uint16_t>();
     ph.pfx = pfx; ph.total = total;
     ph.live = h->lme_ctl.as<int32_t>(); ph.pair_live = h->lme_pair_live.as<int32_t>();
+    ph.pair_acc = ph.pair_live + 2 * (size_t)std::max(batch, 1); ph.accpart = h->lme_accpart.as<double>();
     ph.first = first; ph.cap = cap; ph.batch = batch; ph.n_max = n_max; ph.nseg = lme_nseg(n_max);
     ph.mask = mask;
     return ph;
@@ -283,13 +314,22 @@ LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, con
 int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, int est_shift, int loss, int max_it, int accum_blocks, int problems_bound,
             int poll_from, int poll_every) {
     HIPCHK(hipMemsetAsync(ph.live, 0, sizeof(int32_t) * LME_RING, stream));
-    HIPCHK(hipMemsetAsync(ph.pair_live, 0, sizeof(int32_t) * 2 * (size_t)std::max(ph.batch, 1), stream));
+    HIPCHK(hipMemsetAsync(ph.pair_live, 0, sizeof(int32_t) * 4 * (size_t)std::max(ph.batch, 1), stream)); // pair_live | pair_acc
     const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
     const int dense_cap = ph.n_max <= LM_LIST_MAX_N ? ((ph.n_max + 63) / 64) * 64 : 0;
     const size_t smem = sizeof(int32_t) * ((size_t)ph.nseg + 1) + sizeof(uint16_t) * (size_t)dense_cap + 8;
     const dim3 solve_grid((unsigned)(std::max(problems_bound, 1) + 63) / 64);
-    MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
+    const bool seg = h->lme_mode == 2;
+    const dim3 lane_grid((unsigned)(std::max(problems_bound, 1) + 255) / 256), reduce_grid((unsigned)std::min((std::max(problems_bound, 1) + 3) / 4, h->num_cu * 32));
+    MDRP_LME_COST(seg, kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
     for (int r = 0; r <= max_it; ++r) {
+        if (seg) {
+            hipLaunchKernelGGL(k_lme_decide, lane_grid, dim3(256), 0, stream, ph, r);
+            if (r < max_it) { // (the closing round only decides: every problem is done)
+                MDRP_LME_ACCUM_SEG(kind, est_shift, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r);
+                MDRP_LME_LM(k_lme_reduce, kind, est_shift, reduce_grid, dim3(256), 0, stream, ph);
+            }
+        } else
         MDRP_LME_ACCUM(kind, est_shift, loss, dim3((unsigned)std::max(accum_blocks, 1)), smem, stream, ph, h->pts.as<double>(),
                        h->dep.as<double>(), r, dense_cap);
         if (r == max_it) break;
@@ -299,7 +339,7 @@ int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, in
             HIPCHK(hipStreamSynchronize(stream));
             if (*h->lme_live_host == 0) break;
         }
-        MDRP_LME_COST(kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
+        MDRP_LME_COST(seg, kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
     }
     HIPCHK(hipGetLastError());
     return MDRP_OK;
@@ -480,7 +520,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // little and the shared cost sweep pays (N = 5000: 53.5 vs 57.1 ms per 1024 pairs).  On the calibrated / shared-focal shapes the
     // persistent one-wavefront-per-problem kernels are faster (11.7 vs 14.5 ms): their problems are short and many, and a round's
     // three kernel boundaries cost more than the stragglers they remove (DESIGN.md §4 "LM engine").
-    const bool use_lme = !classic && env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 1 : 0) != 0;
+    // MDRP_LM_ENGINE: 0 = persistent kernels, 1 = list engine, 2 = segment engine (dense sweeps per (pair, segment), mdrp_lm.h)
+    const int lme_mode = classic ? 0 : env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 2 : 0);
+    const bool use_lme = lme_mode != 0;
+    h->lme_mode = lme_mode;
     const int lme_cap = std::max(batch, env_int("MDRP_LME_CAP", batch * 48 + 2048));
     if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
@@ -895,7 +938,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
     // the LM engine's problem table (lme_ensure in run_pass: max(batch, MDRP_LME_CAP or 48 per pair + 2048) problems) only where it runs
-    const bool budget_lme = kind <= 2 && env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 1 : 0) != 0;
+    const bool budget_lme = kind <= 2 && env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 2 : 0) != 0;
     const size_t lme_fixed = budget_lme ? (size_t)std::max(env_int("MDRP_LME_CAP", 0), 2048) * lme_bytes_per_problem(n_max) : 0; // per pass, not per pair
     const size_t per_pair_all = per_pair + (budget_lme ? 49 * lme_bytes_per_problem(n_max) : 0) /*LM engine: 48 problems per pair and pass*/ +
                                 (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
@@ -1025,7 +1068,7 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
                       &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
-                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota, &h->lme_pair_live};
+                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota, &h->lme_pair_live, &h->lme_accpart};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -1413,6 +1456,7 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
     if (env_int("MDRP_LM_ENGINE", 0) != 0) {
         // the phase-batched engine with all `count` problems on one pair (pair 0 = the packed records)
+        h->lme_mode = env_int("MDRP_LM_ENGINE", 0);
         if ((rc = lme_ensure(h, count, 1, nn)) || (rc = h->st.ensure(sizeof(PairState)))) return rc;
         PairState ps;
         std::memset(&ps, 0, sizeof ps);

@@ -1556,7 +1556,7 @@ __device__ __forceinline__ void lm_state_uniform(LmState &st) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) st.t[i] = uniform_f64(st.t[i]);
     st.s = uniform_f64(st.s); st.u = uniform_f64(st.u); st.v = uniform_f64(st.v);
-    st.f1 = uniform_f64(st.f1); st.f2 = uniform_f64(st.f2);
+    st.f1 = uniform_f64(st.f1); st.f2 = uniform_f64(st.f2); st.if1 = uniform_f64(st.if1); st.if2 = uniform_f64(st.if2);
 }
 
 struct LmShared {
@@ -1576,7 +1576,12 @@ __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
     sh.ev[0] = 0; sh.ev[1] = 0;
 }
 
-template <int KIND, int T>
+// LOSS: the loss type when the caller knows it at compile time (1 = TRUNCATED: every LO refinement), -1 = o.loss.
+// Round 4: the loop body is straight-line — padding lanes evaluate a harmless record and every `if` of the round-3 body (record
+// valid, forward / backward depth positive, loss type) is a select on the three cost terms, added in the round-3 order, so the sums
+// are bit-identical to it — and it is unrolled by two with ping-pong record buffers, which removes the register rotation of the
+// one-trip software pipeline (round 3: 244 instructions per trip for 123 fp64 ones; profiles/r04_*).
+template <int KIND, int T, int LOSS = -1>
 __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                           const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, LmShared &sh, int buf) {
     LmState stt;
@@ -1587,46 +1592,59 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     uint16_t *list = sh.list + (size_t)buf * sh.stride;
     const int seg = ((n + T - 1) / T) * 64; // correspondences per wavefront, multiple of 64
     const int lo = wave * seg, hi = min(n, lo + seg);
+    const int loss = LOSS >= 0 ? LOSS : o.loss;
+    const double lsc = o.loss_scale, mu = o.mu, t2 = lsc * lsc;
+    const bool ws_nz = ws != 0.0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     double cost = 0;
-    int cnt = 0;
-    // software-pipelined by one step: the next 64 records are requested before the current ones are consumed (two
-    // wavefronts per SIMD are not enough to hide an L2 round trip behind ~130 fp64 ops)
+    int cnt = 0, evaluated = 0;
     struct Rec { double a, b, c, d, e1, e2; bool ok; };
-    auto fetch = [&](int base) {
+    const int last = max(n - 1, 0);
+    auto fetch = [&](int base) { // unconditional loads from a clamped index: no exec-mask branch around them; `ok` says whether the lane counts
         Rec r;
-        const int i = base + lane;
-        r.ok = i < hi && (!mask || mask[i]);
-        if (r.ok) {
-            const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
-            const double2 p01 = P[0], p23 = P[1];
-            const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i);
-            r.a = p01.x; r.b = p01.y; r.c = p23.x; r.d = p23.y; r.e1 = dd.x; r.e2 = dd.y;
-        } else { r.a = r.b = r.c = r.d = 0; r.e1 = r.e2 = 1; }
+        const int i = base + lane, ic = min(i, last);
+        r.ok = (i < hi) & (mask ? mask[ic] != 0 : true);
+        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
+        const double2 p01 = P[0], p23 = P[1];
+        const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)ic);
+        r.a = p01.x; r.b = p01.y; r.c = p23.x; r.d = p23.y; r.e1 = dd.x; r.e2 = dd.y;
         return r;
     };
-    Rec nxt = fetch(lo);
-    int evaluated = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const Rec cur = nxt;
-        if (base + 64 < hi) nxt = fetch(base + 64);
-        const int i = base + lane;
-        evaluated += __popcll(__ballot(cur.ok));
-        bool contrib = false;
-        if (cur.ok) {
-            double r[5], zf, zb;
-            point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
-            const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
-            cost += ws * loss_value(o.loss, o.loss_scale, rs);
-            if (!(zf < 0)) cost += loss_value(o.loss, o.loss_scale, rf);
-            if (!(zb < 0)) cost += loss_value(o.loss, o.loss_scale, rb);
-            contrib = (ws * loss_weight(o.loss, o.loss_scale, rs, o.mu) != 0.0) || (!(zf < 0) && loss_weight(o.loss, o.loss_scale, rf, o.mu) != 0.0) ||
-                      (!(zb < 0) && loss_weight(o.loss, o.loss_scale, rb, o.mu) != 0.0);
+    auto step = [&](const Rec &cur, int base) {
+        double r[5], zf, zb;
+        point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
+        const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
+        const bool fwd = cur.ok & !(zf < 0), bwd = cur.ok & !(zb < 0); // (bitwise on purpose: no short-circuit branches)
+        double vs, vf, vb;
+        bool contrib;
+        if (LOSS == 1) { // TRUNCATED: min(r^2, t^2); IRLS weight 1 below the threshold, 0 at and above it (and for NaN)
+            const bool is = rs < t2, jf = rf < t2, jb = rb < t2;
+            vs = ws * (is ? rs : t2); vf = jf ? rf : t2; vb = jb ? rb : t2;
+            contrib = (cur.ok & is & ws_nz) | (fwd & jf) | (bwd & jb);
+        } else {
+            vs = ws * loss_value(loss, lsc, rs); vf = loss_value(loss, lsc, rf); vb = loss_value(loss, lsc, rb);
+            contrib = (cur.ok & (ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | (fwd & (loss_weight(loss, lsc, rf, mu) != 0.0)) |
+                      (bwd & (loss_weight(loss, lsc, rb, mu) != 0.0));
         }
+        cost += cur.ok ? vs : 0.0; // (+ 0.0 leaves a non-negative sum as it is: the order and the values of round 3's `if`s)
+        cost += fwd ? vf : 0.0;
+        cost += bwd ? vb : 0.0;
+        if (mask && sh.stats) evaluated += __popcll(__ballot(cur.ok));
         if (use_list) {
             const unsigned long long ball = __ballot(contrib);
-            if (contrib) list[lo + cnt + __popcll(ball & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            if (contrib) list[lo + cnt + __popcll(ball & lt)] = (uint16_t)(base + lane);
             cnt += __popcll(ball);
         }
+    };
+    if (!mask) evaluated = max(hi - lo, 0);
+    // the next 64 records are requested before the current ones are consumed (two wavefronts per SIMD do not hide an L2 round trip
+    // behind ~130 fp64 operations); two trips per loop iteration, the buffers swap roles instead of being copied
+    Rec A = fetch(lo);
+    for (int base = lo; base < hi; base += 128) {
+        const Rec B = fetch(base + 64); // past `hi`: an all-padding trip (one wasted trip when the trip count is odd)
+        step(A, base);
+        A = fetch(base + 128);
+        if (base + 64 < hi) step(B, base + 64);
     }
     if (use_list && lane == 0) sh.count[buf][wave] = cnt;
     if (sh.stats && lane == 0 && evaluated) atomicAdd(&sh.ev[0], (unsigned long long)evaluated);
@@ -1638,7 +1656,8 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
 // JtJ (lower triangle, row-major) and Jtr of one weighted residual row.  ZMASK: columns of the full 11-wide row that are
 // structurally zero for this term (no shift / scale / cross-translation dependence); their products are skipped — the
 // compiler cannot drop `acc += w * 0.0 * x` on its own under IEEE rules (18-22 % of the normal-equation FMAs).
-template <int KIND, bool SHIFT, unsigned ZMASK>
+// UNIT: the weight is known to be exactly 1 (a TRUNCATED loss below its threshold): w * J is J bit for bit, so the NP products are skipped
+template <int KIND, bool SHIFT, unsigned ZMASK, bool UNIT = false>
 __device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jrow, double r, double w, double *acc) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     double Ja[NP];
@@ -1653,26 +1672,54 @@ __device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jro
     int idx = 0;
 #pragma unroll
     for (int a = 0; a < NP; ++a) {
-        const double wa = w * Ja[a];
+        const double wa = UNIT ? Ja[a] : w * Ja[a];
 #pragma unroll
         for (int b = 0; b <= a; ++b, ++idx)
             if (nz[a] && nz[b]) acc[idx] += wa * Ja[b];
     }
 #pragma unroll
     for (int a = 0; a < NP; ++a)
-        if (nz[a]) acc[NP * (NP + 1) / 2 + a] += w * Ja[a] * r;
+        if (nz[a]) acc[NP * (NP + 1) / 2 + a] += UNIT ? Ja[a] * r : w * Ja[a] * r;
 }
 
 // One correspondence of the accumulate sweep, term by term: each term's Jacobian rows are folded into the accumulators
 // before the next term is computed, so at most two rows need to be live beside the NP (NP + 3) / 2 accumulators.
-template <int KIND, bool SHIFT>
+// what a row of weight ZERO does to the sums in lm_accumulate_row: acc += (0 * J_a) * J_b and (0 * J_a) * r add +-0 — or NaN when an
+// entry of the row or its residual is not finite (the Sampson row of E = 0, a point at depth zero), and one NaN in J'J | J'r stalls the
+// whole LM (no step is ever accepted: the model comes back unchanged).  The reference shows exactly that behaviour on
+// tests/golden/initial.npz case 11, so skipping a zero-weight row must keep it: `0 * (r + sum of the row's entries)` is +-0 for a finite
+// row and NaN otherwise.
+template <int KIND, bool SHIFT, unsigned ZMASK>
+__device__ __forceinline__ double lm_zero_row_effect(const double *__restrict__ Jrow, double r) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    double s = r;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int col = lm_col<KIND, SHIFT>(q);
+        if (!((ZMASK >> col) & 1u)) s += Jrow[col];
+        if (KIND == 1 && q == 7 && !((ZMASK >> 10) & 1u)) s += Jrow[10];
+    }
+    return 0.0 * s;
+}
+
+// LOSS == 1 (TRUNCATED, known at compile time: every LO refinement): the weights of the reprojection terms are exactly 0 or 1.  A row
+// of weight 1 is accumulated without the NP products by the weight (w J = J bit for bit); a row of weight 0 only leaves its NaN-or-zero
+// effect (above) — and only if the correspondence has a non-zero weight at all: one whose three weights are all zero is not on the work
+// list of the list-based sweeps, so the dense sweeps must not let it act either.  Same sums bit for bit as the general path.
+template <int KIND, bool SHIFT, int LOSS = -1>
 __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 p01, double2 p23, double2 dd,
                                                     double sqrt_sr, double ws, const LmOpt &o, double *acc) {
+    const int loss = LOSS >= 0 ? LOSS : o.loss;
+    double zero_rows = 0.0; // LOSS == 1: sum of the zero-weight rows' effects
+    bool any_w = false;
     {
         double r0, J0[LM_NPAR];
         lm_sampson_term<true, KIND != 0>(stt, p01.x, p01.y, p23.x, p23.y, r0, J0);
-        const double w = ws * loss_weight(o.loss, o.loss_scale, r0 * r0, o.mu);
-        lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); // no scale / shift dependence
+        const double w = ws * loss_weight(loss, o.loss_scale, r0 * r0, o.mu);
+        if (LOSS == 1) {
+            if (w != 0.0) { lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); any_w = true; } // (ws is a run-time weight: its product stays)
+            else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x1C0u>(J0, r0);
+        } else lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); // no scale / shift dependence
     }
 #ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
@@ -1680,9 +1727,17 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
     {
         double r1, r2, zf, J1[LM_NPAR], J2[LM_NPAR];
         lm_forward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.x, r1, r2, zf, J1, J2);
-        const double w = (zf < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r1 * r1 + r2 * r2, o.mu);
-        lm_accumulate_row<KIND, SHIFT, 0x150u>(J1, r1, w, acc); // t.y, scale, shift2
-        lm_accumulate_row<KIND, SHIFT, 0x148u>(J2, r2, w, acc); // t.x, scale, shift2
+        const double w = (zf < 0) ? 0.0 : loss_weight(loss, o.loss_scale, r1 * r1 + r2 * r2, o.mu);
+        if (LOSS == 1) {
+            if (w != 0.0) {
+                lm_accumulate_row<KIND, SHIFT, 0x150u, true>(J1, r1, w, acc);
+                lm_accumulate_row<KIND, SHIFT, 0x148u, true>(J2, r2, w, acc);
+                any_w = true;
+            } else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x150u>(J1, r1) + lm_zero_row_effect<KIND, SHIFT, 0x148u>(J2, r2);
+        } else {
+            lm_accumulate_row<KIND, SHIFT, 0x150u>(J1, r1, w, acc); // t.y, scale, shift2
+            lm_accumulate_row<KIND, SHIFT, 0x148u>(J2, r2, w, acc); // t.x, scale, shift2
+        }
     }
 #ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
@@ -1690,13 +1745,22 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
     {
         double r3, r4, zb, J3[LM_NPAR], J4[LM_NPAR];
         lm_backward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.y, r3, r4, zb, J3, J4);
-        const double w = (zb < 0) ? 0.0 : loss_weight(o.loss, o.loss_scale, r3 * r3 + r4 * r4, o.mu);
-        lm_accumulate_row<KIND, SHIFT, 0x080u>(J3, r3, w, acc); // shift1
-        lm_accumulate_row<KIND, SHIFT, 0x080u>(J4, r4, w, acc); // shift1
+        const double w = (zb < 0) ? 0.0 : loss_weight(loss, o.loss_scale, r3 * r3 + r4 * r4, o.mu);
+        if (LOSS == 1) {
+            if (w != 0.0) {
+                lm_accumulate_row<KIND, SHIFT, 0x080u, true>(J3, r3, w, acc);
+                lm_accumulate_row<KIND, SHIFT, 0x080u, true>(J4, r4, w, acc);
+                any_w = true;
+            } else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x080u>(J3, r3) + lm_zero_row_effect<KIND, SHIFT, 0x080u>(J4, r4);
+        } else {
+            lm_accumulate_row<KIND, SHIFT, 0x080u>(J3, r3, w, acc); // shift1
+            lm_accumulate_row<KIND, SHIFT, 0x080u>(J4, r4, w, acc); // shift1
+        }
     }
+    if (LOSS == 1 && any_w) acc[0] += zero_rows; // (+-0, or NaN: see lm_zero_row_effect; acc[0] takes part in every row)
 }
 
-template <int KIND, bool SHIFT, int T>
+template <int KIND, bool SHIFT, int T, int LOSS = -1>
 __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                               const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, LmShared &sh, int buf) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
@@ -1727,7 +1791,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
         for (int k = lane; k < cnt; k += 64) {
             const double2 c01 = n01, c23 = n23, cdd = ndd;
             fetch(k + 64);
-            lm_accumulate_point<KIND, SHIFT>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
+            lm_accumulate_point<KIND, SHIFT, LOSS>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
         }
         if (sh.stats && lane == 0 && cnt) atomicAdd(&sh.ev[1], (unsigned long long)cnt);
     } else {
@@ -1735,7 +1799,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
         for (int i = lo + lane; i < hi; i += 64)
             if (!mask || mask[i]) {
                 const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
-                lm_accumulate_point<KIND, SHIFT>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i), sqrt_sr, ws, o, acc);
+                lm_accumulate_point<KIND, SHIFT, LOSS>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i), sqrt_sr, ws, o, acc);
             }
     }
     block_sum<NA, T>(acc, sh.scratch);
@@ -1743,23 +1807,48 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
 
 // lm_impl<> loop of the reference (upstream PoseLib convention): executed redundantly and uniformly by every
 // thread of the workgroup; only the two sweeps over the correspondences are distributed.
-template <int KIND, bool SHIFT, int T>
-__device__ void lm_refine(Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o_in, LmShared &sh) {
+// Round 4: ONE call site each for the cost and the normal-equation sweep (the initial cost is the first trip of the loop), and
+// lm_refine itself is inlined into its kernel: every sweep is compiled under the kernel's launch bounds.  (With two call sites the
+// sweeps stayed separate functions, compiled without the bounds: 256 VGPRs + 44-70 AGPRs = one wavefront per SIMD.)
+template <int KIND, bool SHIFT, int T, int LOSS = -1>
+__device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+                                          const uint8_t *__restrict__ mask, double scale_reproj, double ws, const LmOpt &o_in, LmShared &sh) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NT = NP * (NP + 1) / 2;
     const double sqrt_sr = sqrt(scale_reproj);
     LmOpt o = o_in;
     o.mu = 0.5;
     int cur = 0; // list buffer that belongs to the current model
-    double cost = lm_cost<KIND, T>(m, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur);
+    double cost = 0;
     double lambda = o.lambda0;
-    bool recompute = true;
+    bool recompute = true, first = true;
     double acc[NT + NP];
     double A[NP * NP], g[NP], sol[NP];
-    for (int it = 0; it < o.max_it; ++it) {
+    Model cand = m;
+    int it = 0;
+#pragma unroll 1
+    for (;;) {
+        // cost of the model under evaluation: the start model on the first trip (into list buffer `cur`), a candidate step afterwards
+        const double cost_new = lm_cost<KIND, T, LOSS>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, first ? cur : cur ^ 1);
+        if (first) { cost = cost_new; first = false; }
+        else {
+            if (cost_new < cost) {
+                m = cand;
+                cur ^= 1;
+                lambda = fmax(o.lambda_min, lambda / 10.0);
+                cost = cost_new;
+                recompute = true;
+            } else {
+                lambda = fmin(o.lambda_max, lambda * 10.0);
+                recompute = false;
+            }
+            o.mu *= 1.5; // the reference's per-iteration callback of TRUNCATED_LE_ZACH; note the work list of the current model
+                         // was built with the previous mu — Le-Zach weights are never zero, so the list holds every record
+            ++it;
+        }
+        if (it >= o.max_it) break;
         if (recompute) {
-            lm_accumulate<KIND, SHIFT, T>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
+            lm_accumulate<KIND, SHIFT, T, LOSS>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
             double gn = 0;
             int idx = 0;
 #pragma unroll
@@ -1787,21 +1876,7 @@ __device__ void lm_refine(Model &m, const double *__restrict__ pts, const double
 #pragma unroll
         for (int q = 0; q < NP; ++q) full[lm_col<KIND, SHIFT>(q)] = sol[q];
         if (KIND == 1) full[10] = full[9];
-        Model cand;
         lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
-        const double cost_new = lm_cost<KIND, T>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, cur ^ 1);
-        if (cost_new < cost) {
-            m = cand;
-            cur ^= 1;
-            lambda = fmax(o.lambda_min, lambda / 10.0);
-            cost = cost_new;
-            recompute = true;
-        } else {
-            lambda = fmin(o.lambda_max, lambda * 10.0);
-            recompute = false;
-        }
-        o.mu *= 1.5; // the reference's per-iteration callback of TRUNCATED_LE_ZACH; note the work list of the current model
-                     // was built with the previous mu — Le-Zach weights are never zero, so the list holds every record
     }
 }
 
@@ -2027,7 +2102,7 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
 #ifdef MDRP_LO_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
+    lm_refine<KIND, SHIFT, T, 1>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // refine_model: always TRUNCATED
     double sc;
     int cn;
     block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
@@ -2104,25 +2179,36 @@ __device__ void final_pair(const RunParams &rp, const PairState &ps, const doubl
     }
     const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     const double *dd = dep + (size_t)pair * rp.n_max * 2;
-    Model m = ps.best;
-    LmOpt o;
-    o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
-    o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-    lm_refine<KIND, SHIFT, T>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
-    res.refinements++;
-    double sc;
-    int cn;
-    block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
-    Model best = ps.best;
-    if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
-    for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
-    block_score<T>(KIND, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
-    __syncthreads();
-    if (res.num_inliers > 3) {
-        LmOpt f;
-        f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
-        f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
-        lm_refine<KIND, SHIFT, T>(best, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, f, sh);
+    // The two refinements of ransac<>'s tail — the last LO from the best model (25 iterations, TRUNCATED, all records), then the
+    // estimator's inlier-only refinement with the user's BundleOptions — run through ONE call site of lm_refine in a two-trip loop:
+    // a single call site is inlined into the kernel, so the kernel's launch bounds govern its registers.  (Called twice, lm_refine
+    // stays a separate function compiled without them; in round 4 it grew to 256 VGPRs + 44 AGPRs = one wavefront per SIMD.)
+    Model best = ps.best, m = ps.best;
+#pragma unroll 1
+    for (int phase = 0; phase < 2; ++phase) {
+        LmOpt o;
+        if (phase == 0) {
+            o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+            o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+        } else {
+            if (!(res.num_inliers > 3)) break;
+            o.max_it = rp.final_max_it; o.loss = rp.final_loss; o.loss_scale = ps.final_loss_scale;
+            o.grad_tol = rp.grad_tol; o.step_tol = rp.step_tol; o.lambda0 = rp.lambda0; o.lambda_min = rp.lambda_min; o.lambda_max = rp.lambda_max;
+        }
+        Model x = phase == 0 ? m : best;
+        lm_refine<KIND, SHIFT, T>(x, pp, dd, ps.n, phase == 0 ? nullptr : mask, ps.scale_reproj, rp.weight_sampson, o, sh);
+        if (phase != 0) { best = x; break; }
+        m = x;
+        {
+            res.refinements++;
+            double sc;
+            int cn;
+            block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+            if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
+            for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
+            block_score<T>(KIND, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
+            __syncthreads();
+        }
     }
     if (KIND != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
     res.model = best;

@@ -41,24 +41,40 @@ constexpr int LME_T = 256;             // threads per problem in k_lme_accum
 constexpr int LME_NW = LME_T / 64;
 constexpr int LME_RING = 64;           // live counters of the rounds live in a ring (a round clears the slot 32 rounds ahead)
 constexpr int LME_STAGE = 16;          // problem states staged in LDS per pass of the cost sweep
-constexpr int LME_HEAD = 48;           // leading doubles of LmProb the cost sweep needs (state, loss parameters, flags)
+constexpr int LME_HEAD = 50;           // leading doubles of LmProb the sweeps need (state, loss parameters, flags)
 
 struct alignas(64) LmProb {
     // --- read by the cost sweep: the first LME_HEAD doubles
-    LmState cs;             // the model under evaluation, expanded (R, t, s, u, v, f1, f2, E, F): 35 doubles
+    LmState cs;             // the model under evaluation, expanded (R, t, s, u, v, f1, f2, E, F, 1 / f1, 1 / f2): 37 doubles
     double sqrt_sr, ws, loss_scale, mu;
     int32_t status;         // 1 = iterating, 0 = finished (m is the result) or unused
     int32_t has_cand;       // 0 nothing to evaluate, 1 candidate step, 2 the initial model (its cost starts the loop)
     int32_t loss, cur;      // cur: list buffer that belongs to the current model m
-    int32_t pair, n, it, max_it, recompute, pad_;
+    int32_t pair, n, it, max_it, recompute;
+    int32_t need_acc;       // segment engine: set by k_lme_decide when the normal equations of m have to be (re)built this round
     unsigned long long ev_cost, ev_acc; // correspondences evaluated by the cost sweeps / the normal-equation sweeps of this problem (mdrp_stats)
-    double pad2_[2];
+    int32_t n_eff, pad3_;   // records a dense normal-equation sweep really visits (n, or the inlier count under a record mask)
+    double pad2_;           // (the header is an even number of doubles: 16-byte rows in the LDS stage)
     // --- LM state
     double cost, lambda, grad_tol, step_tol, lambda_min, lambda_max;
     Model m, cand;
     double acc[MAX_ACC];    // J'J (lower triangle, row major) | J'r of the current model (kept for rejected steps)
 };
-static_assert(offsetof(LmProb, cost) == LME_HEAD * sizeof(double), "cost-sweep header of LmProb");
+static_assert(offsetof(LmProb, cost) == LME_HEAD * sizeof(double), "sweep header of LmProb");
+// positions (in doubles) of the header fields inside the staged copy
+constexpr int LME_O_SQRT_SR = offsetof(LmProb, sqrt_sr) / 8, LME_O_WS = offsetof(LmProb, ws) / 8, LME_O_LSC = offsetof(LmProb, loss_scale) / 8,
+              LME_O_MU = offsetof(LmProb, mu) / 8, LME_O_STATUS = offsetof(LmProb, status) / 8 /*.x status .y has_cand*/,
+              LME_O_LOSS = offsetof(LmProb, loss) / 8 /*.x loss .y cur*/, LME_O_NEED = offsetof(LmProb, recompute) / 8 /*.x recompute .y need_acc*/;
+static_assert(offsetof(LmProb, status) % 8 == 0 && offsetof(LmProb, loss) % 8 == 0 && offsetof(LmProb, recompute) % 8 == 0 && sizeof(LmState) == 37 * 8, "header layout");
+// the staged header of one problem -> its expanded state in scalar registers
+__device__ __forceinline__ void lme_state_from_header(const double *S, LmState &stt) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { stt.R[i] = S[i]; stt.E[i] = S[17 + i]; stt.F[i] = S[26 + i]; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) stt.t[i] = S[9 + i];
+    stt.s = S[12]; stt.u = S[13]; stt.v = S[14]; stt.f1 = S[15]; stt.f2 = S[16]; stt.if1 = S[35]; stt.if2 = S[36];
+    lm_state_uniform(stt);
+}
 
 struct LmePhase {
     LmProb *probs;          // [cap]
@@ -71,6 +87,8 @@ struct LmePhase {
     int32_t *live;          // [LME_RING] problems still iterating after the round
     int32_t *pair_live;     // [2][batch] live problems per pair after round r in half r & 1 (k_lme_solve); lets the cost sweep of a
                             // pair without live problems leave after its first round trip
+    int32_t *pair_acc;      // [2][batch] segment engine: problems of pair p whose normal equations are rebuilt in round r, in half r & 1 (k_lme_decide)
+    double *accpart;        // [cap][nseg][MAX_ACC] segment engine: J'J | J'r partial of (problem, segment)
     int first, cap;         // this pass handles the dense problems [first, first + cap)
     int batch, n_max, nseg;
     const uint8_t *mask;    // [batch][n_max] record mask (the inlier-only final refinement) or null
@@ -166,7 +184,8 @@ __device__ __forceinline__ void wave_reduce_scatter(const double *acc, double *o
 // ------------------------------------------------------------------------------------------------ cost sweep
 // grid (nseg, batch), 64 threads.  Record i of the segment sits in lane i & 63, slot i >> 6.
 // LOSS: the phase's loss type when it is known at compile time (1 = TRUNCATED: every LO refinement), -1 = read per problem
-template <int KIND, int LOSS>
+// DENSE (segment engine): no work lists — the normal-equation sweep of that engine visits every record with its weight as a select
+template <int KIND, int LOSS, bool DENSE = false>
 __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                  const double *__restrict__ dep, int live_half /*-1: the initial sweep, every problem is live*/) {
     __shared__ double s_state[LME_STAGE][LME_HEAD];
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
         }
         __syncthreads();
         bool live = false;
-        if (lane < kk) { const int2 fl = *reinterpret_cast<const int2 *>(&s_state[lane][39]); live = fl.x != 0 && fl.y != 0; } // status, has_cand
+        if (lane < kk) { const int2 fl = *reinterpret_cast<const int2 *>(&s_state[lane][LME_O_STATUS]); live = fl.x != 0 && fl.y != 0; } // status, has_cand
         const unsigned long long lb = __ballot(live);
         const int k = __popcll(lb);
         if (k == 0) continue;
@@ -222,14 +241,9 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
             const int sl = s_idx[q], j = base + sl;
             const double *S = s_state[sl];
             LmState stt;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) { stt.R[i] = S[i]; stt.E[i] = S[17 + i]; stt.F[i] = S[26 + i]; }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) stt.t[i] = S[9 + i];
-            stt.s = S[12]; stt.u = S[13]; stt.v = S[14]; stt.f1 = S[15]; stt.f2 = S[16];
-            lm_state_uniform(stt);
-            const double sqrt_sr = uniform_f64(S[35]), ws = uniform_f64(S[36]), lsc = uniform_f64(S[37]), mu = uniform_f64(S[38]);
-            const int2 lc = *reinterpret_cast<const int2 *>(S + 40); // loss, cur
+            lme_state_from_header(S, stt);
+            const double sqrt_sr = uniform_f64(S[LME_O_SQRT_SR]), ws = uniform_f64(S[LME_O_WS]), lsc = uniform_f64(S[LME_O_LSC]), mu = uniform_f64(S[LME_O_MU]);
+            const int2 lc = *reinterpret_cast<const int2 *>(S + LME_O_LOSS); // loss, cur
             const int loss = LOSS >= 0 ? LOSS : __builtin_amdgcn_readfirstlane(lc.x), buf = __builtin_amdgcn_readfirstlane(lc.y) ^ 1;
             double cost = 0;
             bool contrib[LME_RPT];
@@ -245,10 +259,15 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
                 c += fwd ? loss_value(loss, lsc, rf) : 0.0;
                 c += bwd ? loss_value(loss, lsc, rbk) : 0.0;
                 cost += ok[r] ? c : 0.0;
-                contrib[r] = ok[r] && ((ws * loss_weight(loss, lsc, rs, mu) != 0.0) || (fwd && loss_weight(loss, lsc, rf, mu) != 0.0) ||
-                                       (bwd && loss_weight(loss, lsc, rbk, mu) != 0.0));
+                if (!DENSE)
+                    contrib[r] = ok[r] && ((ws * loss_weight(loss, lsc, rs, mu) != 0.0) || (fwd && loss_weight(loss, lsc, rf, mu) != 0.0) ||
+                                           (bwd && loss_weight(loss, lsc, rbk, mu) != 0.0));
             }
             cost = wave_sum_swap(cost);
+            if (DENSE) {
+                if (lane == 0) ph.part[(size_t)j * ph.nseg + seg] = cost;
+                continue;
+            }
             uint8_t *L = ph.list + (((size_t)j * 2 + buf) * ph.nseg + seg) * LME_SEG;
             int fill = 0;
 #pragma unroll
@@ -399,6 +418,141 @@ __global__ __launch_bounds__(LME_T, MDRP_LME_MINWAVES) void k_lme_accum(LmePhase
             P->m = m; P->cost = cost; P->lambda = lambda; P->mu = mu; P->it = it; P->cur = cur; P->recompute = recompute;
             P->has_cand = 0;
             if (done) P->status = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ segment engine (dense sweeps)
+// Where the loss cannot truncate enough to pay for a work list — the varying-focal LO leaves loss_scale at 1.0 on scale-normalised
+// points, so every sweep of every problem covers all N records — the normal equations are built the way the cost sweep
+// works: one wavefront per (pair, segment of 256 records) keeps the records in registers and visits the pair's problems that need
+// new normal equations one after the other; the 35-54 sums of (problem, segment) are reduce-scattered across the wavefront and stored,
+// and a second kernel adds the segments in order.  No lists, no list -> record indirection, every wavefront of a round has the same
+// amount of work, and a pair's records are read once per round for all of its problems.  A round is
+//     k_lme_cost<DENSE> | k_lme_decide | k_lme_accum_seg | k_lme_reduce | k_lme_solve
+// k_lme_decide: one lane per problem — lm_impl<>'s accept / reject once the candidate's cost is known (the first half of k_lme_accum)
+__global__ void k_lme_decide(LmePhase ph, int round) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0) ph.live[(round + LME_RING / 2) & (LME_RING - 1)] = 0; // free: every earlier round has ended
+    if (j < ph.batch) ph.pair_acc[(size_t)((round + 1) & 1) * ph.batch + j] = 0; // the half the NEXT round counts into (its reader, the previous round's accum sweep, is done)
+    if (j >= lme_count(ph)) return;
+    LmProb *P = ph.probs + j;
+    if (P->status == 0 || P->has_cand == 0) { P->need_acc = 0; return; }
+    Model m = P->m;
+    double cost = P->cost, lambda = P->lambda, mu = P->mu;
+    int it = P->it, cur = P->cur, recompute = 0;
+    const int has_cand = P->has_cand, n = P->n, max_it = P->max_it;
+    const int nseg = (n + LME_SEG - 1) / LME_SEG;
+    double cost_new = 0;
+    for (int s = 0; s < nseg; ++s) cost_new += ph.part[(size_t)j * ph.nseg + s];
+    P->ev_cost += (unsigned long long)n;
+    if (has_cand == 2) { cost = cost_new; cur ^= 1; recompute = 1; }
+    else {
+        if (cost_new < cost) { m = P->cand; cur ^= 1; lambda = fmax(P->lambda_min, lambda / 10.0); cost = cost_new; recompute = 1; }
+        else { lambda = fmin(P->lambda_max, lambda * 10.0); }
+        mu *= 1.5; // TRUNCATED_LE_ZACH: the reference's per-iteration callback
+        ++it;
+    }
+    const bool done = it >= max_it;
+    const int need = (!done && recompute) ? 1 : 0;
+    // (P->cs is the expanded state of the model just evaluated: of m whenever `recompute` is set)
+    P->m = m; P->cost = cost; P->lambda = lambda; P->mu = mu; P->it = it; P->cur = cur; P->recompute = recompute;
+    P->has_cand = 0; P->need_acc = need;
+    if (done) P->status = 0;
+    if (need) { P->ev_acc += (unsigned long long)P->n_eff; atomicAdd(ph.pair_acc + (size_t)(round & 1) * ph.batch + P->pair, 1); }
+}
+
+// J'J | J'r of (problem, segment) for every problem of the pair flagged by k_lme_decide.  grid (nseg, batch), 64 threads.
+template <int KIND, bool SHIFT, int LOSS>
+__global__ __launch_bounds__(64, MDRP_LME_MINWAVES) void k_lme_accum_seg(LmePhase ph, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                                         const double *__restrict__ dep, int round) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NA = NP * (NP + 1) / 2 + NP;
+    __shared__ double s_state[LME_STAGE][LME_HEAD];
+    __shared__ int s_idx[LME_STAGE];
+    const int pair = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
+    if (ph.pair_acc[(size_t)(round & 1) * ph.batch + pair] == 0) return;
+    const int n = st[pair].n;
+    if (seg * LME_SEG >= n) return;
+    const int cnt = lme_count(ph);
+    const int j0 = max(ph.pfx[pair] - ph.first, 0), j1 = min(ph.pfx[pair + 1] - ph.first, cnt);
+    if (j0 >= j1) return;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    bool loaded = false;
+    double2 r01[LME_RPT], r23[LME_RPT], rdd[LME_RPT];
+    bool ok[LME_RPT];
+    for (int base = j0; base < j1; base += LME_STAGE) {
+        const int kk = min(LME_STAGE, j1 - base);
+        __syncthreads();
+        for (int e = lane; e < kk * LME_HEAD; e += 64) {
+            const int r = e / LME_HEAD, f = e - r * LME_HEAD;
+            s_state[r][f] = reinterpret_cast<const double *>(ph.probs + base + r)[f];
+        }
+        if (!loaded) {
+            loaded = true;
+            const double *pp = pts + (size_t)pair * ph.n_max * PT_STRIDE;
+            const double *dd = dep + (size_t)pair * ph.n_max * 2;
+            const uint8_t *mk = ph.mask ? ph.mask + (size_t)pair * ph.n_max : nullptr;
+#pragma unroll
+            for (int r = 0; r < LME_RPT; ++r) {
+                const int i = seg * LME_SEG + r * 64 + lane;
+                ok[r] = i < n && (!mk || mk[i]);
+                r01[r] = r23[r] = make_double2(0, 0); rdd[r] = make_double2(1, 1);
+                if (ok[r]) {
+                    const double2 *P = reinterpret_cast<const double2 *>(pp + (size_t)i * PT_STRIDE);
+                    r01[r] = P[0]; r23[r] = P[1];
+                    rdd[r] = *reinterpret_cast<const double2 *>(dd + 2 * (size_t)i);
+                }
+            }
+        }
+        __syncthreads();
+        bool want = false;
+        if (lane < kk) {
+            const int status = reinterpret_cast<const int2 *>(&s_state[lane][LME_O_STATUS])->x, need = reinterpret_cast<const int2 *>(&s_state[lane][LME_O_NEED])->y;
+            want = status != 0 && need != 0;
+        }
+        const unsigned long long wb = __ballot(want);
+        const int k = __popcll(wb);
+        if (k == 0) continue;
+        if (want) s_idx[__popcll(wb & lt)] = lane;
+        __syncthreads();
+        for (int q = 0; q < k; ++q) {
+            const int sl = s_idx[q], j = base + sl;
+            const double *S = s_state[sl];
+            LmState stt;
+            lme_state_from_header(S, stt);
+            const double sqrt_sr = uniform_f64(S[LME_O_SQRT_SR]), ws = uniform_f64(S[LME_O_WS]);
+            LmOpt o;
+            o.max_it = 0; o.loss = LOSS >= 0 ? LOSS : __builtin_amdgcn_readfirstlane(reinterpret_cast<const int2 *>(S + LME_O_LOSS)->x);
+            o.loss_scale = uniform_f64(S[LME_O_LSC]); o.mu = uniform_f64(S[LME_O_MU]);
+            o.grad_tol = o.step_tol = o.lambda0 = o.lambda_min = o.lambda_max = 0;
+            double acc[NA];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) acc[i] = 0;
+#pragma unroll
+            for (int r = 0; r < LME_RPT; ++r)
+                if (ok[r]) lm_accumulate_point<KIND, SHIFT, LOSS>(stt, r01[r], r23[r], rdd[r], sqrt_sr, ws, o, acc);
+            wave_reduce_scatter<NA>(acc, ph.accpart + ((size_t)j * ph.nseg + seg) * MAX_ACC);
+        }
+    }
+}
+
+// the segments of a problem in order: one wavefront per problem, lane a owns accumulator a
+template <int KIND, bool SHIFT>
+__global__ __launch_bounds__(256) void k_lme_reduce(LmePhase ph) {
+    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
+    constexpr int NA = NP * (NP + 1) / 2 + NP;
+    const int lane = threadIdx.x & 63;
+    const int count = lme_count(ph);
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < count; j += gridDim.x * 4) {
+        LmProb *P = ph.probs + j;
+        if (P->status == 0 || P->need_acc == 0) continue;
+        const int nseg = (P->n + LME_SEG - 1) / LME_SEG;
+        if (lane < NA) {
+            const double *src = ph.accpart + (size_t)j * ph.nseg * MAX_ACC + lane;
+            double s = 0;
+            for (int k = 0; k < nseg; ++k) s += src[(size_t)k * MAX_ACC];
+            P->acc[lane] = s;
         }
     }
 }
@@ -554,7 +708,7 @@ __device__ __forceinline__ void lme_start(LmProb &P, const Model &m0, bool focal
     lm_state_from_model(m0, focal, P.cs);
     P.sqrt_sr = sqrt(scale_reproj); P.ws = ws; P.loss_scale = o.loss_scale; P.mu = 0.5;
     P.status = 1; P.has_cand = 2; P.loss = o.loss; P.cur = 0;
-    P.pair = pair; P.n = n; P.it = 0; P.max_it = o.max_it; P.recompute = 0; P.pad_ = 0;
+    P.pair = pair; P.n = n; P.it = 0; P.max_it = o.max_it; P.recompute = 0; P.need_acc = 0; P.n_eff = n; P.pad3_ = 0;
     P.cost = 0; P.lambda = o.lambda0; P.grad_tol = o.grad_tol; P.step_tol = o.step_tol; P.lambda_min = o.lambda_min; P.lambda_max = o.lambda_max;
 }
 
@@ -657,6 +811,7 @@ __global__ void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__re
     f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
     const Model m0 = ph.probs[pair].m;
     lme_start(ph.probs[pair], m0, rp.kind != 0, pair, ps.n, ps.scale_reproj, rp.weight_sampson, f);
+    ph.probs[pair].n_eff = (int32_t)results[pair].num_inliers; // the record mask of this phase = the inliers
 }
 
 __global__ void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results,

@@ -822,6 +822,7 @@ MDRP_HD float bound_r2_32(const float Ef[9], float eC, float eD, float a, float 
 struct LmState {
     double R[9], t[3], s, u, v, f1, f2;
     double E[9], F[9];
+    double if1, if2; // 1 / f1, 1 / f2: the same IEEE quotients the reprojection terms used to form per correspondence (round 4: once per state)
 };
 
 MDRP_HD void lm_state_from_model(const Model &m, bool focal, LmState &st) {
@@ -829,6 +830,7 @@ MDRP_HD void lm_state_from_model(const Model &m, bool focal, LmState &st) {
     st.t[0] = m.t[0]; st.t[1] = m.t[1]; st.t[2] = m.t[2];
     st.s = m.scale; st.u = m.shift1; st.v = m.shift2;
     st.f1 = focal ? m.f1 : 1.0; st.f2 = focal ? m.f2 : 1.0;
+    st.if1 = 1.0 / st.f1; st.if2 = 1.0 / st.f2;
     essential_from_Rt(st.R, st.t, st.E);
     fundamental_from_E(st.E, st.f1, st.f2, st.F);
 }
@@ -893,7 +895,7 @@ MDRP_HD void lm_forward_term(const LmState &st, double sqrt_sr, double x1x, doub
                              double &r1, double &r2, double &zf, double *J1, double *J2) {
     const double *R = st.R, *t = st.t;
     const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
-    const double if1 = 1.0 / f1;
+    const double if1 = FOCAL ? st.if1 : 1.0;
     const double b1x = x1x * if1, b1y = x1y * if1;
     const double dd1 = d1 + st.u;
     const double X1[3] = {dd1 * b1x, dd1 * b1y, dd1};
@@ -941,7 +943,7 @@ MDRP_HD void lm_backward_term(const LmState &st, double sqrt_sr, double x1x, dou
                               double &r3, double &r4, double &zb, double *J3, double *J4) {
     const double *R = st.R, *t = st.t;
     const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
-    const double if2 = 1.0 / f2;
+    const double if2 = FOCAL ? st.if2 : 1.0;
     const double b2x = x2x * if2, b2y = x2y * if2;
     const double dd2 = d2 + st.v;
     const double sd = st.s * dd2;

@@ -257,6 +257,67 @@ def estimate_monodepth_varying_focal_relative_pose(points2D_1, points2D_2, depth
     return p[0], i[0]
 
 
+# ------------------------------------------------------------------------------------------------ the older wheel's names
+# demo/poselib_old-2.0.5-cp312-*.whl (poselib/_core.pyi:171-199, 441-497) ships the same three estimators as estimate_monodepth_pose,
+# estimate_monodepth_shared_focal_pose and estimate_monodepth_varying_focal_pose; its result type is MonoDepthCameraPose — a CameraPose
+# that carries scale, shift_1 and shift_2 itself — and its MonoDepthImagePair holds that as `.pose`.
+class MonoDepthCameraPose(CameraPose):
+    def __init__(self, q=None, t=None, scale=1.0, shift_1=0.0, shift_2=0.0):
+        if isinstance(q, CameraPose):
+            q, t = q.q, q.t
+        super().__init__(q, t)
+        self.scale, self.shift_1, self.shift_2 = float(scale), float(shift_1), float(shift_2)
+
+    def __repr__(self):
+        return f"[q: {self.q}, t: {self.t}, scale: {self.scale}, shift_1: {self.shift_1}, shift_2: {self.shift_2}]"
+
+
+def _old_pose(g):
+    return MonoDepthCameraPose(g.pose.q, g.pose.t, g.scale, g.shift1, g.shift2)
+
+
+def _old_initial(initial):
+    """a MonoDepthCameraPose / old-style image pair handed in as the initial value -> today's types (the pose itself is never read:
+    the reference resets it, include/mdrp.h score_initial_model)"""
+    if initial is None:
+        return None
+    if isinstance(initial, MonoDepthCameraPose):
+        return MonoDepthTwoViewGeometry(CameraPose(initial.q, initial.t), initial.scale, initial.shift_1, initial.shift_2)
+    if isinstance(getattr(initial, "pose", None), MonoDepthCameraPose):  # an old-style image pair
+        return MonoDepthImagePair(_old_initial(initial.pose), getattr(initial, "camera1", None), getattr(initial, "camera2", None))
+    return initial
+
+
+def estimate_monodepth_pose(points2D_1, points2D_2, depth_1, depth_2, camera1, camera2, ransac_opt={}, bundle_opt={}, initial_pose=None):
+    """older wheel's name of estimate_monodepth_relative_pose (poselib_old _core.pyi:441-470); returns (MonoDepthCameraPose, info)"""
+    g, info = estimate_monodepth_relative_pose(points2D_1, points2D_2, depth_1, depth_2, camera1, camera2, ransac_opt, bundle_opt, _old_initial(initial_pose))
+    return _old_pose(g), info
+
+
+class _OldImagePair:
+    """MonoDepthImagePair of the older wheel: camera1, camera2, pose (a MonoDepthCameraPose)"""
+
+    def __init__(self, pair):
+        self.camera1, self.camera2, self.pose = pair.camera1, pair.camera2, _old_pose(pair.geometry)
+
+    def __repr__(self):
+        return f"[pose: {self.pose}, camera1: {self.camera1}, camera2: {self.camera2}]"
+
+
+def estimate_monodepth_shared_focal_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt={}, bundle_opt={}, initial_image_pair=None):
+    """older wheel's name of estimate_monodepth_shared_focal_relative_pose (poselib_old _core.pyi:472-483)"""
+    p, info = estimate_monodepth_shared_focal_relative_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt,
+                                                            _old_initial(initial_image_pair))
+    return _OldImagePair(p), info
+
+
+def estimate_monodepth_varying_focal_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt={}, bundle_opt={}, initial_image_pair=None):
+    """older wheel's name of estimate_monodepth_varying_focal_relative_pose (poselib_old _core.pyi:485-497)"""
+    p, info = estimate_monodepth_varying_focal_relative_pose(points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt,
+                                                             _old_initial(initial_image_pair))
+    return _OldImagePair(p), info
+
+
 # ------------------------------------------------------------------------------------------------ minimal solvers
 def _solver(solver, x1, x2, d1, d2, wrap):
     x1 = np.asarray(x1, dtype=np.float64).reshape(3, 3)
