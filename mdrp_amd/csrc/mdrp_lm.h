@@ -99,87 +99,7 @@ __device__ __forceinline__ int lme_count(const LmePhase &ph) {
     return t < 0 ? 0 : (t < ph.cap ? t : ph.cap);
 }
 
-// ------------------------------------------------------------------------------------------------ cross-lane sums (gfx950)
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-// every lane of a row of 16 gets the row's sum (row_ror 8, 4, 2, 1)
-__device__ __forceinline__ double row_sum16(double s) {
-    s += dpp_f64<0x128>(s);
-    s += dpp_f64<0x124>(s);
-    s += dpp_f64<0x122>(s);
-    s += dpp_f64<0x121>(s);
-    return s;
-}
-typedef unsigned int lme_u2 __attribute__((ext_vector_type(2)));
-// v_permlane32_swap: lanes 32-63 of a <-> lanes 0-31 of b;  v_permlane16_swap: odd rows (of 16 lanes) of a <-> even rows of b
-__device__ __forceinline__ void swap32(double &a, double &b) {
-    const lme_u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const lme_u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
-}
-__device__ __forceinline__ void swap16(double &a, double &b) {
-    const lme_u2 lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    const lme_u2 hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)hi.x, (int)lo.x); b = __hiloint2double((int)hi.y, (int)lo.y);
-}
-__device__ __forceinline__ void swap32i(int &a, int &b) {
-    const lme_u2 r = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-    a = (int)r.x; b = (int)r.y;
-}
-__device__ __forceinline__ void swap16i(int &a, int &b) {
-    const lme_u2 r = __builtin_amdgcn_permlane16_swap((unsigned)a, (unsigned)b, false, false);
-    a = (int)r.x; b = (int)r.y;
-}
-// sum over the wavefront, every lane gets it: two swap levels + the row rotations, no LDS round trips
-__device__ __forceinline__ double wave_sum_swap(double v) {
-    double b = v;
-    swap32(v, b); v += b;
-    b = v;
-    swap16(v, b); v += b;
-    return row_sum16(v);
-}
-__device__ __forceinline__ int wave_sum_swap_i(int v) {
-    int b = v;
-    swap32i(v, b); v += b;
-    b = v;
-    swap16i(v, b); v += b;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, false);
-    return v;
-}
-// Reduce-scatter of NA per-lane accumulators over the wavefront.  Level 1 pairs accumulators (2i, 2i+1): after the half swap one
-// add leaves accumulator 2i in lanes 0-31 and 2i+1 in lanes 32-63; level 2 pairs those sums the same way over the rows of 16;
-// the row rotations finish.  A tag travels through the same swaps, so the write-out index is whatever the hardware moved where.
-template <int NA>
-__device__ __forceinline__ void wave_reduce_scatter(const double *acc, double *out /*LDS or global, [NA]*/) {
-    constexpr int M1 = (NA + 1) / 2, M2 = (M1 + 1) / 2;
-    double w[M1];
-    int t1[M1];
-#pragma unroll
-    for (int i = 0; i < M1; ++i) {
-        double a = acc[2 * i], b = (2 * i + 1 < NA) ? acc[2 * i + 1] : 0.0;
-        int ta = 2 * i, tb = (2 * i + 1 < NA) ? 2 * i + 1 : -1;
-        swap32(a, b);
-        swap32i(ta, tb);
-        w[i] = a + b; t1[i] = ta;
-    }
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int i = 0; i < M2; ++i) {
-        double c = w[2 * i], d = (2 * i + 1 < M1) ? w[2 * i + 1] : 0.0;
-        int tc = t1[2 * i], td = (2 * i + 1 < M1) ? t1[2 * i + 1] : -1;
-        swap16(c, d);
-        swap16i(tc, td);
-        const double x = row_sum16(c + d);
-        if ((lane & 15) == 0 && tc >= 0) out[tc] = x;
-    }
-}
+// (the cross-lane sums — dpp_f64, swap32 / swap16, wave_sum_swap, wave_reduce_scatter — live in mdrp_kernels.h since round 4: block_sum uses them too)
 
 // ------------------------------------------------------------------------------------------------ cost sweep
 // grid (nseg, batch), 64 threads.  Record i of the segment sits in lane i & 63, slot i >> 6.

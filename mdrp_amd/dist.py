@@ -34,7 +34,7 @@ def _unpad(allbuf, total, world, per):
     return np.concatenate(parts) if parts else allbuf[:0]
 
 
-def gather_records(local, total, group=None, device=None):
+def gather_records(local, total, group=None, device=None, force_collective=False):
     """All `total` result records on every rank.  `local`: this rank's records, either a numpy RESULT_DTYPE array or a
     (rows, 136) uint8 torch tensor already on the GPU (then the all-gather runs device to device).  Blocks are padded to
     ceil(total / world) rows for the collective and trimmed afterwards."""
@@ -43,8 +43,9 @@ def gather_records(local, total, group=None, device=None):
 
     rank, world = _world(group)
     per = (total + world - 1) // world
+    single = world == 1 and not force_collective  # (force_collective: run the all-gather even with one rank — the tests' way to cover the RCCL path on one GPU)
     if isinstance(local, np.ndarray):
-        if world == 1:
+        if single:
             return local[:total].copy()
         mine = torch.zeros((per, RECORD_BYTES), dtype=torch.uint8)
         if len(local):
@@ -52,7 +53,7 @@ def gather_records(local, total, group=None, device=None):
         if device is not None:
             mine = mine.to(device)
     else:
-        if world == 1:
+        if single:
             return local[:total].cpu().numpy().reshape(-1).view(_capi.RESULT_DTYPE).copy()
         mine = local
         if mine.shape[0] != per:
@@ -120,6 +121,37 @@ def estimate_local_shard(kind, total, x1, x2, d1, d2, ransac_opt=None, bundle_op
     if want_mask:
         return all_res, gather_masks(mask, total, group, device)
     return all_res
+
+
+def estimate_local_shard_device(kind, total, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_per_pair=None, cam1=None, cam2=None,
+                                group=None, handle=None, mask=None, force_collective=False):
+    """The same on DEVICE-RESIDENT inputs, the way bench.py runs BASELINE configs[4]: x1, x2 (rows, N, 2) and d1, d2 (rows, N) are
+    float64 CUDA tensors holding this rank's block; the estimate runs through mdrp_estimate_batch_async, the 136-byte records go
+    device to device into the rank's slot (mdrp_copy_results_device) and from there through ONE all_gather_into_tensor over
+    RCCL / xGMI — nothing crosses PCIe until the caller reads the gathered records.  `mask`: optional (rows, N) uint8 CUDA tensor
+    that receives this rank's inlier masks.  Returns all `total` records as a numpy RESULT_DTYPE array."""
+    import torch
+
+    rank, world = _world(group)
+    lo, hi, per = shard_bounds(total, rank, world)
+    rows = hi - lo
+    if x1.shape[0] != rows or not x1.is_cuda or x1.dtype != torch.float64:
+        raise ValueError(f"rank {rank} owns pairs [{lo}, {hi}) = {rows} rows of float64 CUDA tensors, got {tuple(x1.shape)} {x1.dtype} on {x1.device}")
+    ro = ransac_opt if isinstance(ransac_opt, _capi.RansacOpt) else _capi.ransac_opt_from_dict(ransac_opt)
+    bo = bundle_opt if isinstance(bundle_opt, _capi.BundleOpt) else _capi.bundle_opt_from_dict(bundle_opt)
+    dev = x1.device
+    h = handle if handle is not None else _capi.default_handle(dev.index if dev.index is not None else torch.cuda.current_device())
+    rec_local = torch.zeros((per, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    torch.cuda.current_stream(dev).synchronize()  # the inputs may have been produced on torch's stream; the handle runs on its own
+    if rows > 0:
+        n = x1.shape[1]
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        d1p = d1.contiguous().data_ptr() if d1 is not None else 0
+        d2p = d2.contiguous().data_ptr() if d2 is not None else 0
+        h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), d1p, d2p, rows, n, ro, bo, n_per_pair, cam1, cam2,
+                                mask.data_ptr() if mask is not None else None)
+        h.copy_results_device(rec_local.data_ptr(), rows)  # returns after the handle's stream has drained
+    return gather_records(rec_local, total, group, dev, force_collective=force_collective)
 
 
 def estimate_sharded(kind, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_per_pair=None, cam1=None, cam2=None, group=None,

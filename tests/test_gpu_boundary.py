@@ -224,3 +224,37 @@ def test_batches_larger_than_one_pass(monkeypatch):
             assert int(out[0][0]["refinements"].max()) > 2
     finally:
         h.close()
+
+
+def test_local_shard_through_the_device_gather_path_one_rank():
+    """BASELINE configs[4]'s data path on ONE GPU: dist.estimate_local_shard_device — device-resident inputs,
+    mdrp_estimate_batch_async, mdrp_copy_results_device into the rank's slot, all_gather_into_tensor over RCCL (a one-rank `nccl`
+    group, the collective forced) — returns the records the host-buffer API returns, bit for bit; the multi-rank bookkeeping
+    (uneven blocks, padding) is covered under gloo in tests/test_dist_gloo.py."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as tdist
+    from mdrp_amd import _capi, dist as mdist, synth
+    B, N = 37, 400
+    b = synth.make_batch(9900, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4)
+    cams = np.zeros(B, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ro = {"max_iterations": 800, "min_iterations": 800, "max_epipolar_error": 2.0, "max_reproj_error": 16.0}
+    bo = {"loss_type": "TRUNCATED_CAUCHY"}
+    ref, ref_mask = _capi.default_handle(0).estimate_batch(0, b["x1"], b["x2"], b["d1"], b["d2"], _capi.ransac_opt_from_dict(ro), _capi.bundle_opt_from_dict(bo), None, cams, cams)
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(b[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
+    mask = torch.zeros((B, N), dtype=torch.uint8, device=dev)
+    created = False
+    if not tdist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        out = mdist.estimate_local_shard_device(0, B, *t, ro, bo, None, cams, cams, mask=mask, force_collective=True)
+    finally:
+        if created:
+            tdist.destroy_process_group()
+    assert out.tobytes() == ref.tobytes() and np.array_equal(mask.cpu().numpy(), ref_mask)
