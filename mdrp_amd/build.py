@@ -52,14 +52,14 @@ def up_to_date():
     return built_hash() == source_hash()
 
 
-def build(force=False, verbose=False, defines=(), out=OUT):
-    if not force and not defines and out == OUT and up_to_date():
+def build(force=False, verbose=False, defines=(), out=OUT, extra_flags=()):
+    if not force and not defines and not extra_flags and out == OUT and up_to_date():
         return out
     # -no-hip-rt: no DT_NEEDED on a particular libamdhip64.  The hip* symbols stay undefined and bind, when the library is loaded,
     # to the ONE HIP runtime the host process already has (PyTorch-ROCm wheels bundle their own; a second runtime instance in the
     # same process cannot share streams or device memory with it).  mdrp_amd/_capi.py makes a runtime globally visible first;
     # a C / C++ host links -lamdhip64 itself.
-    cmd = [hipcc(), *FLAGS,
+    cmd = [hipcc(), *FLAGS, *extra_flags,
            f'-DMDRP_SRC_HASH="{source_hash()}"', *[f"-D{d}" for d in defines], SRC, "-o", out + ".tmp"]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

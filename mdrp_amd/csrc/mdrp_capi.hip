@@ -112,7 +112,8 @@ struct mdrp_handle {
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
     // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
     DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live, lme_accpart;
-    int lme_mode = 0;                  // 1 = list engine (k_lme_accum), 2 = segment engine (dense sweeps: k_lme_decide / k_lme_accum_seg / k_lme_reduce)
+    int lme_mode = 0;                  // LO phases: 1 = list engine (k_lme_accum), 2 = segment engine (dense sweeps: k_lme_decide / k_lme_accum_seg / k_lme_reduce)
+    int lme_mode_final = 0;            // the final phase (one problem per pair, an inlier mask in its second half): 1 or 2
     int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
     DevBuf lm_stats;                  // six u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel |
                                       // fused tail: gate time-outs | final-refinement wait time-outs
@@ -285,12 +286,14 @@ size_t lme_bytes_per_problem(int n_max) {
 
 int lme_ensure(mdrp_handle *h, int cap, int batch, int n_max) {
     const size_t nseg = (size_t)lme_nseg(n_max), c = (size_t)std::max(cap, 1);
-    const bool seg_engine = h->lme_mode == 2; // dense sweeps: per (problem, segment) normal-equation partials instead of work lists
+    // work lists for the phases that run on the list engine, normal-equation partials for those on the segment engine (dense sweeps)
+    const size_t c_list = h->lme_mode == 1 ? c : (h->lme_mode_final == 1 ? (size_t)std::max(batch, 1) : 0);
+    const size_t c_seg = h->lme_mode == 2 ? c : (h->lme_mode_final == 2 ? (size_t)std::max(batch, 1) : 0);
     int rc;
     if ((rc = h->lme_probs.ensure(sizeof(LmProb) * c)) || (rc = h->lme_part.ensure(sizeof(double) * c * nseg)) ||
-        (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (!seg_engine && (rc = h->lme_list.ensure(c * 2 * nseg * LME_SEG))) ||
-        (!seg_engine && (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c * 2 * nseg))) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
-        (seg_engine && (rc = h->lme_accpart.ensure(sizeof(double) * c * nseg * MAX_ACC))) ||
+        (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (c_list && (rc = h->lme_list.ensure(c_list * 2 * nseg * LME_SEG))) ||
+        (c_list && (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c_list * 2 * nseg))) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
+        (c_seg && (rc = h->lme_accpart.ensure(sizeof(double) * c_seg * nseg * MAX_ACC))) ||
         (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))) || (rc = h->lme_pair_live.ensure(sizeof(int32_t) * 4 * (size_t)std::max(batch, 1))))
         return rc;
     return MDRP_OK;
@@ -312,14 +315,13 @@ LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, con
 // iteration.  max_it <= 25 (the LO refinements) is launched blind; an open-ended phase (the user's BundleOptions) reads the live
 // counter back every `poll_every` rounds from round `poll_from` on and stops when nothing iterates any more.
 int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, int est_shift, int loss, int max_it, int accum_blocks, int problems_bound,
-            int poll_from, int poll_every) {
+            int poll_from, int poll_every, bool seg /*segment engine (dense sweeps) instead of the list engine*/) {
     HIPCHK(hipMemsetAsync(ph.live, 0, sizeof(int32_t) * LME_RING, stream));
     HIPCHK(hipMemsetAsync(ph.pair_live, 0, sizeof(int32_t) * 4 * (size_t)std::max(ph.batch, 1), stream)); // pair_live | pair_acc
     const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
     const int dense_cap = ph.n_max <= LM_LIST_MAX_N ? ((ph.n_max + 63) / 64) * 64 : 0;
     const size_t smem = sizeof(int32_t) * ((size_t)ph.nseg + 1) + sizeof(uint16_t) * (size_t)dense_cap + 8;
     const dim3 solve_grid((unsigned)(std::max(problems_bound, 1) + 63) / 64);
-    const bool seg = h->lme_mode == 2;
     const dim3 lane_grid((unsigned)(std::max(problems_bound, 1) + 255) / 256), reduce_grid((unsigned)std::min((std::max(problems_bound, 1) + 3) / 4, h->num_cu * 32));
     MDRP_LME_COST(seg, kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
     for (int r = 0; r <= max_it; ++r) {
@@ -351,7 +353,7 @@ int lme_lo(mdrp_handle *h, hipStream_t stream, const RunParams &rp, int kind, in
     const LmePhase ph = lme_phase(h, rp.batch, rp.n_max, lo_plan /*prefix*/, total, first, cap, nullptr);
     hipLaunchKernelGGL(k_lme_lo_init, dim3((cap + 255) / 256), dim3(256), 0, stream, ph, rp, h->st.as<PairState>(), h->models.as<Model>(),
                        h->triggers.as<Trigger>(), trig_cap, lo_plan);
-    int rc = lme_run(h, stream, ph, kind, est_shift, 1, 25, h->num_cu * 8, cap, 0, 0);
+    int rc = lme_run(h, stream, ph, kind, est_shift, 1, 25, h->num_cu * 8, cap, 0, 0, h->lme_mode == 2);
     if (rc) return rc;
     const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
     MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
@@ -370,14 +372,15 @@ int lme_final(mdrp_handle *h, hipStream_t s, const RunParams &rp, int kind, int 
     const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)batch), pair_grid((unsigned)(batch + 255) / 256);
     hipLaunchKernelGGL(k_lme_fin_init, dim3(batch), dim3(64), 0, s, ph, rp, h->st.as<PairState>(), mask_dev, results_dev);
     const int step_blocks = std::min(batch, h->num_cu * 8);
-    int rc = lme_run(h, s, ph, kind, est_shift, 1, 25, step_blocks, batch, env_int("MDRP_LME_POLL_FROM", 3), env_int("MDRP_LME_POLL_EVERY", 4));
+    const bool seg = h->lme_mode_final == 2;
+    int rc = lme_run(h, s, ph, kind, est_shift, 1, 25, step_blocks, batch, env_int("MDRP_LME_POLL_FROM", 3), env_int("MDRP_LME_POLL_EVERY", 4), seg);
     if (rc) return rc;
     MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, s, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
     hipLaunchKernelGGL(k_lme_fin_select, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
     MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, s, ph, h->st.as<PairState>(), h->pts.as<double>(), mask_dev);
     hipLaunchKernelGGL(k_lme_fin_init2, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
     ph.mask = mask_dev;
-    rc = lme_run(h, s, ph, kind, est_shift, rp.final_loss, rp.final_max_it, step_blocks, batch, env_int("MDRP_LME_POLL_FROM2", 8), env_int("MDRP_LME_POLL_EVERY", 4));
+    rc = lme_run(h, s, ph, kind, est_shift, rp.final_loss, rp.final_max_it, step_blocks, batch, env_int("MDRP_LME_POLL_FROM2", 8), env_int("MDRP_LME_POLL_EVERY", 4), seg);
     if (rc) return rc;
     hipLaunchKernelGGL(k_lme_fin_write, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev,
                        h->lm_stats.as<unsigned long long>() + 2);
@@ -524,6 +527,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int lme_mode = classic ? 0 : env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 2 : 0);
     const bool use_lme = lme_mode != 0;
     h->lme_mode = lme_mode;
+    // The final phase has one problem per pair and, in its second half, an inlier mask: dense sweeps waste the masked lanes and its
+    // ~100 rounds pay five launches each instead of three — it stays on the list engine (varying focal, 1024 x 5000: 14.8 against 19.4 ms)
+    h->lme_mode_final = use_lme ? env_int("MDRP_LM_ENGINE_FINAL", 1) : 0;
     const int lme_cap = std::max(batch, env_int("MDRP_LME_CAP", batch * 48 + 2048));
     if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
@@ -1456,7 +1462,7 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
     if (env_int("MDRP_LM_ENGINE", 0) != 0) {
         // the phase-batched engine with all `count` problems on one pair (pair 0 = the packed records)
-        h->lme_mode = env_int("MDRP_LM_ENGINE", 0);
+        h->lme_mode = env_int("MDRP_LM_ENGINE", 0); h->lme_mode_final = 0;
         if ((rc = lme_ensure(h, count, 1, nn)) || (rc = h->st.ensure(sizeof(PairState)))) return rc;
         PairState ps;
         std::memset(&ps, 0, sizeof ps);
@@ -1466,7 +1472,7 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
         hipLaunchKernelGGL(k_lme_iota, dim3(1), dim3(64), 0, s, iota, 2, total, count, count);
         const LmePhase ph = lme_phase(h, 1, nn, iota, total, 0, count, nullptr);
         hipLaunchKernelGGL(k_lme_unit_init, dim3((count + 255) / 256), dim3(256), 0, s, ph, count, h->unit_e.as<Model>(), kind, n, scale_reproj, weight_sampson, o);
-        if ((rc = lme_run(h, s, ph, kind, (kind == MDRP_CALIB && estimate_shift) ? 1 : 0, o.loss, o.max_it, std::min(count, h->num_cu * 8), count, 8, 8))) return rc;
+        if ((rc = lme_run(h, s, ph, kind, (kind == MDRP_CALIB && estimate_shift) ? 1 : 0, o.loss, o.max_it, std::min(count, h->num_cu * 8), count, 8, 8, h->lme_mode == 2))) return rc;
         hipLaunchKernelGGL(k_lme_unit_finish, dim3((count + 255) / 256), dim3(256), 0, s, ph, count, h->unit_e.as<Model>(), h->unit_a.as<double>());
     } else
     MDRP_LM_DISPATCH(k_refine_unit, (count >= 2048 ? 64 : 256), kind, (kind == MDRP_CALIB && estimate_shift), dim3(count), lm_list_bytes(n), s,

@@ -1658,6 +1658,9 @@ struct LmShared {
     int stride;
     unsigned long long *stats; // [0] correspondences evaluated by cost sweeps, [1] by accumulate sweeps (or null): bench.py's fp64 roofline
     unsigned long long ev[2];  // ... collected here per problem, flushed by lm_flush_stats
+#ifdef MDRP_LO_TRACE
+    unsigned long long ph[4];  // experiment build: wall-clock ticks of the last lm_refine in cost sweeps | normal-equation sweeps | total; iterations | accepted << 16
+#endif
 };
 // one pair of global atomics per LM problem (thread 0, after the problem's last barrier)
 __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
@@ -1918,10 +1921,20 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
     double A[NP * NP], g[NP], sol[NP];
     Model cand = m;
     int it = 0;
+#ifdef MDRP_LO_TRACE
+    unsigned long long tr_c = 0, tr_a = 0, tr_t;
+    const unsigned long long tr_0 = wall_clock64();
+    int tr_acc = 0;
+#define MDRP_TR(x) x
+#else
+#define MDRP_TR(x)
+#endif
 #pragma unroll 1
     for (;;) {
         // cost of the model under evaluation: the start model on the first trip (into list buffer `cur`), a candidate step afterwards
+        MDRP_TR(tr_t = wall_clock64();)
         const double cost_new = lm_cost<KIND, T, LOSS>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, first ? cur : cur ^ 1);
+        MDRP_TR(tr_c += wall_clock64() - tr_t;)
         if (first) { cost = cost_new; first = false; }
         else {
             if (cost_new < cost) {
@@ -1940,7 +1953,9 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
         }
         if (it >= o.max_it) break;
         if (recompute) {
+            MDRP_TR(tr_t = wall_clock64(); ++tr_acc;)
             lm_accumulate<KIND, SHIFT, T, LOSS>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
+            MDRP_TR(tr_a += wall_clock64() - tr_t;)
             double gn = 0;
             int idx = 0;
 #pragma unroll
@@ -1970,6 +1985,8 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
         if (KIND == 1) full[10] = full[9];
         lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
     }
+    MDRP_TR(if (threadIdx.x == 0) { sh.ph[0] = tr_c; sh.ph[1] = tr_a; sh.ph[2] = wall_clock64() - tr_0; sh.ph[3] = (unsigned long long)it | ((unsigned long long)tr_acc << 16); })
+#undef MDRP_TR
 }
 
 // workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask output
@@ -2213,7 +2230,9 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
         const unsigned int k = atomicAdd(&g_lo_trace_n, 1u);
         unsigned long long *e = g_lo_trace + 8ull * k;
         e[0] = (unsigned long long)pair; e[1] = (unsigned long long)pos; e[2] = (unsigned long long)tr.cnt_ref; e[3] = (unsigned long long)cn;
-        e[4] = t_start; e[5] = wall_clock64(); e[6] = (unsigned long long)tr.iter + rp.chunk_start; e[7] = (unsigned long long)rp.chunk_off;
+        e[4] = t_start; e[5] = wall_clock64();
+        e[6] = (sh.ph[0] & 0xFFFFFFFFull) | (sh.ph[1] << 32);                       // ticks in cost sweeps | in normal-equation sweeps
+        e[7] = (unsigned long long)(rp.chunk_off != 0) | (sh.ph[3] << 8) | (sh.ph[2] << 40); // chunk flag | iterations, accepted | ticks inside lm_refine
     }
 #endif
 }

@@ -544,8 +544,9 @@ def test_lm_engines_agree_on_every_estimator(capi, monkeypatch, kind, es, rf, lo
     h = capi.Handle(0)
     try:
         out = []
-        for eng in ("0", "1", "2"):
-            monkeypatch.setenv("MDRP_LM_ENGINE", eng)
+        for eng in ("0", "1", "2", "22"):  # "22": the final phase on the segment engine as well (default: LO phases only)
+            monkeypatch.setenv("MDRP_LM_ENGINE", eng[0])
+            monkeypatch.setenv("MDRP_LM_ENGINE_FINAL", "2" if eng == "22" else "1")
             res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, np.array(ns, dtype=np.int32), cams if kind == 0 else None, cams if kind == 0 else None)
             out.append((res.copy(), mask.copy()))
     finally:
@@ -555,7 +556,7 @@ def test_lm_engines_agree_on_every_estimator(capi, monkeypatch, kind, es, rf, lo
         return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
     (r0, m0) = out[0]
     assert int(r0["refinements"].max()) > 3 and int(r0["num_inliers"].max()) > 400
-    for eng, (r, m) in zip("12", out[1:]):
+    for eng, (r, m) in zip(("1", "2", "22"), out[1:]):
         for f in ("refinements", "iterations", "num_inliers"):
             assert np.array_equal(r[f], r0[f]), (eng, f, r[f], r0[f])
         assert np.array_equal(m, m0), eng
