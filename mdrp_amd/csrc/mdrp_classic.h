@@ -180,9 +180,10 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
     int n = 0;
     Model out[CK == CLASSIC_FUND ? MAXM : 1]; // the 5- and 6-point solvers write their poses straight into their slots
     const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * MPS;
-    if (live) {
-        const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it) * K;
-        double x1h[K][3], x2h[K][3];
+    const int lane = threadIdx.x & 63;
+    const size_t tag_base = (size_t)pair * rp.slot_stride;
+    auto gather = [&](int it_, double (*x1h)[3], double (*x2h)[3]) { // unit bearings of sample `it_` of this pair
+        const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it_) * K;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const double *p = pts + ((size_t)pair * rp.n_max + sm[k]) * PT_STRIDE;
@@ -191,11 +192,79 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
             x1h[k][0] = p01.x * p45.x; x1h[k][1] = p01.y * p45.x; x1h[k][2] = p45.x;
             x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
         }
-        if (CK == CLASSIC_RELPOSE) n = solver_relpose_5pt_emit(x1h, x2h, lds_solve5_store(), [&](const Model &m, int k) { models[slot0 + k] = m; });
-        else if (CK == CLASSIC_SHARED) { PlainStore6 st6; n = solver_relpose_6pt_emit(x1h, x2h, st6, [&](const Model &m, int k) { models[slot0 + k] = m; }); }
+    };
+    if (CK == CLASSIC_RELPOSE) {
+        // Round 4: the essential matrices of the wavefront's 64 samples (0-10 each, ~3 on average) are decomposed by whichever lane is
+        // free, not by the lane that found them.  Each lane parks its matrices in its own LDS column (the LU storage is dead by then),
+        // a table of (source lane, root) codes is built with one prefix sum, and the lanes walk that table 64 items at a time: every
+        // trip of motion_from_essential + 4 x 5 cheirality tests has all lanes busy, where the round-3 kernel ran max-over-lanes trips
+        // with a third of the lanes active (30 % of the solver's time).  A pose goes into slot `root index` of its
+        // sample (at most one decomposition of an essential matrix has all five points in front of both cameras): k_scan walks the
+        // slots of an iteration in order and skips empty ones, so the order of the reference is kept without counting.
+        extern __shared__ double solve5_lds[];
+        int ne = 0;
+        if (live) {
+            double x1h[K][3], x2h[K][3];
+            gather(it, x1h, x2h);
+            relpose_5pt_emit(x1h, x2h, lds_solve5_store(), [&](const double *e) {
+                if (ne < MAX_MODELS_5PT) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) solve5_lds[(9 * ne + k) * 64 + lane] = e[k];
+                    ++ne;
+                }
+            });
+#pragma unroll
+            for (int g = 0; g < MPS / 4; ++g) *reinterpret_cast<int4 *>(slot_inl + slot0 + 4 * g) = make_int4(-1, -1, -1, -1);
+        }
+        int pre = ne;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(pre, o, 64);
+            if (lane >= o) pre += v;
+        }
+        const int total = __shfl(pre, 63, 64);
+        int *codes = reinterpret_cast<int *>(solve5_lds + 90 * 64); // 640 items fit the ten spare elements of the 64 columns
+        for (int r = 0; r < ne; ++r) codes[pre - ne + r] = lane * 16 + r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i0 = 0; i0 < total; i0 += 64) {
+            const int i = i0 + lane;
+            bool found = false;
+            int src_it = 0, root = 0;
+            if (i < total) {
+                const int code = codes[i];
+                const int src = code >> 4;
+                root = code & 15;
+                src_it = blockIdx.x * 64 + src;
+                double e[9], x1h[K][3], x2h[K][3];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) e[k] = solve5_lds[(9 * root + k) * 64 + src];
+                gather(src_it, x1h, x2h);
+                const size_t dst = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + src_it) * MPS + root;
+                motion_from_essential_emit(e, x1h, x2h, 5, [&](const Model &m) {
+                    if (!found) { models[dst] = m; slot_inl[dst] = -2; found = true; }
+                    // (a second decomposition with all five points in front of both cameras would need exactly singular geometry;
+                    //  the round-3 kernel would have given it the next slot)
+                });
+            }
+            const unsigned long long fb = __ballot(found);
+            if (fb) {
+                int base = 0;
+                const int first = __ffsll((long long)fb) - 1;
+                if (lane == first) base = atomicAdd(&model_count[2 * pair], __popcll(fb));
+                base = __shfl(base, first, 64);
+                if (found) tags[tag_base + base + __popcll(fb & ((1ull << lane) - 1ull))] = (uint32_t)((rp.chunk_off + src_it) * MPS + root);
+            }
+        }
+        return;
+    }
+    if (live) {
+        double x1h[K][3], x2h[K][3];
+        gather(it, x1h, x2h);
+        if (CK == CLASSIC_SHARED) { PlainStore6 st6; n = solver_relpose_6pt_emit(x1h, x2h, st6, [&](const Model &m, int k) { models[slot0 + k] = m; }); }
         else { extern __shared__ double solve5_lds[]; n = solver_fundamental_7pt(x1h, x2h, out, solve5_lds + (threadIdx.x & 63), 64); }
     }
-    const int lane = threadIdx.x & 63;
     int pre = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -208,7 +277,6 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
     base = __shfl(base, 63, 64);
     if (!live) return;
     int pos = base + pre - n;
-    const size_t tag_base = (size_t)pair * rp.slot_stride;
 #pragma unroll
     for (int g = 0; g < MPS / 4; ++g)
         *reinterpret_cast<int4 *>(slot_inl + slot0 + 4 * g) =
