@@ -263,16 +263,17 @@ def test_large_batch_one_wavefront_per_lo_problem(kind):
     assert off == 0, off
 
 
-@pytest.mark.parametrize("kind", [3, 5])
+@pytest.mark.parametrize("kind", [3, 4, 5])
 def test_fused_tail_is_bit_identical(kind, monkeypatch):
     """The fused tail of the baselines (kc_lo replays a pair when its last trigger is refined, kc_final starts from the ready
     list while the LO drains) against LO | k_walk | kc_final one after the other: records and masks bit for bit."""
     import mdrp_amd.poselib as poselib
     from mdrp_amd import synth
-    B = 150
+    B = 150 if kind != 4 else 96  # (the 6-point solver is two orders of magnitude slower: fewer pairs and iterations, still > 64 LO problems)
     pairs = [synth.make_pair(9700 + k, [300, 200, 4, 120][k % 4] if k % 5 == 0 else 300, f1=850.0, f2=850.0, pp=(640.0, 480.0), noise_px=0.6,
                              outlier_frac=[0.4, 0.1][k % 2]) for k in range(B)]
-    ro = {"max_iterations": 1500, "min_iterations": 1500, "max_epipolar_error": 1.5, "seed": 2}
+    its = 1500 if kind != 4 else 400
+    ro = {"max_iterations": its, "min_iterations": its, "max_epipolar_error": 1.5, "seed": 2}
     bo = {"loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.5}
     cam = {"model": "SIMPLE_PINHOLE", "width": 1280, "height": 960, "params": [850.0, 640.0, 480.0]}
     x1, x2 = [p["x1"] for p in pairs], [p["x2"] for p in pairs]
@@ -282,6 +283,9 @@ def test_fused_tail_is_bit_identical(kind, monkeypatch):
         if kind == 3:
             models, infos = poselib.estimate_relative_pose_batch(x1, x2, cam, cam, ro, bo)
             models = [np.r_[m.q, m.t] for m in models]
+        elif kind == 4:
+            models, infos = poselib.estimate_shared_focal_relative_pose_batch(x1, x2, (640.0, 480.0), ro, bo)
+            models = [np.r_[m.pose.q, m.pose.t, m.camera1.params[0]] for m in models]
         else:
             models, infos = poselib.estimate_fundamental_batch(x1, x2, ro, bo)
             models = [np.asarray(m).reshape(-1) for m in models]

@@ -25,9 +25,10 @@ def flops(lines):
 
 def main(path):
     text = open(path).read().split("\n")
-    starts = [(i, m.group(1)) for i, ln in enumerate(text) for m in [re.match(r"^(_ZN4mdrp4k_loILi(\d)ELb(\d)ELi64EE\S*):", ln)] if m]
+    starts = [(i, m.group(1)) for i, ln in enumerate(text) for m in [re.match(r"^(_ZN4mdrp(?:4k_loILi(\d)ELb(\d)ELi64EE|7k_finalILi(\d)ELb(\d)ELi256EE)\S*):", ln)] if m]
     for i0, name in starts:
-        kind, shift = re.match(r"_ZN4mdrp4k_loILi(\d)ELb(\d)", name).groups()
+        kname = "k_lo" if "4k_lo" in name else "k_final"
+        kind, shift = re.match(r"_ZN4mdrp(?:4k_lo|7k_final)ILi(\d)ELb(\d)", name).groups()
         i1 = next(j for j in range(i0, len(text)) if ".end_amdhsa_kernel" in text[j] or text[j].startswith(".Lfunc_end"))
         body = text[i0:i1]
         labels = {m.group(1): j for j, ln in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", ln)] if m}
@@ -49,7 +50,7 @@ def main(path):
             stats.append((f, n, ballot, b - a))
         acc = max(stats)
         cost = max((s for s in stats if 2 * s[0] < acc[0]), default=(0, 0, True, 0))  # the largest loop below half of it: residuals only
-        print(f"k_lo<{kind}, {'true' if shift == '1' else 'false'}, 64>: cost sweep {cost[0]} flop ({cost[1]} fp64 instructions) per correspondence, "
+        print(f"{kname}<{kind}, {'true' if shift == '1' else 'false'}, {64 if kname == 'k_lo' else 256}>: cost sweep {cost[0]} flop ({cost[1]} fp64 instructions) per correspondence, "
               f"normal equations {acc[0]} flop ({acc[1]} fp64 instructions)")
 
 
