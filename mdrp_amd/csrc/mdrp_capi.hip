@@ -96,6 +96,9 @@ struct mdrp_handle {
     DevBuf fuse;                       // fused tail: control words (64 B) | done_cnt[batch] | fin_done[batch] | ready[batch]
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
     hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
+    static constexpr int PARTS_MAX = 4; // sub-ranges of one chunk's solver launch (k_count of part i runs beside the solver of part i + 1)
+    hipEvent_t ev_part[2][PARTS_MAX] = {};
+    DevBuf tag_snap;                   // [2 (chunk parity)][PARTS_MAX - 1][2 batch] tag counts after each solver part
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples;
@@ -447,6 +450,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
     if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
     if ((rc = h->surv2_count.ensure(sizeof(int32_t) * batch))) return rc;
+    if ((rc = h->tag_snap.ensure(sizeof(int32_t) * 2 * (mdrp_handle::PARTS_MAX - 1) * 2 * (size_t)batch))) return rc;
     const size_t groups_max = ((size_t)n_max + 15) / 16;
     if ((rc = h->rfrag.ensure(std::max<size_t>(1024, (size_t)batch * groups_max * 1024)))) return rc;
     const int trig_cap = chunk_cap;
@@ -625,6 +629,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
             else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
         };
+        // solver sub-ranges: only where the solver of a long chunk has the chip to itself (piped schedule, not the run's first chunk)
+        // Measured (1024 x 2000, 10^4 iterations): 1 part 10.61 ms, 2 parts 10.72, 3: 10.80, 4: 10.90 — the solver (fp64 VALU) and k_count (MFMA + 8 fp32
+        // VALU instructions per tile) compete for the same issue ports, overlap creates no slots; default 1 (off).
+        const int solve_parts_env = std::min(std::max(env_int("MDRP_SOLVE_PARTS", 1), 1), (int)mdrp_handle::PARTS_MAX);
+        auto parts_of = [&](int c) { return (piped && !classic && c >= 1 && lens[c] >= 2048) ? solve_parts_env : 1; };
         bool presampled[2] = {false, false};
         if (piped && it0 == 0) {
             HIPCHK(hipStreamWaitEvent(aux2, h->ev_tables, 0));
@@ -634,7 +643,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 presampled[c] = true;
             }
         }
-        auto issue_solve = [&](int c, hipStream_t st_) -> int {
+        auto issue_solve = [&](int c, hipStream_t st_, int parts = 1) -> int {
             RunParams r = rp;
             r.chunk_len = (int)lens[c]; r.chunk_off = offs[c];
             const bool odd = c & 1;
@@ -663,13 +672,24 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 return MDRP_OK;
             }
 #define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
-    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp, \
-                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc)
-            switch (r.solver) {
-            case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
-            case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;
-            case SOLVER_SHARED: MDRP_SOLVE_LAUNCH(SOLVER_SHARED); break;
-            default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
+    hipLaunchKernelGGL(k_solve<S>, dim3((sub_e - sub_b + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp, \
+                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc, sub_b, sub_e)
+            // Sub-ranges (round 4): the solver of a big chunk runs alone on the chip for ~0.8 ms (the chunk before it is short).  Solved
+            // as `parts` launches over consecutive iteration ranges, with the tag counts snapshotted in between, k_count of the first
+            // range runs on the matrix cores beside the solver of the second (same retirement bar: results are unchanged).
+            for (int part = 0; part < parts; ++part) {
+                const int sub_b = (int)((long long)r.chunk_len * part / parts), sub_e = (int)((long long)r.chunk_len * (part + 1) / parts);
+                switch (r.solver) {
+                case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
+                case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;
+                case SOLVER_SHARED: MDRP_SOLVE_LAUNCH(SOLVER_SHARED); break;
+                default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
+                }
+                if (part + 1 < parts) { // the tag counts after this part = where the next part's tags begin
+                    HIPCHK(hipMemcpyAsync(h->tag_snap.as<int32_t>() + ((size_t)(c & 1) * (mdrp_handle::PARTS_MAX - 1) + part) * 2 * batch, mc, sizeof(int32_t) * 2 * batch,
+                                          hipMemcpyDeviceToDevice, st_));
+                    HIPCHK(hipEventRecord(h->ev_part[c & 1][part], st_));
+                }
             }
 #undef MDRP_SOLVE_LAUNCH
             return MDRP_OK;
@@ -687,27 +707,38 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 if (piped) {
                     // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
                     HIPCHK(hipStreamWaitEvent(aux, c == 0 ? h->ev_solved[0] : h->ev_scanned[c - 1], 0));
-                    if ((rc = issue_solve(c + 1, aux))) return rc;
+                    if ((rc = issue_solve(c + 1, aux, parts_of(c + 1)))) return rc;
                     HIPCHK(hipEventRecord(h->ev_solved[c + 1], aux));
                 }
             }
-            if (piped && c > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
+            const int parts_c = parts_of(c);
+            if (piped && c > 0 && parts_c == 1) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
             if (!piped && c > 0 && (rc = issue_solve(c, s))) return rc;
             {
-                hipEvent_t e0, e1, c0, c1;
-                if ((rc = get_events(h, &e0, &e1, 0)) || (rc = get_events(h, &c0, &c1, 1))) return rc;
-                // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
+                hipEvent_t e0, e1;
+                if ((rc = get_events(h, &e0, &e1, 0))) return rc;
+                // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on.
+                // One launch per solver part: part i is counted while the solver works on part i + 1 (tags [snap[i-1], snap[i]) per pair).
                 const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
-                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
-                                   h->surv_count.as<int32_t>()); // also clears the survivor counters k_count appends to
-                const dim3 cgrid((unsigned)batch * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                 unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
-                HIPCHK(hipEventRecord(c0, s));
-                MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                                    tags_c, mcount_c, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
-                                    h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr);
-                HIPCHK(hipEventRecord(c1, s));
-                h->count_launches++;
+                for (int part = 0; part < parts_c; ++part) {
+                    hipEvent_t c0, c1;
+                    if ((rc = get_events(h, &c0, &c1, 1))) return rc;
+                    if (parts_c > 1) HIPCHK(hipStreamWaitEvent(s, part + 1 < parts_c ? h->ev_part[c & 1][part] : h->ev_solved[c], 0));
+                    const int32_t *snap = h->tag_snap.as<int32_t>() + (size_t)(c & 1) * (mdrp_handle::PARTS_MAX - 1) * 2 * batch;
+                    const int32_t *t_begin = part == 0 ? nullptr : snap + (size_t)(part - 1) * 2 * batch;
+                    const int32_t *t_end = part + 1 < parts_c ? snap + (size_t)part * 2 * batch : mcount_c;
+                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), t_end, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
+                                       part == 0 ? h->surv_count.as<int32_t>() : (int32_t *)nullptr, t_begin); // (part 0 also clears the survivor counters k_count appends to)
+                    const int part_len = (int)((long long)len * (part + 1) / parts_c) - (int)((long long)len * part / parts_c);
+                    const dim3 cgrid((unsigned)batch * (unsigned)((part_len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
+                    HIPCHK(hipEventRecord(c0, s));
+                    MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
+                                        tags_c, t_end, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
+                                        h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr, t_begin);
+                    HIPCHK(hipEventRecord(c1, s));
+                    h->count_launches++;
+                }
                 if (pending_lo) {
                     HIPCHK(hipEventRecord(h->ev_counted, s));
                     HIPCHK(hipStreamWaitEvent(aux2, h->ev_counted, 0));
@@ -1050,6 +1081,7 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     HIPCHK(hipEventCreateWithFlags(&h->ev_tables, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[0], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[1], hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < mdrp_handle::PARTS_MAX; ++j) HIPCHK(hipEventCreateWithFlags(&h->ev_part[i][j], hipEventDisableTiming));
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_solved[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scanned[i], hipEventDisableTiming));
@@ -1074,7 +1106,7 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
                       &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
-                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota, &h->lme_pair_live, &h->lme_accpart};
+                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota, &h->lme_pair_live, &h->lme_accpart, &h->tag_snap};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
@@ -1087,6 +1119,7 @@ void mdrp_destroy(mdrp_handle *h) {
     if (h->ev_counted) (void)hipEventDestroy(h->ev_counted);
     if (h->ev_tables) (void)hipEventDestroy(h->ev_tables);
     for (int i = 0; i < 2; ++i) if (h->ev_sampled[i]) (void)hipEventDestroy(h->ev_sampled[i]);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < mdrp_handle::PARTS_MAX; ++j) if (h->ev_part[i][j]) (void)hipEventDestroy(h->ev_part[i][j]);
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         if (h->ev_solved[i]) (void)hipEventDestroy(h->ev_solved[i]);
         if (h->ev_scanned[i]) (void)hipEventDestroy(h->ev_scanned[i]);

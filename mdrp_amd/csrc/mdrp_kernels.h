@@ -473,12 +473,13 @@ template <int SOLVER> // one solver per kernel (host dispatch): a runtime switch
 __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
                                                const double *__restrict__ pts, const double *__restrict__ dep,
                                                Model *__restrict__ models, int32_t *__restrict__ slot_inl,
-                                               uint32_t *__restrict__ tags, int32_t *__restrict__ model_count) {
+                                               uint32_t *__restrict__ tags, int32_t *__restrict__ model_count,
+                                               int it_begin, int it_end /*iterations [it_begin, it_end) of the chunk: one launch solves a sub-range*/) {
     const int pair = blockIdx.y;
-    const int it = blockIdx.x * 256 + threadIdx.x;
+    const int it = it_begin + blockIdx.x * 256 + threadIdx.x;
     const PairState &ps = st[pair];
     if (!ps.active) return;
-    const bool live = it < rp.chunk_len;
+    const bool live = it < it_end;
     int n = 0;
     Model out[4];
     if (live) {
@@ -899,13 +900,15 @@ __device__ __forceinline__ int plan_block_scan(int v, int &total, int *s_w) {
     return inc - v + s_w[wave];
 }
 // zero_a / zero_b: per-pair counters the next sweep accumulates into (or null) - cleared here instead of by a memset node in front
+// begin (or null): the plan covers list entries [begin[stride p], counts[stride p]) of every pair — a sub-range of a list that is still growing
 __global__ __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
-                                                             int per_wg, int32_t *__restrict__ plan, int32_t *__restrict__ zero_a) {
+                                                             int per_wg, int32_t *__restrict__ plan, int32_t *__restrict__ zero_a,
+                                                             const int32_t *__restrict__ begin = nullptr) {
     __shared__ int s_w[PLAN_THREADS / 64 + 1];
     int run = 0;
     for (int p0 = 0; p0 < batch; p0 += PLAN_THREADS) {
         const int p = p0 + threadIdx.x;
-        const int b = (p < batch && st[p].active) ? (counts[stride * p] + per_wg - 1) / per_wg : 0;
+        const int b = (p < batch && st[p].active) ? (counts[stride * p] - (begin ? begin[stride * p] : 0) + per_wg - 1) / per_wg : 0;
         int tot;
         const int ex = plan_block_scan(b, tot, s_w);
         if (p < batch) { plan[p] = run + ex; if (zero_a) zero_a[p] = 0; }
@@ -920,7 +923,8 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
                                                           const int32_t *__restrict__ model_count, const int32_t *__restrict__ plan,
                                                           int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_surv,
                                                           int32_t *__restrict__ surv_count, unsigned long long *__restrict__ stats,
-                                                          int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/) {
+                                                          int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/,
+                                                          const int32_t *__restrict__ tag_begin = nullptr /*or: entries [tag_begin[2 p], model_count[2 p]) of the tag lists*/) {
     // LDS: first the B fragments of the workgroup's 512 hypotheses (prologue), then the A-fragment tiles of the sweep
     constexpr int A_TILE_GROUPS = 16;                                   // 16 groups = 256 correspondences = 16 KiB per tile
     __shared__ uint4 s_lds[2 * A_TILE_GROUPS * 64];                     // 32 KiB: two tiles (double buffer)
@@ -932,10 +936,12 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const int pair = plan_find(plan, rp.batch, w);
     const int blk = w - plan[pair];
     const PairState &ps = st[pair];
-    const int n = ps.n, cnt = model_count[2 * pair];
+    const int tbeg = tag_begin ? tag_begin[2 * pair] : 0;
+    const int n = ps.n, cnt = model_count[2 * pair] - tbeg;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blk * CNT_WG_MODELS + wave * CNT_WAVE_MODELS; // first hypothesis of this wavefront in the pair's tag list
+    const int m0 = blk * CNT_WG_MODELS + wave * CNT_WAVE_MODELS; // first hypothesis of this wavefront in the (sub-range of the) pair's tag list
     const size_t slot_base = (size_t)pair * rp.slot_stride;
+    const uint32_t *tags_p = tags + slot_base + tbeg;
     const double thr = ps.sq_thr;
     // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS); the loads of both rounds
     // are issued before the arithmetic of the first (tag -> model is a dependent pair of L2 round trips)
@@ -944,7 +950,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
 #pragma unroll
     for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
-        if (i < cnt) slot_r[r] = tags[slot_base + i] & 0xFFFFFFu;
+        if (i < cnt) slot_r[r] = tags_p[i] & 0xFFFFFFu;
     }
 #pragma unroll
     for (int r = 0; r < CNT_ROUNDS; ++r) {

@@ -70,3 +70,28 @@ def test_library_carries_the_hash_of_its_sources():
     assert b.built_hash() == b.source_hash()
     assert _capi.library_source_hash() == b.source_hash()
     assert _capi.library_version().startswith("mdrp-hip")
+
+
+def test_c_host_links_and_loads(tmp_path):
+    """a plain C host links libmdrp_hip.so next to the ONE HIP runtime it uses (the library itself has no DT_NEEDED
+    on one) and reaches the ABI; without a GPU mdrp_create reports MDRP_ERR_NO_DEVICE through the return code, not a crash."""
+    import shutil
+    import subprocess
+    b.build()
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not (shutil.which("gcc") and os.path.exists(os.path.join(rocm, "lib", "libamdhip64.so"))):
+        import pytest
+        pytest.skip("no gcc / system HIP runtime")
+    src = tmp_path / "host.c"
+    src.write_text('#include "mdrp.h"\n#include <stdio.h>\nint main(void) {\n'
+                   '    printf("%s hip %d\\n", mdrp_version(), mdrp_hip_build_version());\n'
+                   '    mdrp_handle *h = 0; int rc = mdrp_create(0, NULL, &h);\n'
+                   '    printf("create rc %d\\n", rc);\n'
+                   '    if (!rc) { mdrp_stats st; rc = mdrp_last_stats_sized(h, &st, sizeof st); mdrp_destroy(h); }\n'
+                   '    return rc == 0 || rc == MDRP_ERR_NO_DEVICE ? 0 : 1;\n}\n')
+    exe = tmp_path / "host"
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.run(["gcc", str(src), "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lmdrp_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+                    f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "mdrp-hip" in out.stdout and "create rc" in out.stdout, (out.stdout, out.stderr)

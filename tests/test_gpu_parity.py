@@ -500,10 +500,11 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
                 {"MDRP_CHUNKS": "512", "MDRP_LO_THREADS": "256", "MDRP_FINAL_THREADS": "64"},
                 {"MDRP_CHUNKS": "128", "MDRP_LO_THREADS": "64"}, {"MDRP_CHUNKS": "128", "MDRP_FINAL_THREADS": "64"},
                 {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "0"}, {"MDRP_CHUNKS": "128,1024", "MDRP_LM_ENGINE": "1"},
+                {"MDRP_CHUNKS": "128", "MDRP_SOLVE_PARTS": "2"}, {"MDRP_CHUNKS": "256", "MDRP_SOLVE_PARTS": "4", "MDRP_LO_AFTER_COUNT": "0"},
                 {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "2"}, {"MDRP_CHUNKS": "64,512", "MDRP_LM_ENGINE": "2", "MDRP_LME_CAP": "16"},
                 {"MDRP_CHUNKS": "128", "MDRP_FUSE_TAIL": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_FUSE_TAIL": "1"}):
         for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_AFTER_COUNT", "MDRP_BOUND",
-                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP"):
+                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP", "MDRP_SOLVE_PARTS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
