@@ -326,10 +326,12 @@ int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, in
     const size_t smem = sizeof(int32_t) * ((size_t)ph.nseg + 1) + sizeof(uint16_t) * (size_t)dense_cap + 8;
     const dim3 solve_grid((unsigned)(std::max(problems_bound, 1) + 63) / 64);
     const dim3 lane_grid((unsigned)(std::max(problems_bound, 1) + 255) / 256), reduce_grid((unsigned)std::min((std::max(problems_bound, 1) + 3) / 4, h->num_cu * 32));
-    MDRP_LME_COST(seg, kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
+    const int cost_seg = seg ? 64 * LME_RPT_DENSE : LME_SEG; // the dense cost sweep holds 8 records per lane
+    const dim3 cost_grid((unsigned)std::max(1, (ph.n_max + cost_seg - 1) / cost_seg), (unsigned)ph.batch);
+    MDRP_LME_COST(seg, kind, loss, cost_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
     for (int r = 0; r <= max_it; ++r) {
         if (seg) {
-            hipLaunchKernelGGL(k_lme_decide, lane_grid, dim3(256), 0, stream, ph, r);
+            hipLaunchKernelGGL(k_lme_decide, lane_grid, dim3(256), 0, stream, ph, r, cost_seg);
             if (r < max_it) { // (the closing round only decides: every problem is done)
                 MDRP_LME_ACCUM_SEG(kind, est_shift, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r);
                 MDRP_LME_LM(k_lme_reduce, kind, est_shift, reduce_grid, dim3(256), 0, stream, ph);
@@ -344,7 +346,7 @@ int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, in
             HIPCHK(hipStreamSynchronize(stream));
             if (*h->lme_live_host == 0) break;
         }
-        MDRP_LME_COST(seg, kind, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
+        MDRP_LME_COST(seg, kind, loss, cost_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
     }
     HIPCHK(hipGetLastError());
     return MDRP_OK;

@@ -104,8 +104,13 @@ __device__ __forceinline__ int lme_count(const LmePhase &ph) {
 // ------------------------------------------------------------------------------------------------ cost sweep
 // grid (nseg, batch), 64 threads.  Record i of the segment sits in lane i & 63, slot i >> 6.
 // LOSS: the phase's loss type when it is known at compile time (1 = TRUNCATED: every LO refinement), -1 = read per problem
-// DENSE (segment engine): no work lists — the normal-equation sweep of that engine visits every record with its weight as a select
-template <int KIND, int LOSS, bool DENSE = false>
+// DENSE (segment engine): no work lists — the normal-equation sweep of that engine visits every record with its weight as a select.
+// Without lists a wavefront may hold more records per lane (RPT is a template parameter; k_lme_decide takes the segment size):
+// measured on varying focal, 1024 x 5000: RPT = 8 halves the per-problem overhead (header -> scalar registers, wave sum, partial store:
+// ~150 of ~280 instructions per record at RPT = 4) but needs 195 VGPRs, two wavefronts per SIMD instead of four: 53.4 against 51.3 ms
+// per step.  4 it is.
+constexpr int LME_RPT_DENSE = 4;
+template <int KIND, int LOSS, bool DENSE = false, int RPT = (DENSE ? LME_RPT_DENSE : LME_RPT)>
 __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                  const double *__restrict__ dep, int live_half /*-1: the initial sweep, every problem is live*/) {
     __shared__ double s_state[LME_STAGE][LME_HEAD];
@@ -113,14 +118,14 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
     const int pair = blockIdx.y, seg = blockIdx.x, lane = threadIdx.x;
     const int n = st[pair].n;
     const int pl = live_half >= 0 ? ph.pair_live[(size_t)live_half * ph.batch + pair] : 1;
-    if (seg * LME_SEG >= n || pl == 0) return;
+    if (seg * (64 * RPT) >= n || pl == 0) return;
     const int cnt = lme_count(ph);
     const int j0 = max(ph.pfx[pair] - ph.first, 0), j1 = min(ph.pfx[pair + 1] - ph.first, cnt);
     if (j0 >= j1) return;
     const unsigned long long lt = (1ull << lane) - 1ull;
     bool loaded = false;
-    double ra[LME_RPT], rb[LME_RPT], rc[LME_RPT], rd[LME_RPT], e1[LME_RPT], e2[LME_RPT];
-    bool ok[LME_RPT];
+    double ra[RPT], rb[RPT], rc[RPT], rd[RPT], e1[RPT], e2[RPT];
+    bool ok[RPT];
     for (int base = j0; base < j1; base += LME_STAGE) {
         // One round trip: the headers (expanded state, loss parameters, flags) of the next LME_STAGE problems of this pair go to
         // LDS whether they are live or not — their addresses depend on the pair alone — together with the records; which of them
@@ -137,8 +142,8 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
             const double *dd = dep + (size_t)pair * ph.n_max * 2;
             const uint8_t *mk = ph.mask ? ph.mask + (size_t)pair * ph.n_max : nullptr;
 #pragma unroll
-            for (int r = 0; r < LME_RPT; ++r) {
-                const int i = seg * LME_SEG + r * 64 + lane;
+            for (int r = 0; r < RPT; ++r) {
+                const int i = seg * (64 * RPT) + r * 64 + lane;
                 ok[r] = i < n && (!mk || mk[i]);
                 ra[r] = rb[r] = rc[r] = rd[r] = 0; e1[r] = e2[r] = 1;
                 if (ok[r]) {
@@ -166,11 +171,11 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
             const int2 lc = *reinterpret_cast<const int2 *>(S + LME_O_LOSS); // loss, cur
             const int loss = LOSS >= 0 ? LOSS : __builtin_amdgcn_readfirstlane(lc.x), buf = __builtin_amdgcn_readfirstlane(lc.y) ^ 1;
             double cost = 0;
-            bool contrib[LME_RPT];
+            bool contrib[RPT];
             // straight-line over the lane's records (padding lanes hold a harmless record and are masked by selects): the
             // RPT residual chains are independent, so the scheduler interleaves them — a branch per record serialised them
 #pragma unroll
-            for (int r = 0; r < LME_RPT; ++r) {
+            for (int r = 0; r < RPT; ++r) {
                 double res[5], zf, zb;
                 point_residuals<false, KIND != 0>(stt, sqrt_sr, ra[r], rb[r], rc[r], rd[r], e1[r], e2[r], res, zf, zb, nullptr);
                 const double rs = res[0] * res[0], rf = res[1] * res[1] + res[2] * res[2], rbk = res[3] * res[3] + res[4] * res[4];
@@ -188,10 +193,10 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
                 if (lane == 0) ph.part[(size_t)j * ph.nseg + seg] = cost;
                 continue;
             }
-            uint8_t *L = ph.list + (((size_t)j * 2 + buf) * ph.nseg + seg) * LME_SEG;
+            uint8_t *L = ph.list + (((size_t)j * 2 + buf) * ph.nseg + seg) * (64 * RPT);
             int fill = 0;
 #pragma unroll
-            for (int r = 0; r < LME_RPT; ++r) {
+            for (int r = 0; r < RPT; ++r) {
                 const unsigned long long ball = __ballot(contrib[r]);
                 if (contrib[r]) L[fill + __popcll(ball & lt)] = (uint8_t)(r * 64 + lane);
                 fill += __popcll(ball);
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(LME_T, MDRP_LME_MINWAVES) void k_lme_accum(LmePhase
 // amount of work, and a pair's records are read once per round for all of its problems.  A round is
 //     k_lme_cost<DENSE> | k_lme_decide | k_lme_accum_seg | k_lme_reduce | k_lme_solve
 // k_lme_decide: one lane per problem — lm_impl<>'s accept / reject once the candidate's cost is known (the first half of k_lme_accum)
-__global__ void k_lme_decide(LmePhase ph, int round) {
+__global__ void k_lme_decide(LmePhase ph, int round, int cost_seg /*records per cost-sweep segment*/) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) ph.live[(round + LME_RING / 2) & (LME_RING - 1)] = 0; // free: every earlier round has ended
     if (j < ph.batch) ph.pair_acc[(size_t)((round + 1) & 1) * ph.batch + j] = 0; // the half the NEXT round counts into (its reader, the previous round's accum sweep, is done)
@@ -362,7 +367,7 @@ __global__ void k_lme_decide(LmePhase ph, int round) {
     double cost = P->cost, lambda = P->lambda, mu = P->mu;
     int it = P->it, cur = P->cur, recompute = 0;
     const int has_cand = P->has_cand, n = P->n, max_it = P->max_it;
-    const int nseg = (n + LME_SEG - 1) / LME_SEG;
+    const int nseg = (n + cost_seg - 1) / cost_seg;
     double cost_new = 0;
     for (int s = 0; s < nseg; ++s) cost_new += ph.part[(size_t)j * ph.nseg + s];
     P->ev_cost += (unsigned long long)n;
