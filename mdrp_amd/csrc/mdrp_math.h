@@ -835,6 +835,35 @@ MDRP_HD void lm_state_from_model(const Model &m, bool focal, LmState &st) {
     fundamental_from_E(st.E, st.f1, st.f2, st.F);
 }
 
+// Reciprocal and reciprocal square root of the LM sweeps.  The oracle (and the host build of this header) divide; on the device an IEEE
+// fp64 division is an 11-instruction dependent chain (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) and `1 / sqrt(x)` a
+// square root followed by one — three of them per correspondence and sweep, ~18 % of the cost sweep's instructions.  The device takes the
+// hardware seed and two Newton steps: <= 1 ulp instead of correctly rounded, the same class of difference as the FMA contraction the
+// device build already has against the oracle (gated by the 3 x 1024-pair fixtures of tests/test_gpu_headline.py: masks and inlier
+// counts identical, models to 1e-8).  x = 0 gives NaN where the division gives inf; both end as "term truncated / row of weight zero".
+#ifndef MDRP_LM_IEEE_DIV
+#define MDRP_LM_IEEE_DIV 0
+#endif
+MDRP_HD double lm_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+#else
+    return 1.0 / x;
+#endif
+}
+MDRP_HD double lm_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    return y * fma(-h * y, y, 1.5);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 constexpr int LM_NPAR = 11; // rot(3) t(3) s u v f1 f2
 
 // residuals r[0..4] = {sampson, fwd.x, fwd.y, bwd.x, bwd.y} (reprojection ones times sqrt(sr)); zf / zb = depth of
@@ -851,7 +880,7 @@ MDRP_HD void lm_sampson_term(const LmState &st, double x1x, double x1y, double x
     const double Ft2_0 = F[0] * x2x + F[3] * x2y + F[6], Ft2_1 = F[1] * x2x + F[4] * x2y + F[7];
     const double C = x2x * Fh1_0 + x2y * Fh1_1 + Fh1_2;
     const double den = Fh1_0 * Fh1_0 + Fh1_1 * Fh1_1 + Ft2_0 * Ft2_0 + Ft2_1 * Ft2_1;
-    const double isd = 1.0 / sqrt(den);
+    const double isd = lm_rsqrt(den);
     r0 = C * isd;
     if (!WITH_J) return;
     // G = d r0 / d F, then chain to E, rotation (post), translation, focals
@@ -902,7 +931,7 @@ MDRP_HD void lm_forward_term(const LmState &st, double sqrt_sr, double x1x, doub
     const double Z0 = R[0] * X1[0] + R[1] * X1[1] + R[2] * X1[2] + t[0];
     const double Z1 = R[3] * X1[0] + R[4] * X1[1] + R[5] * X1[2] + t[1];
     const double Z2 = R[6] * X1[0] + R[7] * X1[1] + R[8] * X1[2] + t[2];
-    const double iz = 1.0 / Z2;
+    const double iz = lm_rcp(Z2);
     r1 = sqrt_sr * (f2 * Z0 * iz - x2x);
     r2 = sqrt_sr * (f2 * Z1 * iz - x2y);
     zf = Z2;
@@ -951,7 +980,7 @@ MDRP_HD void lm_backward_term(const LmState &st, double sqrt_sr, double x1x, dou
     const double W0 = R[0] * Y[0] + R[3] * Y[1] + R[6] * Y[2];
     const double W1 = R[1] * Y[0] + R[4] * Y[1] + R[7] * Y[2];
     const double W2 = R[2] * Y[0] + R[5] * Y[1] + R[8] * Y[2];
-    const double iw = 1.0 / W2;
+    const double iw = lm_rcp(W2);
     r3 = sqrt_sr * (f1 * W0 * iw - x1x);
     r4 = sqrt_sr * (f1 * W1 * iw - x1y);
     zb = W2;
