@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) void k_lme_reduce(LmePhase ph) {
 template <int N>
 __device__ __forceinline__ void chol_solve_packed(double *L /*in: A + lambda I, out: factor*/, const double *b, double *x) {
 #define LME_TRI(i, j) ((i) * ((i) + 1) / 2 + (j))
+    double inv[N]; // 1 / L(j, j) as in chol_solve<> (one reciprocal square root per column, products instead of quotients)
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -494,8 +495,8 @@ __device__ __forceinline__ void chol_solve_packed(double *L /*in: A + lambda I, 
             double s = L[LME_TRI(i, j)];
 #pragma unroll
             for (int k = 0; k < j; ++k) s -= L[LME_TRI(i, k)] * L[LME_TRI(j, k)];
-            if (i == j) L[LME_TRI(i, i)] = sqrt(s);
-            else L[LME_TRI(i, j)] = s / L[LME_TRI(j, j)];
+            if (i == j) { inv[i] = lm_rsqrt(s); L[LME_TRI(i, i)] = s * inv[i]; }
+            else L[LME_TRI(i, j)] = s * inv[j];
         }
     double y[N];
 #pragma unroll
@@ -503,14 +504,14 @@ __device__ __forceinline__ void chol_solve_packed(double *L /*in: A + lambda I, 
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[LME_TRI(i, k)] * y[k];
-        y[i] = s / L[LME_TRI(i, i)];
+        y[i] = s * inv[i];
     }
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
         double s = y[i];
 #pragma unroll
         for (int k = i + 1; k < N; ++k) s -= L[LME_TRI(k, i)] * x[k];
-        x[i] = s / L[LME_TRI(i, i)];
+        x[i] = s * inv[i];
     }
 #undef LME_TRI
 }

@@ -599,14 +599,48 @@ MDRP_HD int run_solver(int solver, const Sample3 &s, Model out[4]) {
     }
 }
 
+// Reciprocal and reciprocal square root of the LM sweeps.  The oracle (and the host build of this header) divide; on the device an IEEE
+// fp64 division is an 11-instruction dependent chain (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) and `1 / sqrt(x)` a
+// square root followed by one — three of them per correspondence and sweep, ~18 % of the cost sweep's instructions.  The device takes the
+// hardware seed and two Newton steps: <= 1 ulp instead of correctly rounded, the same class of difference as the FMA contraction the
+// device build already has against the oracle (gated by the 3 x 1024-pair fixtures of tests/test_gpu_headline.py: masks and inlier
+// counts identical, models to 1e-8).  x = 0 gives NaN where the division gives inf; both end as "term truncated / row of weight zero".
+#ifndef MDRP_LM_IEEE_DIV
+#define MDRP_LM_IEEE_DIV 0
+#endif
+MDRP_HD double lm_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+#else
+    return 1.0 / x;
+#endif
+}
+MDRP_HD double lm_rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    return y * fma(-h * y, y, 1.5);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+
 // ---------------------------------------------------------------- robust losses (a-8)
 MDRP_HD double loss_value(int type, double thr, double r2) {
     const double t2 = thr * thr;
     switch (type) {
     case 1: case 5: return r2 < t2 ? r2 : t2;
     case 2: { const double r = sqrt(r2); return r <= thr ? r2 : thr * (2.0 * r - thr); }
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV // (1 / t^2 is invariant over a sweep: one reciprocal, products per record)
+    case 3: return t2 * log1p(r2 * lm_rcp(t2));
+    case 4: return t2 * log1p((r2 < t2 ? r2 : t2) * lm_rcp(t2));
+#else
     case 3: return t2 * log1p(r2 / t2);
     case 4: return t2 * log1p((r2 < t2 ? r2 : t2) / t2);
+#endif
     default: return r2;
     }
 }
@@ -627,8 +661,13 @@ MDRP_HD double loss_weight(int type, double thr, double r2, double mu = 0.5) {
         return (1.0 - zbar) / rho;
     }
     case 2: { const double r = sqrt(r2); return r <= thr ? 1.0 : thr / r; }
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+    case 3: { const double w = lm_rcp(1.0 + r2 * lm_rcp(t2)); return w > dmin ? w : dmin; }
+    case 4: { if (!(r2 < t2)) return 0.0; const double w = lm_rcp(1.0 + r2 * lm_rcp(t2)); return w > dmin ? w : dmin; }
+#else
     case 3: { const double w = 1.0 / (1.0 + r2 / t2); return w > dmin ? w : dmin; }
     case 4: { if (!(r2 < t2)) return 0.0; const double w = 1.0 / (1.0 + r2 / t2); return w > dmin ? w : dmin; }
+#endif
     default: return 1.0;
     }
 }
@@ -835,35 +874,6 @@ MDRP_HD void lm_state_from_model(const Model &m, bool focal, LmState &st) {
     fundamental_from_E(st.E, st.f1, st.f2, st.F);
 }
 
-// Reciprocal and reciprocal square root of the LM sweeps.  The oracle (and the host build of this header) divide; on the device an IEEE
-// fp64 division is an 11-instruction dependent chain (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) and `1 / sqrt(x)` a
-// square root followed by one — three of them per correspondence and sweep, ~18 % of the cost sweep's instructions.  The device takes the
-// hardware seed and two Newton steps: <= 1 ulp instead of correctly rounded, the same class of difference as the FMA contraction the
-// device build already has against the oracle (gated by the 3 x 1024-pair fixtures of tests/test_gpu_headline.py: masks and inlier
-// counts identical, models to 1e-8).  x = 0 gives NaN where the division gives inf; both end as "term truncated / row of weight zero".
-#ifndef MDRP_LM_IEEE_DIV
-#define MDRP_LM_IEEE_DIV 0
-#endif
-MDRP_HD double lm_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
-    double y = __builtin_amdgcn_rcp(x);
-    y = fma(fma(-x, y, 1.0), y, y);
-    return fma(fma(-x, y, 1.0), y, y);
-#else
-    return 1.0 / x;
-#endif
-}
-MDRP_HD double lm_rsqrt(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
-    double y = __builtin_amdgcn_rsq(x);
-    const double h = 0.5 * x;
-    y = y * fma(-h * y, y, 1.5);
-    return y * fma(-h * y, y, 1.5);
-#else
-    return 1.0 / sqrt(x);
-#endif
-}
-
 constexpr int LM_NPAR = 11; // rot(3) t(3) s u v f1 f2
 
 // residuals r[0..4] = {sampson, fwd.x, fwd.y, bwd.x, bwd.y} (reprojection ones times sqrt(sr)); zf / zb = depth of
@@ -1048,10 +1058,41 @@ MDRP_HD void lm_apply_step(const Model &m, const double d[LM_NPAR], bool focal, 
     o.f2 = focal ? m.f2 + d[10] : m.f2;
 }
 
-// Cholesky solve of the (lower-stored, row-major n x n) damped normal equations; n <= 9
+// Cholesky solve of the (lower-stored, row-major n x n) damped normal equations; n <= 9.
+// Device (round 4): one reciprocal square root per column (lm_rsqrt: hardware seed + two Newton steps) instead of a square root and
+// N (N + 3) / 2 divisions by the diagonal — 35 division chains of 11 dependent instructions each for N = 7, on the serial path of
+// every LM iteration.  L(j, j) is kept as s * rsqrt(s); every quotient by it becomes a product with rsqrt(s): <= 1 ulp each.
 template <int N>
 MDRP_HD void chol_solve(const double *A, const double *b, double *x) {
     double L[N * N];
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+    double inv[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = A[i * N + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k];
+            if (i == j) { inv[i] = lm_rsqrt(s); L[i * N + i] = s * inv[i]; }
+            else L[i * N + j] = s * inv[j];
+        }
+    double y[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= L[i * N + k] * y[k];
+        y[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
+        x[i] = s * inv[i];
+    }
+#else
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -1077,6 +1118,7 @@ MDRP_HD void chol_solve(const double *A, const double *b, double *x) {
         for (int k = i + 1; k < N; ++k) s -= L[k * N + i] * x[k];
         x[i] = s / L[i * N + i];
     }
+#endif
 }
 
 // ---------------------------------------------------------------- sampler (a-3)
