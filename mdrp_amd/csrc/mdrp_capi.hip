@@ -66,7 +66,8 @@ struct Progress {
     unsigned long long evals_bound; // evaluations executed by k_bound in fp32 (k_count's survivors * n)
 };
 constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
-constexpr size_t COUNTERS_BYTES = 128;
+constexpr int CNT_XCD_HEAD = 32; // int32 index of the per-XCD LO queue heads: [chunk][8] at LO_XCD_STRIDE ints (lo_take, mdrp_kernels.h)
+constexpr size_t COUNTERS_BYTES = sizeof(int32_t) * (CNT_XCD_HEAD + 8 /*NC_MAX*/ * 8 * LO_XCD_STRIDE);
 constexpr size_t LM_STATS_BYTES = 6 * sizeof(unsigned long long); // mdrp_handle::lm_stats
 
 // Every entry point runs on the handle's device and puts the caller's current device back on return (the caller is
@@ -117,6 +118,7 @@ struct mdrp_handle {
     DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live, lme_accpart;
     int lme_mode = 0;                  // LO phases: 1 = list engine (k_lme_accum), 2 = segment engine (dense sweeps: k_lme_decide / k_lme_accum_seg / k_lme_reduce)
     int lme_mode_final = 0;            // the final phase (one problem per pair, an inlier mask in its second half): 1 or 2
+    bool lme_trace = false;
     int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
     DevBuf lm_stats;                  // six u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel |
                                       // fused tail: gate time-outs | final-refinement wait time-outs
@@ -344,6 +346,7 @@ int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, in
         if (poll_every > 0 && r >= poll_from && (r - poll_from) % poll_every == 0) {
             HIPCHK(hipMemcpyAsync(h->lme_live_host, ph.live + (r & (LME_RING - 1)), sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
+            if (h->lme_trace) std::fprintf(stderr, "[mdrp] lme round %d: %d live\n", r, *h->lme_live_host); // MDRP_LME_TRACE=1
             if (*h->lme_live_host == 0) break;
         }
         MDRP_LME_COST(seg, kind, loss, cost_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
@@ -509,7 +512,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const bool lo_after_count = env_int("MDRP_LO_AFTER_COUNT", 1) != 0;
     const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
     const bool use_bound = env_int("MDRP_BOUND", 1) != 0; // fp32 lower-bound stage between k_count and the fp64 sweep
-    const int lo_threads = env_int("MDRP_LO_THREADS", batch >= 128 ? 64 : 256);
+    const bool lo_xcd = env_int("MDRP_LO_XCD", 1) != 0; // one LO queue per XCD (lo_take) instead of one for the chip
+    // lanes per LO problem: one wavefront when there are many short problems; four when the batch is small or the pairs are large (N = 5000:
+    // a one-wavefront problem is 4 ms long and the launch ends with its stragglers — 45.6 against 43.9 ms per 1024 varying-focal pairs)
+    const int lo_threads = env_int("MDRP_LO_THREADS", (batch >= 128 && n_max < 4096) ? 64 : 256);
     const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
     // Fused tail (mdrp_kernels.h FuseTail): when the end of the run is known on the host (the super-chunk reaches max_iterations), the
@@ -524,18 +530,19 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     bool final_done = false;
     // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
     // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)
-    // Default: on for the varying-focal estimator only.  Its LO leaves loss_scale at 1.0 (reference quirk), nothing is
-    // truncated, every sweep of every problem covers all N correspondences — long, uniform sweeps, where the round structure costs
-    // little and the shared cost sweep pays (N = 5000: 53.5 vs 57.1 ms per 1024 pairs).  On the calibrated / shared-focal shapes the
-    // persistent one-wavefront-per-problem kernels are faster (11.7 vs 14.5 ms): their problems are short and many, and a round's
-    // three kernel boundaries cost more than the stragglers they remove (DESIGN.md §4 "LM engine").
+    // Default since round 4: off.  The engines were built for the varying-focal estimator, whose LO leaves loss_scale at 1.0 (reference
+    // quirk): nothing is truncated, every sweep of every problem covers all N correspondences, and with the round-2/3 sweeps the
+    // round structure won there (N = 5000: 53.5 vs 57.1 ms per 1024 pairs in round 3, 48.6 with the segment engine in round 4).  With the
+    // round-4 sweeps (no division chains, LDS work lists written as LDS) the persistent kernels are ahead on every shape: varying focal
+    // N = 5000 41.7 ms with 256 lanes per LO problem (MDRP_LO_THREADS, chosen by N below) against 48.6; calibrated / shared focal 9.5 vs 14.5.
     // MDRP_LM_ENGINE: 0 = persistent kernels, 1 = list engine, 2 = segment engine (dense sweeps per (pair, segment), mdrp_lm.h)
-    const int lme_mode = classic ? 0 : env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 2 : 0);
+    const int lme_mode = classic ? 0 : env_int("MDRP_LM_ENGINE", 0);
     const bool use_lme = lme_mode != 0;
     h->lme_mode = lme_mode;
     // The final phase has one problem per pair and, in its second half, an inlier mask: dense sweeps waste the masked lanes and its
     // ~100 rounds pay five launches each instead of three — it stays on the list engine (varying focal, 1024 x 5000: 14.8 against 19.4 ms)
     h->lme_mode_final = use_lme ? env_int("MDRP_LM_ENGINE_FINAL", 1) : 0;
+    h->lme_trace = env_int("MDRP_LME_TRACE", 0) != 0;
     const int lme_cap = std::max(batch, env_int("MDRP_LME_CAP", batch * 48 + 2048));
     if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
@@ -736,7 +743,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     const dim3 cgrid((unsigned)batch * (unsigned)((part_len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                     HIPCHK(hipEventRecord(c0, s));
                     MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                                        tags_c, t_end, h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(), h->tags_v.as<uint32_t>(),
+                                        tags_c, t_end, h->cplan.as<int32_t>(), h->tags_v.as<uint32_t>(),
                                         h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr, t_begin);
                     HIPCHK(hipEventRecord(c1, s));
                     h->count_launches++;
@@ -760,7 +767,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     if ((rc = get_events(h, &b0, &b1, 4))) return rc;
                     HIPCHK(hipEventRecord(b0, s));
                     MDRP_SWEEP_DISPATCH(k_bound, kind, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
-                                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(),
                                         tags_b, h->surv2_count.as<int32_t>(), bstats);
                     HIPCHK(hipEventRecord(b1, s));
                     surv_tags = tags_b; surv_cnt = h->surv2_count.as<int32_t>();
@@ -806,17 +813,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const FuseTail fz = fuse_here ? FuseTail{fz_done, fz_ready, fz_ctl, h->st.as<PairState>()} : FuseTail{nullptr, nullptr, nullptr, nullptr};
             const RunParams rp_lo = rp;
             unsigned long long *lm_stats = h->lm_stats.as<unsigned long long>();
+            int32_t *xheads_c = lo_xcd ? cnt + CNT_XCD_HEAD + (size_t)c * 8 * LO_XCD_STRIDE : nullptr;
             auto launch_lo_kernels = [=]() -> int {
                 if (use_lme) return lme_lo(h, aux2, rp_lo, kind, est_shift, lo_plan, trig_cap, 0, lme_cap);
                 if (classic) {
                     MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), 0, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
-                                             h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c,
+                                             h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, xheads_c,
                                              h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max, fz);
                     return MDRP_OK;
                 }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
                                  h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, lm_list_stride(n_max), lm_stats, fz);
+                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, xheads_c, lm_list_stride(n_max), lm_stats, fz);
                 return MDRP_OK;
             };
             auto launch_lo = [=]() -> int { // bracketed by HIP events on the stream the LO runs on (mdrp_stats::lo_ms)
@@ -1390,7 +1398,7 @@ int mdrp_count_candidates(mdrp_handle *h, int kind, const mdrp_model *models, in
                        (int32_t *)nullptr);
     const dim3 grid((unsigned)((num_models + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
     MDRP_SWEEP_DISPATCH(k_count, kind, grid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                        h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                        h->tags.as<uint32_t>(), h->model_count.as<int32_t>(), h->cplan.as<int32_t>(),
                         h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(candidates, h->unit_f.p, sizeof(int32_t) * num_models, hipMemcpyDeviceToHost, s));
@@ -1439,7 +1447,7 @@ int mdrp_bound_models(mdrp_handle *h, int kind, const mdrp_model *models, int nu
                        h->cplan.as<int32_t>(), h->surv2_count.as<int32_t>());
     const dim3 grid((unsigned)((num_models + BND_THREADS - 1) / BND_THREADS));
     MDRP_SWEEP_DISPATCH(k_bound, kind, grid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
-                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(), h->slot_inl.as<int32_t>(),
+                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(),
                         h->tags.as<uint32_t>(), h->surv2_count.as<int32_t>(), (unsigned long long *)nullptr, h->unit_a.as<double>(), h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(score_lb, h->unit_a.p, sizeof(double) * num_models, hipMemcpyDeviceToHost, s));

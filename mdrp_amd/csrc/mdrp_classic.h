@@ -652,6 +652,7 @@ template <int CK, int T>
 __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                               const Model *__restrict__ models, Trigger *__restrict__ triggers, int trig_cap,
                                               const int32_t *__restrict__ plan, int32_t *__restrict__ head /*zeroed*/,
+                                              int32_t *__restrict__ xheads /*zeroed, or null: lo_take (mdrp_kernels.h)*/,
                                               uint8_t *__restrict__ lo_mask /*[gridDim.x][n_max]*/, FuseTail fz /*ready == null: off*/) {
     __shared__ double scratch[4 * MAX_ACC];
     __shared__ int s_item;
@@ -665,7 +666,7 @@ __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__r
     }
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
+        if (threadIdx.x == 0) s_item = lo_take(head, xheads, total);
         __syncthreads();
         const int w = s_item;
         if (w >= total) break;

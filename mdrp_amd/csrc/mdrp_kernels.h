@@ -921,7 +921,7 @@ template <bool POSE, bool RAWF = false> // RAWF: the model IS a fundamental matr
 __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const PairState *__restrict__ st, const uint4 *__restrict__ rfrag,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags,
                                                           const int32_t *__restrict__ model_count, const int32_t *__restrict__ plan,
-                                                          int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_surv,
+                                                          uint32_t *__restrict__ tags_surv,
                                                           int32_t *__restrict__ surv_count, unsigned long long *__restrict__ stats,
                                                           int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/,
                                                           const int32_t *__restrict__ tag_begin = nullptr /*or: entries [tag_begin[2 p], model_count[2 p]) of the tag lists*/) {
@@ -1180,7 +1180,7 @@ template <bool POSE, bool RAWF = false>
 __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags_in,
                                                           const int32_t *__restrict__ cnt_in, const int32_t *__restrict__ plan,
-                                                          int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags_out,
+                                                          uint32_t *__restrict__ tags_out,
                                                           int32_t *__restrict__ cnt_out, unsigned long long *__restrict__ stats,
                                                           double *__restrict__ dbg_lb = nullptr /*unit entry point: the two bounds per model*/,
                                                           int32_t *__restrict__ dbg_cnt_ub = nullptr) {
@@ -1657,6 +1657,9 @@ __device__ __forceinline__ void lm_state_uniform(LmState &st) {
     st.f1 = uniform_f64(st.f1); st.f2 = uniform_f64(st.f2); st.if1 = uniform_f64(st.if1); st.if2 = uniform_f64(st.if2);
 }
 
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+__device__ __forceinline__ lds_u16 *lds_cast(uint16_t *p) { return (lds_u16 *)p; }
+
 struct LmShared {
     double scratch[4 * MAX_ACC];
     int count[2][4];
@@ -1665,6 +1668,7 @@ struct LmShared {
     unsigned long long *stats; // [0] correspondences evaluated by cost sweeps, [1] by accumulate sweeps (or null): bench.py's fp64 roofline
     unsigned long long ev[2];  // ... collected here per problem, flushed by lm_flush_stats
 #ifdef MDRP_LO_TRACE
+    unsigned long long tloop;  // (MDRP_EXP_COSTSPLIT) ticks inside the record loop of lm_cost
     unsigned long long ph[4];  // experiment build: wall-clock ticks of the last lm_refine in cost sweeps | normal-equation sweeps | total; iterations | accepted << 16
 #endif
 };
@@ -1677,6 +1681,9 @@ __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
     sh.ev[0] = 0; sh.ev[1] = 0;
 }
 
+#ifndef MDRP_LM_COST_DEPTH
+#define MDRP_LM_COST_DEPTH 1 // trips between the request of a record and its use in the cost sweep (lm_cost): 1 or 2 (measured: 2 is 1-2 % slower)
+#endif
 // LOSS: the loss type when the caller knows it at compile time (1 = TRUNCATED: every LO refinement), -1 = o.loss.
 // Round 4: the loop body is straight-line — padding lanes evaluate a harmless record and every `if` of the round-3 body (record
 // valid, forward / backward depth positive, loss type) is a select on the three cost terms, added in the round-3 order, so the sums
@@ -1690,7 +1697,12 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     lm_state_uniform(stt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool use_list = sh.stride > 0;
-    uint16_t *list = sh.list + (size_t)buf * sh.stride;
+    // sh.list is a pointer kept IN LDS: read back, the compiler no longer knows it points to LDS and emitted flat_store_short for the list
+    // entries — and a FLAT operation may return out of order with the global loads around it, so every wait in the loop became
+    // s_waitcnt vmcnt(0): the record prefetch was waited for a few instructions after it was issued and each trip paid a full memory
+    // round trip (14.6 cycles per instruction against 5.2 in the normal-equation sweep; found in the ISA in round 4).  Stating the
+    // address space gives ds_write_b16 and partial vmcnt waits back.
+    lds_u16 *list = lds_cast(sh.list) + (size_t)buf * sh.stride;
     const int seg = ((n + T - 1) / T) * 64; // correspondences per wavefront, multiple of 64
     const int lo = wave * seg, hi = min(n, lo + seg);
     const int loss = LOSS >= 0 ? LOSS : o.loss;
@@ -1704,7 +1716,7 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     auto fetch = [&](int base) { // unconditional loads from a clamped index: no exec-mask branch around them; `ok` says whether the lane counts
         Rec r;
         const int i = base + lane, ic = min(i, last);
-        r.ok = (i < hi) & (mask ? mask[ic] != 0 : true);
+        r.ok = (int)(i < hi) & (int)(mask ? mask[ic] != 0 : true); // (integer AND on purpose, here and below: no short-circuit branches)
         const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
         const double2 p01 = P[0], p23 = P[1];
         const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)ic);
@@ -1715,17 +1727,18 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         double r[5], zf, zb;
         point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
         const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
-        const bool fwd = cur.ok & !(zf < 0), bwd = cur.ok & !(zb < 0); // (bitwise on purpose: no short-circuit branches)
+        const int oki = cur.ok;
+        const bool fwd = oki & (int)!(zf < 0), bwd = oki & (int)!(zb < 0);
         double vs, vf, vb;
         bool contrib;
         if (LOSS == 1) { // TRUNCATED: min(r^2, t^2); IRLS weight 1 below the threshold, 0 at and above it (and for NaN)
             const bool is = rs < t2, jf = rf < t2, jb = rb < t2;
             vs = ws * (is ? rs : t2); vf = jf ? rf : t2; vb = jb ? rb : t2;
-            contrib = (cur.ok & is & ws_nz) | (fwd & jf) | (bwd & jb);
+            contrib = ((oki & (int)is & (int)ws_nz) | ((int)fwd & (int)jf) | ((int)bwd & (int)jb)) != 0;
         } else {
             vs = ws * loss_value(loss, lsc, rs); vf = loss_value(loss, lsc, rf); vb = loss_value(loss, lsc, rb);
-            contrib = (cur.ok & (ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | (fwd & (loss_weight(loss, lsc, rf, mu) != 0.0)) |
-                      (bwd & (loss_weight(loss, lsc, rb, mu) != 0.0));
+            contrib = ((oki & (int)(ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | ((int)fwd & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
+                       ((int)bwd & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
         }
         cost += cur.ok ? vs : 0.0; // (+ 0.0 leaves a non-negative sum as it is: the order and the values of round 3's `if`s)
         cost += fwd ? vf : 0.0;
@@ -1738,8 +1751,26 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         }
     };
     if (!mask) evaluated = max(hi - lo, 0);
-    // the next 64 records are requested before the current ones are consumed (two wavefronts per SIMD do not hide an L2 round trip
-    // behind ~130 fp64 operations); two trips per loop iteration, the buffers swap roles instead of being copied
+#if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
+    const unsigned long long tl0 = wall_clock64();
+#endif
+#if MDRP_LM_COST_DEPTH == 2
+    // records are requested TWO trips before they are consumed (a trip is ~80 instructions, ~0.4 us for a lone wavefront; the records come
+    // from the fabric side, 0.6-0.7 us away); four trips per loop iteration, the four buffers swap roles instead of being copied.  Trips
+    // past `hi` are all padding (loads from a clamped index, nothing counted).
+    Rec A = fetch(lo), B = fetch(lo + 64);
+    for (int base = lo; base < hi; base += 256) {
+        const Rec C = fetch(base + 128);
+        step(A, base);
+        const Rec D = fetch(base + 192);
+        if (base + 64 < hi) step(B, base + 64);
+        A = fetch(base + 256);
+        if (base + 128 < hi) step(C, base + 128);
+        B = fetch(base + 320);
+        if (base + 192 < hi) step(D, base + 192);
+    }
+#else
+    // the next 64 records are requested before the current ones are consumed; two trips per loop iteration, the buffers swap roles
     Rec A = fetch(lo);
     for (int base = lo; base < hi; base += 128) {
         const Rec B = fetch(base + 64); // past `hi`: an all-padding trip (one wasted trip when the trip count is odd)
@@ -1747,6 +1778,10 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         A = fetch(base + 128);
         if (base + 64 < hi) step(B, base + 64);
     }
+#endif
+#if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
+    if (threadIdx.x == 0) sh.tloop += wall_clock64() - tl0;
+#endif
     if (use_list && lane == 0) sh.count[buf][wave] = cnt;
     if (sh.stats && lane == 0 && evaluated) atomicAdd(&sh.ev[0], (unsigned long long)evaluated);
     double v[1] = {cost};
@@ -1875,7 +1910,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
     const int seg = ((n + T - 1) / T) * 64;
     const int lo = wave * seg;
     if (sh.stride > 0) {
-        const uint16_t *list = sh.list + (size_t)buf * sh.stride;
+        const lds_u16 *list = lds_cast(sh.list) + (size_t)buf * sh.stride; // (LDS, stated: see lm_cost)
         const int cnt = sh.count[buf][wave];
         // software-pipelined by one step like the cost sweep: list entry and record of the next trip are requested
         // before the current record's ~700 fp64 ops (an unhidden LDS + L2 round trip was ~30 % of the sweep: PMC SQ_WAIT_ANY)
@@ -1991,6 +2026,9 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
         if (KIND == 1) full[10] = full[9];
         lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
     }
+#if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
+    if (threadIdx.x == 0) { tr_a = sh.tloop; sh.tloop = 0; } // the "normal equations" column then reads: ticks inside lm_cost's record loop
+#endif
     MDRP_TR(if (threadIdx.x == 0) { sh.ph[0] = tr_c; sh.ph[1] = tr_a; sh.ph[2] = wall_clock64() - tr_0; sh.ph[3] = (unsigned long long)it | ((unsigned long long)tr_acc << 16); })
 #undef MDRP_TR
 }
@@ -2033,8 +2071,9 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 // next chunk's scan keeps appending triggers — the LO of the first, short chunk (most of a run's LO work: records fall
 // fast at the start) hides behind the second chunk's sweep instead of leaving the chip to the tail of a launch whose
 // single problems take ~1 ms on one wavefront.
-// (Measured and dropped: longest-first ordering by inlier count — no change; XCD-affine queues, pair p on XCD p mod 8 —
-// 2.8x less HBM fetch, same time: LO is bound by dependent fp64 latency at 2 waves/SIMD, not by bandwidth or order.)
+// (Measured and dropped: longest-first ordering by inlier count — no change.  XCD-affine queues, pair p on XCD p mod 8: 2.8x less HBM
+// fetch, same time in round 2; as contiguous eighths of the plan with stealing (lo_take, round 4) 2-5 % of k_lo: the LO is bound by
+// instruction issue at 1-2 waves/SIMD, not by bandwidth or order.)
 // plan layout: prefix[B+1] | begin[B] | end[B] | total
 __global__ __launch_bounds__(PLAN_THREADS) void k_lo_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ prev_plan /*or null*/,
                                                           int32_t *__restrict__ plan) {
@@ -2174,6 +2213,31 @@ struct FuseTail {
 // different streams cannot run side by side (rocprofv3 --pmc serialises dispatches, debuggers do) the LO launch may be stuck behind
 // the very kernels that wait for it.  Then the gate gives up, the final workgroups give up and leave their pairs undone, the LO
 // launch runs, and the ordinary k_final pass behind it (`skip`) refines what is left: slower, never stuck.
+// LO queue with XCD affinity.  The problems of a launch are sorted by pair (k_lo_plan) and every LM sweep re-reads its pair's records
+// (96 KB at N = 2000, 240 KB at N = 5000; ~18 sweeps per problem): with one queue the ~5 problems of a pair run on five different XCDs and
+// every sweep comes over the fabric.  Eight queues, one per XCD, each over a contiguous eighth of the plan: an XCD's wavefronts work on ~46
+// consecutive pairs at a time and the problems of a pair share its L2.  The LO is bound by instruction issue, not by the memory side
+// (DESIGN.md 4): this buys 2-5 % of k_lo, no more.  A workgroup whose own queue is empty takes from the others (the tail stays balanced);
+// which problem runs where changes nothing but speed.  `head` counts the tickets handed out (k_gate waits on it); xheads == null: one queue.
+constexpr int LO_XCD_STRIDE = 16; // int32 between two queue heads (their own 64-byte blocks)
+__device__ __forceinline__ int lo_xcc_id() {
+    int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 7;
+}
+__device__ __forceinline__ int lo_take(int32_t *__restrict__ head, int32_t *__restrict__ xheads, int total) {
+    if (!xheads) return atomicAdd(head, 1);
+    const int x = lo_xcc_id();
+    for (int k = 0; k < 8; ++k) {
+        const int y = (x + k) & 7;
+        const int b = (int)((long long)total * y / 8), len = (int)((long long)total * (y + 1) / 8) - b;
+        if (len <= 0 || __hip_atomic_load(xheads + y * LO_XCD_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
+        const int t = atomicAdd(xheads + y * LO_XCD_STRIDE, 1);
+        if (t < len) { atomicAdd(head, 1); return b + t; }
+    }
+    return total;
+}
+
 __global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks,
                        unsigned long long ticks, unsigned long long *__restrict__ timeouts /*[0] gate, [1] final waits: mdrp_stats.fuse_*_timeouts*/) {
     const int total = *plan_total;
@@ -2247,12 +2311,15 @@ template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
                                                    const double *__restrict__ dep, const Model *__restrict__ models,
                                                    Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan,
-                                                   int32_t *__restrict__ head /*zeroed*/, int list_stride, unsigned long long *__restrict__ lm_stats,
-                                                   FuseTail fz /*ready == null: off*/) {
+                                                   int32_t *__restrict__ head /*zeroed*/, int32_t *__restrict__ xheads /*zeroed, or null: lo_take*/,
+                                                   int list_stride, unsigned long long *__restrict__ lm_stats, FuseTail fz /*ready == null: off*/) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
     if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
+#ifdef MDRP_LO_TRACE
+    if (threadIdx.x == 0) sh.tloop = 0;
+#endif
     __syncthreads();
     const int total = plan[3 * (size_t)rp.batch + 1];
     if (fz.ready && threadIdx.x == 0) { // pairs without a trigger in this launch are ready as they are (earlier LO launches have ended: stream order)
@@ -2263,7 +2330,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
     }
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(head, 1);
+        if (threadIdx.x == 0) s_item = lo_take(head, xheads, total);
         __syncthreads();
         const int w = s_item;
         if (w >= total) break;

@@ -933,7 +933,7 @@ template <bool WITH_J, bool FOCAL>
 MDRP_HD void lm_forward_term(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d1,
                              double &r1, double &r2, double &zf, double *J1, double *J2) {
     const double *R = st.R, *t = st.t;
-    const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
+    const double f2 = FOCAL ? st.f2 : 1.0;
     const double if1 = FOCAL ? st.if1 : 1.0;
     const double b1x = x1x * if1, b1y = x1y * if1;
     const double dd1 = d1 + st.u;
@@ -981,7 +981,7 @@ template <bool WITH_J, bool FOCAL>
 MDRP_HD void lm_backward_term(const LmState &st, double sqrt_sr, double x1x, double x1y, double x2x, double x2y, double d2,
                               double &r3, double &r4, double &zb, double *J3, double *J4) {
     const double *R = st.R, *t = st.t;
-    const double f1 = FOCAL ? st.f1 : 1.0, f2 = FOCAL ? st.f2 : 1.0;
+    const double f1 = FOCAL ? st.f1 : 1.0;
     const double if2 = FOCAL ? st.if2 : 1.0;
     const double b2x = x2x * if2, b2y = x2y * if2;
     const double dd2 = d2 + st.v;

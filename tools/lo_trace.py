@@ -1,28 +1,28 @@
 """Per-problem timing of the LO kernel (experiment build -DMDRP_LO_TRACE), with the time inside every LM split into cost sweeps,
 normal-equation sweeps and the rest (solve, step, state expansion, reductions).  Build HERE (no GPU needed), run ON THE GPU BOX:
     python tools/lo_trace.py build          -> tools/gpu/libmdrp_lo_trace.so (travels with gpurun; *.so is git-ignored)
-    gpurun -- python tools/lo_trace.py      -> prints the distributions"""
+    gpurun -- python tools/lo_trace.py [bench workload name]     -> prints the distributions (environment knobs such as MDRP_LO_THREADS apply)"""
 import os
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-lib = os.path.join(ROOT, "tools", "gpu", "libmdrp_lo_trace.so")
+lib = os.environ.get("LO_TRACE_LIB") or os.path.join(ROOT, "tools", "gpu", "libmdrp_lo_trace.so")
 trace = "/tmp/lo_trace.bin"
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     from mdrp_amd import build
     build.build(force=True, defines=("MDRP_LO_TRACE",), out=lib)
 elif len(sys.argv) > 1 and sys.argv[1] == "child":
     import numpy as np
-    from mdrp_amd import _capi, synth
-    b = synth.make_batch(0, 1024, 2000, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
-    cams = np.zeros(1024, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
-    ro = _capi.ransac_opt_from_dict({"max_iterations": 10000, "min_iterations": 10000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
-    bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
-    h = _capi.Handle(0)
+    import torch
+    import bench
+    name = os.environ.get("LO_TRACE_WORKLOAD", "calib_p3p_n2000_i10k")
+    w = bench.Workload(name, 0, 1024, 1024, 0, torch.device("cuda:0"))
     for _ in range(2):
-        h.estimate_batch(0, b["x1"], b["x2"], b["d1"], b["d2"], ro, bo, None, cams, cams)
+        w.launch()
+        w.h.fetch_results(1024)
+    print(f"workload {name}")
     ev = np.fromfile(trace, dtype=np.uint64).reshape(-1, 8)
     dur = (ev[:, 5] - ev[:, 4]).astype(np.int64) / 100.0   # wall_clock64 ticks at 100 MHz -> microseconds
     t_cost = (ev[:, 6] & np.uint64(0xFFFFFFFF)).astype(np.int64) / 100.0
@@ -50,4 +50,6 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
                       f"normal equations {t_acc[sel][w].sum() / np.maximum(accs[sel][w], 1).sum():.1f} us, rest per iteration {rest[w].sum() / np.maximum(its[sel][w], 1).sum():.1f} us")
 else:
     env = dict(os.environ, MDRP_LIB=lib, MDRP_LO_TRACE_FILE=trace)
+    if len(sys.argv) > 1:
+        env["LO_TRACE_WORKLOAD"] = sys.argv[1]
     subprocess.call([sys.executable, os.path.abspath(__file__), "child"], env=env)
