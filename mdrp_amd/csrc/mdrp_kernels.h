@@ -1681,8 +1681,8 @@ __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
     sh.ev[0] = 0; sh.ev[1] = 0;
 }
 
-#ifndef MDRP_LM_COST_DEPTH
-#define MDRP_LM_COST_DEPTH 1 // trips between the request of a record and its use in the cost sweep (lm_cost): 1 or 2 (measured: 2 is 1-2 % slower)
+#ifndef MDRP_LM_COST_UNROLL
+#define MDRP_LM_COST_UNROLL 1 // records per lane and trip of the cost sweep (lm_cost)
 #endif
 // LOSS: the loss type when the caller knows it at compile time (1 = TRUNCATED: every LO refinement), -1 = o.loss.
 // Round 4: the loop body is straight-line — padding lanes evaluate a harmless record and every `if` of the round-3 body (record
@@ -1723,62 +1723,66 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
         r.a = p01.x; r.b = p01.y; r.c = p23.x; r.d = p23.y; r.e1 = dd.x; r.e2 = dd.y;
         return r;
     };
-    auto step = [&](const Rec &cur, int base) {
-        double r[5], zf, zb;
-        point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
-        const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
-        const int oki = cur.ok;
-        const bool fwd = oki & (int)!(zf < 0), bwd = oki & (int)!(zb < 0);
-        double vs, vf, vb;
-        bool contrib;
-        if (LOSS == 1) { // TRUNCATED: min(r^2, t^2); IRLS weight 1 below the threshold, 0 at and above it (and for NaN)
-            const bool is = rs < t2, jf = rf < t2, jb = rb < t2;
-            vs = ws * (is ? rs : t2); vf = jf ? rf : t2; vb = jb ? rb : t2;
-            contrib = ((oki & (int)is & (int)ws_nz) | ((int)fwd & (int)jf) | ((int)bwd & (int)jb)) != 0;
-        } else {
-            vs = ws * loss_value(loss, lsc, rs); vf = loss_value(loss, lsc, rf); vb = loss_value(loss, lsc, rb);
-            contrib = ((oki & (int)(ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | ((int)fwd & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
-                       ((int)bwd & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
+    // A trip is U records per lane, in two phases.  Phase 1 evaluates the U residual chains in one straight-line block: a chain is ~30
+    // dependent fp64 operations deep (rotations, three reciprocals with their Newton steps, the Sampson denominator), a wavefront issues in
+    // order, and the branches of the list append used to end the scheduler's block after every record.  Phase 2 adds the terms and appends
+    // the list entries in record order: sums and lists are those of the one-record-at-a-time loop bit for bit.
+    constexpr int U = MDRP_LM_COST_UNROLL;
+    struct Trip { Rec r[U]; };
+    auto fetch_trip = [&](int base) {
+        Trip t;
+#pragma unroll
+        for (int u = 0; u < U; ++u) t.r[u] = fetch(base + 64 * u);
+        return t;
+    };
+    auto step_trip = [&](const Trip &t, int base) {
+        double vs[U], vf[U], vb[U];
+        bool fwd[U], bwd[U], contrib[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const Rec &cur = t.r[u];
+            double r[5], zf, zb;
+            point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
+            const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
+            const int oki = cur.ok;
+            fwd[u] = oki & (int)!(zf < 0); bwd[u] = oki & (int)!(zb < 0);
+            if (LOSS == 1) { // TRUNCATED: min(r^2, t^2); IRLS weight 1 below the threshold, 0 at and above it (and for NaN)
+                const bool is = rs < t2, jf = rf < t2, jb = rb < t2;
+                vs[u] = ws * (is ? rs : t2); vf[u] = jf ? rf : t2; vb[u] = jb ? rb : t2;
+                contrib[u] = ((oki & (int)is & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
+            } else {
+                vs[u] = ws * loss_value(loss, lsc, rs); vf[u] = loss_value(loss, lsc, rf); vb[u] = loss_value(loss, lsc, rb);
+                contrib[u] = ((oki & (int)(ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
+                              ((int)bwd[u] & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
+            }
         }
-        cost += cur.ok ? vs : 0.0; // (+ 0.0 leaves a non-negative sum as it is: the order and the values of round 3's `if`s)
-        cost += fwd ? vf : 0.0;
-        cost += bwd ? vb : 0.0;
-        if (mask && sh.stats) evaluated += __popcll(__ballot(cur.ok));
-        if (use_list) {
-            const unsigned long long ball = __ballot(contrib);
-            if (contrib) list[lo + cnt + __popcll(ball & lt)] = (uint16_t)(base + lane);
-            cnt += __popcll(ball);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            cost += t.r[u].ok ? vs[u] : 0.0; // (+ 0.0 leaves a non-negative sum as it is: the order and the values of round 3's `if`s)
+            cost += fwd[u] ? vf[u] : 0.0;
+            cost += bwd[u] ? vb[u] : 0.0;
+            if (mask && sh.stats) evaluated += __popcll(__ballot(t.r[u].ok));
+            if (use_list) {
+                const unsigned long long ball = __ballot(contrib[u]);
+                if (contrib[u]) list[lo + cnt + __popcll(ball & lt)] = (uint16_t)(base + 64 * u + lane);
+                cnt += __popcll(ball);
+            }
         }
     };
     if (!mask) evaluated = max(hi - lo, 0);
 #if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
     const unsigned long long tl0 = wall_clock64();
 #endif
-#if MDRP_LM_COST_DEPTH == 2
-    // records are requested TWO trips before they are consumed (a trip is ~80 instructions, ~0.4 us for a lone wavefront; the records come
-    // from the fabric side, 0.6-0.7 us away); four trips per loop iteration, the four buffers swap roles instead of being copied.  Trips
-    // past `hi` are all padding (loads from a clamped index, nothing counted).
-    Rec A = fetch(lo), B = fetch(lo + 64);
-    for (int base = lo; base < hi; base += 256) {
-        const Rec C = fetch(base + 128);
-        step(A, base);
-        const Rec D = fetch(base + 192);
-        if (base + 64 < hi) step(B, base + 64);
-        A = fetch(base + 256);
-        if (base + 128 < hi) step(C, base + 128);
-        B = fetch(base + 320);
-        if (base + 192 < hi) step(D, base + 192);
+    // the next trip's records are requested before the current ones are consumed; two trips per loop iteration, the buffers swap roles
+    // instead of being copied (a trip past `hi` is all padding: loads from a clamped index, nothing counted).  Requesting two trips ahead
+    // (four rotating buffers) was measured 1-2 % slower.
+    Trip A = fetch_trip(lo);
+    for (int base = lo; base < hi; base += 128 * U) {
+        const Trip B = fetch_trip(base + 64 * U);
+        step_trip(A, base);
+        A = fetch_trip(base + 128 * U);
+        if (base + 64 * U < hi) step_trip(B, base + 64 * U);
     }
-#else
-    // the next 64 records are requested before the current ones are consumed; two trips per loop iteration, the buffers swap roles
-    Rec A = fetch(lo);
-    for (int base = lo; base < hi; base += 128) {
-        const Rec B = fetch(base + 64); // past `hi`: an all-padding trip (one wasted trip when the trip count is odd)
-        step(A, base);
-        A = fetch(base + 128);
-        if (base + 64 < hi) step(B, base + 64);
-    }
-#endif
 #if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
     if (threadIdx.x == 0) sh.tloop += wall_clock64() - tl0;
 #endif

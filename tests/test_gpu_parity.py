@@ -502,9 +502,12 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
                 {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "0"}, {"MDRP_CHUNKS": "128,1024", "MDRP_LM_ENGINE": "1"},
                 {"MDRP_CHUNKS": "128", "MDRP_SOLVE_PARTS": "2"}, {"MDRP_CHUNKS": "256", "MDRP_SOLVE_PARTS": "4", "MDRP_LO_AFTER_COUNT": "0"},
                 {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "2"}, {"MDRP_CHUNKS": "64,512", "MDRP_LM_ENGINE": "2", "MDRP_LME_CAP": "16"},
-                {"MDRP_CHUNKS": "128", "MDRP_FUSE_TAIL": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_FUSE_TAIL": "1"}):
+                {"MDRP_CHUNKS": "128", "MDRP_FUSE_TAIL": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_FUSE_TAIL": "1"},
+                # one LO queue for the chip instead of one per XCD (lo_take): which workgroup refines which trigger is scheduling only
+                {"MDRP_CHUNKS": "128", "MDRP_LO_XCD": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_LO_XCD": "0", "MDRP_FUSE_TAIL": "0"},
+                {"MDRP_CHUNKS": "64,256", "MDRP_LO_XCD": "1", "MDRP_LO_OVERLAP_WAVES": "2"}):
         for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_AFTER_COUNT", "MDRP_BOUND",
-                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP", "MDRP_SOLVE_PARTS"):
+                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP", "MDRP_SOLVE_PARTS", "MDRP_LO_XCD"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -524,8 +527,7 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
 @pytest.mark.parametrize("kind,es,rf", [(0, False, None), (0, True, None), (1, False, "shared"), (2, False, "varying")])
 @pytest.mark.parametrize("loss", ["TRUNCATED_CAUCHY", "CAUCHY", "TRUNCATED_LE_ZACH", "TRIVIAL"])
 def test_lm_engines_agree_on_every_estimator(capi, monkeypatch, kind, es, rf, loss):
-    """The three LM schedules — persistent kernels (0), list engine (1), segment engine with dense sweeps (2: the varying-focal
-    default) — run the same lm_impl<> arithmetic with different summation trees: integer statistics and masks identical, models
+    """The three LM schedules — persistent kernels (0: the default), list engine (1), segment engine with dense sweeps (2) — run the same lm_impl<> arithmetic with different summation trees: integer statistics and masks identical, models
     to 1e-9, on a ragged batch (pairs below the sample size and below one segment included) for every estimator and for final
     losses with and without truncation / per-iteration state."""
     from mdrp_amd import synth
