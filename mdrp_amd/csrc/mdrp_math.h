@@ -36,6 +36,53 @@ MDRP_HD void model_identity(Model &m) {
     m.scale = 1.0; m.shift1 = 0.0; m.shift2 = 0.0; m.f1 = 1.0; m.f2 = 1.0;
 }
 
+// ---------------------------------------------------------------- division and square root of the minimal solvers
+// On the device an IEEE fp64 division is an 11-instruction dependent chain (v_div_scale x 2, v_rcp, four FMAs, v_div_fmas, v_div_fixup) and a
+// square root ~15 with its range scaling; the calibrated P3P path has 71 + 35 of them among 5 800 instructions (round 4 count).  The device
+// build takes the hardware seed and two Newton steps (<= 1.5 ulp instead of correctly rounded: the same class of difference as the FMA
+// contraction it already has against the oracle; every solution is Newton-polished against its own equations afterwards).  The host build of
+// this header — the CPU tests against the oracle — keeps the IEEE operations.  MDRP_SOLVER_IEEE_DIV=1 restores them on the device.
+#ifndef MDRP_SOLVER_IEEE_DIV
+#define MDRP_SOLVER_IEEE_DIV 0
+#endif
+MDRP_HD double sv_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+    double y = __builtin_amdgcn_rcp(x);
+    y = fma(fma(-x, y, 1.0), y, y);
+    return fma(fma(-x, y, 1.0), y, y);
+#else
+    return 1.0 / x;
+#endif
+}
+MDRP_HD double sv_div(double a, double b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+    return a * sv_rcp(b);
+#else
+    return a / b;
+#endif
+}
+MDRP_HD double sv_rsqrt(double x) { // 1 / sqrt(x), x > 0
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-h * y, y, 1.5);
+    return y * fma(-h * y, y, 1.5);
+#else
+    return 1.0 / sqrt(x);
+#endif
+}
+MDRP_HD double sv_sqrt(double x) { // sqrt(x) without the compiler's range scaling (the solvers' arguments are O(1) quantities)
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * fma(-0.5 * x * r, r, 1.5);
+    const double g = x * r;
+    const double s = fma(0.5 * r, fma(-g, g, x), g); // Heron correction: <= 1 ulp; NaN for x < 0 as sqrt, and for x = 0 (inf * 0)
+    return x == 0.0 ? x : s;
+#else
+    return sqrt(x);
+#endif
+}
+
 // ---------------------------------------------------------------- pose algebra
 MDRP_HD void quat_to_R(const double q[4], double R[9]) {
     const double w = q[0], x = q[1], y = q[2], z = q[3];
@@ -52,23 +99,23 @@ MDRP_HD void R_to_quat(const double R[9], double q[4]) {
     const double tr = R[0] + R[4] + R[8];
     double w, x, y, z;
     if (tr > 0) {
-        double t = sqrt(tr + 1.0);
-        w = 0.5 * t; t = 0.5 / t;
+        double t = sv_sqrt(tr + 1.0);
+        w = 0.5 * t; t = sv_div(0.5, t);
         x = (R[7] - R[5]) * t; y = (R[2] - R[6]) * t; z = (R[3] - R[1]) * t;
     } else if (R[0] >= R[4] && R[0] >= R[8]) {
-        double t = sqrt(R[0] - R[4] - R[8] + 1.0);
-        x = 0.5 * t; t = 0.5 / t;
+        double t = sv_sqrt(R[0] - R[4] - R[8] + 1.0);
+        x = 0.5 * t; t = sv_div(0.5, t);
         w = (R[7] - R[5]) * t; y = (R[3] + R[1]) * t; z = (R[6] + R[2]) * t;
     } else if (R[4] >= R[8]) {
-        double t = sqrt(R[4] - R[8] - R[0] + 1.0);
-        y = 0.5 * t; t = 0.5 / t;
+        double t = sv_sqrt(R[4] - R[8] - R[0] + 1.0);
+        y = 0.5 * t; t = sv_div(0.5, t);
         w = (R[2] - R[6]) * t; z = (R[7] + R[5]) * t; x = (R[1] + R[3]) * t;
     } else {
-        double t = sqrt(R[8] - R[0] - R[4] + 1.0);
-        z = 0.5 * t; t = 0.5 / t;
+        double t = sv_sqrt(R[8] - R[0] - R[4] + 1.0);
+        z = 0.5 * t; t = sv_div(0.5, t);
         w = (R[3] - R[1]) * t; x = (R[2] + R[6]) * t; y = (R[5] + R[7]) * t;
     }
-    const double inv = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+    const double inv = sv_rsqrt(w * w + x * x + y * y + z * z);
     q[0] = w * inv; q[1] = x * inv; q[2] = y * inv; q[3] = z * inv;
 }
 
@@ -103,7 +150,7 @@ MDRP_HD void align3(const double X[9], const double Y[9], double R[9], double t[
     for (int i = 0; i < 3; ++i) { a[i] = X[3 + i] - X[i]; b[i] = X[6 + i] - X[i]; u[i] = Y[3 + i] - Y[i]; v[i] = Y[6 + i] - Y[i]; }
     cross3(a, b, c); cross3(u, v, w);
     cross3(b, c, bc); cross3(c, a, ca); cross3(a, b, ab);
-    const double idet = 1.0 / dot3(a, bc);
+    const double idet = sv_rcp(dot3(a, bc));
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -117,17 +164,17 @@ MDRP_HD void align3(const double X[9], const double Y[9], double R[9], double t[
 MDRP_HD int solve_cubic_real(double b, double c, double d, double &r0, double &r1, double &r2) {
     const double third = 1.0 / 3.0;
     const double p = c - b * b * third;
-    const double q = 2.0 * b * b * b / 27.0 - b * c * third + d;
-    const double disc = q * q * 0.25 + p * p * p / 27.0;
+    const double q = sv_div(2.0 * b * b * b, 27.0) - b * c * third + d;
+    const double disc = q * q * 0.25 + sv_div(p * p * p, 27.0);
     int n;
     if (disc > 0) {
-        const double sq = sqrt(disc);
+        const double sq = sv_sqrt(disc);
         r0 = cbrt(-0.5 * q + sq) + cbrt(-0.5 * q - sq) - b * third;
         r1 = r0; r2 = r0;
         n = 1;
     } else {
-        const double rr = sqrt(-p * third);
-        double arg = (rr > 0) ? (-0.5 * q) / (rr * rr * rr) : 0.0;
+        const double rr = sv_sqrt(-p * third);
+        double arg = (rr > 0) ? sv_div(-0.5 * q, rr * rr * rr) : 0.0;
         arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
         const double phi = acos(arg) * third;
         const double tp3 = 2.0943951023931954923; // 2 pi / 3
@@ -141,9 +188,9 @@ MDRP_HD int solve_cubic_real(double b, double c, double d, double &r0, double &r
         const double f0 = ((r0 + b) * r0 + c) * r0 + d, g0 = (3.0 * r0 + 2.0 * b) * r0 + c;
         const double f1 = ((r1 + b) * r1 + c) * r1 + d, g1 = (3.0 * r1 + 2.0 * b) * r1 + c;
         const double f2 = ((r2 + b) * r2 + c) * r2 + d, g2 = (3.0 * r2 + 2.0 * b) * r2 + c;
-        if (g0 != 0.0) r0 -= f0 / g0;
-        if (g1 != 0.0) r1 -= f1 / g1;
-        if (g2 != 0.0) r2 -= f2 / g2;
+        if (g0 != 0.0) r0 -= sv_div(f0, g0);
+        if (g1 != 0.0) r1 -= sv_div(f1, g1);
+        if (g2 != 0.0) r2 -= sv_div(f2, g2);
     }
     return n;
 }
@@ -161,22 +208,22 @@ MDRP_HD int solve_quartic_real(double b, double c, double d, double e, double ro
     if (nz == 3) { z = z1 > z ? z1 : z; z = z2 > z ? z2 : z; }
     int mask = 0;
     double y0 = 0, y1 = 0, y2 = 0, y3 = 0;
-    const double scale = fabs(p) + sqrt(fabs(r)) + 1e-300;
+    const double scale = fabs(p) + sv_sqrt(fabs(r)) + 1e-300;
     if (z <= 1e-14 * scale) { // biquadratic
         const double disc = p * p - 4.0 * r;
         if (disc >= 0) {
-            const double sq = sqrt(disc);
+            const double sq = sv_sqrt(disc);
             const double ya = 0.5 * (-p + sq), yb = 0.5 * (-p - sq);
-            if (ya >= 0) { y0 = sqrt(ya); y1 = -y0; mask |= 3; }
-            if (yb >= 0) { y2 = sqrt(yb); y3 = -y2; mask |= 12; }
+            if (ya >= 0) { y0 = sv_sqrt(ya); y1 = -y0; mask |= 3; }
+            if (yb >= 0) { y2 = sv_sqrt(yb); y3 = -y2; mask |= 12; }
         }
     } else {
-        const double s = sqrt(z);
-        const double qs = q / s;
+        const double s = sv_sqrt(z);
+        const double qs = sv_div(q, s);
         const double t1 = 0.5 * (p + z - qs), t2 = 0.5 * (p + z + qs);
         const double disc1 = z - 4.0 * t1, disc2 = z - 4.0 * t2;
-        if (disc1 >= 0) { const double sq = sqrt(disc1); y0 = 0.5 * (-s + sq); y1 = 0.5 * (-s - sq); mask |= 3; }
-        if (disc2 >= 0) { const double sq = sqrt(disc2); y2 = 0.5 * (s + sq); y3 = 0.5 * (s - sq); mask |= 12; }
+        if (disc1 >= 0) { const double sq = sv_sqrt(disc1); y0 = 0.5 * (-s + sq); y1 = 0.5 * (-s - sq); mask |= 3; }
+        if (disc2 >= 0) { const double sq = sv_sqrt(disc2); y2 = 0.5 * (s + sq); y3 = 0.5 * (s - sq); mask |= 12; }
     }
     double x[4] = {y0 - 0.25 * b, y1 - 0.25 * b, y2 - 0.25 * b, y3 - 0.25 * b};
 #pragma unroll
@@ -185,7 +232,7 @@ MDRP_HD int solve_quartic_real(double b, double c, double d, double e, double ro
         for (int it = 0; it < 3; ++it) {
             const double f = (((x[k] + b) * x[k] + c) * x[k] + d) * x[k] + e;
             const double fp = ((4.0 * x[k] + 3.0 * b) * x[k] + 2.0 * c) * x[k] + d;
-            if (fp != 0.0) x[k] -= f / fp;
+            if (fp != 0.0) x[k] -= sv_div(f, fp);
         }
         roots[k] = x[k];
     }
@@ -196,7 +243,7 @@ MDRP_HD bool solve3x3(const double A[9], const double b[3], double x[3]) {
     const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
     const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
     if (!(fabs(det) > 0)) return false;
-    const double id = 1.0 / det;
+    const double id = sv_rcp(det);
     x[0] = (c00 * b[0] + (A[2] * A[7] - A[1] * A[8]) * b[1] + (A[1] * A[5] - A[2] * A[4]) * b[2]) * id;
     x[1] = (c01 * b[0] + (A[0] * A[8] - A[2] * A[6]) * b[1] + (A[2] * A[3] - A[0] * A[5]) * b[2]) * id;
     x[2] = (c02 * b[0] + (A[1] * A[6] - A[0] * A[7]) * b[1] + (A[0] * A[4] - A[1] * A[3]) * b[2]) * id;
@@ -235,7 +282,7 @@ MDRP_HD double linepair_quality(const double D1[6], const double D2[6], double g
     double mx = -A[0];
     mx = (-A[3] > mx) ? -A[3] : mx;
     mx = (-A[5] > mx) ? -A[5] : mx;
-    return mx / nrm;
+    return sv_div(mx, nrm);
 }
 
 // one candidate (tau:sigma) on a line spanned by u,v -> scaled, sign-fixed, polished depths; returns validity
@@ -247,7 +294,7 @@ MDRP_HD bool p3p_finish(double tau, double sig, const double u[3], const double 
     else if (a02 >= a01) { qv = l0 * l0 + l2 * l2 - 2 * m02 * l0 * l2; av = a02; }
     else { qv = l0 * l0 + l1 * l1 - 2 * m01 * l0 * l1; av = a01; }
     if (!(qv > 0)) return false;
-    double sc = sqrt(av / qv);
+    double sc = sv_sqrt(sv_div(av, qv));
     if (l0 < 0) sc = -sc;
     l0 *= sc; l1 *= sc; l2 *= sc;
     if (!(l0 > 0 && l1 > 0 && l2 > 0)) return false;
@@ -278,7 +325,7 @@ MDRP_HD int p3p_depths(double m01, double m02, double m12, double a01, double a0
     sym_adj(D1, A1); sym_adj(D2, A2);
     const double c3 = sym_det(D2), c2 = sym_trprod(A2, D1), c1 = sym_trprod(A1, D2), c0 = sym_det(D1);
     if (!(fabs(c3) > 1e-300)) return 0;
-    const double ic3 = 1.0 / c3;
+    const double ic3 = sv_rcp(c3);
     double g0, g1, g2;
     const int nr = solve_cubic_real(c2 * ic3, c1 * ic3, c0 * ic3, g0, g1, g2);
     double g = g0, best = linepair_quality(D1, D2, g0);
@@ -295,9 +342,9 @@ MDRP_HD int p3p_depths(double m01, double m02, double m12, double a01, double a0
 #pragma unroll
     for (int i = 0; i < 6; ++i) B[i] = -B[i];
     double p0, p1, p2; // p = l x m, B = p p'
-    if (B[0] >= B[3] && B[0] >= B[5]) { const double s = sqrt(B[0]), is = 1.0 / s; p0 = s; p1 = B[1] * is; p2 = B[2] * is; }
-    else if (B[3] >= B[5]) { const double s = sqrt(B[3]), is = 1.0 / s; p0 = B[1] * is; p1 = s; p2 = B[4] * is; }
-    else { const double s = sqrt(B[5]), is = 1.0 / s; p0 = B[2] * is; p1 = B[4] * is; p2 = s; }
+    if (B[0] >= B[3] && B[0] >= B[5]) { const double s = sv_sqrt(B[0]), is = sv_rcp(s); p0 = s; p1 = B[1] * is; p2 = B[2] * is; }
+    else if (B[3] >= B[5]) { const double s = sv_sqrt(B[3]), is = sv_rcp(s); p0 = B[1] * is; p1 = s; p2 = B[4] * is; }
+    else { const double s = sv_sqrt(B[5]), is = sv_rcp(s); p0 = B[2] * is; p1 = B[4] * is; p2 = s; }
     // M = C + [p]x = 2 m l' : rows ~ l, columns ~ m
     const double M[9] = {C[0], C[1] - p2, C[2] + p1, C[1] + p2, C[3], C[4] - p0, C[2] - p1, C[4] + p0, C[5]};
     double la[3], lb[3];
@@ -334,7 +381,7 @@ MDRP_HD int p3p_depths(double m01, double m02, double m12, double a01, double a0
         const double qa = sym_quad(Dq, v, v), qb = sym_quad(Dq, u, v), qc = sym_quad(Dq, u, u);
         const double disc = qb * qb - qa * qc;
         if (disc >= 0) {
-            const double sq = sqrt(disc);
+            const double sq = sv_sqrt(disc);
             const double qq = -(qb + (qb >= 0 ? sq : -sq));
             double lam[3];
             if (n < 4 && p3p_finish(qq, qa, u, v, m01, m02, m12, a01, a02, a12, lam)) { L[n][0] = lam[0]; L[n][1] = lam[1]; L[n][2] = lam[2]; ++n; }
@@ -355,7 +402,7 @@ MDRP_HD int solver_calib_p3p(const Sample3 &s, Model out[4]) {
     double X[9], xb[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const double inv = 1.0 / sqrt(s.x2[i][0] * s.x2[i][0] + s.x2[i][1] * s.x2[i][1] + 1.0);
+        const double inv = sv_rsqrt(s.x2[i][0] * s.x2[i][0] + s.x2[i][1] * s.x2[i][1] + 1.0);
         X[3 * i] = s.d1[i] * s.x1[i][0]; X[3 * i + 1] = s.d1[i] * s.x1[i][1]; X[3 * i + 2] = s.d1[i];
         xb[3 * i] = s.x2[i][0] * inv; xb[3 * i + 1] = s.x2[i][1] * inv; xb[3 * i + 2] = inv;
     }
@@ -379,7 +426,7 @@ MDRP_HD int solver_calib_p3p(const Sample3 &s, Model out[4]) {
             double Rq[9];
             quat_to_R(out[k].q, Rq);
             const double px = Rq[0] * X[0] + Rq[1] * X[1] + Rq[2] * X[2] + out[k].t[0];
-            out[k].scale = px / (s.d2[0] * s.x2[0][0]);
+            out[k].scale = sv_div(px, s.d2[0] * s.x2[0][0]);
         }
     }
     return n;
@@ -409,7 +456,7 @@ MDRP_HD int solver_calib_shift(const Sample3 &s, Model out[4]) {
     const double k1 = g0[0] * g1[2] + g1[0] * g0[2] - 2.0 * g0[1] * g1[1];
     const double k0 = g0[0] * g0[2] - g0[1] * g0[1];
     if (!(fabs(k4) > 0)) return 0;
-    const double ik4 = 1.0 / k4;
+    const double ik4 = sv_rcp(k4);
     double us[4];
     const int mask = solve_quartic_real(k3 * ik4, k2 * ik4, k1 * ik4, k0 * ik4, us);
     int n = 0;
@@ -420,7 +467,7 @@ MDRP_HD int solver_calib_shift(const Sample3 &s, Model out[4]) {
         const double a = g0[0] + u * (g1[0] + u * g2[0]);
         const double b = g0[1] + u * (g1[1] + u * g2[1]);
         if (!(a > 0)) continue;
-        double sc = sqrt(a), v = b / a;
+        double sc = sv_sqrt(a), v = sv_div(b, a);
         for (int it = 0; it < 5; ++it) { // Newton polish of (s,u,v) on the three distance equations
             double J[9], res[3], dx[3];
 #pragma unroll
@@ -476,12 +523,12 @@ MDRP_HD int solver_varying(const Sample3 &s, Model out[4]) {
     }
     if (!solve3x3(A, rhs, sol)) return 0;
     if (!(sol[0] > 0 && sol[1] > 0 && sol[2] > 0)) return 0;
-    const double f1 = 1.0 / sqrt(sol[0]), sc = sqrt(sol[2]), f2 = sqrt(sol[2] / sol[1]);
+    const double f1 = sv_rsqrt(sol[0]), sc = sv_sqrt(sol[2]), f2 = sv_sqrt(sv_div(sol[2], sol[1]));
     double X[9], Y[9], R[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        X[3 * i] = s.d1[i] * s.x1[i][0] / f1; X[3 * i + 1] = s.d1[i] * s.x1[i][1] / f1; X[3 * i + 2] = s.d1[i];
-        Y[3 * i] = sc * s.d2[i] * s.x2[i][0] / f2; Y[3 * i + 1] = sc * s.d2[i] * s.x2[i][1] / f2; Y[3 * i + 2] = sc * s.d2[i];
+        X[3 * i] = sv_div(s.d1[i] * s.x1[i][0], f1); X[3 * i + 1] = sv_div(s.d1[i] * s.x1[i][1], f1); X[3 * i + 2] = s.d1[i];
+        Y[3 * i] = sv_div(sc * s.d2[i] * s.x2[i][0], f2); Y[3 * i + 1] = sv_div(sc * s.d2[i] * s.x2[i][1], f2); Y[3 * i + 2] = sc * s.d2[i];
     }
     model_identity(out[0]);
     align3(X, Y, R, out[0].t);
@@ -540,7 +587,7 @@ MDRP_HD int solver_shared(const Sample3 &s, Model out[4]) {
     const double q4 = 4 * (K2 * G2 + K3 * G1) + 4 * (W2 * U2 + W3 * U1) - (e0 * V4 + e1 * V3);
     const double q5 = 4 * (K3 * G2) + 4 * (W3 * U2) - (e1 * V4);
     if (!(fabs(q5) > 0)) return 0;
-    const double iq = 1.0 / q5;
+    const double iq = sv_rcp(q5);
     double ws[4];
     const int mask = solve_quartic_real(q4 * iq, q3 * iq, q2 * iq, q1 * iq, ws);
     int n = 0;
@@ -550,9 +597,9 @@ MDRP_HD int solver_shared(const Sample3 &s, Model out[4]) {
         double w = ws[r];
         if (!(w > 0)) continue;
         double Nw = N0 + N1 * w, Dw = D0 + D1 * w;
-        double sig = Nw / Dw;
+        double sig = sv_div(Nw, Dw);
         if (!(sig > 0)) continue;
-        double rho = (U0 + w * (U1 + w * U2)) / (2.0 * Nw * (dc0 + dc1 * w));
+        double rho = sv_div(U0 + w * (U1 + w * U2), 2.0 * Nw * (dc0 + dc1 * w));
         for (int it = 0; it < 4; ++it) { // Newton polish of (w, sigma, rho)
             const double ga0 = a00 + a01 * w, ga1 = a10 + a11 * w, gc0 = c00 + c01 * w, gc1 = c10 + c11 * w, ge = e0 + e1 * w;
             const double h0 = ga0 - 2 * rho * gc0 + rho * rho * ge, h1 = ga1 - 2 * rho * gc1 + rho * rho * ge;
@@ -568,8 +615,8 @@ MDRP_HD int solver_shared(const Sample3 &s, Model out[4]) {
             if (fabs(dx[0]) + fabs(dx[1]) + fabs(dx[2]) < 1e-15 * (fabs(w) + fabs(sig) + fabs(rho))) break;
         }
         if (!(w > 0 && sig > 0 && rho > 0)) continue;
-        const double f = 1.0 / sqrt(w), sc = sqrt(sig), lam2 = rho * sc;
-        const double invf = 1.0 / f;
+        const double f = sv_rsqrt(w), sc = sv_sqrt(sig), lam2 = rho * sc;
+        const double invf = sv_rcp(f);
         double X[9], Y[9], R[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {

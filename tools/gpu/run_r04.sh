@@ -14,6 +14,8 @@ timeout 600 python tests/tools/stress_parity.py 96 > gpurun_out/r04_stress_parit
 MDRP_STRESS_KINDS=3,5 timeout 900 python tests/tools/stress_parity_classic.py 384 > gpurun_out/r04_stress_parity_classic.txt 2>&1
 MDRP_STRESS_KINDS=4 timeout 600 python tests/tools/stress_parity_classic.py 32 > gpurun_out/r04_stress_parity_sixpt.txt 2>&1
 timeout 300 python tools/lo_trace.py > gpurun_out/r04_lo_trace.txt 2>&1
+timeout 300 python tools/lo_trace.py varying_n5000_i10k > gpurun_out/r04_lo_trace_varying.txt 2>&1
+timeout 120 tools/ubench/lm_sweeps 2000 1024 1 10 > gpurun_out/r04_lm_sweeps_ubench.txt 2>&1; timeout 120 tools/ubench/lm_sweeps 2000 1024 2 10 >> gpurun_out/r04_lm_sweeps_ubench.txt 2>&1; timeout 120 tools/ubench/lm_sweeps 2000 8 1 10 >> gpurun_out/r04_lm_sweeps_ubench.txt 2>&1
 timeout 900 python -m pytest tests -q -m gpu -s 2>&1 | grep -E "passed|failed|^FAILED|pairs identical" > gpurun_out/r04_pytest_gpu.txt
 mkdir -p gpurun_out/profiles_r04; cp profiles/r04_* gpurun_out/profiles_r04/ 2>/dev/null
 ls gpurun_out/profiles_r04 | wc -l
