@@ -161,6 +161,12 @@ MDRP_HD void align3(const double X[9], const double Y[9], double R[9], double t[
 
 // ---------------------------------------------------------------- univariate polynomials
 // real roots of x^3 + b x^2 + c x + d; Newton-polished; r0 always valid, (r1,r2) valid iff return value is 3
+// FAST (device builds only; the minimal solvers of the monodepth estimators): the three-real-root branch takes acos from the 8-term
+// form sqrt(1 - x) P(x) (Abramowitz & Stegun 4.4.46, 2e-8) and cos / sin of phi in [0, pi / 3] from their Taylor polynomials (1e-13)
+// instead of the library's acos + three cos (606 of the P3P kernel's 4 980 instructions); the three Newton steps below bring the roots
+// to the rounding level of the closed form either way (quadratic convergence from 1e-8), and what the solvers do with a root
+// is polished against its own equations afterwards (p3p_finish, the Newton loops of the shift / focal solvers).
+template <bool FAST = false>
 MDRP_HD int solve_cubic_real(double b, double c, double d, double &r0, double &r1, double &r2) {
     const double third = 1.0 / 3.0;
     const double p = c - b * b * third;
@@ -176,12 +182,38 @@ MDRP_HD int solve_cubic_real(double b, double c, double d, double &r0, double &r
         const double rr = sv_sqrt(-p * third);
         double arg = (rr > 0) ? sv_div(-0.5 * q, rr * rr * rr) : 0.0;
         arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
-        const double phi = acos(arg) * third;
-        const double tp3 = 2.0943951023931954923; // 2 pi / 3
-        r0 = 2.0 * rr * cos(phi) - b * third;
-        r1 = 2.0 * rr * cos(phi - tp3) - b * third;
-        r2 = 2.0 * rr * cos(phi - 2.0 * tp3) - b * third;
-        n = 3;
+#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+        if (FAST) {
+            const double ax = fabs(arg);
+            double pa = -0.0012624911;
+            pa = fma(pa, ax, 0.0066700901); pa = fma(pa, ax, -0.0170881256); pa = fma(pa, ax, 0.0308918810); pa = fma(pa, ax, -0.0501743046);
+            pa = fma(pa, ax, 0.0889789874); pa = fma(pa, ax, -0.2145988016); pa = fma(pa, ax, 1.5707963050);
+            const double ac = sv_sqrt(1.0 - ax) * pa;                                  // acos(|arg|)
+            const double phi = (arg < 0.0 ? 3.14159265358979323846 - ac : ac) * third; // in [0, pi / 3]
+            const double x2 = phi * phi;
+            double cs = -1.0 / 87178291200.0, sn = -1.0 / 1307674368000.0;             // -x^14 / 14!, -x^15 / 15!
+            cs = fma(cs, x2, 1.0 / 479001600.0); sn = fma(sn, x2, 1.0 / 6227020800.0);
+            cs = fma(cs, x2, -1.0 / 3628800.0); sn = fma(sn, x2, -1.0 / 39916800.0);
+            cs = fma(cs, x2, 1.0 / 40320.0); sn = fma(sn, x2, 1.0 / 362880.0);
+            cs = fma(cs, x2, -1.0 / 720.0); sn = fma(sn, x2, -1.0 / 5040.0);
+            cs = fma(cs, x2, 1.0 / 24.0); sn = fma(sn, x2, 1.0 / 120.0);
+            cs = fma(cs, x2, -0.5); sn = fma(sn, x2, -1.0 / 6.0);
+            cs = fma(cs, x2, 1.0); sn = fma(sn, x2, 1.0) * phi;
+            const double h = 0.86602540378443864676 * sn;                              // sin(2 pi / 3) sin(phi)
+            r0 = 2.0 * rr * cs - b * third;
+            r1 = 2.0 * rr * (h - 0.5 * cs) - b * third;                                // cos(phi - 2 pi / 3)
+            r2 = 2.0 * rr * (-h - 0.5 * cs) - b * third;                               // cos(phi - 4 pi / 3)
+            n = 3;
+        } else
+#endif
+        {
+            const double phi = acos(arg) * third;
+            const double tp3 = 2.0943951023931954923; // 2 pi / 3
+            r0 = 2.0 * rr * cos(phi) - b * third;
+            r1 = 2.0 * rr * cos(phi - tp3) - b * third;
+            r2 = 2.0 * rr * cos(phi - 2.0 * tp3) - b * third;
+            n = 3;
+        }
     }
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
@@ -203,7 +235,7 @@ MDRP_HD int solve_quartic_real(double b, double c, double d, double e, double ro
     const double q = d - 0.5 * b * c + 0.125 * b2 * b;
     const double r = e - 0.25 * b * d + b2 * c * 0.0625 - 3.0 * b2 * b2 / 256.0;
     double z0, z1, z2;
-    const int nz = solve_cubic_real(2.0 * p, p * p - 4.0 * r, -q * q, z0, z1, z2);
+    const int nz = solve_cubic_real<true>(2.0 * p, p * p - 4.0 * r, -q * q, z0, z1, z2);
     double z = z0;
     if (nz == 3) { z = z1 > z ? z1 : z; z = z2 > z ? z2 : z; }
     int mask = 0;
@@ -327,7 +359,7 @@ MDRP_HD int p3p_depths(double m01, double m02, double m12, double a01, double a0
     if (!(fabs(c3) > 1e-300)) return 0;
     const double ic3 = sv_rcp(c3);
     double g0, g1, g2;
-    const int nr = solve_cubic_real(c2 * ic3, c1 * ic3, c0 * ic3, g0, g1, g2);
+    const int nr = solve_cubic_real<true>(c2 * ic3, c1 * ic3, c0 * ic3, g0, g1, g2);
     double g = g0, best = linepair_quality(D1, D2, g0);
     if (nr == 3) {
         const double q1 = linepair_quality(D1, D2, g1), q2 = linepair_quality(D1, D2, g2);
