@@ -2280,8 +2280,13 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
     LmOpt o;
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
     o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+#ifdef MDRP_EXP_SAMEPAIR // experiment (wrong results, timing only): every problem sweeps one of 8 pairs' records — what would a perfect L2 buy?
+    const double *pp = pts + (size_t)(pair & 7) * rp.n_max * PT_STRIDE;
+    const double *dd = dep + (size_t)(pair & 7) * rp.n_max * 2;
+#else
     const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     const double *dd = dep + (size_t)pair * rp.n_max * 2;
+#endif
 #ifdef MDRP_LO_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
