@@ -2,7 +2,8 @@
 """Wide GPU-vs-oracle comparison (not part of the test suite): for every estimator, many noisy pairs over a spread of
 sizes, outlier rates, seeds and option sets.  Prints, per configuration, how many pairs land on exactly the oracle's
 trajectory (iterations, refinements, inliers, mask) and the worst model deviation among those.  Run on the GPU box:
-    python tests/tools/stress_parity.py [pairs_per_config]"""
+    python tests/tools/stress_parity.py [pairs_per_config]
+MDRP_STRESS_ONLY="kind,N" restricts the run to one configuration; pairs off the oracle's trajectory are listed."""
 import os
 import sys
 import time
@@ -21,6 +22,9 @@ t0 = time.time()
 for kind, es, rf in ((0, False, None), (0, True, None), (1, False, "shared"), (2, False, "varying")):
     for N, of, opts in ((150, 0.2, {}), (400, 0.5, {"min_iterations": 500}), (1000, 0.6, {"max_iterations": 3000, "min_iterations": 3000}),
                         (64, 0.0, {"min_iterations": 200, "seed": 7}), (2500, 0.35, {"max_iterations": 1500, "min_iterations": 1500, "seed": 3})):
+        only = os.environ.get("MDRP_STRESS_ONLY")
+        if only and (kind, N) != tuple(int(v) for v in only.split(",")):
+            continue
         b = synth.make_batch(9000 + 37 * N + 11 * kind + int(es), B, N, noise_px=0.7, depth_noise=0.03, outlier_frac=of, random_focal=rf,
                              shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
         ro = {"max_epipolar_error": 2.0, "max_reproj_error": 16.0, "monodepth_estimate_shift": es, **opts}
@@ -41,6 +45,9 @@ for kind, es, rf in ((0, False, None), (0, True, None), (1, False, "shared"), (2
             ok = (int(res[i]["iterations"]) == st.iterations and int(res[i]["refinements"]) == st.refinements
                   and int(res[i]["num_inliers"]) == st.num_inliers and (mask[i] == mk).all())
             same += ok
+            if not ok:
+                print(f"   pair {i}: gpu (ref {int(res[i]['refinements'])}, it {int(res[i]['iterations'])}, inl {int(res[i]['num_inliers'])}) "
+                      f"oracle ({st.refinements}, {st.iterations}, {st.num_inliers}), mask differs on {int((mask[i] != mk).sum())}", flush=True)
             dinl.append(int(res[i]["num_inliers"]) - st.num_inliers)
             if ok:
                 a = capi.model_to_array(res[i]["model"])
