@@ -190,6 +190,9 @@ int env_int(const char *name, int dflt) {
 // LDS work lists: 2 buffers of u16 indices, stride = n_max rounded to 64 (0 disables the lists)
 int lm_list_stride(int n_max) { return n_max <= LM_LIST_MAX_N ? ((n_max + 63) / 64) * 64 : 0; }
 size_t lm_list_bytes(int n_max) { return (size_t)2 * lm_list_stride(n_max) * sizeof(uint16_t); }
+// k_final: a third list (the indices a record mask lets through, lm_mask_index) while the three stay within 32 KiB of dynamic LDS
+int lm_mask_index_on(int n_max) { return lm_list_stride(n_max) > 0 && (size_t)3 * lm_list_stride(n_max) * sizeof(uint16_t) <= 32768 ? 1 : 0; }
+size_t lm_final_list_bytes(int n_max) { return (size_t)(2 + lm_mask_index_on(n_max)) * lm_list_stride(n_max) * sizeof(uint16_t); }
 
 int get_events(mdrp_handle *h, hipEvent_t *a, hipEvent_t *b, int what = 0) {
     if (h->ev_used == h->ev_pool.size()) {
@@ -518,6 +521,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int lo_threads = env_int("MDRP_LO_THREADS", (batch >= 128 && n_max < 4096) ? 64 : 256);
     const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
+    // the inlier-only final refinement walks a compacted index of the inliers instead of masking every record (MDRP_FINAL_MASK_INDEX=0: off)
+    const int mask_index = env_int("MDRP_FINAL_MASK_INDEX", 1) ? lm_mask_index_on(n_max) : 0;
     // Fused tail (mdrp_kernels.h FuseTail): when the end of the run is known on the host (the super-chunk reaches max_iterations), the
     // last LO launch replays each pair as its last trigger is refined (no k_walk launch), and k_final starts - on the main stream,
     // behind k_gate - as soon as the LO queue is empty, taking pairs in the order they became ready: the final refinements fill
@@ -855,8 +860,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                          (const int32_t *)fz_ready, fz_fin, wait_ticks, h->lm_stats.as<unsigned long long>() + 5);
             else
-                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
-                                 h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
+                                 h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
                                  h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready, fz_fin, wait_ticks,
                                  h->lm_stats.as<unsigned long long>() + 5);
             HIPCHK(hipEventRecord(g1, s));
@@ -868,8 +873,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                          (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr);
             else
-                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
-                                 h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
+                                 h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
                                  h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr);
         }
         if (!fuse_tail)
@@ -942,8 +947,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                  (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
     else {
-        MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), lm_list_bytes(n_max), s, rp, h->st.as<PairState>(),
-                         h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max),
+        MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
+                         h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
                          h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
     }
     HIPCHK(hipEventRecord(f1, s));

@@ -1663,8 +1663,11 @@ __device__ __forceinline__ lds_u16 *lds_cast(uint16_t *p) { return (lds_u16 *)p;
 struct LmShared {
     double scratch[4 * MAX_ACC];
     int count[2][4];
-    uint16_t *list;  // dynamic LDS, 2 * stride entries
+    uint16_t *list;  // dynamic LDS, 2 * stride entries (+ stride more when `midx` is set)
     int stride;
+    int midx;        // 1: a third list of `stride` entries behind the two work lists holds the indices of the records a record mask lets
+                     // through, per wavefront segment (lm_mask_index; the inlier-only final refinement); mcount = entries per wavefront
+    int mcount[4];
     unsigned long long *stats; // [0] correspondences evaluated by cost sweeps, [1] by accumulate sweeps (or null): bench.py's fp64 roofline
     unsigned long long ev[2];  // ... collected here per problem, flushed by lm_flush_stats
 #ifdef MDRP_LO_TRACE
@@ -1704,19 +1707,26 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     // address space gives ds_write_b16 and partial vmcnt waits back.
     lds_u16 *list = lds_cast(sh.list) + (size_t)buf * sh.stride;
     const int seg = ((n + T - 1) / T) * 64; // correspondences per wavefront, multiple of 64
-    const int lo = wave * seg, hi = min(n, lo + seg);
+    const int lo = wave * seg;
+    // Under a record mask (the inlier-only final refinement: about half of the records) the sweep walks the wavefront's compacted index list
+    // (lm_mask_index, built once per refinement) instead of evaluating every record and discarding the masked ones.
+    const lds_u16 *midx = (mask && use_list && sh.midx) ? lds_cast(sh.list) + 2 * (size_t)sh.stride : nullptr;
+    const int hi = midx ? lo + sh.mcount[wave] : min(n, lo + seg); // end of this wavefront's trips (list positions under a mask index)
     const int loss = LOSS >= 0 ? LOSS : o.loss;
     const double lsc = o.loss_scale, mu = o.mu, t2 = lsc * lsc;
     const bool ws_nz = ws != 0.0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     double cost = 0;
     int cnt = 0, evaluated = 0;
-    struct Rec { double a, b, c, d, e1, e2; bool ok; };
+    struct Rec { double a, b, c, d, e1, e2; int id; bool ok; };
     const int last = max(n - 1, 0);
     auto fetch = [&](int base) { // unconditional loads from a clamped index: no exec-mask branch around them; `ok` says whether the lane counts
         Rec r;
-        const int i = base + lane, ic = min(i, last);
-        r.ok = (int)(i < hi) & (int)(mask ? mask[ic] != 0 : true); // (integer AND on purpose, here and below: no short-circuit branches)
+        const int i = base + lane;
+        int ic;
+        if (midx) { r.ok = i < hi; ic = r.ok ? (int)midx[i] : last; }
+        else { ic = min(i, last); r.ok = (int)(i < hi) & (int)(mask ? mask[ic] != 0 : true); } // (integer AND on purpose, here and below: no short-circuit branches)
+        r.id = ic;
         const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
         const double2 p01 = P[0], p23 = P[1];
         const double2 dd = *reinterpret_cast<const double2 *>(dep + 2 * (size_t)ic);
@@ -1761,15 +1771,15 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
             cost += t.r[u].ok ? vs[u] : 0.0; // (+ 0.0 leaves a non-negative sum as it is: the order and the values of round 3's `if`s)
             cost += fwd[u] ? vf[u] : 0.0;
             cost += bwd[u] ? vb[u] : 0.0;
-            if (mask && sh.stats) evaluated += __popcll(__ballot(t.r[u].ok));
+            if (mask && !midx && sh.stats) evaluated += __popcll(__ballot(t.r[u].ok));
             if (use_list) {
                 const unsigned long long ball = __ballot(contrib[u]);
-                if (contrib[u]) list[lo + cnt + __popcll(ball & lt)] = (uint16_t)(base + 64 * u + lane);
+                if (contrib[u]) list[lo + cnt + __popcll(ball & lt)] = (uint16_t)t.r[u].id;
                 cnt += __popcll(ball);
             }
         }
     };
-    if (!mask) evaluated = max(hi - lo, 0);
+    if (!mask || midx) evaluated = max(hi - lo, 0);
 #if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
     const unsigned long long tl0 = wall_clock64();
 #endif
@@ -1945,6 +1955,27 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
     block_sum<NA, T>(acc, sh.scratch);
 }
 
+// indices of the records a mask lets through, compacted per wavefront segment in record order (the segments of lm_cost / lm_accumulate):
+// the third list behind the two work lists.  The inlier-only final refinement sweeps ~half of the records up to 100 times.
+template <int T>
+__device__ void lm_mask_index(const uint8_t *__restrict__ mask, int n, LmShared &sh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = ((n + T - 1) / T) * 64;
+    const int lo = wave * seg, hi = min(n, lo + seg);
+    lds_u16 *midx = lds_cast(sh.list) + 2 * (size_t)sh.stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int cnt = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int i = base + lane;
+        const bool in = i < hi && mask[i] != 0;
+        const unsigned long long ball = __ballot(in);
+        if (in) midx[lo + cnt + __popcll(ball & lt)] = (uint16_t)i;
+        cnt += __popcll(ball);
+    }
+    if (lane == 0) sh.mcount[wave] = cnt;
+    __syncthreads();
+}
+
 // lm_impl<> loop of the reference (upstream PoseLib convention): executed redundantly and uniformly by every
 // thread of the workgroup; only the two sweeps over the correspondences are distributed.
 // Round 4: ONE call site each for the cost and the normal-equation sweep (the initial cost is the first trip of the loop), and
@@ -1966,6 +1997,7 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
     double A[NP * NP], g[NP], sol[NP];
     Model cand = m;
     int it = 0;
+    if (mask && sh.stride > 0 && sh.midx) lm_mask_index<T>(mask, n, sh);
 #ifdef MDRP_LO_TRACE
     unsigned long long tr_c = 0, tr_a = 0, tr_t;
     const unsigned long long tr_0 = wall_clock64();
@@ -2325,7 +2357,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
 #ifdef MDRP_LO_TRACE
     if (threadIdx.x == 0) sh.tloop = 0;
 #endif
@@ -2412,7 +2444,8 @@ __device__ void final_pair(const RunParams &rp, const PairState &ps, const doubl
 template <int KIND, bool SHIFT, int T>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
-                                                      ResultDev *__restrict__ results, int list_stride, unsigned long long *__restrict__ lm_stats,
+                                                      ResultDev *__restrict__ results, int list_stride, int mask_index /*1: 3 * list_stride entries of dynamic LDS*/,
+                                                      unsigned long long *__restrict__ lm_stats,
                                                       const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/,
                                                       int32_t *__restrict__ fin_done /*fused: set per refined pair; unfused: pairs to skip, or null*/,
                                                       unsigned long long ticks, unsigned long long *__restrict__ timeouts /*fused: expired bounded waits*/) {
@@ -2421,7 +2454,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     __shared__ int s_pair;
     __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
     if (threadIdx.x == 0) {
-        sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0;
+        sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = mask_index; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0;
         int p = blockIdx.x;
         if (ready) { // fused tail: the blockIdx-th pair to become ready (bounded wait, see k_gate)
             const unsigned long long t0 = wall_clock64();
@@ -2517,7 +2550,7 @@ __global__ __launch_bounds__(T) void k_refine_unit(int count, Model *__restrict_
                                                             double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost, int list_stride) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.stats = nullptr; sh.ev[0] = 0; sh.ev[1] = 0; }
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = nullptr; sh.ev[0] = 0; sh.ev[1] = 0; }
     __syncthreads();
     const int i = blockIdx.x;
     if (i >= count) return;
