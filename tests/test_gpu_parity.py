@@ -505,9 +505,12 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
                 {"MDRP_CHUNKS": "128", "MDRP_FUSE_TAIL": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_FUSE_TAIL": "1"},
                 # one LO queue for the chip instead of one per XCD (lo_take): which workgroup refines which trigger is scheduling only
                 {"MDRP_CHUNKS": "128", "MDRP_LO_XCD": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_LO_XCD": "0", "MDRP_FUSE_TAIL": "0"},
-                {"MDRP_CHUNKS": "64,256", "MDRP_LO_XCD": "1", "MDRP_LO_OVERLAP_WAVES": "2"}):
+                {"MDRP_CHUNKS": "64,256", "MDRP_LO_XCD": "1", "MDRP_LO_OVERLAP_WAVES": "2"},
+                # the inlier-only final refinement over every record with a mask instead of the compacted inlier index (lm_mask_index)
+                {"MDRP_CHUNKS": "128", "MDRP_FINAL_MASK_INDEX": "0"}, {"MDRP_CHUNKS": "128", "MDRP_FINAL_MASK_INDEX": "1", "MDRP_FINAL_THREADS": "64"}):
         for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_AFTER_COUNT", "MDRP_BOUND",
-                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP", "MDRP_SOLVE_PARTS", "MDRP_LO_XCD"):
+                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP", "MDRP_SOLVE_PARTS", "MDRP_LO_XCD",
+                  "MDRP_FINAL_MASK_INDEX"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -516,7 +519,7 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
             assert np.array_equal(res[f], ref[f]), (env, f)
         assert np.array_equal(mask, ref_mask), env
         # thread-count variants reduce in a different order: models agree to rounding, not bitwise
-        tol = 1e-9 if ("MDRP_LO_THREADS" in env or "MDRP_FINAL_THREADS" in env or "MDRP_LM_ENGINE" in env) else 0.0
+        tol = 1e-9 if ("MDRP_LO_THREADS" in env or "MDRP_FINAL_THREADS" in env or "MDRP_LM_ENGINE" in env or "MDRP_FINAL_MASK_INDEX" in env) else 0.0
         def flat(m):
             return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
         assert np.allclose(flat(res["model"]), flat(ref["model"]), rtol=tol, atol=tol), env
@@ -570,6 +573,46 @@ def test_lm_engines_agree_on_every_estimator(capi, monkeypatch, kind, es, rf, lo
         dm = np.abs(flat(r["model"]) - flat(r0["model"])).max(axis=1)
         assert (dm[big] < (1e-7 if es else 1e-9)).all() and (dm < 1e-6).all(), (eng, dm)
         assert np.allclose(r["model_score"], r0["model_score"], rtol=1e-8, atol=1e-12), eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_max", [900, 5440, 5441, 6000])
+def test_final_refinement_over_the_inlier_index_matches_the_masked_sweep(capi, monkeypatch, n_max):
+    """The inlier-only final refinement (estimate_* tail @0x2247c3 / @0x223815) walks a compacted index of the inliers (lm_mask_index: a third LDS list,
+    N <= 5440) instead of evaluating every record under the mask: same arithmetic, another lane -> record assignment.  Integer statistics and masks
+    identical, models to 1e-9 — on ragged pairs (short ones, few inliers, N at and beyond the list limit) for the calibrated and the varying-focal estimator,
+    64 and 256 lanes per pair; beyond the limit both settings take the old path and must agree bit for bit."""
+    from mdrp_amd import synth
+    ns = [n_max, n_max - 1, 700, 257, 64, 5, 3, 0]
+    B = len(ns)
+    for kind, rf in ((0, None), (2, "varying")):
+        x1, x2 = np.zeros((B, n_max, 2)), np.zeros((B, n_max, 2))
+        d1, d2 = np.ones((B, n_max)), np.ones((B, n_max))
+        for i, n in enumerate(ns):
+            if n:
+                b = synth.make_batch(7100 + 13 * i + kind, 1, n, noise_px=0.6, depth_noise=0.02, outlier_frac=0.7 if i == 2 else 0.4, random_focal=rf)
+                x1[i, :n], x2[i, :n], d1[i, :n], d2[i, :n] = b["x1"][0], b["x2"][0], b["d1"][0], b["d2"][0]
+        cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+        ro = capi.ransac_opt_from_dict({"max_iterations": 400, "min_iterations": 400, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+        bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+        out = {}
+        for threads in ("256", "64"):
+            for mi in ("0", "1"):
+                monkeypatch.setenv("MDRP_FINAL_THREADS", threads); monkeypatch.setenv("MDRP_FINAL_MASK_INDEX", mi)
+                h = capi.Handle(0)
+                res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, np.array(ns, dtype=np.int32), cams if kind == 0 else None, cams if kind == 0 else None)
+                out[(threads, mi)] = (res.copy(), mask.copy())
+                h.close()
+        def flat(m):
+            return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
+        for threads in ("256", "64"):
+            (r0, m0), (r1, m1) = out[(threads, "0")], out[(threads, "1")]
+            for f in ("refinements", "iterations", "num_inliers"):
+                assert np.array_equal(r0[f], r1[f]), (kind, threads, f)
+            assert np.array_equal(m0, m1), (kind, threads)
+            tol = 0.0 if n_max > 5440 else 1e-9
+            assert np.allclose(flat(r0["model"]), flat(r1["model"]), rtol=tol, atol=tol), (kind, threads)
+        assert int(out[("256", "1")][0]["num_inliers"][0]) > n_max // 3
 
 
 @pytest.mark.gpu
