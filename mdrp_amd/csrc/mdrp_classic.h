@@ -394,12 +394,27 @@ __device__ double clm_cost(const Model &m, const double *__restrict__ pts, int n
     ClmState<CK> s;
     clm_setup<CK>(m, s);
     double cost = 0;
+    // the next record is requested before the current one is consumed (unconditional loads from a clamped index): a trip is ~50 instructions,
+    // the records come from L2 or beyond — without the look-ahead every trip paid the round trip (round 4; same records, same order: bit-identical)
+    const int last = n > 0 ? n - 1 : 0;
+    auto fetch = [&](int i, double2 &p01, double2 &p23, bool &ok) {
+        const int ic = i < last ? i : last;
+        ok = (int)(i < n) & (int)(mask ? mask[ic] != 0 : true);
+        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
+        p01 = P[0]; p23 = P[1];
+    };
+    double2 c01, c23;
+    bool cok;
+    fetch(threadIdx.x, c01, c23, cok);
     for (int i = threadIdx.x; i < n; i += T) {
-        if (mask && !mask[i]) continue;
-        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
-        const double2 p01 = P[0], p23 = P[1];
-        const double r = clm_point<CK, false>(s, p01.x, p01.y, p23.x, p23.y, nullptr);
-        cost += loss_value(o.loss, o.loss_scale, r * r);
+        double2 n01, n23;
+        bool nok;
+        fetch(i + T, n01, n23, nok);
+        if (cok) {
+            const double r = clm_point<CK, false>(s, c01.x, c01.y, c23.x, c23.y, nullptr);
+            cost += loss_value(o.loss, o.loss_scale, r * r);
+        }
+        c01 = n01; c23 = n23; cok = nok;
     }
     double v[1] = {cost};
     block_sum<1, T>(v, scratch);
@@ -416,23 +431,37 @@ __device__ void clm_accumulate(const Model &m, const double *__restrict__ pts, i
     for (int i = 0; i < 6; ++i) tb_out[i] = (CK == CLASSIC_FUND) ? 0.0 : s.tb[i];
 #pragma unroll
     for (int i = 0; i < NT + NP; ++i) acc[i] = 0;
+    const int last = n > 0 ? n - 1 : 0;
+    auto fetch = [&](int i, double2 &p01, double2 &p23, bool &ok) { // one record ahead, as in clm_cost
+        const int ic = i < last ? i : last;
+        ok = (int)(i < n) & (int)(mask ? mask[ic] != 0 : true);
+        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
+        p01 = P[0]; p23 = P[1];
+    };
+    double2 c01, c23;
+    bool cok;
+    fetch(threadIdx.x, c01, c23, cok);
     for (int i = threadIdx.x; i < n; i += T) {
-        if (mask && !mask[i]) continue;
-        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
-        const double2 p01 = P[0], p23 = P[1];
-        double J[NP];
-        const double r = clm_point<CK, true>(s, p01.x, p01.y, p23.x, p23.y, J);
-        const double w = loss_weight(o.loss, o.loss_scale, r * r, o.mu);
-        if (w == 0.0) continue;
-        int idx = 0;
+        double2 n01, n23;
+        bool nok;
+        fetch(i + T, n01, n23, nok);
+        if (cok) {
+            double J[NP];
+            const double r = clm_point<CK, true>(s, c01.x, c01.y, c23.x, c23.y, J);
+            const double w = loss_weight(o.loss, o.loss_scale, r * r, o.mu);
+            if (w != 0.0) {
+                int idx = 0;
 #pragma unroll
-        for (int a = 0; a < NP; ++a) {
-            const double wa = w * J[a];
+                for (int a = 0; a < NP; ++a) {
+                    const double wa = w * J[a];
 #pragma unroll
-            for (int b = 0; b <= a; ++b) acc[idx++] += wa * J[b];
+                    for (int b = 0; b <= a; ++b) acc[idx++] += wa * J[b];
+                }
+#pragma unroll
+                for (int a = 0; a < NP; ++a) acc[NT + a] += w * r * J[a];
+            }
         }
-#pragma unroll
-        for (int a = 0; a < NP; ++a) acc[NT + a] += w * r * J[a];
+        c01 = n01; c23 = n23; cok = nok;
     }
     block_sum<NT + NP, T>(acc, scratch);
 }
