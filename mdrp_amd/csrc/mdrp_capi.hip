@@ -523,6 +523,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
     // the inlier-only final refinement walks a compacted index of the inliers instead of masking every record (MDRP_FINAL_MASK_INDEX=0: off)
     const int mask_index = env_int("MDRP_FINAL_MASK_INDEX", 1) ? lm_mask_index_on(n_max) : 0;
+    // work lists of the classic LM (mdrp_classic.h ClmList; MDRP_CLASSIC_LISTS=0: every sweep visits every record)
+    const int clm_list_stride = env_int("MDRP_CLASSIC_LISTS", 1) ? lm_list_stride(n_max) : 0;
+    const size_t clm_list_bytes = (size_t)2 * clm_list_stride * sizeof(uint16_t);
     // Fused tail (mdrp_kernels.h FuseTail): when the end of the run is known on the host (the super-chunk reaches max_iterations), the
     // last LO launch replays each pair as its last trigger is refined (no k_walk launch), and k_final starts - on the main stream,
     // behind k_gate - as soon as the LO queue is empty, taking pairs in the order they became ready: the final refinements fill
@@ -822,9 +825,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             auto launch_lo_kernels = [=]() -> int {
                 if (use_lme) return lme_lo(h, aux2, rp_lo, kind, est_shift, lo_plan, trig_cap, 0, lme_cap);
                 if (classic) {
-                    MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), 0, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
+                    MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), clm_list_bytes, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
                                              h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, xheads_c,
-                                             h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max, fz);
+                                             h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max, clm_list_stride, fz);
                     return MDRP_OK;
                 }
                 MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
@@ -857,8 +860,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if ((rc = get_events(h, &g0, &g1, 3))) return rc;
             HIPCHK(hipEventRecord(g0, s));
             if (classic)
-                MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                         (const int32_t *)fz_ready, fz_fin, wait_ticks, h->lm_stats.as<unsigned long long>() + 5);
+                MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
+                                         (const int32_t *)fz_ready, fz_fin, wait_ticks, h->lm_stats.as<unsigned long long>() + 5, clm_list_stride);
             else
                 MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
@@ -870,8 +873,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         if (piped) { HIPCHK(hipEventRecord(h->ev_lo, aux2)); HIPCHK(hipStreamWaitEvent(s, h->ev_lo, 0)); }
         if (fuse_tail) { // behind the LO launch: the pairs a bounded wait gave up on (none in a healthy run: 1024 workgroups that read a flag)
             if (classic)
-                MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                         (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr);
+                MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
+                                         (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr, clm_list_stride);
             else
                 MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
@@ -944,8 +947,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     HIPCHK(hipEventRecord(f0, s));
     if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
     else if (classic)
-        MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
-                                 (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
+        MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
+                                 (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr, clm_list_stride);
     else {
         MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
                          h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,

@@ -388,34 +388,59 @@ __device__ __forceinline__ double clm_point(const ClmState<CK> &s, double a, dou
     return r0;
 }
 
+// Work lists of the classic LM (round 4, the scheme of mdrp_kernels.h lm_cost / lm_accumulate): with a truncated loss a record beyond the
+// threshold has IRLS weight zero and adds nothing to J'J, but inside a wavefront its lanes ride along through the ~300-instruction Jacobian
+// code whenever one lane contributes.  The cost sweep — which runs for every candidate anyway — appends the indices of the contributing
+// records to an LDS list, compacted per wavefront with a ballot; the normal-equation sweep of an accepted model walks its list with every
+// lane busy.  Two lists: the current model's and the candidate's.  stride == 0 (pairs beyond LM_LIST_MAX_N records, the unit entry point): off.
+struct ClmList {
+    uint16_t *list; // dynamic LDS, 2 * stride entries
+    int stride;
+    int count[2][4];
+};
+
 template <int CK, int T>
 __device__ double clm_cost(const Model &m, const double *__restrict__ pts, int n, const uint8_t *__restrict__ mask, const LmOpt &o,
-                           double *scratch) {
+                           double *scratch, ClmList &cl, int buf) {
     ClmState<CK> s;
     clm_setup<CK>(m, s);
     double cost = 0;
-    // the next record is requested before the current one is consumed (unconditional loads from a clamped index): a trip is ~50 instructions,
-    // the records come from L2 or beyond — without the look-ahead every trip paid the round trip (round 4; same records, same order: bit-identical)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool use_list = cl.stride > 0;
+    // wavefront w sweeps the records [w * seg, (w + 1) * seg) in trips of 64; the next record is requested before the current one is consumed
+    // (unconditional loads from a clamped index): a trip is ~50 instructions, the records come from L2 or beyond
+    const int seg = ((n + T - 1) / T) * 64, lo = wave * seg, hi = n < lo + seg ? n : lo + seg;
+    lds_u16 *list = lds_cast(cl.list) + (size_t)buf * cl.stride;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int last = n > 0 ? n - 1 : 0;
     auto fetch = [&](int i, double2 &p01, double2 &p23, bool &ok) {
         const int ic = i < last ? i : last;
-        ok = (int)(i < n) & (int)(mask ? mask[ic] != 0 : true);
+        ok = (int)(i < hi) & (int)(mask ? mask[ic] != 0 : true);
         const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
         p01 = P[0]; p23 = P[1];
     };
     double2 c01, c23;
     bool cok;
-    fetch(threadIdx.x, c01, c23, cok);
-    for (int i = threadIdx.x; i < n; i += T) {
+    int cnt = 0;
+    fetch(lo + lane, c01, c23, cok);
+    for (int base = lo; base < hi; base += 64) {
         double2 n01, n23;
         bool nok;
-        fetch(i + T, n01, n23, nok);
+        fetch(base + 64 + lane, n01, n23, nok);
+        bool contrib = false;
         if (cok) {
             const double r = clm_point<CK, false>(s, c01.x, c01.y, c23.x, c23.y, nullptr);
             cost += loss_value(o.loss, o.loss_scale, r * r);
+            contrib = loss_weight(o.loss, o.loss_scale, r * r, o.mu) != 0.0;
+        }
+        if (use_list) {
+            const unsigned long long ball = __ballot(contrib);
+            if (contrib) list[lo + cnt + __popcll(ball & lt)] = (uint16_t)(base + lane);
+            cnt += __popcll(ball);
         }
         c01 = n01; c23 = n23; cok = nok;
     }
+    if (use_list && lane == 0) cl.count[buf][wave] = cnt;
     double v[1] = {cost};
     block_sum<1, T>(v, scratch);
     return v[0];
@@ -423,7 +448,7 @@ __device__ double clm_cost(const Model &m, const double *__restrict__ pts, int n
 
 template <int CK, int T>
 __device__ void clm_accumulate(const Model &m, const double *__restrict__ pts, int n, const uint8_t *__restrict__ mask, const LmOpt &o,
-                               double *acc, double *tb_out, double *scratch) {
+                               double *acc, double *tb_out, double *scratch, ClmList &cl, int buf) {
     constexpr int NP = ClassicTraits<CK>::NP, NT = NP * (NP + 1) / 2;
     ClmState<CK> s;
     clm_setup<CK>(m, s);
@@ -431,20 +456,27 @@ __device__ void clm_accumulate(const Model &m, const double *__restrict__ pts, i
     for (int i = 0; i < 6; ++i) tb_out[i] = (CK == CLASSIC_FUND) ? 0.0 : s.tb[i];
 #pragma unroll
     for (int i = 0; i < NT + NP; ++i) acc[i] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int seg = ((n + T - 1) / T) * 64, lo = wave * seg, hi = n < lo + seg ? n : lo + seg;
+    const bool use_list = cl.stride > 0;
+    const lds_u16 *list = lds_cast(cl.list) + (size_t)buf * cl.stride;
+    const int trips_end = use_list ? cl.count[buf][wave] : (hi > lo ? hi - lo : 0); // list entries, or records of the segment
     const int last = n > 0 ? n - 1 : 0;
-    auto fetch = [&](int i, double2 &p01, double2 &p23, bool &ok) { // one record ahead, as in clm_cost
-        const int ic = i < last ? i : last;
-        ok = (int)(i < n) & (int)(mask ? mask[ic] != 0 : true);
+    auto fetch = [&](int k, double2 &p01, double2 &p23, bool &ok) { // k: position in the list / in the segment; one record ahead, as in clm_cost
+        ok = k < trips_end;
+        int ic;
+        if (use_list) ic = ok ? (int)list[lo + k] : last;
+        else { ic = lo + k < last ? lo + k : last; ok = (int)ok & (int)(mask ? mask[ic] != 0 : true); }
         const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)ic * PT_STRIDE);
         p01 = P[0]; p23 = P[1];
     };
     double2 c01, c23;
     bool cok;
-    fetch(threadIdx.x, c01, c23, cok);
-    for (int i = threadIdx.x; i < n; i += T) {
+    fetch(lane, c01, c23, cok);
+    for (int k0 = 0; k0 < trips_end; k0 += 64) {
         double2 n01, n23;
         bool nok;
-        fetch(i + T, n01, n23, nok);
+        fetch(k0 + 64 + lane, n01, n23, nok);
         if (cok) {
             double J[NP];
             const double r = clm_point<CK, true>(s, c01.x, c01.y, c23.x, c23.y, J);
@@ -577,19 +609,20 @@ __device__ __forceinline__ void clm_compose(const Model &ff, Model &out) {
 // lm_impl<> loop, executed uniformly by all threads of the problem's workgroup; the two sweeps are distributed
 template <int CK, int T>
 __device__ void clm_refine(Model &model, const double *__restrict__ pts, int n, const uint8_t *__restrict__ mask, const LmOpt &o_in,
-                           double *scratch) {
+                           double *scratch, ClmList &cl) {
     constexpr int NP = ClassicTraits<CK>::NP, NT = NP * (NP + 1) / 2;
     LmOpt o = o_in;
     o.mu = 0.5;
     Model m = model;
     if (CK == CLASSIC_FUND) clm_factorize(model_F(model), m);
-    double cost = clm_cost<CK, T>(m, pts, n, mask, o, scratch);
+    int cur = 0; // list buffer of the current model
+    double cost = clm_cost<CK, T>(m, pts, n, mask, o, scratch, cl, cur);
     double lambda = o.lambda0;
     bool recompute = true;
     double acc[NT + NP], A[NP * NP], g[NP], sol[NP], tb[6];
     for (int it = 0; it < o.max_it; ++it) {
         if (recompute) {
-            clm_accumulate<CK, T>(m, pts, n, mask, o, acc, tb, scratch);
+            clm_accumulate<CK, T>(m, pts, n, mask, o, acc, tb, scratch, cl, cur);
             double gn = 0;
             int idx = 0;
 #pragma unroll
@@ -612,9 +645,10 @@ __device__ void clm_refine(Model &model, const double *__restrict__ pts, int n, 
         if (sqrt(sn) < o.step_tol) break;
         Model cand;
         clm_step<CK>(m, sol, tb, cand);
-        const double cost_new = clm_cost<CK, T>(cand, pts, n, mask, o, scratch);
+        const double cost_new = clm_cost<CK, T>(cand, pts, n, mask, o, scratch, cl, cur ^ 1);
         if (cost_new < cost) {
             m = cand;
+            cur ^= 1;
             lambda = fmax(o.lambda_min, lambda / 10.0);
             cost = cost_new;
             recompute = true;
@@ -664,15 +698,15 @@ __device__ void cblock_score(const Model &m, const double *__restrict__ pts, int
 // refine_model of the estimators: RelativePoseEstimator refines on the inliers at 5 thr^2 of the incoming model (get_inliers,
 // kept only if more than the sample size), FundamentalEstimator on all correspondences; 25 iterations, TRUNCATED at eps
 template <int CK, int T>
-__device__ void clm_lo(Model &m, const PairState &ps, const double *__restrict__ pp, uint8_t *__restrict__ wg_mask, double *scratch) {
+__device__ void clm_lo(Model &m, const PairState &ps, const double *__restrict__ pp, uint8_t *__restrict__ wg_mask, double *scratch, ClmList &cl) {
     LmOpt o;
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
     o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-    if (CK == CLASSIC_FUND) { clm_refine<CK, T>(m, pp, ps.n, nullptr, o, scratch); return; }
+    if (CK == CLASSIC_FUND) { clm_refine<CK, T>(m, pp, ps.n, nullptr, o, scratch, cl); return; }
     double sc;
     int ni;
     cblock_score<CK, T>(m, pp, ps.n, 5.0 * ps.sq_thr, scratch, sc, ni, wg_mask);
-    if (ni > ClassicTraits<CK>::K) clm_refine<CK, T>(m, pp, ps.n, wg_mask, o, scratch);
+    if (ni > ClassicTraits<CK>::K) clm_refine<CK, T>(m, pp, ps.n, wg_mask, o, scratch, cl);
     __syncthreads(); // wg_mask is rewritten by the next problem
 }
 
@@ -682,9 +716,13 @@ __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__r
                                               const Model *__restrict__ models, Trigger *__restrict__ triggers, int trig_cap,
                                               const int32_t *__restrict__ plan, int32_t *__restrict__ head /*zeroed*/,
                                               int32_t *__restrict__ xheads /*zeroed, or null: lo_take (mdrp_kernels.h)*/,
-                                              uint8_t *__restrict__ lo_mask /*[gridDim.x][n_max]*/, FuseTail fz /*ready == null: off*/) {
+                                              uint8_t *__restrict__ lo_mask /*[gridDim.x][n_max]*/, int list_stride /*2 * list_stride u16 of dynamic LDS, or 0*/,
+                                              FuseTail fz /*ready == null: off*/) {
+    extern __shared__ uint16_t clm_dyn_list[];
     __shared__ double scratch[4 * MAX_ACC];
+    __shared__ ClmList cl;
     __shared__ int s_item;
+    if (threadIdx.x == 0) { cl.list = clm_dyn_list; cl.stride = list_stride; }
     const int32_t *prefix = plan, *begin = plan + rp.batch + 1, *end = begin + rp.batch;
     const int total = plan[3 * (size_t)rp.batch + 1];
     uint8_t *wg_mask = lo_mask + (size_t)blockIdx.x * rp.n_max;
@@ -706,7 +744,7 @@ __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__r
         const size_t slot_base = (size_t)pair * rp.slot_stride;
         Model m = models[slot_base + (size_t)tr.iter * rp.mps + tr.k_ref];
         const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
-        clm_lo<CK, T>(m, ps, pp, wg_mask, scratch);
+        clm_lo<CK, T>(m, ps, pp, wg_mask, scratch, cl);
         double sc;
         int cn;
         cblock_score<CK, T>(m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
@@ -728,7 +766,7 @@ __global__ __launch_bounds__(T, 2) void kc_lo(RunParams rp, const PairState *__r
 // @0x21f800: if more than 5 inliers; estimate_fundamental @0x221a00: more than 7, then F <- T2' F T1 / |.|)
 template <int CK, int T>
 __device__ void cfinal_pair(const RunParams &rp, const PairState &ps, const double *__restrict__ pts, uint8_t *__restrict__ mask_all,
-                            ResultDev *__restrict__ results, int pair, double *scratch) {
+                            ResultDev *__restrict__ results, int pair, double *scratch, ClmList &cl) {
     ResultDev res;
     res.model = ps.best;
     res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
@@ -742,7 +780,7 @@ __device__ void cfinal_pair(const RunParams &rp, const PairState &ps, const doub
     const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     Model m = ps.best;
     for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
-    clm_lo<CK, T>(m, ps, pp, mask, scratch); // the output mask doubles as the LO's subset mask
+    clm_lo<CK, T>(m, ps, pp, mask, scratch, cl); // the output mask doubles as the LO's subset mask
     res.refinements++;
     double sc;
     int cn;
@@ -754,7 +792,7 @@ __device__ void cfinal_pair(const RunParams &rp, const PairState &ps, const doub
         LmOpt f;
         f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
         f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;
-        clm_refine<CK, T>(best, pp, ps.n, mask, f, scratch);
+        clm_refine<CK, T>(best, pp, ps.n, mask, f, scratch, cl);
     }
     if (CK == CLASSIC_FUND) { // F <- T2' F T1, T = [1/s 0 -cx/s; 0 1/s -cy/s; 0 0 1], unit Frobenius norm
         double *F = model_F(best);
@@ -782,13 +820,18 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
                                                  uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results,
                                                  const int32_t *__restrict__ ready /*or null: pair = blockIdx.x*/,
                                                  int32_t *__restrict__ fin_done /*fused: set per refined pair; unfused: pairs to skip, or null*/,
-                                                 unsigned long long ticks, unsigned long long *__restrict__ timeouts /*fused: expired bounded waits*/) {
+                                                 unsigned long long ticks, unsigned long long *__restrict__ timeouts /*fused: expired bounded waits*/,
+                                                 int list_stride /*2 * list_stride u16 of dynamic LDS, or 0*/) {
+    extern __shared__ uint16_t clm_dyn_list[];
     __shared__ double scratch[4 * MAX_ACC];
+    __shared__ ClmList cl;
     __shared__ int s_pair;
+    if (threadIdx.x == 0) { cl.list = clm_dyn_list; cl.stride = list_stride; }
+    __syncthreads();
     __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
     if (!ready) {
         if (fin_done && fin_done[blockIdx.x]) return; // (uniform) the pass behind a fused tail: only what that left undone
-        cfinal_pair<CK, T>(rp, st[blockIdx.x], pts, mask_all, results, blockIdx.x, scratch);
+        cfinal_pair<CK, T>(rp, st[blockIdx.x], pts, mask_all, results, blockIdx.x, scratch, cl);
         return;
     }
     if (threadIdx.x == 0) { // fused tail: the blockIdx-th pair to become ready, bounded wait (k_final / k_gate, mdrp_kernels.h)
@@ -807,7 +850,7 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
         for (int i = threadIdx.x; i < (int)(sizeof(PairState) / 4); i += T) s_ps[i] = src[i];
     }
     __syncthreads();
-    cfinal_pair<CK, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, mask_all, results, s_pair, scratch);
+    cfinal_pair<CK, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, mask_all, results, s_pair, scratch, cl);
     if (threadIdx.x == 0) fin_done[s_pair] = 1;
 }
 
@@ -833,13 +876,16 @@ template <int CK, int T>
 __global__ __launch_bounds__(T) void kc_refine_unit(int count, Model *__restrict__ models, const double *__restrict__ pts, int n, LmOpt o,
                                                     double *__restrict__ final_cost) {
     __shared__ double scratch[4 * MAX_ACC];
+    __shared__ ClmList cl;
     const int i = blockIdx.x;
     if (i >= count) return;
+    if (threadIdx.x == 0) { cl.list = nullptr; cl.stride = 0; } // the unit entry point sweeps every record (no work lists)
+    __syncthreads();
     Model m = models[i];
-    clm_refine<CK, T>(m, pts, n, nullptr, o, scratch);
+    clm_refine<CK, T>(m, pts, n, nullptr, o, scratch, cl);
     Model f = m;
     if (CK == CLASSIC_FUND) clm_factorize(model_F(m), f);
-    const double c = clm_cost<CK, T>(f, pts, n, nullptr, o, scratch);
+    const double c = clm_cost<CK, T>(f, pts, n, nullptr, o, scratch, cl, 0);
     if (threadIdx.x == 0) { models[i] = m; if (final_cost) final_cost[i] = c; }
 }
 
