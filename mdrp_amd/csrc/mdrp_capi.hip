@@ -993,7 +993,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
     // the LM engine's problem table (lme_ensure in run_pass: max(batch, MDRP_LME_CAP or 48 per pair + 2048) problems) only where it runs
-    const bool budget_lme = kind <= 2 && env_int("MDRP_LM_ENGINE", kind == MDRP_VARYING_FOCAL ? 2 : 0) != 0;
+    const bool budget_lme = kind <= 2 && env_int("MDRP_LM_ENGINE", 0) != 0; // (the same default as run_pass)
     const size_t lme_fixed = budget_lme ? (size_t)std::max(env_int("MDRP_LME_CAP", 0), 2048) * lme_bytes_per_problem(n_max) : 0; // per pass, not per pair
     const size_t per_pair_all = per_pair + (budget_lme ? 49 * lme_bytes_per_problem(n_max) : 0) /*LM engine: 48 problems per pair and pass*/ +
                                 (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
