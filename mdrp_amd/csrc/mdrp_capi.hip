@@ -569,6 +569,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         const unsigned int zero = 0;
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace), &trace_buf, sizeof trace_buf));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace_n), &zero, sizeof zero));
+        static unsigned long long *fin_buf = nullptr;
+        if (!fin_buf) HIPCHK(hipMalloc(&fin_buf, 32ull * 65536));
+        HIPCHK(hipMemset(fin_buf, 0, 32ull * std::min(batch, 65536)));
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fin_trace), &fin_buf, sizeof fin_buf));
     }
 #endif
     uint64_t it0 = 0;
@@ -956,6 +960,19 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     }
     HIPCHK(hipEventRecord(f1, s));
     HIPCHK(hipGetLastError());
+#ifdef MDRP_LO_TRACE
+    if (const char *path = getenv("MDRP_LO_TRACE_FILE")) { // per-pair timing of the (unfused) final refinements: <file>.final
+        HIPCHK(hipStreamSynchronize(s));
+        unsigned long long *buf = nullptr;
+        HIPCHK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_fin_trace), sizeof buf));
+        if (buf && !classic) {
+            std::vector<unsigned long long> host(4ull * std::min(batch, 65536));
+            HIPCHK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
+            const std::string fp = std::string(path) + ".final";
+            if (FILE *f = fopen(fp.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
+        }
+    }
+#endif
     return MDRP_OK;
 }
 

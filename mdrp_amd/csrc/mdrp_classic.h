@@ -837,8 +837,10 @@ __global__ __launch_bounds__(T, 2) void kc_final(RunParams rp, PairState *__rest
     if (threadIdx.x == 0) { // fused tail: the blockIdx-th pair to become ready, bounded wait (k_final / k_gate, mdrp_kernels.h)
         int p;
         const unsigned long long t0 = wall_clock64();
-        while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
+        // polled RELAXED, one acquire fence when the pair is there (see k_final, mdrp_kernels.h)
+        while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
             __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (p < 0 && timeouts) atomicAdd(timeouts, 1ull); // gave up: the pass behind the LO launch refines this pair (mdrp_stats.fuse_wait_timeouts)
         __threadfence();
         s_pair = p;

@@ -2296,6 +2296,7 @@ __device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams
 #ifdef MDRP_LO_TRACE // experiment: per-problem timing of the LO kernels (tools/lo_trace.py)
 __device__ unsigned long long *g_lo_trace = nullptr; // 8 x u64 per problem
 __device__ unsigned int g_lo_trace_n = 0;
+__device__ unsigned long long *g_fin_trace = nullptr; // 4 x u64 per pair: pair | start | end | iterations of the inlier refinement | of the LO << 32
 #endif
 // LO of item w of the launch's plan (refine_model + score_model of the refined model), by the whole workgroup
 template <int KIND, bool SHIFT, int T>
@@ -2409,6 +2410,10 @@ __device__ void final_pair(const RunParams &rp, const PairState &ps, const doubl
     // a single call site is inlined into the kernel, so the kernel's launch bounds govern its registers.  (Called twice, lm_refine
     // stays a separate function compiled without them; in round 4 it grew to 256 VGPRs + 44 AGPRs = one wavefront per SIMD.)
     Model best = ps.best, m = ps.best;
+#ifdef MDRP_LO_TRACE
+    const unsigned long long tf0 = wall_clock64();
+    unsigned long long tf_it = 0;
+#endif
 #pragma unroll 1
     for (int phase = 0; phase < 2; ++phase) {
         LmOpt o;
@@ -2422,6 +2427,9 @@ __device__ void final_pair(const RunParams &rp, const PairState &ps, const doubl
         }
         Model x = phase == 0 ? m : best;
         lm_refine<KIND, SHIFT, T>(x, pp, dd, ps.n, phase == 0 ? nullptr : mask, ps.scale_reproj, rp.weight_sampson, o, sh);
+#ifdef MDRP_LO_TRACE
+        if (threadIdx.x == 0) tf_it |= (sh.ph[3] & 0xFFFFull) << (phase == 0 ? 32 : 0);
+#endif
         if (phase != 0) { best = x; break; }
         m = x;
         {
@@ -2439,6 +2447,12 @@ __device__ void final_pair(const RunParams &rp, const PairState &ps, const doubl
     res.model = best;
     __syncthreads();
     if (threadIdx.x == 0) { results[pair] = res; lm_flush_stats(sh); }
+#ifdef MDRP_LO_TRACE
+    if (threadIdx.x == 0 && g_fin_trace) {
+        unsigned long long *e = g_fin_trace + 4ull * pair;
+        e[0] = (unsigned long long)pair; e[1] = tf0; e[2] = wall_clock64(); e[3] = tf_it;
+    }
+#endif
 }
 
 template <int KIND, bool SHIFT, int T>
@@ -2458,8 +2472,12 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
         int p = blockIdx.x;
         if (ready) { // fused tail: the blockIdx-th pair to become ready (bounded wait, see k_gate)
             const unsigned long long t0 = wall_clock64();
-            while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
+            // polled RELAXED, one acquire fence when the pair is there: an acquire LOAD is followed by an invalidate of the XCD's L2, and the few
+            // hundred workgroups waiting here did that every microsecond while the last LO problems were still sweeping.  (Found with an experimental
+            // queue-driven k_final whose idle workgroups polled the same way: the pairs still running took twice as long per iteration.)
+            while ((p = __hip_atomic_load(ready + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0 && wall_clock64() - t0 < ticks)
                 __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             if (p < 0 && timeouts) atomicAdd(timeouts, 1ull); // gave up: the pass behind the LO launch refines this pair
             __threadfence(); // the replayed pair state (written on another CU / XCD) before anyone of this workgroup reads it
         } else if (fin_done && fin_done[p]) p = -1; // the pass behind a fused tail: only what that left undone

@@ -48,6 +48,23 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
             if w.any():
                 print(f"   started in [{lo_:.2f}, {hi_:.2f}) of the makespan: {w.sum()} problems; per sweep cost {t_cost[sel][w].sum() / (its[sel][w] + 1).sum():.1f} us, "
                       f"normal equations {t_acc[sel][w].sum() / np.maximum(accs[sel][w], 1).sum():.1f} us, rest per iteration {rest[w].sum() / np.maximum(its[sel][w], 1).sum():.1f} us")
+    try:
+        fin = np.fromfile(trace + ".final", dtype=np.uint64).reshape(-1, 4)
+        fin = fin[fin[:, 2] > 0]
+        t0 = fin[:, 1].min()
+        st = (fin[:, 1] - t0).astype(np.int64) / 100.0; en = (fin[:, 2] - t0).astype(np.int64) / 100.0
+        d = en - st
+        it1 = (fin[:, 3] & np.uint64(0xFFFF)).astype(np.int64); it0 = (fin[:, 3] >> np.uint64(32)).astype(np.int64)
+        print(f"final refinements (k_final): {len(d)} pairs; duration us: mean {d.mean():.0f} median {np.median(d):.0f} p90 {np.percentile(d, 90):.0f} p99 {np.percentile(d, 99):.0f} max {d.max():.0f}; "
+              f"makespan {en.max():.0f} us; sum / 512 workgroups = {d.sum() / 512:.0f} us")
+        print(f"   iterations: LO from the best model mean {it0.mean():.1f} max {it0.max()}; inlier refinement mean {it1.mean():.1f} p90 {np.percentile(it1, 90):.0f} max {it1.max()}; "
+              f"us per iteration of the inlier refinement ~ {(d.sum() / np.maximum(it0 + it1, 1).sum()):.1f} (both refinements pooled)")
+        order = np.argsort(-d)[:8]
+        print("   longest pairs (start us, duration us, iterations): " + ", ".join(f"({st[i]:.0f}, {d[i]:.0f}, {it0[i]}+{it1[i]})" for i in order))
+        late = st > 0.5 * en.max()
+        print(f"   pairs started in the second half of the makespan: {late.sum()}, their mean duration {d[late].mean() if late.any() else 0:.0f} us")
+    except FileNotFoundError:
+        pass
 else:
     env = dict(os.environ, MDRP_LIB=lib, MDRP_LO_TRACE_FILE=trace)
     if len(sys.argv) > 1:
