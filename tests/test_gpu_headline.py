@@ -1,4 +1,10 @@
-"""The batches bench.py times, pair by pair, through the entry point bench.py times (VERDICT r03, item 1).
+"""The batches bench.py times, pair by pair, through the entry point bench.py times (VERDICT r03 item 1, r04 item 1).
+
+Round 5: tests/golden/headline_ref_<workload>.npz (tests/tools/gen_golden_headline_ref.py) holds the output of the REFERENCE's own
+PoseLib binary for every one of the 1024 pairs of the four timed workloads (calibrated P3P, calibrated with shifts, shared focal,
+varying focal N = 5000) and `test_every_pair_of_the_bench_batch_vs_reference_fixture` compares the HIP path with those directly; the
+oracle fixture below stays as the second witness.  Where the reference and the oracle differ (LO count only, causes enumerated per pair
+in tests/golden/headline_ref_deviations.json by tests/tools/classify_ref_deviations.py) the test asserts the exact list.
 
 tests/golden/headline_<workload>.npz (tests/tools/gen_golden_headline.py) holds the CPU oracle's output for EVERY pair of
 the 1024-pair batches of BASELINE.json configs[1..3]: refinements, iterations, num_inliers, inlier_ratio, model_score, the
@@ -8,6 +14,8 @@ DEVICE-RESIDENT buffers + `mdrp_fetch_results` — what bench.py's timed region 
 A soak test repeats the headline step 200 times and demands bit-identical records and masks (fused tail on: the
 stale-read race of round 3 showed once in ~10^4 pairs).  Needs an MI355X:  pytest -m gpu."""
 import hashlib
+import json
+import os
 
 import numpy as np
 import pytest
@@ -17,10 +25,11 @@ from helpers import model_diff
 pytestmark = pytest.mark.gpu
 
 WORKLOADS = {
-    # name: (kind, shift flag, n, outlier_frac, random_focal)  == bench.py WORKLOADS / gen_golden_headline.HEADLINE
-    "calib_p3p_n2000_i10k": (0, False, 2000, 0.5, None),
-    "shared_n2000_i10k": (1, False, 2000, 0.5, "shared"),
-    "varying_n5000_i10k": (2, True, 5000, 0.5, "varying"),
+    # name: (kind, shift flag, n, outlier_frac, random_focal, depth shifts)  == bench.py WORKLOADS / gen_golden_headline.HEADLINE
+    "calib_p3p_n2000_i10k": (0, False, 2000, 0.5, None, (0.0, 0.0)),
+    "calib_shift_n2000_i10k": (0, True, 2000, 0.5, None, (0.2, -0.1)),
+    "shared_n2000_i10k": (1, False, 2000, 0.5, "shared", (0.0, 0.0)),
+    "varying_n5000_i10k": (2, True, 5000, 0.5, "varying", (0.0, 0.0)),
 }
 RO = {"max_iterations": 10000, "min_iterations": 10000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0}
 
@@ -45,9 +54,9 @@ class DeviceBatch:
         import torch
         from mdrp_amd import synth
         self.capi, self.torch = capi, torch
-        self.kind, es, self.n, of, rf = WORKLOADS[workload]
+        self.kind, es, self.n, of, rf, (s1, s2) = WORKLOADS[workload]
         self.B = B
-        self.host = synth.make_batch(0, B, self.n, noise_px=0.5, depth_noise=0.02, outlier_frac=of, random_focal=rf)
+        self.host = synth.make_batch(0, B, self.n, noise_px=0.5, depth_noise=0.02, outlier_frac=of, random_focal=rf, shift1=s1, shift2=s2)
         dev = torch.device("cuda", 0)
         self.t = [torch.from_numpy(self.host[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
         self.mask = torch.zeros((B, self.n), dtype=torch.uint8, device=dev)
@@ -72,7 +81,7 @@ def test_every_pair_of_the_bench_batch_vs_oracle_fixture(capi, golden, workload)
     """All 1024 pairs of the batch bench.py times for this workload, through the device-resident entry point: iterations,
     inlier count and inlier mask identical on every pair, model to 1e-6 (north_star's tolerance; measured 1e-9), score to 1e-9.
     The LO count (`refinements`) equals the oracle's except on the rounding-tie class of DESIGN.md §5 (v): two scores that
-    agree to ~1e-14 compared with `<`, decided by FMA contraction — at most 4 pairs in 1024 may differ, by exactly one LO,
+    agree to ~1e-14 compared with `<`, decided by FMA contraction — the pairs are listed in GPU_MINUS_ORACLE_LO (exact list),
     with everything else on those pairs identical."""
     g = golden(f"headline_{workload}")
     db = DeviceBatch(capi, workload)
@@ -101,8 +110,81 @@ def test_every_pair_of_the_bench_batch_vs_oracle_fixture(capi, golden, workload)
     assert np.allclose(res["inlier_ratio"], fst[:, 0], rtol=1e-12, atol=0), workload
     dlo = res["refinements"].astype(np.int64) - ist[:, 0]
     off = np.nonzero(dlo)[0]
-    assert len(off) <= 4 and (np.abs(dlo[off]) == 1).all(), (workload, off, dlo[off])
+    assert dict(zip(off.tolist(), dlo[off].tolist())) == GPU_MINUS_ORACLE_LO[workload], (workload, off, dlo[off])
     print(f"{workload}: 1024 / 1024 pairs identical (iterations, inliers, mask); worst model diff {worst:.2e}; LO count differs on {len(off)} pairs {off.tolist()}")
+
+
+# ---- against the reference binary's own output for every pair (round 5) -------------------------------------------------------------
+# LO count (`refinements`) of the HIP path minus the CPU oracle's, by pair: the rounding-tie class of DESIGN.md 5 (v) — two scores that
+# agree to ~1e-14 compared with `<`, decided by FMA contraction / the LM's summation tree.  Everything else on these pairs is identical.
+# An explicit list, not a budget: a build that moves a tie fails here and the list is updated deliberately.
+GPU_MINUS_ORACLE_LO = {
+    "calib_p3p_n2000_i10k": {},
+    "calib_shift_n2000_i10k": {},
+    "shared_n2000_i10k": {957: -1},
+    "varying_n5000_i10k": {},
+}
+# pairs whose final MODEL differs from the reference's by more than north_star's 1e-6: the reference's relpose_monodepth_3pt returns a NaN
+# model where ours returns a true root of the minimal problem (residual 4e-16); that root's LO ends 5e-8 lower in score, the RANSAC winner
+# differs in the 8th digit of its score, and the inlier-only refinement of the weakly observable shifts stops 1.2e-3 apart
+# (tests/tools/diag_headline_pair.py calib_shift_n2000_i10k 897; inliers and mask identical).  On these pairs the HIP path must equal the oracle.
+MODEL_FOLLOWS_ORACLE = {"calib_shift_n2000_i10k": (897,)}
+
+
+@pytest.mark.parametrize("workload", list(WORKLOADS))
+def test_every_pair_of_the_bench_batch_vs_reference_fixture(capi, golden, workload):
+    """All 1024 pairs of the batch bench.py times for this workload against the output of the reference's own PoseLib binary
+    (estimate_monodepth_relative_pose @0x224170 / estimate_shared_focal_... @0x223300 / estimate_varying_focal_... @0x223a40;
+    options of /root/reference/make_video.py:192-196): iterations, inlier count and inlier mask identical on every pair, model
+    within 1e-6, model_score to 1e-9; `refinements` equal to the reference's except on the pairs enumerated, with their cause, in
+    tests/golden/headline_ref_deviations.json (reference solver returns NaN / misses a root / returns an extra root; rounding ties) and
+    in GPU_MINUS_ORACLE_LO above — asserted as an exact list."""
+    ref = golden(f"headline_ref_{workload}")
+    orc = golden(f"headline_{workload}")
+    dev = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "headline_ref_deviations.json")))["deviations"][workload]
+    db = DeviceBatch(capi, workload)
+    try:
+        for i in range(0, db.B, 37):
+            assert _digest(db.host, i) == ref["digest"][i] == orc["digest"][i], "synthetic generator drifted"
+        res = db.run()
+        mask = db.mask.cpu().numpy()
+    finally:
+        db.close()
+    n = db.n
+    ist, fst = ref["istats"], ref["fstats"]
+    assert np.array_equal(res["iterations"].astype(np.int64), ist[:, 1]) and (ist[:, 1] == 10000).all()
+    bad_cnt = np.nonzero(res["num_inliers"].astype(np.int64) != ist[:, 2])[0]
+    assert len(bad_cnt) == 0, (workload, bad_cnt[:8], res["num_inliers"][bad_cnt[:8]], ist[bad_cnt[:8], 2])
+    ref_mask = np.unpackbits(ref["mask"], axis=1)[:, :n]
+    bad_mask = np.nonzero((mask != ref_mask).any(axis=1))[0]
+    assert len(bad_mask) == 0, (workload, bad_mask[:8])
+    assert np.allclose(res["inlier_ratio"], fst[:, 0], rtol=1e-12, atol=0), workload
+    follows = set(MODEL_FOLLOWS_ORACLE.get(workload, ()))
+    worst = 0.0
+    for i in range(db.B):
+        want = orc["model"][i] if i in follows else ref["model"][i]
+        d = model_diff(capi.model_to_array(res[i]["model"]), want)
+        worst = max(worst, d)
+        assert d < 1e-6, (workload, i, d)
+        if i in follows:
+            assert str(i) in dev and "ref_" in dev[str(i)]["cause"], (workload, i)
+    # the RANSAC winner's score: where the reference's solver lost a root the winner can differ in the last digits (oracle and HIP path agree there)
+    sc_ref_ok = np.isclose(res["model_score"], fst[:, 1], rtol=1e-9, atol=0)
+    sc_orc_ok = np.isclose(res["model_score"], orc["fstats"][:, 1], rtol=1e-9, atol=0)
+    assert sc_orc_ok.all(), (workload, np.nonzero(~sc_orc_ok)[0])
+    for i in np.nonzero(~sc_ref_ok)[0]:
+        assert str(i) in dev and "ref_" in dev[str(i)]["cause"], (workload, int(i), res["model_score"][i], fst[i, 1])
+    expected = np.zeros(db.B, dtype=np.int64)
+    for k, v in dev.items():
+        expected[int(k)] += v["oracle_minus_reference"]
+    for k, v in GPU_MINUS_ORACLE_LO[workload].items():
+        expected[k] += v
+    dlo = res["refinements"].astype(np.int64) - ist[:, 0]
+    wrong = np.nonzero(dlo != expected)[0]
+    assert len(wrong) == 0, (workload, {int(i): (int(dlo[i]), int(expected[i])) for i in wrong})
+    off = np.nonzero(dlo)[0]
+    print(f"{workload} vs REFERENCE binary: 1024 / 1024 pairs identical (iterations, inliers, mask); worst model diff {worst:.2e}; score differs beyond 1e-9 on "
+          f"{int((~sc_ref_ok).sum())} pairs; LO count differs on {len(off)} pairs (all enumerated): {dict(zip(off.tolist(), dlo[off].tolist()))}")
 
 
 def test_headline_step_soak_is_bit_identical(capi):
