@@ -38,7 +38,10 @@ enum { /* return codes */
     MDRP_OK = 0,
     MDRP_ERR_INVALID = 1,   /* bad argument */
     MDRP_ERR_HIP = 2,       /* a HIP runtime call failed; mdrp_last_error() has the text */
-    MDRP_ERR_NO_DEVICE = 3  /* no usable gfx950 device */
+    MDRP_ERR_NO_DEVICE = 3, /* no usable gfx950 device */
+    MDRP_ERR_UNSUPPORTED = 4 /* ABI 0.4: a RansacOptions switch of the reference that selects behaviour this library does not build
+                              * (progressive_sampling = PROSAC; real_focal_check on the 6- / 7-point baselines).  Refused, never ignored:
+                              * the reference would switch samplers / drop models and return different results. */
 };
 
 enum { /* where the caller's buffers live */
@@ -71,6 +74,14 @@ typedef struct {
                                        * (black-box: any initial pose gives the same result).  The reset model has E = 0: no inliers,
                                        * score N eps^2; its LO changes nothing.  Reproduced as that state: records start at
                                        * (0, N eps^2) and `refinements` at 1 (tests/golden/initial.npz). */
+    /* ---- ABI 0.4: the remaining RansacOptions fields of the reference (+0x38 progressive_sampling,
+     * +0x40 max_prosac_iterations, +0x48 real_focal_check), so that a host can hand its options over unabridged.
+     * PROSAC (RandomSampler::initialize_prosac @0x4f8a20) is not built — every caller in the reference passes
+     * progressive_sampling = False (eval.py:99, make_video.py:192): a non-zero value is refused with MDRP_ERR_UNSUPPORTED
+     * on every estimator.  (This field sits where ABI 0.3 had a zero `reserved_` word.) */
+    int32_t progressive_sampling;    /* 0 */
+    uint64_t max_prosac_iterations;  /* 100000; read only with progressive_sampling, i.e. never */
+    int32_t real_focal_check;        /* 0.  Only the 6- / 7-point baselines look at it in the reference; refused there when set */
     int32_t reserved_;
 } mdrp_ransac_opt;
 
@@ -115,6 +126,11 @@ const char *mdrp_last_error(void);
 /* "mdrp-hip <ver> (gfx950) MDRP_SRC_HASH=<16 hex digits>": the hash covers mdrp_capi.hip, mdrp_kernels.h, mdrp_math.h,
  * mdrp_classic.h, mdrp_classic_math.h and this header as they were when the library was built (mdrp_amd/build.py source_hash()) */
 const char *mdrp_version(void);
+/* ABI 0.4: (major << 16) | minor of the structs and entry points in this header = 0x00000004.  Within one major, minors only append
+ * (fields behind the existing ones, new entry points); mdrp_ransac_opt grew from 72 to 88 bytes in 0.4, so a host built against 0.3
+ * must be recompiled — compare this with MDRP_ABI_VERSION of the header it was compiled against. */
+#define MDRP_ABI_VERSION 0x00000004
+int mdrp_abi_version(void);
 /* HIP_VERSION (major * 10^7 + minor * 10^5 + patch) of the toolchain the library was compiled with.  The library carries no HIP
  * runtime of its own (it binds to the host process's libamdhip64 when it is loaded): a host compares this with
  * hipRuntimeGetVersion() of the runtime it links; mdrp_amd/_capi.py refuses a different major. */
@@ -222,7 +238,7 @@ typedef struct {
      * Fused tail (the last LO launch and the final refinements overlap on two streams): bounded waits that expired in the
      * last call.  Non-zero means kernels of the handle's streams did not run side by side (serialising profiler / debugger,
      * AMD_SERIALIZE_KERNEL, a busy shared GPU): results are unaffected, the call was slower, final_ms includes the waits, and the
-     * handle runs unfused from the next call on. */
+     * handle runs unfused for its next 64 calls (MDRP_FUSE_RETRY_CALLS), then tries again. */
     int64_t fuse_gate_timeouts;
     int64_t fuse_wait_timeouts;
 } mdrp_stats;

@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
-    "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_hip_build_version", "mdrp_synchronize", "mdrp_estimate_batch",
+    "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_abi_version", "mdrp_hip_build_version", "mdrp_synchronize", "mdrp_estimate_batch",
     "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_copy_results_device", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_bound_models", "mdrp_refine_models",
     "mdrp_last_sweep_stats", "mdrp_last_stats", "mdrp_last_stats_sized", "mdrp_classic_solver_batch",
 )
@@ -33,7 +33,8 @@ class RansacOpt(C.Structure):
     _fields_ = [("max_iterations", C.c_uint64), ("min_iterations", C.c_uint64), ("dyn_num_trials_mult", C.c_double),
                 ("success_prob", C.c_double), ("max_reproj_error", C.c_double), ("max_epipolar_error", C.c_double),
                 ("seed", C.c_uint64), ("monodepth_estimate_shift", C.c_int32), ("monodepth_weight_sampson", C.c_float),
-                ("score_initial_model", C.c_int32), ("reserved_", C.c_int32)]
+                ("score_initial_model", C.c_int32), ("progressive_sampling", C.c_int32), ("max_prosac_iterations", C.c_uint64),
+                ("real_focal_check", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class BundleOpt(C.Structure):
@@ -88,6 +89,9 @@ def load_library():
         vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
         lib.mdrp_last_error.restype = C.c_char_p
         lib.mdrp_version.restype = C.c_char_p
+        lib.mdrp_abi_version.restype = C.c_int
+        if lib.mdrp_abi_version() != ABI_VERSION:
+            raise MdrpError(f"{LIB_PATH} speaks ABI {lib.mdrp_abi_version():#x}, this binding {ABI_VERSION:#x}: rebuild (mdrp_amd/build.py)")
         lib.mdrp_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
         lib.mdrp_create_on_stream.argtypes = [C.c_int, vp, C.POINTER(vp)]
         lib.mdrp_destroy.argtypes = [vp]
@@ -113,7 +117,13 @@ def load_library():
         return lib
 
 
+ABI_VERSION = 0x00000004  # include/mdrp.h MDRP_ABI_VERSION
+ERR_UNSUPPORTED = 4  # include/mdrp.h MDRP_ERR_UNSUPPORTED: a reference option that selects behaviour the library does not build
+
+
 def _check(lib, rc):
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(f"mdrp: {lib.mdrp_last_error().decode(errors='replace')} (DESIGN.md 9)")
     if rc != 0:
         raise MdrpError(f"mdrp error {rc}: {lib.mdrp_last_error().decode(errors='replace')}")
 
@@ -124,13 +134,16 @@ def _ptr(a):
 
 def ransac_opt_from_dict(d=None):
     """RansacOptions from a poselib-style dict; defaults as the reference's pybind wrapper (SURVEY.md §5);
-    unknown keys are ignored like the reference does."""
+    unknown keys are ignored like the reference does.  progressive_sampling / max_prosac_iterations / real_focal_check travel to the
+    library, which refuses what it does not build (MDRP_ERR_UNSUPPORTED -> NotImplementedError) instead of ignoring it."""
     d = d or {}
     return RansacOpt(int(d.get("max_iterations", 100000)), int(d.get("min_iterations", 1000)),
                      float(d.get("dyn_num_trials_mult", 3.0)), float(d.get("success_prob", 0.9999)),
                      float(d.get("max_reproj_error", 12.0)), float(d.get("max_epipolar_error", 1.0)),
                      int(d.get("seed", 0)), int(bool(d.get("monodepth_estimate_shift", False))),
-                     float(d.get("monodepth_weight_sampson", 1.0)), int(bool(d.get("score_initial_model", False))), 0)
+                     float(d.get("monodepth_weight_sampson", 1.0)), int(bool(d.get("score_initial_model", False))),
+                     int(bool(d.get("progressive_sampling", False))), int(d.get("max_prosac_iterations", 100000)),
+                     int(bool(d.get("real_focal_check", False))), 0)
 
 
 LOSS_TYPES = {"TRIVIAL": 0, "TRUNCATED": 1, "HUBER": 2, "CAUCHY": 3, "TRUNCATED_CAUCHY": 4, "TRUNCATED_LE_ZACH": 5}
@@ -218,7 +231,10 @@ def _ensure_hip_runtime():
     import glob
     # the SONAME major follows the ROCm release: whatever /opt/rocm (or ROCM_PATH) ships, newest first, then the linker's search
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-    cands += sorted(glob.glob(os.path.join(rocm, "lib", "libamdhip64.so.*")), key=len)[:1] + ["libamdhip64.so", os.path.join(rocm, "lib", "libamdhip64.so")]
+    def _soname_version(path):
+        tail = os.path.basename(path).split(".so.", 1)[-1]
+        return tuple(int(x) for x in tail.split(".") if x.isdigit())
+    cands += sorted(glob.glob(os.path.join(rocm, "lib", "libamdhip64.so.*")), key=_soname_version, reverse=True) + ["libamdhip64.so", os.path.join(rocm, "lib", "libamdhip64.so")]
     errs = []
     for c in cands:
         try:

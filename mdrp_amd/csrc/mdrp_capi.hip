@@ -124,7 +124,8 @@ struct mdrp_handle {
                                       // fused tail: gate time-outs | final-refinement wait time-outs
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
     int64_t fuse_gate_timeouts = 0, fuse_wait_timeouts = 0; // of the last call
-    bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, stay unfused
+    bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, run unfused ...
+    int fuse_retry_in = 0;            // ... for this many calls, then try the fused tail again (a busy moment on a shared GPU is not a profiler)
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -161,6 +162,32 @@ namespace {
     do {                                                                                                             \
         if ((threads) == 64) MDRP_LM_DISPATCH_T(KERNEL, 64, kind, shift, grid, smem, stream, __VA_ARGS__);           \
         else MDRP_LM_DISPATCH_T(KERNEL, 256, kind, shift, grid, smem, stream, __VA_ARGS__);                          \
+    } while (0)
+
+// k_final: the user's loss type of the inlier-only refinement is a template parameter as well (rp.final_loss): the reference's default CAUCHY,
+// the paper scripts' TRUNCATED_CAUCHY and TRIVIAL as constants, every other type through the run-time switch (-1)
+#ifdef MDRP_FAST_BUILD
+#define MDRP_FINAL_DISPATCH_L(T, FL, kind, shift, grid, smem, stream, ...) hipLaunchKernelGGL((k_final<0, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__)
+#else
+#define MDRP_FINAL_DISPATCH_L(T, FL, kind, shift, grid, smem, stream, ...)                                                  \
+    do {                                                                                                                   \
+        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((k_final<0, true, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);  \
+        else if ((kind) == 0) hipLaunchKernelGGL((k_final<0, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
+        else if ((kind) == 1) hipLaunchKernelGGL((k_final<1, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL((k_final<2, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);                        \
+    } while (0)
+#endif
+#define MDRP_FINAL_DISPATCH_T(T, floss, kind, shift, grid, smem, stream, ...)                                               \
+    do {                                                                                                                   \
+        if ((floss) == 4) MDRP_FINAL_DISPATCH_L(T, 4, kind, shift, grid, smem, stream, __VA_ARGS__);                       \
+        else if ((floss) == 3) MDRP_FINAL_DISPATCH_L(T, 3, kind, shift, grid, smem, stream, __VA_ARGS__);                  \
+        else if ((floss) == 0) MDRP_FINAL_DISPATCH_L(T, 0, kind, shift, grid, smem, stream, __VA_ARGS__);                  \
+        else MDRP_FINAL_DISPATCH_L(T, -1, kind, shift, grid, smem, stream, __VA_ARGS__);                                   \
+    } while (0)
+#define MDRP_FINAL_DISPATCH(threads, floss, kind, shift, grid, smem, stream, ...)                                           \
+    do {                                                                                                                   \
+        if ((threads) == 64) MDRP_FINAL_DISPATCH_T(64, floss, kind, shift, grid, smem, stream, __VA_ARGS__);               \
+        else MDRP_FINAL_DISPATCH_T(256, floss, kind, shift, grid, smem, stream, __VA_ARGS__);                              \
     } while (0)
 
 // scoring sweeps: pose models with cheirality (calibrated monodepth, 5-point), F = diag(1,1,f2) E diag(1,1,f1) (focal estimators),
@@ -534,6 +561,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // with the shift solver's 9-parameter LM the final refinements are 1.5x the LO's tail and gain nothing (12.75 -> 12.9 ms): off there.
     // After a bounded wait expired on this handle (kernels of two streams do not run side by side here: serialising profiler,
     // AMD_SERIALIZE_KERNEL, a busy shared GPU) the handle stays unfused, unless MDRP_FUSE_TAIL is set explicitly.
+    if (h->fuse_disabled && --h->fuse_retry_in <= 0) h->fuse_disabled = false; // re-armed: one expired wait costs FUSE_RETRY_CALLS unfused calls, not the handle's lifetime
     const bool fuse_env = env_int("MDRP_FUSE_TAIL", ((kind == MDRP_CALIB && est_shift) || h->fuse_disabled) ? 0 : 1) != 0;
     bool final_done = false;
     // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
@@ -856,8 +884,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             const int32_t *plan_l = h->work_pair.as<int32_t>() + (size_t)cl * lo_plan_ints;
             const int lo_blocks_l = h->num_cu * (lo_threads_last == 64 ? 8 : 2); // = lo_blocks of the last chunk's launch above
             // bounded waits (k_gate): far beyond anything a healthy run needs (the LO queue of 1024 pairs is empty after ~1 ms)
-            const unsigned long long gate_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_GATE_US", 50000 + 40 * batch);
-            const unsigned long long wait_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_WAIT_US", 20000 + 4 * batch);
+            // ... and scaled with the problem size: one LO problem is ~0.4 ms at N = 2000 and grows linearly with N (4 ms at 5000 on one wavefront)
+            const int n_scale = std::max(1, (n_max + 1999) / 2000);
+            const unsigned long long gate_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_GATE_US", (50000 + 40 * batch) * n_scale);
+            const unsigned long long wait_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_WAIT_US", (20000 + 4 * batch) * n_scale);
             hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const int32_t *)(cnt + CNT_LO_HEAD + cl), plan_l + 3 * (size_t)batch + 1,
                                (const int32_t *)fz_ctl, lo_blocks_l, gate_ticks, h->lm_stats.as<unsigned long long>() + 4);
             hipEvent_t g0, g1;
@@ -867,7 +897,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                          (const int32_t *)fz_ready, fz_fin, wait_ticks, h->lm_stats.as<unsigned long long>() + 5, clm_list_stride);
             else
-                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
+                MDRP_FINAL_DISPATCH(final_threads, rp.final_loss, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
                                  h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)fz_ready, fz_fin, wait_ticks,
                                  h->lm_stats.as<unsigned long long>() + 5);
@@ -880,7 +910,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                          (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr, clm_list_stride);
             else
-                MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
+                MDRP_FINAL_DISPATCH(final_threads, rp.final_loss, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
                                  h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
                                  h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, fz_fin, 0ull, (unsigned long long *)nullptr);
         }
@@ -954,7 +984,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                  (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr, clm_list_stride);
     else {
-        MDRP_LM_DISPATCH(k_final, final_threads, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
+        MDRP_FINAL_DISPATCH(final_threads, rp.final_loss, kind, est_shift, dim3(batch), (mask_index ? lm_final_list_bytes(n_max) : lm_list_bytes(n_max)), s, rp, h->st.as<PairState>(),
                          h->pts.as<double>(), h->dep.as<double>(), mask_dev, results_dev, lm_list_stride(n_max), mask_index,
                          h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
     }
@@ -984,6 +1014,9 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     if (kind == MDRP_SHARED_6PT && batch > 0 && !cam1) { g_err = "the 6-point estimator needs the principal point in cam1"; return MDRP_ERR_INVALID; }
     if ((kind == MDRP_CALIB || kind == MDRP_RELPOSE_5PT) && batch > 0 && (!cam1 || !cam2)) { g_err = "calibrated estimator needs cameras"; return MDRP_ERR_INVALID; }
     if (kind <= 2 && batch > 0 && n_max > 0 && (!d1 || !d2)) { g_err = "monodepth estimator needs depths"; return MDRP_ERR_INVALID; }
+    // RansacOptions switches of the reference that are not built are refused, never ignored (the reference would return different results)
+    if (ro->progressive_sampling) { g_err = "progressive_sampling (PROSAC, RandomSampler::initialize_prosac) is not built"; return MDRP_ERR_UNSUPPORTED; }
+    if (ro->real_focal_check && (kind == MDRP_SHARED_6PT || kind == MDRP_FUNDAMENTAL_7PT)) { g_err = "real_focal_check is not built"; return MDRP_ERR_UNSUPPORTED; }
     const int mps = kind == MDRP_RELPOSE_5PT ? 12 : (kind == MDRP_SHARED_6PT ? 16 : 4);
     h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch; h->lm_cost_evals = 0; h->lm_accum_evals = 0;
     int rc;
@@ -1039,10 +1072,11 @@ int finish_timing(mdrp_handle *h) {
     if ((h->fuse_gate_timeouts || h->fuse_wait_timeouts) && !h->fuse_disabled) {
         // results are unaffected (the pass behind the LO launch refined what the waits gave up on), the call was slower than unfused
         h->fuse_disabled = true;
+        h->fuse_retry_in = env_int("MDRP_FUSE_RETRY_CALLS", 64);
         if (!getenv("MDRP_QUIET"))
             fprintf(stderr, "[mdrp] fused tail: %lld gate / %lld final-refinement waits timed out (kernels of two streams did not overlap: "
-                            "profiler or serialised dispatch?); this handle continues unfused\n",
-                    (long long)h->fuse_gate_timeouts, (long long)h->fuse_wait_timeouts);
+                            "profiler or serialised dispatch?); this handle runs unfused for its next %d calls\n",
+                    (long long)h->fuse_gate_timeouts, (long long)h->fuse_wait_timeouts, h->fuse_retry_in);
     }
     for (int k = 0; k < 6; ++k) { h->kind_ms[k] = 0; h->kind_launches[k] = 0; }
     for (size_t i = 0; i < h->ev_used; ++i) {
@@ -1073,7 +1107,8 @@ extern "C" {
 
 const char *mdrp_last_error(void) { return g_err.c_str(); }
 // the build embeds a hash of the source files (mdrp_amd/build.py) so that a stale prebuilt library can be told from the tree
-const char *mdrp_version(void) { return "mdrp-hip 0.3 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
+int mdrp_abi_version(void) { return MDRP_ABI_VERSION; }
+const char *mdrp_version(void) { return "mdrp-hip 0.4 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
 
 // HIP_VERSION of the toolchain this library was compiled with (the runtime is bound at load time: mdrp_amd/_capi.py compares the two)
 int mdrp_hip_build_version(void) { return HIP_VERSION; }

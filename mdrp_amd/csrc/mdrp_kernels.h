@@ -2389,64 +2389,75 @@ struct ResultDev {
     double inlier_ratio, model_score;
 };
 
-template <int KIND, bool SHIFT, int T>
-__device__ void final_pair(const RunParams &rp, const PairState &ps, const double *__restrict__ pts, const double *__restrict__ dep,
-                           uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results, int pair, LmShared &sh) {
+// FLOSS: the user's loss type of the inlier-only refinement as a compile-time constant (rp.final_loss; -1 = read o.loss at run time).
+// Round 5: the two refinements of ransac<>'s tail are two call sites of lm_refine, each with its loss (and whether a record mask
+// exists) known to the compiler — the LO with TRUNCATED exactly as k_lo compiles it (unit-weight rows, no products by the weight), the
+// inlier-only refinement without the six-way loss switch in its sweeps.  Nothing but the model under refinement is live across an LM:
+// the round-4 kernel carried `best`, `m`, `x` and the result record (100 VGPRs) through both refinements and spilled 201-449 VGPRs.
+template <int KIND, bool SHIFT, int T, int FLOSS>
+__device__ __forceinline__ void final_pair(const RunParams &rp, const PairState &ps, const double *__restrict__ pts, const double *__restrict__ dep,
+                                           uint8_t *__restrict__ mask_all, ResultDev *__restrict__ results, int pair, LmShared &sh) {
     double *scratch = sh.scratch;
-    ResultDev res;
-    res.model = ps.best;
-    res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
-    res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
     uint8_t *mask = mask_all + (size_t)pair * rp.n_max;
     if (ps.n < 3) {
         for (int i = threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
-        if (threadIdx.x == 0) results[pair] = res;
+        if (threadIdx.x == 0) {
+            ResultDev res;
+            res.model = ps.best;
+            res.refinements = ps.refinements; res.iterations = ps.iterations; res.num_inliers = ps.num_inliers;
+            res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
+            results[pair] = res;
+        }
         return;
     }
     const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     const double *dd = dep + (size_t)pair * rp.n_max * 2;
-    // The two refinements of ransac<>'s tail — the last LO from the best model (25 iterations, TRUNCATED, all records), then the
-    // estimator's inlier-only refinement with the user's BundleOptions — run through ONE call site of lm_refine in a two-trip loop:
-    // a single call site is inlined into the kernel, so the kernel's launch bounds govern its registers.  (Called twice, lm_refine
-    // stays a separate function compiled without them; in round 4 it grew to 256 VGPRs + 44 AGPRs = one wavefront per SIMD.)
-    Model best = ps.best, m = ps.best;
 #ifdef MDRP_LO_TRACE
     const unsigned long long tf0 = wall_clock64();
     unsigned long long tf_it = 0;
 #endif
-#pragma unroll 1
-    for (int phase = 0; phase < 2; ++phase) {
+    // ransac<>'s last LO from the best model: 25 iterations, TRUNCATED, all records
+    Model x = ps.best;
+    {
         LmOpt o;
-        if (phase == 0) {
-            o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
-            o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-        } else {
-            if (!(res.num_inliers > 3)) break;
-            o.max_it = rp.final_max_it; o.loss = rp.final_loss; o.loss_scale = ps.final_loss_scale;
-            o.grad_tol = rp.grad_tol; o.step_tol = rp.step_tol; o.lambda0 = rp.lambda0; o.lambda_min = rp.lambda_min; o.lambda_max = rp.lambda_max;
-        }
-        Model x = phase == 0 ? m : best;
-        lm_refine<KIND, SHIFT, T>(x, pp, dd, ps.n, phase == 0 ? nullptr : mask, ps.scale_reproj, rp.weight_sampson, o, sh);
-#ifdef MDRP_LO_TRACE
-        if (threadIdx.x == 0) tf_it |= (sh.ph[3] & 0xFFFFull) << (phase == 0 ? 32 : 0);
-#endif
-        if (phase != 0) { best = x; break; }
-        m = x;
-        {
-            res.refinements++;
-            double sc;
-            int cn;
-            block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
-            if (sc < ps.model_score) { best = m; res.num_inliers = (uint64_t)cn; } // score / ratio NOT updated (reference)
-            for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
-            block_score<T>(KIND, best, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask);
-            __syncthreads();
-        }
+        o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
+        o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
+        lm_refine<KIND, SHIFT, T, 1>(x, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
     }
-    if (KIND != 0) { best.f1 *= ps.norm; best.f2 *= ps.norm; }
-    res.model = best;
+#ifdef MDRP_LO_TRACE
+    if (threadIdx.x == 0) tf_it |= (sh.ph[3] & 0xFFFFull) << 32;
+#endif
+    uint64_t num_inliers = ps.num_inliers;
+    {
+        double sc;
+        int cn;
+        block_score<T>(KIND, x, pp, ps.n, ps.sq_thr, scratch, sc, cn, nullptr);
+        if (sc < ps.model_score) num_inliers = (uint64_t)cn; // the refined model is adopted; score / ratio NOT updated (reference)
+        else x = ps.best;                                    // (re-read: no second model is kept live across the LM)
+        for (int i = ps.n + threadIdx.x; i < rp.n_max; i += T) mask[i] = 0;
+        block_score<T>(KIND, x, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask); // get_inliers of the winner
+        __syncthreads();
+    }
+    // the estimator's inlier-only refinement with the user's BundleOptions
+    if (num_inliers > 3) {
+        LmOpt o;
+        o.max_it = rp.final_max_it; o.loss = FLOSS >= 0 ? FLOSS : rp.final_loss; o.loss_scale = ps.final_loss_scale;
+        o.grad_tol = rp.grad_tol; o.step_tol = rp.step_tol; o.lambda0 = rp.lambda0; o.lambda_min = rp.lambda_min; o.lambda_max = rp.lambda_max;
+        lm_refine<KIND, SHIFT, T, FLOSS>(x, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, o, sh);
+#ifdef MDRP_LO_TRACE
+        if (threadIdx.x == 0) tf_it |= sh.ph[3] & 0xFFFFull;
+#endif
+    }
+    if (KIND != 0) { x.f1 *= ps.norm; x.f2 *= ps.norm; }
     __syncthreads();
-    if (threadIdx.x == 0) { results[pair] = res; lm_flush_stats(sh); }
+    if (threadIdx.x == 0) {
+        ResultDev res;
+        res.model = x;
+        res.refinements = ps.refinements + 1; res.iterations = ps.iterations; res.num_inliers = num_inliers;
+        res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
+        results[pair] = res;
+        lm_flush_stats(sh);
+    }
 #ifdef MDRP_LO_TRACE
     if (threadIdx.x == 0 && g_fin_trace) {
         unsigned long long *e = g_fin_trace + 4ull * pair;
@@ -2455,7 +2466,7 @@ __device__ void final_pair(const RunParams &rp, const PairState &ps, const doubl
 #endif
 }
 
-template <int KIND, bool SHIFT, int T>
+template <int KIND, bool SHIFT, int T, int FLOSS>
 __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, PairState *__restrict__ st, const double *__restrict__ pts,
                                                       const double *__restrict__ dep, uint8_t *__restrict__ mask_all,
                                                       ResultDev *__restrict__ results, int list_stride, int mask_index /*1: 3 * list_stride entries of dynamic LDS*/,
@@ -2485,17 +2496,17 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     }
     __syncthreads();
     if (s_pair < 0) return;
-    if (!ready) { final_pair<KIND, SHIFT, T>(rp, st[s_pair], pts, dep, mask_all, results, s_pair, sh); return; }
-    // The pair state was written DURING this launch (by the LO workgroup that replayed the pair).  This kernel never writes `st`, so the
-    // compiler may fetch st[pair] through the scalar cache, which an acquire does not invalidate and which can hold the cache line that
-    // the previous pair's last field shares with this pair's head from BEFORE the replay: read it once, with vector loads, into LDS.
+    // The pair state is read ONCE, with vector loads, into LDS.  Fused: it was written DURING this launch (by the LO workgroup that replayed the
+    // pair); this kernel never writes `st`, so the compiler may fetch st[pair] through the scalar cache, which an acquire does not invalidate and
+    // which can hold the cache line that the previous pair's last field shares with this pair's head from BEFORE the replay.  Unfused: the same
+    // copy keeps ONE call site of final_pair (round 4 compiled the 17 k-instruction body twice) and the pair's fields re-readable from LDS.
     {
         const volatile unsigned int *src = reinterpret_cast<const volatile unsigned int *>(st + s_pair);
         for (int i = threadIdx.x; i < (int)(sizeof(PairState) / 4); i += T) s_ps[i] = src[i];
     }
     __syncthreads();
-    final_pair<KIND, SHIFT, T>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, dep, mask_all, results, s_pair, sh);
-    if (threadIdx.x == 0) fin_done[s_pair] = 1;
+    final_pair<KIND, SHIFT, T, FLOSS>(rp, *reinterpret_cast<const PairState *>(s_ps), pts, dep, mask_all, results, s_pair, sh);
+    if (ready && threadIdx.x == 0) fin_done[s_pair] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels

@@ -142,15 +142,21 @@ def estimate_local_shard_device(kind, total, x1, x2, d1, d2, ransac_opt=None, bu
     dev = x1.device
     h = handle if handle is not None else _capi.default_handle(dev.index if dev.index is not None else torch.cuda.current_device())
     rec_local = torch.zeros((per, RECORD_BYTES), dtype=torch.uint8, device=dev)
+    if mask is not None and (not mask.is_contiguous() or mask.dtype != torch.uint8 or tuple(mask.shape) != tuple(x1.shape[:2])):
+        raise ValueError("mask must be a contiguous (rows, N) uint8 CUDA tensor")
+    # Contiguous views FIRST, bound to locals that live until the results are copied out: .contiguous() of a strided tensor queues a copy
+    # kernel on torch's stream and returns a temporary — the synchronize below must come after those copies, and the temporaries must not
+    # be freed (and their memory reused by the caching allocator) while the handle's stream still reads them.
+    x1c, x2c = x1.contiguous(), x2.contiguous()
+    d1c = d1.contiguous() if d1 is not None else None
+    d2c = d2.contiguous() if d2 is not None else None
     torch.cuda.current_stream(dev).synchronize()  # the inputs may have been produced on torch's stream; the handle runs on its own
     if rows > 0:
-        n = x1.shape[1]
-        x1, x2 = x1.contiguous(), x2.contiguous()
-        d1p = d1.contiguous().data_ptr() if d1 is not None else 0
-        d2p = d2.contiguous().data_ptr() if d2 is not None else 0
-        h.estimate_batch_device(kind, x1.data_ptr(), x2.data_ptr(), d1p, d2p, rows, n, ro, bo, n_per_pair, cam1, cam2,
-                                mask.data_ptr() if mask is not None else None)
+        n = x1c.shape[1]
+        h.estimate_batch_device(kind, x1c.data_ptr(), x2c.data_ptr(), d1c.data_ptr() if d1c is not None else 0, d2c.data_ptr() if d2c is not None else 0,
+                                rows, n, ro, bo, n_per_pair, cam1, cam2, mask.data_ptr() if mask is not None else None)
         h.copy_results_device(rec_local.data_ptr(), rows)  # returns after the handle's stream has drained
+    del x1c, x2c, d1c, d2c  # (kept alive until here on purpose)
     return gather_records(rec_local, total, group, dev, force_collective=force_collective)
 
 

@@ -28,7 +28,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_capi.Model) == 96 and C.sizeof(_capi.Camera) == 40 and C.sizeof(_capi.Result) == 136
-    assert C.sizeof(_capi.RansacOpt) == 72 and C.sizeof(_capi.BundleOpt) == 64
+    assert C.sizeof(_capi.RansacOpt) == 88 and C.sizeof(_capi.BundleOpt) == 64  # ABI 0.4: + progressive_sampling, max_prosac_iterations, real_focal_check
+    assert _capi.RansacOpt.progressive_sampling.offset == 68 and _capi.RansacOpt.max_prosac_iterations.offset == 72 and _capi.RansacOpt.real_focal_check.offset == 80
+    hdr0 = open(os.path.join(ROOT, "include", "mdrp.h")).read()
+    assert int(re.search(r"#define MDRP_ABI_VERSION (0x[0-9a-fA-F]+)", hdr0).group(1), 16) == _capi.ABI_VERSION == _capi.load_library().mdrp_abi_version()
     # mdrp_stats: every field is 8 bytes; the binding's field list must be the header's, in order
     hdr = open(os.path.join(ROOT, "include", "mdrp.h")).read()
     body = hdr[hdr.index("typedef struct {", hdr.index("fp64 sweep of the hypotheses")):hdr.index("} mdrp_stats;")]
@@ -59,6 +62,9 @@ def test_no_cpu_fallback_in_product():
 def test_option_dicts_follow_reference_defaults():
     ro = _capi.ransac_opt_from_dict({"lo_iterations": 25, "weight_sampson": 1.0})  # unknown keys ignored (make_pair.py:31-33)
     assert (ro.max_iterations, ro.min_iterations, ro.max_reproj_error, ro.max_epipolar_error, ro.seed) == (100000, 1000, 12.0, 1.0, 0)
+    assert (ro.progressive_sampling, ro.max_prosac_iterations, ro.real_focal_check) == (0, 100000, 0)
+    ro = _capi.ransac_opt_from_dict({"progressive_sampling": True, "max_prosac_iterations": 5000, "real_focal_check": True})
+    assert (ro.progressive_sampling, ro.max_prosac_iterations, ro.real_focal_check) == (1, 5000, 1)  # handed to the library, which refuses them
     bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
     assert (bo.max_iterations, bo.loss_type, bo.loss_scale, bo.gradient_tol) == (100, 4, 1.0, 1e-10)
 
@@ -88,6 +94,7 @@ def test_c_host_links_and_loads(tmp_path):
                    '    mdrp_handle *h = 0; int rc = mdrp_create(0, NULL, &h);\n'
                    '    printf("create rc %d\\n", rc);\n'
                    '    if (!rc) { mdrp_stats st; rc = mdrp_last_stats_sized(h, &st, sizeof st); mdrp_destroy(h); }\n'
+                   '    if (mdrp_abi_version() != MDRP_ABI_VERSION || sizeof(mdrp_ransac_opt) != 88) return 2;\n'
                    '    return rc == 0 || rc == MDRP_ERR_NO_DEVICE ? 0 : 1;\n}\n')
     exe = tmp_path / "host"
     libdir = os.path.dirname(_capi.LIB_PATH)

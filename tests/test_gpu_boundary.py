@@ -258,3 +258,111 @@ def test_local_shard_through_the_device_gather_path_one_rank():
         if created:
             tdist.destroy_process_group()
     assert out.tobytes() == ref.tobytes() and np.array_equal(mask.cpu().numpy(), ref_mask)
+
+
+def test_prosac_is_refused_on_every_entry_point_including_the_c_abi():
+    """VERDICT r04 item 6: `progressive_sampling=True` switches the reference to PROSAC (RandomSampler::initialize_prosac @0x4f8a20) — different
+    samples, different results.  It is not built, so it must be refused, not dropped: MDRP_ERR_UNSUPPORTED (4) from the C ABI (ABI 0.4:
+    mdrp_ransac_opt carries the reference's progressive_sampling / max_prosac_iterations / real_focal_check), NotImplementedError from
+    every Python entry point — the three monodepth estimators included, which ignored the key until round 4."""
+    import ctypes as C
+    from mdrp_amd import _capi, poselib, synth
+    p = synth.make_pair(4242, 300, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3)
+    pros = {**RO, "progressive_sampling": True, "max_prosac_iterations": 1000}
+    for call in (lambda: poselib.estimate_monodepth_relative_pose(p["x1"], p["x2"], p["d1"], p["d2"], CAM, CAM, pros, BO),
+                 lambda: poselib.estimate_monodepth_shared_focal_relative_pose(p["x1"], p["x2"], p["d1"], p["d2"], pros, BO),
+                 lambda: poselib.estimate_monodepth_varying_focal_relative_pose(p["x1"], p["x2"], p["d1"], p["d2"], pros, BO),
+                 lambda: poselib.estimate_monodepth_relative_pose_batch([p["x1"]], [p["x2"]], [p["d1"]], [p["d2"]], [CAM], [CAM], pros, BO),
+                 lambda: poselib.estimate_relative_pose(p["x1"], p["x2"], CAM, CAM, pros, BO),
+                 lambda: poselib.estimate_fundamental(p["x1"], p["x2"], pros, BO),
+                 lambda: poselib.estimate_shared_focal_relative_pose(p["x1"], p["x2"], [0.0, 0.0], pros, BO)):
+        with pytest.raises(NotImplementedError):
+            call()
+    # the C ABI itself: return code 4 and a message, for every kind; max_prosac_iterations alone changes nothing
+    lib = _capi.load_library()
+    h = _capi.Handle(0)
+    try:
+        x1 = np.ascontiguousarray(p["x1"][None]); x2 = np.ascontiguousarray(p["x2"][None]); d1 = np.ascontiguousarray(p["d1"][None]); d2 = np.ascontiguousarray(p["d2"][None])
+        cams = np.zeros(1, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+        out = np.zeros(1, dtype=_capi.RESULT_DTYPE)
+        bo = _capi.bundle_opt_from_dict(BO)
+        for kind in range(6):
+            ro = _capi.ransac_opt_from_dict(pros)
+            rc = lib.mdrp_estimate_batch(h._h, kind, 0, _capi._ptr(x1), _capi._ptr(x2), _capi._ptr(d1), _capi._ptr(d2), 1, 300, None, _capi._ptr(cams), _capi._ptr(cams),
+                                         C.byref(ro), C.byref(bo), _capi._ptr(out), None)
+            assert rc == 4 and b"PROSAC" in lib.mdrp_last_error(), (kind, rc)
+        for kind in (4, 5):
+            ro = _capi.ransac_opt_from_dict({**RO, "real_focal_check": True})
+            rc = lib.mdrp_estimate_batch(h._h, kind, 0, _capi._ptr(x1), _capi._ptr(x2), None, None, 1, 300, None, _capi._ptr(cams), _capi._ptr(cams),
+                                         C.byref(ro), C.byref(bo), _capi._ptr(out), None)
+            assert rc == 4, (kind, rc)
+        a = h.estimate_batch(0, x1, x2, d1, d2, _capi.ransac_opt_from_dict(RO), bo, None, cams, cams)[0]
+        b_ = h.estimate_batch(0, x1, x2, d1, d2, _capi.ransac_opt_from_dict({**RO, "max_prosac_iterations": 7, "real_focal_check": True}), bo, None, cams, cams)[0]
+        assert a.tobytes() == b_.tobytes()  # without progressive_sampling the PROSAC budget is not read; real_focal_check is the baselines' switch
+    finally:
+        h.close()
+
+
+C_HOST = r"""
+/* a plain C host of libmdrp_hip.so (INTEGRATION.md 3): one image pair from a file through mdrp_estimate_batch, record to stdout */
+#include "mdrp.h"
+#include <stdio.h>
+#include <stdlib.h>
+int main(int argc, char **argv) {
+    if (argc < 3 || mdrp_abi_version() != MDRP_ABI_VERSION) return 2;
+    const int n = atoi(argv[2]);
+    double *buf = malloc(sizeof(double) * 6 * (size_t)n); /* x1 [n][2] | x2 [n][2] | d1 [n] | d2 [n] */
+    FILE *f = fopen(argv[1], "rb");
+    if (!f || fread(buf, sizeof(double), 6 * (size_t)n, f) != 6 * (size_t)n) return 3;
+    fclose(f);
+    mdrp_ransac_opt ro = {10000, 10000, 3.0, 0.9999, 16.0, 2.0, 0, 0, 1.0f, 0, 0, 100000, 0, 0};
+    mdrp_bundle_opt bo = {100, 4 /* TRUNCATED_CAUCHY */, 1.0, 1e-10, 1e-8, 1e-3, 1e-10, 1e10};
+    mdrp_camera cam = {0, 0, {800.0, 0.0, 0.0, 0.0}};
+    mdrp_handle *h = NULL;
+    mdrp_result r;
+    unsigned char *mask = malloc((size_t)n);
+    int rc = mdrp_create(0, NULL, &h);
+    if (!rc) rc = mdrp_estimate_batch(h, MDRP_CALIB, MDRP_MEM_HOST, buf, buf + 2 * n, buf + 4 * n, buf + 5 * n, 1, n, NULL, &cam, &cam, &ro, &bo, &r, mask);
+    if (rc) { fprintf(stderr, "mdrp error %d: %s\n", rc, mdrp_last_error()); return 1; }
+    ro.progressive_sampling = 1;
+    if (mdrp_estimate_batch(h, MDRP_CALIB, MDRP_MEM_HOST, buf, buf + 2 * n, buf + 4 * n, buf + 5 * n, 1, n, NULL, &cam, &cam, &ro, &bo, &r, mask) != MDRP_ERR_UNSUPPORTED) return 4;
+    int inl = 0;
+    for (int i = 0; i < n; ++i) inl += mask[i];
+    printf("%llu %llu %llu %d %.17g %.17g", (unsigned long long)r.refinements, (unsigned long long)r.iterations, (unsigned long long)r.num_inliers, inl, r.inlier_ratio, r.model_score);
+    for (int i = 0; i < 4; ++i) printf(" %.17g", r.model.q[i]);
+    for (int i = 0; i < 3; ++i) printf(" %.17g", r.model.t[i]);
+    printf(" %.17g %.17g %.17g\n", r.model.scale, r.model.shift1, r.model.shift2);
+    mdrp_destroy(h);
+    return 0;
+}
+"""
+
+
+def test_c_host_runs_an_estimate_on_the_gpu(tmp_path, golden):
+    """a C host — no Python, no ctypes, its own libamdhip64 — compiles against include/mdrp.h, links libmdrp_hip.so,
+    estimates pair 3 of the headline batch from a file and prints the record: iterations, inliers, mask count and model equal the
+    REFERENCE binary's record for that pair (tests/golden/headline_ref_calib_p3p_n2000_i10k.npz)."""
+    import os
+    import shutil
+    import subprocess
+    from mdrp_amd import _capi, synth
+    from helpers import model_diff
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    assert shutil.which("gcc") and os.path.exists(os.path.join(rocm, "lib", "libamdhip64.so")), "the image has gcc and a system HIP runtime"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    idx, n = 3, 2000
+    p = synth.make_pair(idx, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
+    np.concatenate([p["x1"].ravel(), p["x2"].ravel(), p["d1"].ravel(), p["d2"].ravel()]).astype(np.float64).tofile(tmp_path / "pair.bin")
+    (tmp_path / "host.c").write_text(C_HOST)
+    libdir = os.path.dirname(_capi.LIB_PATH)
+    subprocess.run(["gcc", "-O1", str(tmp_path / "host.c"), "-I", os.path.join(root, "include"), "-L", libdir, "-lmdrp_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
+                    f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", f"-Wl,-rpath,{libdir}", "-o", str(tmp_path / "host")], check=True)
+    out = subprocess.run([str(tmp_path / "host"), str(tmp_path / "pair.bin"), str(n)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    v = out.stdout.split()
+    ref = golden("headline_ref_calib_p3p_n2000_i10k")
+    assert (int(v[1]), int(v[2]), int(v[3])) == (int(ref["istats"][idx, 1]), int(ref["istats"][idx, 2]), int(ref["istats"][idx, 2]))
+    assert int(v[0]) == int(ref["istats"][idx, 0])  # pair 3 is not among the enumerated LO-count deviations
+    assert abs(float(v[5]) / ref["fstats"][idx, 1] - 1.0) < 1e-9 and float(v[4]) == ref["fstats"][idx, 0]
+    model = np.r_[[float(x) for x in v[6:16]], 1.0, 1.0]
+    assert model_diff(model, ref["model"][idx]) < 1e-6
