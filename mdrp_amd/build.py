@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "mdrp_capi.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "mdrp_kernels.h"), os.path.join(HERE, "csrc", "mdrp_math.h"),
         os.path.join(HERE, "csrc", "mdrp_classic.h"), os.path.join(HERE, "csrc", "mdrp_classic_math.h"),
-        os.path.join(HERE, "csrc", "mdrp_lm.h"),
+        os.path.join(HERE, "csrc", "mdrp_lm.h"), os.path.join(HERE, "csrc", "mdrp_logtab.h"),
         os.path.join(HERE, "..", "include", "mdrp.h")]
 OUT = os.path.join(HERE, "libmdrp_hip.so")
 _MARK = b"MDRP_SRC_HASH="

@@ -598,8 +598,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace), &trace_buf, sizeof trace_buf));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace_n), &zero, sizeof zero));
         static unsigned long long *fin_buf = nullptr;
-        if (!fin_buf) HIPCHK(hipMalloc(&fin_buf, 32ull * 65536));
-        HIPCHK(hipMemset(fin_buf, 0, 32ull * std::min(batch, 65536)));
+        if (!fin_buf) HIPCHK(hipMalloc(&fin_buf, 64ull * 65536));
+        HIPCHK(hipMemset(fin_buf, 0, 64ull * std::min(batch, 65536)));
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fin_trace), &fin_buf, sizeof fin_buf));
     }
 #endif
@@ -996,7 +996,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         unsigned long long *buf = nullptr;
         HIPCHK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_fin_trace), sizeof buf));
         if (buf && !classic) {
-            std::vector<unsigned long long> host(4ull * std::min(batch, 65536));
+            std::vector<unsigned long long> host(8ull * std::min(batch, 65536));
             HIPCHK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
             const std::string fp = std::string(path) + ".final";
             if (FILE *f = fopen(fp.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }

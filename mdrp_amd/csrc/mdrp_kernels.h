@@ -26,6 +26,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include "mdrp_logtab.h"
 #include "mdrp_math.h"
 
 namespace mdrp {
@@ -1660,6 +1661,12 @@ __device__ __forceinline__ void lm_state_uniform(LmState &st) {
 typedef __attribute__((address_space(3))) uint16_t lds_u16;
 __device__ __forceinline__ lds_u16 *lds_cast(uint16_t *p) { return (lds_u16 *)p; }
 
+static __device__ const double g_logtab[MDRP_LOGTAB_N][2] = MDRP_LOGTAB_INIT;
+// the workgroup's LDS copy of the table (dst: 2 * MDRP_LOGTAB_N doubles); the caller's next barrier publishes it
+__device__ __forceinline__ void lm_logtab_load(double *dst) {
+    for (int i = threadIdx.x; i < 2 * MDRP_LOGTAB_N; i += blockDim.x) dst[i] = g_logtab[i >> 1][i & 1];
+}
+
 struct LmShared {
     double scratch[4 * MAX_ACC];
     int count[2][4];
@@ -1668,6 +1675,7 @@ struct LmShared {
     int midx;        // 1: a third list of `stride` entries behind the two work lists holds the indices of the records a record mask lets
                      // through, per wavefront segment (lm_mask_index; the inlier-only final refinement); mcount = entries per wavefront
     int mcount[4];
+    const double *logtab;      // LDS copy of the log table of lm_log1p (the Cauchy losses of the final refinements), or null: library log1p
     unsigned long long *stats; // [0] correspondences evaluated by cost sweeps, [1] by accumulate sweeps (or null): bench.py's fp64 roofline
     unsigned long long ev[2];  // ... collected here per problem, flushed by lm_flush_stats
 #ifdef MDRP_LO_TRACE
@@ -1714,6 +1722,7 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
     const int hi = midx ? lo + sh.mcount[wave] : min(n, lo + seg); // end of this wavefront's trips (list positions under a mask index)
     const int loss = LOSS >= 0 ? LOSS : o.loss;
     const double lsc = o.loss_scale, mu = o.mu, t2 = lsc * lsc;
+    const double *logtab = sh.logtab;
     const bool ws_nz = ws != 0.0;
     const unsigned long long lt = (1ull << lane) - 1ull;
     double cost = 0;
@@ -1761,9 +1770,15 @@ __device__ double lm_cost(const Model &m, const double *__restrict__ pts, const 
                 vs[u] = ws * (is ? rs : t2); vf[u] = jf ? rf : t2; vb[u] = jb ? rb : t2;
                 contrib[u] = ((oki & (int)is & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
             } else {
-                vs[u] = ws * loss_value(loss, lsc, rs); vf[u] = loss_value(loss, lsc, rf); vb[u] = loss_value(loss, lsc, rb);
-                contrib[u] = ((oki & (int)(ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
-                              ((int)bwd[u] & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
+                vs[u] = ws * loss_value_tab(loss, lsc, rs, logtab); vf[u] = loss_value_tab(loss, lsc, rf, logtab); vb[u] = loss_value_tab(loss, lsc, rb, logtab);
+                if (LOSS == 3 || LOSS == 4) {
+                    // the Cauchy weights 1 / (1 + r^2 / t^2), floored at DBL_MIN, are never zero (NaN included: the floor takes it); TRUNCATED_CAUCHY's is
+                    // zero exactly at and beyond the threshold — the same predicate as `loss_weight(...) != 0` without three reciprocal chains
+                    const bool is = LOSS == 3 || rs < t2, jf = LOSS == 3 || rf < t2, jb = LOSS == 3 || rb < t2;
+                    contrib[u] = ((oki & (int)is & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
+                } else
+                    contrib[u] = ((oki & (int)(ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
+                                  ((int)bwd[u] & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
             }
         }
 #pragma unroll
@@ -2082,11 +2097,23 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
     } else fundamental_from_E(Em, m.f1, m.f2, E);
     double score = 0;
     int cnt = 0;
+    // one record of look-ahead (all 48 bytes, unconditional loads from a clamped index): round 4 loaded a record, waited for it, and loaded
+    // its inverse norms behind the inlier test — two exposed memory round trips per trip, 32 trips per LO problem at one wavefront (found
+    // in the ISA in round 5: most of the 55 us a problem spent outside its LM).  Same arithmetic, same order: bit-identical.
+    const int last = n > 0 ? n - 1 : 0;
+    double2 nx0 = make_double2(0, 0), nx1 = nx0, nx2 = nx0;
+    auto fetch = [&](int i) {
+        const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)(i < last ? i : last) * PT_STRIDE);
+        nx0 = P[0]; nx1 = P[1]; nx2 = P[2];
+    };
+    fetch(threadIdx.x);
     for (int i = threadIdx.x; i < n; i += T) {
+        const double rec[6] = {nx0.x, nx0.y, nx1.x, nx1.y, nx2.x, nx2.y};
+        fetch(i + T);
         double s1 = 0;
         int c1 = 0;
-        if (kind == 0) score_point<true>(pts + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
-        else score_point<false>(pts + (size_t)i * PT_STRIDE, E, R, m.t, thr, s1, c1);
+        if (kind == 0) score_point<true>(rec, E, R, m.t, thr, s1, c1);
+        else score_point<false>(rec, E, R, m.t, thr, s1, c1);
         score += s1; cnt += c1;
         if (mask_out) mask_out[i] = (uint8_t)c1;
     }
@@ -2296,7 +2323,7 @@ __device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams
 #ifdef MDRP_LO_TRACE // experiment: per-problem timing of the LO kernels (tools/lo_trace.py)
 __device__ unsigned long long *g_lo_trace = nullptr; // 8 x u64 per problem
 __device__ unsigned int g_lo_trace_n = 0;
-__device__ unsigned long long *g_fin_trace = nullptr; // 4 x u64 per pair: pair | start | end | iterations of the inlier refinement | of the LO << 32
+__device__ unsigned long long *g_fin_trace = nullptr; // 8 x u64 per pair: pair | start | end | iterations of the inlier refinement | of the LO << 32 | ticks of the inlier refinement in cost sweeps | normal equations | whole LM | accepted steps
 #endif
 // LO of item w of the launch's plan (refine_model + score_model of the refined model), by the whole workgroup
 template <int KIND, bool SHIFT, int T>
@@ -2358,7 +2385,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
     __shared__ int s_item;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; }
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; sh.logtab = nullptr; }
 #ifdef MDRP_LO_TRACE
     if (threadIdx.x == 0) sh.tloop = 0;
 #endif
@@ -2414,7 +2441,7 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
     const double *dd = dep + (size_t)pair * rp.n_max * 2;
 #ifdef MDRP_LO_TRACE
     const unsigned long long tf0 = wall_clock64();
-    unsigned long long tf_it = 0;
+    unsigned long long tf_it = 0, tf_ph[4] = {0, 0, 0, 0};
 #endif
     // ransac<>'s last LO from the best model: 25 iterations, TRUNCATED, all records
     Model x = ps.best;
@@ -2445,7 +2472,7 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         o.grad_tol = rp.grad_tol; o.step_tol = rp.step_tol; o.lambda0 = rp.lambda0; o.lambda_min = rp.lambda_min; o.lambda_max = rp.lambda_max;
         lm_refine<KIND, SHIFT, T, FLOSS>(x, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, o, sh);
 #ifdef MDRP_LO_TRACE
-        if (threadIdx.x == 0) tf_it |= sh.ph[3] & 0xFFFFull;
+        if (threadIdx.x == 0) { tf_it |= sh.ph[3] & 0xFFFFull; tf_ph[0] = sh.ph[0]; tf_ph[1] = sh.ph[1]; tf_ph[2] = sh.ph[2]; tf_ph[3] = sh.ph[3] >> 16; }
 #endif
     }
     if (KIND != 0) { x.f1 *= ps.norm; x.f2 *= ps.norm; }
@@ -2460,8 +2487,9 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
     }
 #ifdef MDRP_LO_TRACE
     if (threadIdx.x == 0 && g_fin_trace) {
-        unsigned long long *e = g_fin_trace + 4ull * pair;
+        unsigned long long *e = g_fin_trace + 8ull * pair;
         e[0] = (unsigned long long)pair; e[1] = tf0; e[2] = wall_clock64(); e[3] = tf_it;
+        e[4] = tf_ph[0]; e[5] = tf_ph[1]; e[6] = tf_ph[2]; e[7] = tf_ph[3];
     }
 #endif
 }
@@ -2478,8 +2506,12 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
     __shared__ LmShared sh;
     __shared__ int s_pair;
     __shared__ __attribute__((aligned(16))) unsigned int s_ps[(sizeof(PairState) + 3) / 4];
+    __shared__ __attribute__((aligned(16))) double s_logtab[(FLOSS == 3 || FLOSS == 4 || FLOSS < 0) ? 2 * MDRP_LOGTAB_N : 2];
+    constexpr bool use_logtab = FLOSS == 3 || FLOSS == 4 || FLOSS < 0;
+    if (use_logtab) lm_logtab_load(s_logtab);
     if (threadIdx.x == 0) {
         sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = mask_index; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0;
+        sh.logtab = use_logtab ? s_logtab : nullptr;
         int p = blockIdx.x;
         if (ready) { // fused tail: the blockIdx-th pair to become ready (bounded wait, see k_gate)
             const unsigned long long t0 = wall_clock64();
@@ -2579,7 +2611,9 @@ __global__ __launch_bounds__(T) void k_refine_unit(int count, Model *__restrict_
                                                             double scale_reproj, double ws, LmOpt o, double *__restrict__ final_cost, int list_stride) {
     extern __shared__ uint16_t lm_dyn_list[];
     __shared__ LmShared sh;
-    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = nullptr; sh.ev[0] = 0; sh.ev[1] = 0; }
+    __shared__ __attribute__((aligned(16))) double s_logtab[2 * MDRP_LOGTAB_N];
+    lm_logtab_load(s_logtab);
+    if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = nullptr; sh.ev[0] = 0; sh.ev[1] = 0; sh.logtab = s_logtab; }
     __syncthreads();
     const int i = blockIdx.x;
     if (i >= count) return;

@@ -723,6 +723,39 @@ MDRP_HD double loss_value(int type, double thr, double r2) {
     default: return r2;
     }
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+// log(1 + x), x >= 0, from a 128-entry table in LDS (mdrp_logtab.h: per mantissa interval of width 1 / 128 the double inv = fl(1 / c), c its
+// midpoint, and -ln(inv)).  1 + x = 2^e m, m in [1, 2);  r = m inv - 1 (one FMA: |r| <= 1 / 256, exact to half an ulp of r);
+// log(1 + x) = e ln 2 - ln(inv) + log1p(r), log1p(r) by its series to r^6 (truncation r^7 / 7 < 2e-18).  The rounding of 1 + x is put back
+// to first order (err / (1 + x), err = x - ((1 + x) - 1)).  ~22 instructions against ~150 of the library's log1p: the Cauchy losses take
+// three per record in every cost sweep of the final refinements (round 5).  Non-finite arguments come back as they are (inf, NaN).
+__device__ __forceinline__ double lm_log1p(double x, const double *tab_lds) {
+    typedef __attribute__((address_space(3))) const double lds_cdouble;
+    const double y = 1.0 + x;
+    const double err = x - (y - 1.0);
+    const unsigned hi = (unsigned)__double2hiint(y);
+    const int e = (int)(hi >> 20) - 1023;
+    const unsigned idx = (hi >> 13) & 127u;
+    const double m = __hiloint2double((int)((hi & 0x000FFFFFu) | 0x3FF00000u), __double2loint(y));
+    lds_cdouble *t = (lds_cdouble *)tab_lds + 2 * idx;
+    const double inv_c = t[0], log_c = t[1];
+    const double r = fma(m, inv_c, -1.0);
+    double q = fma(r, -1.0 / 6.0, 0.2);
+    q = fma(r, q, -0.25);
+    q = fma(r, q, 1.0 / 3.0);
+    q = fma(r, q, -0.5);
+    const double lp = fma(r * r, q, r) + ldexp(err * inv_c, -e);
+    const double v = fma((double)e, 0.69314718055994530942, log_c + lp);
+    return y < __builtin_huge_val() ? v : y;
+}
+// loss_value with the table for the two Cauchy losses (tab == nullptr: the plain function)
+__device__ __forceinline__ double loss_value_tab(int type, double thr, double r2, const double *tab_lds) {
+    if (!tab_lds || (type != 3 && type != 4)) return loss_value(type, thr, r2);
+    const double t2 = thr * thr;
+    const double x = (type == 4 ? (r2 < t2 ? r2 : t2) : r2) * lm_rcp(t2);
+    return t2 * lm_log1p(x, tab_lds);
+}
+#endif
 // mu: penalty strength of TRUNCATED_LE_ZACH (Le & Zach, 3DV 2021): 0.5, multiplied by 1.5 after every LM iteration
 // (the reference's per-iteration callback; pinned against the binary to 1e-15 over 5 iterations)
 MDRP_HD double loss_weight(int type, double thr, double r2, double mu = 0.5) {

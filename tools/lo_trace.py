@@ -49,7 +49,7 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
                 print(f"   started in [{lo_:.2f}, {hi_:.2f}) of the makespan: {w.sum()} problems; per sweep cost {t_cost[sel][w].sum() / (its[sel][w] + 1).sum():.1f} us, "
                       f"normal equations {t_acc[sel][w].sum() / np.maximum(accs[sel][w], 1).sum():.1f} us, rest per iteration {rest[w].sum() / np.maximum(its[sel][w], 1).sum():.1f} us")
     try:
-        fin = np.fromfile(trace + ".final", dtype=np.uint64).reshape(-1, 4)
+        fin = np.fromfile(trace + ".final", dtype=np.uint64).reshape(-1, 8)
         fin = fin[fin[:, 2] > 0]
         t0 = fin[:, 1].min()
         st = (fin[:, 1] - t0).astype(np.int64) / 100.0; en = (fin[:, 2] - t0).astype(np.int64) / 100.0
@@ -59,6 +59,16 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
               f"makespan {en.max():.0f} us; sum / 512 workgroups = {d.sum() / 512:.0f} us")
         print(f"   iterations: LO from the best model mean {it0.mean():.1f} max {it0.max()}; inlier refinement mean {it1.mean():.1f} p90 {np.percentile(it1, 90):.0f} max {it1.max()}; "
               f"us per iteration of the inlier refinement ~ {(d.sum() / np.maximum(it0 + it1, 1).sum()):.1f} (both refinements pooled)")
+        tc, ta, tl, acc1 = (fin[:, k].astype(np.int64) / (100.0 if k < 7 else 1.0) for k in (4, 5, 6, 7))
+        have = it1 > 0
+        if have.any():
+            rest = tl - tc - ta
+            print(f"   inlier refinement, per pair: LM {tl[have].mean():.0f} us = cost sweeps {tc[have].mean():.0f} + normal equations {ta[have].mean():.0f} + rest {rest[have].mean():.0f}; "
+                  f"per sweep: cost {tc[have].sum() / (it1[have] + 1).sum():.1f} us, normal equations {ta[have].sum() / np.maximum(acc1[have], 1).sum():.1f} us; "
+                  f"rest per iteration {rest[have].sum() / it1[have].sum():.1f} us; accepted steps mean {acc1[have].mean():.1f} of {it1[have].mean():.1f}")
+            long_ = it1 >= np.percentile(it1, 95)
+            print(f"   the 5 % longest refinements ({long_.sum()} pairs, {it1[long_].mean():.0f} iterations): LM {tl[long_].mean():.0f} us = cost {tc[long_].mean():.0f} + normal equations {ta[long_].mean():.0f} + rest {rest[long_].mean():.0f}; "
+                  f"per sweep: cost {tc[long_].sum() / (it1[long_] + 1).sum():.1f} us, normal equations {ta[long_].sum() / np.maximum(acc1[long_], 1).sum():.1f} us, rest per iteration {rest[long_].sum() / it1[long_].sum():.1f} us")
         order = np.argsort(-d)[:8]
         print("   longest pairs (start us, duration us, iterations): " + ", ".join(f"({st[i]:.0f}, {d[i]:.0f}, {it0[i]}+{it1[i]})" for i in order))
         late = st > 0.5 * en.max()
