@@ -723,13 +723,15 @@ MDRP_HD double loss_value(int type, double thr, double r2) {
     default: return r2;
     }
 }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIPCC__)
 // log(1 + x), x >= 0, from a 128-entry table in LDS (mdrp_logtab.h: per mantissa interval of width 1 / 128 the double inv = fl(1 / c), c its
 // midpoint, and -ln(inv)).  1 + x = 2^e m, m in [1, 2);  r = m inv - 1 (one FMA: |r| <= 1 / 256, exact to half an ulp of r);
 // log(1 + x) = e ln 2 - ln(inv) + log1p(r), log1p(r) by its series to r^6 (truncation r^7 / 7 < 2e-18).  The rounding of 1 + x is put back
 // to first order (err / (1 + x), err = x - ((1 + x) - 1)).  ~22 instructions against ~150 of the library's log1p: the Cauchy losses take
 // three per record in every cost sweep of the final refinements (round 5).  Non-finite arguments come back as they are (inf, NaN).
+// (Declared in the host pass too — templates that call it are parsed there — with the device body only in the device pass.)
 __device__ __forceinline__ double lm_log1p(double x, const double *tab_lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) const double lds_cdouble;
     const double y = 1.0 + x;
     const double err = x - (y - 1.0);
@@ -747,6 +749,10 @@ __device__ __forceinline__ double lm_log1p(double x, const double *tab_lds) {
     const double lp = fma(r * r, q, r) + ldexp(err * inv_c, -e);
     const double v = fma((double)e, 0.69314718055994530942, log_c + lp);
     return y < __builtin_huge_val() ? v : y;
+#else
+    (void)tab_lds;
+    return log1p(x);
+#endif
 }
 // loss_value with the table for the two Cauchy losses (tab == nullptr: the plain function)
 __device__ __forceinline__ double loss_value_tab(int type, double thr, double r2, const double *tab_lds) {
