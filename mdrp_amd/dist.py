@@ -171,3 +171,36 @@ def estimate_sharded(kind, x1, x2, d1, d2, ransac_opt=None, bundle_opt=None, n_p
     return estimate_local_shard(kind, total, x1[sl], x2[sl], None if d1 is None else d1[sl], None if d2 is None else d2[sl], ransac_opt, bundle_opt,
                                 None if n_per_pair is None else n_per_pair[sl], None if cam1 is None else cam1[sl],
                                 None if cam2 is None else cam2[sl], group, local_fn, want_mask)
+
+
+def device_identity(dev_index=None):
+    """A string that names the PHYSICAL device behind a torch device ordinal (uuid when the runtime reports one, else PCI domain:bus:device
+    + name): two ranks that print the same string share a GPU, whatever their ordinals say (ROCR_/HIP_VISIBLE_DEVICES masks renumber)."""
+    import torch
+    i = torch.cuda.current_device() if dev_index is None else int(dev_index)
+    p = torch.cuda.get_device_properties(i)
+    uuid = getattr(p, "uuid", None)
+    pci = ":".join(str(getattr(p, k, "?")) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return f"{uuid}|{pci}|{p.name}" if uuid is not None else f"{pci}|{p.name}"
+
+
+def gather_device_identities(dev_index=None, group=None):
+    """[(rank, device_identity)] of every rank of the group (one all_gather_object), for the N > 1 bench line: the proof that N distinct GPUs took part"""
+    import torch.distributed as dist
+    rank, world = _world(group)
+    mine = (rank, device_identity(dev_index))
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine, group=group)
+    return out
+
+
+def local_device_index(local_rank):
+    """device ordinal of a rank: LOCAL_RANK modulo the devices this process can see — with one visible device per rank
+    (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES set by the launcher) every rank uses ordinal 0"""
+    import torch
+    n = torch.cuda.device_count()
+    if n <= 0:
+        raise RuntimeError("no GPU visible to this rank")
+    return int(local_rank) % n

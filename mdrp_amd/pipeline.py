@@ -72,3 +72,85 @@ class BatchPipeline:
 
     def __exit__(self, *exc):
         self.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Large batches through the drop-in entry points (VERDICT r04 item 5).  Measured through the Python entry points (tools/entry_rate.py,
+# profiles/r05_python_entry_points.txt; headline pairs, one MI355X):
+#   resident tensors (estimate_batch_torch):   ONE call is always the fastest - 126 k pairs/s at 2048 pairs, 132 k at 4096, 137 k at 8192,
+#       139 k at 16384 (the LM tails amortise inside a large call); chunks of 1024 / 2048 / 4096 pairs two in flight: 126 / 132 / 134 k at 8192.
+#   pageable host buffers (estimate_*_batch):  chunks of 1024 pairs two in flight win from ~8 k pairs on - 117.8 k against 109.1 k for one
+#       call at 8192 pairs (a chunk's H2D copy runs beside the previous chunk's kernels); at 4096 pairs one call is still ahead (103 k vs 100 k).
+# So: host batches of more than PIPELINE_MIN pairs are cut into chunks of PIPELINE_CHUNK pairs that go through a per-(thread, device)
+# BatchPipeline(depth 2); resident batches go through one call unless MDRP_PIPELINE_DEVICE=1.  Pairs are independent units and every
+# summation order depends on the record index and list position only, so the records and masks are those of sequential chunk calls bit for
+# bit (tests/test_gpu_boundary.py::test_batch_pipeline_equals_sequential_calls, tests/test_gpu_headline.py::test_large_batches_...).
+def _env_int(name, dflt):
+    import os
+    try:
+        return int(os.environ.get(name, dflt))
+    except ValueError:
+        return dflt
+
+
+PIPELINE_MIN = _env_int("MDRP_PIPELINE_MIN", 6144)      # host batches up to this size go through one call on the thread's default handle
+PIPELINE_CHUNK = _env_int("MDRP_PIPELINE_CHUNK", 1024)  # pairs per chunk beyond that (0 = never split)
+PIPELINE_DEPTH = _env_int("MDRP_PIPELINE_DEPTH", 2)
+PIPELINE_DEVICE = _env_int("MDRP_PIPELINE_DEVICE", 0)   # 1: resident batches (estimate_batch_torch) are chunked as well (measured: slower)
+_auto_tls = threading.local()
+
+
+def chunk_bounds(batch, chunk=None):
+    """[lo, hi) of the chunks a batch of `batch` pairs is cut into: `chunk` pairs each, a short remainder (< chunk / 4) joins the last one"""
+    chunk = PIPELINE_CHUNK if chunk is None else chunk
+    if chunk <= 0 or batch <= max(PIPELINE_MIN, chunk):
+        return [(0, batch)]
+    cuts = list(range(0, batch, chunk)) + [batch]
+    if len(cuts) > 2 and cuts[-1] - cuts[-2] < chunk // 4:
+        del cuts[-2]
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def _auto_pipe(device):
+    pipes = getattr(_auto_tls, "pipes", None)
+    if pipes is None:
+        pipes = _auto_tls.pipes = {}
+    p = pipes.get(device)
+    if p is None:
+        p = pipes[device] = BatchPipeline(depth=PIPELINE_DEPTH, device=device)
+    return p
+
+
+def estimate_host(kind, x1, x2, d1, d2, ro, bo, n_per_pair=None, cam1=None, cam2=None, device=0, want_mask=True):
+    """Handle.estimate_batch for a batch of any size (host buffers): one call up to PIPELINE_MIN pairs, pipelined chunks beyond.
+    Returns (records, mask) in pair order."""
+    B = len(x1)
+    bounds = chunk_bounds(B)
+    if len(bounds) == 1:
+        return _capi.default_handle(device).estimate_batch(kind, x1, x2, d1, d2, ro, bo, n_per_pair, cam1, cam2, want_mask)
+    pipe = _auto_pipe(device)
+
+    def cut(a, lo, hi):
+        return None if a is None else a[lo:hi]
+    futs = [pipe.submit(kind, x1[lo:hi], x2[lo:hi], cut(d1, lo, hi), cut(d2, lo, hi), ro, bo, cut(n_per_pair, lo, hi), cut(cam1, lo, hi), cut(cam2, lo, hi), want_mask)
+            for lo, hi in bounds]
+    parts = [f.result() for f in futs]
+    res = np.concatenate([p[0] for p in parts])
+    mask = np.concatenate([p[1] for p in parts]) if want_mask else None
+    return res, mask
+
+
+def estimate_device(kind, x1_ptr, x2_ptr, d1_ptr, d2_ptr, batch, n_max, ro, bo, n_per_pair=None, cam1=None, cam2=None, mask_ptr=None, device=0):
+    """The same on device pointers ([batch][n_max][2] / [batch][n_max] float64, mask [batch][n_max] bytes): chunks are pointer offsets into the
+    caller's buffers.  Only called for batches beyond PIPELINE_MIN; the caller has made sure the inputs are complete (stream synchronised).
+    Returns the records (numpy) in pair order."""
+    pipe = _auto_pipe(device)
+
+    def cut(a, lo, hi):
+        return None if a is None else a[lo:hi]
+    futs = []
+    for lo, hi in chunk_bounds(batch):
+        futs.append(pipe.submit_device(kind, x1_ptr + 16 * n_max * lo, x2_ptr + 16 * n_max * lo, d1_ptr + 8 * n_max * lo if d1_ptr else 0,
+                                       d2_ptr + 8 * n_max * lo if d2_ptr else 0, hi - lo, n_max, ro, bo, cut(n_per_pair, lo, hi), cut(cam1, lo, hi), cut(cam2, lo, hi),
+                                       mask_ptr + n_max * lo if mask_ptr else None))
+    return np.concatenate([f.result() for f in futs])

@@ -12,7 +12,7 @@ adapters at the bottom.
 """
 import numpy as np
 
-from . import _capi
+from . import _capi, pipeline
 
 __version__ = "2.0.5+mdrp_amd"
 
@@ -176,6 +176,20 @@ def _initial_fallback(initial, geometry):
     return geometry
 
 
+def _camera_records(c, B):
+    """[B] mdrp_camera records: one Camera | dict for all pairs (one record, repeated — no per-pair Python objects), a list of B, or a
+    ready CAMERA_DTYPE array"""
+    if isinstance(c, np.ndarray) and c.dtype == _capi.CAMERA_DTYPE:
+        if len(c) != B:
+            raise ValueError(f"expected {B} camera records, got {len(c)}")
+        return np.ascontiguousarray(c)
+    if not isinstance(c, (list, tuple)):
+        return np.repeat(np.asarray(Camera.from_any(c)._record()).reshape(1), B)
+    if len(c) != B:
+        raise ValueError(f"expected {B} cameras, got {len(c)}")
+    return np.array([Camera.from_any(v)._record() for v in c], dtype=_capi.CAMERA_DTYPE)
+
+
 # ------------------------------------------------------------------------------------------------ batch API
 def _stack(points1, points2, depth1, depth2):
     """list of ragged pairs or already-stacked arrays -> padded (B,N,2),(B,N,2),(B,N),(B,N), n_per_pair"""
@@ -195,38 +209,41 @@ def _stack(points1, points2, depth1, depth2):
 
 
 def estimate_monodepth_relative_pose_batch(points2D_1, points2D_2, depth_1, depth_2, cameras1, cameras2, ransac_opt=None,
-                                           bundle_opt=None, device=0):
+                                           bundle_opt=None, device=0, as_arrays=False):
     """B calibrated pairs at once.  cameras1/2: one Camera|dict for all pairs, or a list of B.  Returns
-    (list[MonoDepthTwoViewGeometry], list[info dict])."""
+    (list[MonoDepthTwoViewGeometry], list[info dict]) — or, with as_arrays=True, (records, inlier masks, n_per_pair) as numpy arrays
+    (_capi.RESULT_DTYPE; (B, N) uint8): building B Python objects and B lists of N bools costs more than the estimate itself beyond
+    a few thousand pairs.  Host batches of more than pipeline.PIPELINE_MIN (6144) pairs are cut into 1024-pair chunks that run two
+    in flight, a chunk's H2D copy beside the previous chunk's kernels (mdrp_amd.pipeline; results identical to sequential chunk calls)."""
     x1, x2, d1, d2, ns = _stack(points2D_1, points2D_2, depth_1, depth_2)
     B = len(ns)
 
     def cams(c):
-        lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
-        return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
+        return _camera_records(c, B)
 
-    h = _capi.default_handle(device)
-    res, mask = h.estimate_batch(_capi.CALIB, x1, x2, d1, d2, _capi.ransac_opt_from_dict(ransac_opt),
-                                 _capi.bundle_opt_from_dict(bundle_opt), ns, cams(cameras1), cams(cameras2))
+    res, mask = pipeline.estimate_host(_capi.CALIB, x1, x2, d1, d2, _capi.ransac_opt_from_dict(ransac_opt),
+                                       _capi.bundle_opt_from_dict(bundle_opt), ns, cams(cameras1), cams(cameras2), device)
+    if as_arrays:
+        return res, mask, ns
     return [_geometry_from_model(r["model"]) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(B)]
 
 
-def _focal_batch(kind, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device):
+def _focal_batch(kind, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device, as_arrays=False):
     x1, x2, d1, d2, ns = _stack(points2D_1, points2D_2, depth_1, depth_2)
-    h = _capi.default_handle(device)
-    res, mask = h.estimate_batch(kind, x1, x2, d1, d2, _capi.ransac_opt_from_dict(ransac_opt),
-                                 _capi.bundle_opt_from_dict(bundle_opt), ns)
+    res, mask = pipeline.estimate_host(kind, x1, x2, d1, d2, _capi.ransac_opt_from_dict(ransac_opt), _capi.bundle_opt_from_dict(bundle_opt), ns, None, None, device)
+    if as_arrays:
+        return res, mask, ns
     return [_pair_from_model(r["model"]) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(len(ns))]
 
 
 def estimate_monodepth_shared_focal_relative_pose_batch(points2D_1, points2D_2, depth_1, depth_2, ransac_opt=None,
-                                                        bundle_opt=None, device=0):
-    return _focal_batch(_capi.SHARED_FOCAL, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device)
+                                                        bundle_opt=None, device=0, as_arrays=False):
+    return _focal_batch(_capi.SHARED_FOCAL, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device, as_arrays)
 
 
 def estimate_monodepth_varying_focal_relative_pose_batch(points2D_1, points2D_2, depth_1, depth_2, ransac_opt=None,
-                                                         bundle_opt=None, device=0):
-    return _focal_batch(_capi.VARYING_FOCAL, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device)
+                                                         bundle_opt=None, device=0, as_arrays=False):
+    return _focal_batch(_capi.VARYING_FOCAL, points2D_1, points2D_2, depth_1, depth_2, ransac_opt, bundle_opt, device, as_arrays)
 
 
 # ------------------------------------------------------------------------------------------------ reference signatures
@@ -472,12 +489,10 @@ def estimate_relative_pose_batch(points2D_1, points2D_2, cameras1, cameras2, ran
     B = len(ns)
 
     def cams(c):
-        lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
-        return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
+        return _camera_records(c, B)
 
-    h = _capi.default_handle(device)
-    res, mask = h.estimate_batch(_capi.RELPOSE_5PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
-                                 _capi.bundle_opt_from_dict(bundle_opt), ns, cams(cameras1), cams(cameras2))
+    res, mask = pipeline.estimate_host(_capi.RELPOSE_5PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
+                                       _capi.bundle_opt_from_dict(bundle_opt), ns, cams(cameras1), cams(cameras2), device)
     return [CameraPose(r["model"]["q"].copy(), r["model"]["t"].copy()) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(B)]
 
 
@@ -485,9 +500,8 @@ def estimate_fundamental_batch(points2D_1, points2D_2, ransac_opt=None, bundle_o
     """B pairs through the 7-point estimator.  Returns (list[3 x 3 ndarray], list[info dict])."""
     _check_baseline_options(ransac_opt)
     x1, x2, ns = _stack2(points2D_1, points2D_2)
-    h = _capi.default_handle(device)
-    res, mask = h.estimate_batch(_capi.FUNDAMENTAL_7PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
-                                 _capi.bundle_opt_from_dict(bundle_opt), ns)
+    res, mask = pipeline.estimate_host(_capi.FUNDAMENTAL_7PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
+                                       _capi.bundle_opt_from_dict(bundle_opt), ns, None, None, device)
     return [_capi.model_to_fundamental(r["model"]) for r in res], [_info(res[i], mask[i], ns[i]) for i in range(len(ns))]
 
 
@@ -554,9 +568,8 @@ def estimate_shared_focal_relative_pose_batch(points2D_1, points2D_2, pp=None, r
     x1, x2, ns = _stack2(points2D_1, points2D_2)
     B = len(ns)
     rec, ppb = _pp_records(pp, B)
-    h = _capi.default_handle(device)
-    res, mask = h.estimate_batch(_capi.SHARED_6PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
-                                 _capi.bundle_opt_from_dict(bundle_opt), ns, rec, rec)
+    res, mask = pipeline.estimate_host(_capi.SHARED_6PT, x1, x2, None, None, _capi.ransac_opt_from_dict(ransac_opt),
+                                       _capi.bundle_opt_from_dict(bundle_opt), ns, rec, rec, device)
     out = []
     for i, r in enumerate(res):
         f = float(r["model"]["f1"])
@@ -642,10 +655,18 @@ def estimate_batch_torch(kind, points2D_1, points2D_2, depth_1, depth_2, cameras
         n_per_pair = n_per_pair.detach().cpu().numpy()
     cams1 = cams2 = None
     if k == _capi.CALIB:
-        def cams(c):
-            lst = [Camera.from_any(c)] * B if not isinstance(c, (list, tuple)) else [Camera.from_any(v) for v in c]
-            return np.array([v._record() for v in lst], dtype=_capi.CAMERA_DTYPE)
-        cams1, cams2 = cams(cameras1), cams(cameras2)
+        cams1, cams2 = _camera_records(cameras1, B), _camera_records(cameras2, B)
+    if pipeline.PIPELINE_DEVICE and len(pipeline.chunk_bounds(B)) > 1:
+        # (MDRP_PIPELINE_DEVICE=1; measured slower than one call, mdrp_amd/pipeline.py) a large resident batch: chunks of pipeline.PIPELINE_CHUNK pairs, two in flight on the pipeline's own handles and streams.  The
+        # inputs were produced on `stream`: wait for them once; the records come back after every chunk's stream has drained, so later
+        # work on `stream` sees complete masks.
+        with torch.cuda.device(x1.device):
+            mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
+            stream.synchronize()
+            res = pipeline.estimate_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N, _capi.ransac_opt_from_dict(ransac_opt),
+                                           _capi.bundle_opt_from_dict(bundle_opt), None if n_per_pair is None else np.ascontiguousarray(n_per_pair, dtype=np.int32),
+                                           cams1, cams2, mask.data_ptr(), dev)
+        return res, mask
     with torch.cuda.device(x1.device):
         mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
         h.estimate_batch_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N,

@@ -16,8 +16,12 @@ Per kernel, means per launch over the profiled steps:
   cycles_per_valu     = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU"""
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mdrp_amd import build as _build  # noqa: E402  (source_hash(): the sources the profiled library was built from)
 
 workload, pairs, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 per_pass = []
@@ -58,6 +62,8 @@ for name in names:
     kernels[name] = out
 json.dump({"command": "rocprofv3 --pmc <counters> --output-format csv -- python3 bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 "
                       "(one pass per counter set; tools/profile_round.sh)",
+           # bench.py attaches these numbers to its line only while the library it runs carries the same hash (mdrp_version())
+           "source_hash": _build.built_hash() or _build.source_hash(),
            "workload": workload, "pairs_per_gpu": pairs, "unit": "mean per launch over the launches of the profiled steps",
            "kernels": kernels}, sys.stdout, indent=1)
 print()
