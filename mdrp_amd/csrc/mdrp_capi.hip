@@ -5,6 +5,17 @@
 #include "mdrp_kernels.h"
 #include "mdrp_classic.h"
 #include "mdrp_lm.h"
+// MDRP_SPLIT_TU (the default build): the k_final family and the baselines' kernels are instantiated in mdrp_tu.hip, compiled in parallel with
+// this file; a single-unit build (experiment builds with -D switches: mdrp_amd/build.py single=True) instantiates them here, implicitly.
+#ifdef MDRP_SPLIT_TU
+#define MDRP_INST extern
+#include "mdrp_instances.h"
+namespace mdrp {
+MDRP_INSTANCES_FINAL_64
+MDRP_INSTANCES_FINAL_256
+MDRP_INSTANCES_CLASSIC
+}
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -164,8 +175,8 @@ namespace {
         else MDRP_LM_DISPATCH_T(KERNEL, 256, kind, shift, grid, smem, stream, __VA_ARGS__);                          \
     } while (0)
 
-// k_final: the user's loss type of the inlier-only refinement is a template parameter as well (rp.final_loss): the reference's default CAUCHY,
-// the paper scripts' TRUNCATED_CAUCHY and TRIVIAL as constants, every other type through the run-time switch (-1)
+// k_final: the user's loss type of the inlier-only refinement is a template parameter as well (rp.final_loss): one instantiation per loss type of
+// BundleOptions (an unknown type is the TRIVIAL loss, as in loss_value)
 #ifdef MDRP_FAST_BUILD
 #define MDRP_FINAL_DISPATCH_L(T, FL, kind, shift, grid, smem, stream, ...) hipLaunchKernelGGL((k_final<0, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__)
 #else
@@ -179,10 +190,14 @@ namespace {
 #endif
 #define MDRP_FINAL_DISPATCH_T(T, floss, kind, shift, grid, smem, stream, ...)                                               \
     do {                                                                                                                   \
-        if ((floss) == 4) MDRP_FINAL_DISPATCH_L(T, 4, kind, shift, grid, smem, stream, __VA_ARGS__);                       \
-        else if ((floss) == 3) MDRP_FINAL_DISPATCH_L(T, 3, kind, shift, grid, smem, stream, __VA_ARGS__);                  \
-        else if ((floss) == 0) MDRP_FINAL_DISPATCH_L(T, 0, kind, shift, grid, smem, stream, __VA_ARGS__);                  \
-        else MDRP_FINAL_DISPATCH_L(T, -1, kind, shift, grid, smem, stream, __VA_ARGS__);                                   \
+        switch (floss) {                                                                                                   \
+        case 1: MDRP_FINAL_DISPATCH_L(T, 1, kind, shift, grid, smem, stream, __VA_ARGS__); break;                          \
+        case 2: MDRP_FINAL_DISPATCH_L(T, 2, kind, shift, grid, smem, stream, __VA_ARGS__); break;                          \
+        case 3: MDRP_FINAL_DISPATCH_L(T, 3, kind, shift, grid, smem, stream, __VA_ARGS__); break;                          \
+        case 4: MDRP_FINAL_DISPATCH_L(T, 4, kind, shift, grid, smem, stream, __VA_ARGS__); break;                          \
+        case 5: MDRP_FINAL_DISPATCH_L(T, 5, kind, shift, grid, smem, stream, __VA_ARGS__); break;                          \
+        default: MDRP_FINAL_DISPATCH_L(T, 0, kind, shift, grid, smem, stream, __VA_ARGS__); break; /* TRIVIAL, like loss_value's default */ \
+        }                                                                                                                  \
     } while (0)
 #define MDRP_FINAL_DISPATCH(threads, floss, kind, shift, grid, smem, stream, ...)                                           \
     do {                                                                                                                   \

@@ -22,7 +22,7 @@ template <> struct ClassicTraits<CLASSIC_FUND> { static constexpr int K = 7, MPS
 // kind 4: x <- (x - pp) / s with the same shared scale s (estimate_shared_focal_relative_pose @0x2205a0; pp in cam1[pair].p[0..1])
 // kind 5: normalize_points(normalize_scale, normalize_centroid, shared_scale) @0x4f6ae0: x <- (x - centroid) / s,
 //         s = sum(|x1 - c1| + |x2 - c2|) / (sqrt2 N); thresholds / s (estimate_fundamental @0x221a00)
-__global__ __launch_bounds__(256) void kc_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
+MDRP_GLOBAL __launch_bounds__(256) void kc_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
                                                const int32_t *__restrict__ n_per_pair, const int32_t *__restrict__ table_of_pair,
                                                const CamDev *__restrict__ cam1, const CamDev *__restrict__ cam2, double max_epi,
                                                double bundle_loss_scale, double *__restrict__ pts, PairState *__restrict__ st,

@@ -29,6 +29,16 @@
 #include "mdrp_logtab.h"
 #include "mdrp_math.h"
 
+// The library is built from several translation units compiled in parallel (mdrp_amd/build.py): mdrp_capi.hip (host API and most kernels) and
+// mdrp_tu.hip compiled once per group of large kernel instantiations (mdrp_instances.h).  Kernel TEMPLATES are instantiated explicitly in
+// exactly one unit (extern template elsewhere); the non-template kernels of these headers belong to the main unit and are `static`
+// (unreferenced, dropped) in the others.
+#ifdef MDRP_SECONDARY_TU
+#define MDRP_GLOBAL static __global__
+#else
+#define MDRP_GLOBAL __global__
+#endif
+
 namespace mdrp {
 
 constexpr int PT_STRIDE = 6;       // doubles per correspondence record
@@ -285,7 +295,7 @@ __device__ __forceinline__ void clear_record_fragment(uint4 *__restrict__ frag, 
 // focal:      x / scale, scale = sum(|x1_i| + |x2_i|) / (sqrt2 N) (normalize_points @0x4f6ae0), thresholds / scale
 struct CamDev { int32_t model_id, pad_; double p[4]; };
 
-__global__ __launch_bounds__(256) void k_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
+MDRP_GLOBAL __launch_bounds__(256) void k_prep(RunParams rp, const double *__restrict__ x1, const double *__restrict__ x2,
                                               const double *__restrict__ d1, const double *__restrict__ d2,
                                               const int32_t *__restrict__ n_per_pair, const int32_t *__restrict__ table_of_pair,
                                               const CamDev *__restrict__ cam1, const CamDev *__restrict__ cam2,
@@ -412,7 +422,7 @@ __device__ __forceinline__ void samples_block(uint64_t n, uint64_t &state_io, in
     }
     state_io = state;
 }
-__global__ __launch_bounds__(SAMP_THREADS) void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
+MDRP_GLOBAL __launch_bounds__(SAMP_THREADS) void k_samples(int n_tables, const int32_t *__restrict__ table_n, uint64_t *__restrict__ table_state,
                                                           int chunk_len, uint32_t *__restrict__ samples /*[n_tables][chunk_len][3]*/) {
     const int t = blockIdx.x;
     if (t >= n_tables) return;
@@ -902,7 +912,7 @@ __device__ __forceinline__ int plan_block_scan(int v, int &total, int *s_w) {
 }
 // zero_a / zero_b: per-pair counters the next sweep accumulates into (or null) - cleared here instead of by a memset node in front
 // begin (or null): the plan covers list entries [begin[stride p], counts[stride p]) of every pair — a sub-range of a list that is still growing
-__global__ __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
+MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
                                                              int per_wg, int32_t *__restrict__ plan, int32_t *__restrict__ zero_a,
                                                              const int32_t *__restrict__ begin = nullptr) {
     __shared__ int s_w[PLAN_THREADS / 64 + 1];
@@ -1331,7 +1341,7 @@ __global__ __launch_bounds__(BND_THREADS, 4) void k_bound(RunParams rp, const Pa
 // change its result.
 // In: surv_count[p] survivors with keys in tags (k_count).  Out: model_count[2p] = sparse, [2p+1] = dense (model_count[2p]
 // held the pair's model count until here: k_count has consumed it).
-__global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState *__restrict__ st, int32_t *__restrict__ model_count,
+MDRP_GLOBAL __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState *__restrict__ st, int32_t *__restrict__ model_count,
                                                    const int32_t *__restrict__ surv_count,
                                                    const uint32_t *__restrict__ tags, uint32_t *__restrict__ tags_sorted) {
     const int pair = blockIdx.x, tid = threadIdx.x;
@@ -1378,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairState
 
 // Work plan of one sweep launch: the workgroups a pair needs (ceil(count / SCORE_THREADS) per density class).
 // One wavefront, 64 pairs per step.  plan[0..B] = prefix sum of blocks per pair, plan[B+1 .. 2B] = sparse blocks of the pair.
-__global__ __launch_bounds__(PLAN_THREADS) void k_plan(int batch, const int32_t *__restrict__ model_count, int32_t *__restrict__ plan,
+MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_plan(int batch, const int32_t *__restrict__ model_count, int32_t *__restrict__ plan,
                                                        int32_t *__restrict__ totals /*[0] dense, [1] dense + sparse, [2] queue head*/) {
     __shared__ int s_w[PLAN_THREADS / 64 + 1];
     int run_d = 0, run_s = 0;
@@ -1701,7 +1711,7 @@ __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
 // are bit-identical to it — and it is unrolled by two with ping-pong record buffers, which removes the register rotation of the
 // one-trip software pipeline (round 3: 244 instructions per trip for 123 fp64 ones; profiles/r04_*).
 template <int KIND, int T, int LOSS = -1>
-__device__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+__device__ __forceinline__ double lm_cost(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                           const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, LmShared &sh, int buf) {
     LmState stt;
     lm_state_from_model(m, KIND != 0, stt);
@@ -1926,7 +1936,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
 }
 
 template <int KIND, bool SHIFT, int T, int LOSS = -1>
-__device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
+__device__ __forceinline__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
                               const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, LmShared &sh, int buf) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NA = NP * (NP + 1) / 2 + NP;
@@ -1973,7 +1983,7 @@ __device__ void lm_accumulate(const Model &m, const double *__restrict__ pts, co
 // indices of the records a mask lets through, compacted per wavefront segment in record order (the segments of lm_cost / lm_accumulate):
 // the third list behind the two work lists.  The inlier-only final refinement sweeps ~half of the records up to 100 times.
 template <int T>
-__device__ void lm_mask_index(const uint8_t *__restrict__ mask, int n, LmShared &sh) {
+__device__ __forceinline__ void lm_mask_index(const uint8_t *__restrict__ mask, int n, LmShared &sh) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int seg = ((n + T - 1) / T) * 64;
     const int lo = wave * seg, hi = min(n, lo + seg);
@@ -2086,7 +2096,7 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
 
 // workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask output
 template <int T>
-__device__ void block_score(int kind, const Model &m, const double *__restrict__ pts, int n, double thr, double *scratch,
+__device__ __forceinline__ void block_score(int kind, const Model &m, const double *__restrict__ pts, int n, double thr, double *scratch,
                             double &score_out, int &cnt_out, uint8_t *__restrict__ mask_out) {
     double R[9], E[9], Em[9];
     quat_to_R(m.q, R);
@@ -2138,7 +2148,7 @@ __device__ void block_score(int kind, const Model &m, const double *__restrict__
 // fetch, same time in round 2; as contiguous eighths of the plan with stealing (lo_take, round 4) 2-5 % of k_lo: the LO is bound by
 // instruction issue at 1-2 waves/SIMD, not by bandwidth or order.)
 // plan layout: prefix[B+1] | begin[B] | end[B] | total
-__global__ __launch_bounds__(PLAN_THREADS) void k_lo_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ prev_plan /*or null*/,
+MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_lo_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ prev_plan /*or null*/,
                                                           int32_t *__restrict__ plan) {
     __shared__ int s_w[PLAN_THREADS / 64 + 1];
     int32_t *prefix = plan, *begin = plan + batch + 1, *end = begin + batch;
@@ -2240,7 +2250,7 @@ __device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__res
     return false;
 }
 
-__global__ void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__restrict__ models, const Trigger *__restrict__ triggers,
+MDRP_GLOBAL void k_walk(RunParams rp, PairState *__restrict__ st, const Model *__restrict__ models, const Trigger *__restrict__ triggers,
                        int trig_cap, int32_t *__restrict__ n_active, unsigned long long *__restrict__ max_needed,
                        const int32_t *__restrict__ lo_plans, int n_plans, int plan_stride, int lo_cap) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2301,7 +2311,7 @@ __device__ __forceinline__ int lo_take(int32_t *__restrict__ head, int32_t *__re
     return total;
 }
 
-__global__ void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks,
+MDRP_GLOBAL void k_gate(const int32_t *__restrict__ lo_head, const int32_t *__restrict__ plan_total, const int32_t *__restrict__ ctl, int lo_blocks,
                        unsigned long long ticks, unsigned long long *__restrict__ timeouts /*[0] gate, [1] final waits: mdrp_stats.fuse_*_timeouts*/) {
     const int total = *plan_total;
     const unsigned long long t0 = wall_clock64();
@@ -2542,7 +2552,7 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_final(RunParams rp, Pai
 }
 
 // ------------------------------------------------------------------------------------------------ unit-parity kernels
-__global__ void k_solver_unit(int solver, int count, const double *__restrict__ x1h, const double *__restrict__ x2h,
+MDRP_GLOBAL void k_solver_unit(int solver, int count, const double *__restrict__ x1h, const double *__restrict__ x2h,
                               const double *__restrict__ d1, const double *__restrict__ d2, Model *__restrict__ out, int32_t *__restrict__ n_out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
@@ -2561,7 +2571,7 @@ __global__ void k_solver_unit(int solver, int count, const double *__restrict__ 
 }
 
 // coordinate box of ONE pair's records into st[0].box (unit sweep path)
-__global__ __launch_bounds__(256) void k_box_unit(int n, const double *__restrict__ pts, PairState *__restrict__ st) {
+MDRP_GLOBAL __launch_bounds__(256) void k_box_unit(int n, const double *__restrict__ pts, PairState *__restrict__ st) {
     __shared__ double red[4][4];
     double bx[4] = {0, 0, 0, 0};
     for (int i = threadIdx.x; i < n; i += 256) {
@@ -2583,7 +2593,7 @@ __global__ __launch_bounds__(256) void k_box_unit(int n, const double *__restric
 }
 
 // MFMA A fragments of ONE pair's packed records (unit path of k_count)
-__global__ void k_frag_unit(int n, const double *__restrict__ pts, uint4 *__restrict__ rfrag) {
+MDRP_GLOBAL void k_frag_unit(int n, const double *__restrict__ pts, uint4 *__restrict__ rfrag) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int g_end = ((n + 15) / 16) * 16;
     if (i < n) {
@@ -2593,7 +2603,7 @@ __global__ void k_frag_unit(int n, const double *__restrict__ pts, uint4 *__rest
 }
 
 // pack raw normalised correspondences of ONE pair into pts records (for mdrp_score_models / mdrp_refine_models)
-__global__ void k_pack_unit(int n, const double *__restrict__ x1, const double *__restrict__ x2, const double *__restrict__ d1,
+MDRP_GLOBAL void k_pack_unit(int n, const double *__restrict__ x1, const double *__restrict__ x2, const double *__restrict__ d1,
                             const double *__restrict__ d2, double *__restrict__ pts, double *__restrict__ dep) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

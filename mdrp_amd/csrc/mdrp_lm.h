@@ -356,7 +356,7 @@ __global__ __launch_bounds__(LME_T, MDRP_LME_MINWAVES) void k_lme_accum(LmePhase
 // amount of work, and a pair's records are read once per round for all of its problems.  A round is
 //     k_lme_cost<DENSE> | k_lme_decide | k_lme_accum_seg | k_lme_reduce | k_lme_solve
 // k_lme_decide: one lane per problem — lm_impl<>'s accept / reject once the candidate's cost is known (the first half of k_lme_accum)
-__global__ void k_lme_decide(LmePhase ph, int round, int cost_seg /*records per cost-sweep segment*/) {
+MDRP_GLOBAL void k_lme_decide(LmePhase ph, int round, int cost_seg /*records per cost-sweep segment*/) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0) ph.live[(round + LME_RING / 2) & (LME_RING - 1)] = 0; // free: every earlier round has ended
     if (j < ph.batch) ph.pair_acc[(size_t)((round + 1) & 1) * ph.batch + j] = 0; // the half the NEXT round counts into (its reader, the previous round's accum sweep, is done)
@@ -649,7 +649,7 @@ __device__ __forceinline__ void lme_flush_evals(const LmProb *P /*or null*/, uns
 
 // ------------------------------------------------------------------------------------------------ LO phase (refine_model)
 // one thread per trigger of the chunk's frozen plan (k_lo_plan): 25 iterations, TRUNCATED at the epipolar threshold
-__global__ void k_lme_lo_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const Model *__restrict__ models,
+MDRP_GLOBAL void k_lme_lo_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const Model *__restrict__ models,
                               const Trigger *__restrict__ triggers, int trig_cap, const int32_t *__restrict__ plan) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= lme_count(ph)) return;
@@ -667,7 +667,7 @@ __global__ void k_lme_lo_init(LmePhase ph, RunParams rp, const PairState *__rest
     ph.probs[j].ev_cost = 0; ph.probs[j].ev_acc = 0;
 }
 
-__global__ void k_lme_lo_finish(LmePhase ph, RunParams rp, const PairState *__restrict__ st, Trigger *__restrict__ triggers, int trig_cap,
+MDRP_GLOBAL void k_lme_lo_finish(LmePhase ph, RunParams rp, const PairState *__restrict__ st, Trigger *__restrict__ triggers, int trig_cap,
                                 const int32_t *__restrict__ plan, unsigned long long *__restrict__ lm_stats) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     const bool mine = j < lme_count(ph);
@@ -689,7 +689,7 @@ __global__ void k_lme_lo_finish(LmePhase ph, RunParams rp, const PairState *__re
 // ransac<> tail (@0x22f1d0-0x22f295) + get_inliers (@0x4f7a10/@0x4f77f0) + the estimator's inlier-only refinement
 // (@0x2247c3 / @0x223815) + focal un-normalisation, one problem per pair.
 // stage 0: result header, mask rows of short pairs, LO from the best model (one wavefront per pair)
-__global__ __launch_bounds__(64) void k_lme_fin_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, uint8_t *__restrict__ mask_all,
+MDRP_GLOBAL __launch_bounds__(64) void k_lme_fin_init(LmePhase ph, RunParams rp, const PairState *__restrict__ st, uint8_t *__restrict__ mask_all,
                                                      ResultDev *__restrict__ results) {
     const int pair = blockIdx.x;
     const PairState &ps = st[pair];
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64) void k_lme_fin_init(LmePhase ph, RunParams rp, 
 
 // stage 1 (after the LO and its score sweep): adopt the refined model if it scores better; the model whose inliers the
 // mask sweep then marks is left in P.m
-__global__ void k_lme_fin_select(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results) {
+MDRP_GLOBAL void k_lme_fin_select(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= rp.batch) return;
     const PairState &ps = st[pair];
@@ -727,7 +727,7 @@ __global__ void k_lme_fin_select(LmePhase ph, RunParams rp, const PairState *__r
 }
 
 // stage 2 (after the mask sweep): the inlier-only refinement with the user's bundle options
-__global__ void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const ResultDev *__restrict__ results) {
+MDRP_GLOBAL void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__restrict__ st, const ResultDev *__restrict__ results) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= rp.batch) return;
     const PairState &ps = st[pair];
@@ -740,7 +740,7 @@ __global__ void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__re
     ph.probs[pair].n_eff = (int32_t)results[pair].num_inliers; // the record mask of this phase = the inliers
 }
 
-__global__ void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results,
+MDRP_GLOBAL void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__restrict__ st, ResultDev *__restrict__ results,
                                 unsigned long long *__restrict__ lm_stats) {
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     lme_flush_evals(pair < rp.batch ? ph.probs + pair : nullptr, lm_stats);
@@ -753,20 +753,20 @@ __global__ void k_lme_fin_write(LmePhase ph, RunParams rp, const PairState *__re
 }
 
 // ------------------------------------------------------------------------------------------------ unit path (mdrp_refine_models)
-__global__ void k_lme_unit_init(LmePhase ph, int count, const Model *__restrict__ models, int kind, int n, double scale_reproj, double ws, LmOpt o) {
+MDRP_GLOBAL void k_lme_unit_init(LmePhase ph, int count, const Model *__restrict__ models, int kind, int n, double scale_reproj, double ws, LmOpt o) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     lme_start(ph.probs[j], models[j], kind != 0, 0, n, scale_reproj, ws, o);
     ph.probs[j].ev_cost = 0; ph.probs[j].ev_acc = 0;
 }
-__global__ void k_lme_unit_finish(LmePhase ph, int count, Model *__restrict__ models, double *__restrict__ final_cost) {
+MDRP_GLOBAL void k_lme_unit_finish(LmePhase ph, int count, Model *__restrict__ models, double *__restrict__ final_cost) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     models[j] = ph.probs[j].m;
     if (final_cost) final_cost[j] = ph.probs[j].cost;
 }
 // pfx = 0, 1, 2, ... (one problem per pair) or 0, count (all problems on pair 0); total
-__global__ void k_lme_iota(int32_t *pfx, int entries, int32_t *total, int total_value, int unit_count) {
+MDRP_GLOBAL void k_lme_iota(int32_t *pfx, int entries, int32_t *total, int total_value, int unit_count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < entries) pfx[i] = unit_count >= 0 ? (i == 0 ? 0 : unit_count) : i;
     if (i == 0) *total = total_value;
