@@ -761,6 +761,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         if ((rc = issue_solve(0, s))) return rc;
         if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
         std::function<int()> pending_lo; // LO of the previous chunk, held back until this chunk's k_count is queued (MDRP_LO_AFTER_COUNT)
+        // ONE LO launch per super-chunk (round 5).  MDRP_LO_MERGE = m: the first m chunks of a schedule launch no LO of their own; their triggers are
+        // refined by the next launch (its plan starts where the last LAUNCHED plan ended).  Default: every chunk but the last, i.e. all of a
+        // super-chunk's triggers in one launch behind its last scan.  Rounds 2-4 launched the first chunk's LO beside the second chunk's sweeps: two
+        // persistent launches, each ending with its own tail of long problems (makespan 2.1 + 1.5 ms for 1.1 + 0.9 ms of balanced work per slot), the
+        // first one holding every wavefront slot while k_sort_tags / k_score waited.  One launch has one tail, twice the problems to balance it with,
+        // and the fused final refinements in its shadow: k_lo 4.32 -> 2.67 ms event-timed, headline 8.72 -> 8.58 ms, shared focal 8.63 -> 8.35,
+        // varying focal 36.6 -> 36.1 (k_lo 25.0 -> 21.7).  LO problems are independent of each other: results are bit-identical.  MDRP_LO_MERGE=0
+        // restores a launch per chunk.
+        const int lo_merge = (piped && !use_lme) ? env_int("MDRP_LO_MERGE", n_chunks - 1) : 0;
+        int last_lo_chunk = -1;
         for (int c = 0; c < n_chunks; ++c) {
             const int len = (int)lens[c];
             rp.chunk_len = len; rp.chunk_off = offs[c];
@@ -851,8 +861,14 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                                    h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
                                    reinterpret_cast<unsigned long long *>(cnt + 10));
             // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
+            const bool skip_lo = c < lo_merge && c + 1 < n_chunks;
+            if (skip_lo) { // (the solver of chunk c + 2 still waits for this chunk's scan)
+                if (piped) HIPCHK(hipEventRecord(h->ev_scanned[c], s));
+                continue;
+            }
             int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
-            const int32_t *prev_plan = c == 0 ? nullptr : lo_plan - lo_plan_ints;
+            const int32_t *prev_plan = last_lo_chunk < 0 ? nullptr : h->work_pair.as<int32_t>() + (size_t)last_lo_chunk * lo_plan_ints;
+            last_lo_chunk = c;
             hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
             const bool fuse_here = fuse_tail && c + 1 == n_chunks;
             if (fuse_here) {
