@@ -48,6 +48,9 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
             if w.any():
                 print(f"   started in [{lo_:.2f}, {hi_:.2f}) of the makespan: {w.sum()} problems; per sweep cost {t_cost[sel][w].sum() / (its[sel][w] + 1).sum():.1f} us, "
                       f"normal equations {t_acc[sel][w].sum() / np.maximum(accs[sel][w], 1).sum():.1f} us, rest per iteration {rest[w].sum() / np.maximum(its[sel][w], 1).sum():.1f} us")
+    pos = ev[:, 1].astype(np.int64)
+    print("duration by trigger ordinal within the pair (ordinal: problems, mean us, p90 us, mean LM iterations): " +
+          ", ".join(f"{k}: {(pos == k).sum()}, {dur[pos == k].mean():.0f}, {np.percentile(dur[pos == k], 90):.0f}, {its[pos == k].mean():.1f}" for k in range(0, int(pos.max()) + 1) if (pos == k).sum() >= 20))
     try:
         fin = np.fromfile(trace + ".final", dtype=np.uint64).reshape(-1, 8)
         fin = fin[fin[:, 2] > 0]
