@@ -184,12 +184,13 @@ def device_identity(dev_index=None):
     return f"{uuid}|{pci}|{p.name}" if uuid is not None else f"{pci}|{p.name}"
 
 
-def gather_device_identities(dev_index=None, group=None):
-    """[(rank, device_identity)] of every rank of the group (one all_gather_object), for the N > 1 bench line: the proof that N distinct GPUs took part"""
+def gather_device_identities(dev_index=None, group=None, force_collective=False):
+    """[(rank, device_identity)] of every rank of the group (one all_gather_object), for the N > 1 bench line: the proof that N distinct GPUs took part
+    (force_collective: run the collective even with one rank — the tests' way to cover the RCCL path on one GPU)"""
     import torch.distributed as dist
     rank, world = _world(group)
     mine = (rank, device_identity(dev_index))
-    if world == 1:
+    if world == 1 and not force_collective:
         return [mine]
     out = [None] * world
     dist.all_gather_object(out, mine, group=group)

@@ -254,6 +254,9 @@ def test_local_shard_through_the_device_gather_path_one_rank():
         created = True
     try:
         out = mdist.estimate_local_shard_device(0, B, *t, ro, bo, None, cams, cams, mask=mask, force_collective=True)
+        # what bench.py puts on its N > 1 line: every rank's physical device, gathered over RCCL (here: one rank, the collective forced)
+        seen = mdist.gather_device_identities(0, force_collective=True)
+        assert seen == [(0, mdist.device_identity(0))] and len(seen[0][1]) > 8 and mdist.local_device_index(5) == 5 % torch.cuda.device_count()
     finally:
         if created:
             tdist.destroy_process_group()
