@@ -300,3 +300,54 @@ def test_emulated_eight_way_split_equals_one_call_and_the_reference(capi, golden
         assert int(sharded[i]["iterations"]) == ref["istats"][j, 1] and int(sharded[i]["num_inliers"]) == ref["istats"][j, 2], i
         assert np.array_equal(m[i], ref_mask[j]), i
         assert model_diff(capi.model_to_array(sharded[i]["model"]), ref["model"][j]) < 1e-6, i
+
+
+@pytest.mark.parametrize("name", ["calib_p3p", "calib_shift", "shared", "varying"])
+def test_dynamic_stopping_full_size_vs_reference_fixture(capi, golden, name):
+    """Round 5: ransac<>'s DYNAMIC stopping rule at full size against the reference binary (tests/golden/dynamic_ref.npz,
+    tests/tools/gen_golden_dynamic_ref.py): the reference's default iteration budget (max 100000, min 1000) on 96 pairs per estimator at 50-85 %
+    outliers — the reference stops them between 1001 and 28714 iterations.  One batched call of the HIP path (several super-chunks, a host read-back of
+    the walk's verdict after each): `iterations` and inlier count identical on every pair; inlier mask identical, model within 1e-6 and model_score to
+    1e-9 on 383 of 384 (the other pair enumerated below with its cause, equal to the oracle);
+    `refinements` may differ by the solver classes of DESIGN.md 5 (counted here: at most 1 pair in 12, as on the fixed-length fixtures)."""
+    from test_oracle_golden import DYNAMIC_CASES, dynamic_pair
+    g = golden("dynamic_ref")
+    kind, es, n, rf, _ = DYNAMIC_CASES[name]
+    ist, fst = g[f"{name}_istats"], g[f"{name}_fstats"]
+    B = len(ist)
+    pairs = [dynamic_pair(g, name, j) for j in range(B)]
+    for j in range(0, B, 11):
+        assert _digest({k: np.stack([p[k] for p in pairs]) for k in ("x1", "x2", "d1", "d2")}, j) == g[f"{name}_digest"][j], "synthetic generator drifted"
+    x1, x2, d1, d2 = (np.ascontiguousarray(np.stack([p[k] for p in pairs])) for k in ("x1", "x2", "d1", "d2"))
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ro = capi.ransac_opt_from_dict({"max_iterations": 100000, "min_iterations": 1000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0, "monodepth_estimate_shift": es})
+    h = capi.Handle(0)
+    try:
+        res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None, cams if kind == 0 else None, cams if kind == 0 else None)
+    finally:
+        h.close()
+    assert np.array_equal(res["iterations"].astype(np.int64), ist[:, 1]), (name, np.nonzero(res["iterations"].astype(np.int64) != ist[:, 1])[0][:8])
+    assert np.array_equal(res["num_inliers"].astype(np.int64), ist[:, 2]), name
+    # Pairs on which the REFERENCE's own solver output changes the RANSAC winner (DESIGN.md 5 (iii): the shared-focal solver of the binary returns a root
+    # ours does not at iteration 552 of pair 27 — tests/tools/classify_ref_deviations.py —, its records differ from there on, it refines 10 models
+    # instead of 12 and ends on a winner whose score differs in the 5th digit: same iterations, same inlier count, 2 mask bits and 1.3e-4 in the model).
+    # There the HIP path must equal the ORACLE, which is run here as the checker.
+    follows_oracle = {"shared": (27,)}.get(name, ())
+    ref_mask = np.unpackbits(g[f"{name}_mask"], axis=1)[:, :n]
+    keep = np.array([j not in follows_oracle for j in range(B)])
+    assert np.array_equal(mask[keep], ref_mask[keep]), (name, np.nonzero((mask != ref_mask).any(axis=1))[0])
+    worst = max(model_diff(capi.model_to_array(res[j]["model"]), g[f"{name}_model"][j]) for j in range(B) if keep[j])
+    assert worst < 1e-6, (name, worst)
+    assert np.allclose(res["model_score"][keep], fst[keep, 1], rtol=1e-9, atol=0), name
+    for j in follows_oracle:
+        from oracle import pyorc as po
+        ro_o = po.ransac_opt(max_iterations=100000, min_iterations=1000, max_epipolar_error=2.0, max_reproj_error=16.0, estimate_shift=es)
+        cam_o = po.cam_flat(0, [800.0, 0.0, 0.0])
+        m, st, mk = po.estimate(kind, x1[j], x2[j], d1[j], d2[j], ro_o, po.bundle_opt(loss_type=4), cam_o if kind == 0 else None, cam_o if kind == 0 else None)
+        assert (int(res[j]["refinements"]), int(res[j]["iterations"]), int(res[j]["num_inliers"])) == (st.refinements, st.iterations, st.num_inliers), (name, j)
+        assert np.array_equal(mask[j], mk) and model_diff(capi.model_to_array(res[j]["model"]), m) < 1e-6 and abs(res[j]["model_score"] / st.model_score - 1.0) < 1e-9, (name, j)
+        assert int((mask[j] != ref_mask[j]).sum()) <= 4 and model_diff(m, g[f"{name}_model"][j]) < 1e-3, (name, j)  # ... and the reference is that close
+    lo_off = np.nonzero(res["refinements"].astype(np.int64) != ist[:, 0])[0]
+    assert len(lo_off) <= B // 12, (name, lo_off)
+    print(f"dynamic stopping, {name}: {int(keep.sum())} / 96 pairs identical to the REFERENCE binary ({len(follows_oracle)} enumerated: equal to the oracle) (iterations {ist[:, 1].min()} ... {ist[:, 1].max()}, inliers, mask); worst model diff {worst:.2e}; "
+          f"LO count differs on {len(lo_off)} pairs {lo_off.tolist()}")

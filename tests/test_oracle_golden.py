@@ -234,3 +234,43 @@ def test_headline_oracle_fixture_vs_reference_fixture(golden, workload):
         m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, po.bundle_opt(loss_type=4), cam if kind == 0 else None, cam if kind == 0 else None)
         assert (st.refinements, st.iterations, st.num_inliers) == tuple(int(v) for v in o["istats"][i]), (workload, i)
         assert (np.packbits(mask) == r["mask"][i]).all() and model_diff(m, r["model"][i]) < 1e-6, (workload, i)
+
+
+DYNAMIC_CASES = {"calib_p3p": (0, False, 2000, None, (0.0, 0.0)), "calib_shift": (0, True, 2000, None, (0.2, -0.1)),
+                 "shared": (1, False, 2000, "shared", (0.0, 0.0)), "varying": (2, False, 3000, "varying", (0.0, 0.0))}
+
+
+def dynamic_pair(g, name, j):
+    from mdrp_amd import synth
+    kind, es, n, rf, (s1, s2) = DYNAMIC_CASES[name]
+    outl = g["outliers"]
+    return synth.make_pair(int(g["first_index"]) + j, n, noise_px=0.5, depth_noise=0.02, outlier_frac=float(outl[j % len(outl)]), random_focal=rf, shift1=s1, shift2=s2)
+
+
+@pytest.mark.parametrize("name", list(DYNAMIC_CASES))
+def test_dynamic_stopping_full_size_vs_reference_fixture(golden, name):
+    """tests/golden/dynamic_ref.npz (tests/tools/gen_golden_dynamic_ref.py): the reference binary with its default iteration budget (max 100000, min 1000)
+    on 96 full-size pairs per estimator at 50-85 % outliers — runs end between 1001 and 28714 iterations by ransac<>'s dynamic rule.  The oracle reproduces
+    every eighth pair now: `iterations`, inlier count and mask identical, model within 1e-6, `refinements` equal except on the enumerated solver classes of
+    DESIGN.md 5 (counted, not hidden).  The GPU suite runs all 4 x 96 pairs against the same file."""
+    import hashlib
+    g = golden("dynamic_ref")
+    kind, es, n, rf, _ = DYNAMIC_CASES[name]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
+    ist = g[f"{name}_istats"]
+    assert ist[:, 1].min() > 1000 and ist[:, 1].max() < 100000 and len(set(ist[:, 1].tolist())) > 20  # the dynamic rule ended them, at many different counts
+    lo_off = 0
+    # (pair 27 of the shared-focal set: the reference's solver returns a root ours does not at iteration 552 and ends on another winner —
+    # 2 mask bits, 1.3e-4 in the model; enumerated in tests/test_gpu_headline.py, which checks the HIP path against the oracle there)
+    for j in range(0, len(ist), 8):
+        p = dynamic_pair(g, name, j)
+        h = hashlib.sha256()
+        for key in ("x1", "x2", "d1", "d2"):
+            h.update(np.ascontiguousarray(p[key], dtype=np.float64).tobytes())
+        assert np.frombuffer(h.digest()[:8], dtype=np.uint64)[0] == g[f"{name}_digest"][j]
+        ro = po.ransac_opt(max_iterations=100000, min_iterations=1000, max_epipolar_error=2.0, max_reproj_error=16.0, estimate_shift=es)
+        m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, po.bundle_opt(loss_type=4), cam if kind == 0 else None, cam if kind == 0 else None)
+        assert (st.iterations, st.num_inliers) == (int(ist[j, 1]), int(ist[j, 2])), (name, j, st.iterations, ist[j])
+        assert (np.packbits(mask) == g[f"{name}_mask"][j]).all() and model_diff(m, g[f"{name}_model"][j]) < 1e-6, (name, j)
+        lo_off += int(st.refinements != int(ist[j, 0]))
+    assert lo_off <= 2, (name, lo_off)
