@@ -351,3 +351,106 @@ def test_dynamic_stopping_full_size_vs_reference_fixture(capi, golden, name):
     assert len(lo_off) <= B // 12, (name, lo_off)
     print(f"dynamic stopping, {name}: {int(keep.sum())} / 96 pairs identical to the REFERENCE binary ({len(follows_oracle)} enumerated: equal to the oracle) (iterations {ist[:, 1].min()} ... {ist[:, 1].max()}, inliers, mask); worst model diff {worst:.2e}; "
           f"LO count differs on {len(lo_off)} pairs {lo_off.tolist()}")
+
+
+# ---- the timed batches of the comparison rows and of the outlier-free shape against the reference binary (round 5) -------------------------------
+BASELINE_SETS = {
+    # workload (bench.py WORKLOADS): kind, pairs, outlier_frac, random_focal
+    "relpose_5pt_n2000_i10k": (3, 1024, 0.5, None),
+    "fundamental_7pt_n2000_i10k": (5, 1024, 0.5, None),
+    "shared_6pt_n2000_i10k": (4, 256, 0.5, "shared"),
+    "calib_p3p_n2000_i10k_clean": (0, 1024, 0.0, None),
+}
+# LO count of the HIP path minus the CPU oracle's (the oracle's own difference to the reference is stored per pair in the fixture: `oracle_refinements`)
+GPU_MINUS_ORACLE_LO_BASELINES = {
+    # 5-point: a degree-10 root at the edge of existence, found by the device's elimination order (LU in LDS) and not by the oracle's (Gauss-Jordan), sets a
+    # record: one more LO, nothing else changes (the class of DESIGN.md 8a; 6 of 3840 pairs in the stress campaign).  On pair 939 the reference has it too.
+    "relpose_5pt_n2000_i10k": {553: 1, 864: 1, 939: 1},
+    "fundamental_7pt_n2000_i10k": {},
+    "shared_6pt_n2000_i10k": {},
+    "calib_p3p_n2000_i10k_clean": {},
+}
+
+
+# Pairs whose RANSAC winner's `model_score` differs from the reference's beyond 1e-9 (exact list).  5-point pair 519: 0.00662927 (HIP) against 0.00663005
+# (reference and oracle) with the same 13 refinements, the same iterations, inlier count and mask and a final model within 1e-6: one of the pair's LO
+# refinements ends in a slightly lower minimum on the HIP path.  The 5-point LO refines over the subset get_inliers(5 thr^2) of the incoming model
+# (RelativePoseEstimator::refine_model); the cause was not isolated further — a membership test of that subset on a rounding boundary or the LM's
+# summation order are the candidates (the tie class of DESIGN.md 8a (ii): LO results that reach the same basin from different starts).
+SCORE_OFF_BASELINES = {"relpose_5pt_n2000_i10k": [519]}
+
+
+def _pose_diff(a, b):
+    dq = min(np.abs(a[:4] - b[:4]).max(), np.abs(a[:4] + b[:4]).max())
+    return dq + np.abs(a[4:7] / np.linalg.norm(a[4:7]) - b[4:7] / np.linalg.norm(b[4:7])).max()
+
+
+def _fund_diff(a, b):
+    a, b = a[:9] / np.linalg.norm(a[:9]), b[:9] / np.linalg.norm(b[:9])
+    return min(np.abs(a - b).max(), np.abs(a + b).max())
+
+
+@pytest.mark.parametrize("workload", list(BASELINE_SETS))
+def test_baseline_and_clean_bench_batches_vs_reference_fixture(capi, golden, workload):
+    """Every pair of the batches bench.py times for the 5- / 7-point baselines (1024 pairs), the 6-point baseline (its 256-pair bench batch) and the
+    outlier-free calibrated shape (1024 pairs) against the reference binary's own output (tests/golden/headline_ref_<workload>.npz,
+    tests/tools/gen_golden_headline_ref_classic.py), through the device-resident entry point bench.py times: iterations, inlier count and inlier mask
+    identical on every pair, model within 1e-6 (|t| of a 5- / 6-point pose and the scale of F are gauges: directions / normalised matrices are compared),
+    model_score to 1e-9, `refinements` = the oracle's stored count (whose own difference to the reference is in the fixture: 12 / 0 / 7 / 1 pairs) plus
+    the exact list above."""
+    import torch
+    from mdrp_amd import synth
+    ref = golden(f"headline_ref_{workload}")
+    kind, B, of, rf = BASELINE_SETS[workload]
+    n = 2000
+    host = synth.make_batch(0, B, n, noise_px=0.5, depth_noise=0.02, outlier_frac=of, random_focal=rf)
+    for i in range(0, B, 37):
+        h_ = hashlib.sha256()
+        for k in ("x1", "x2", "d1", "d2"):
+            h_.update(np.ascontiguousarray(host[k][i], dtype=np.float64).tobytes())
+        assert np.frombuffer(h_.digest()[:8], dtype=np.uint64)[0] == ref["digest"][i], "synthetic generator drifted"
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(host[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
+    mask_t = torch.zeros((B, n), dtype=torch.uint8, device=dev)
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE)
+    if kind != 4:
+        cams["params"][:, 0] = 800.0  # (kind 4: cam1 carries the principal point, 0 here)
+    ro = capi.ransac_opt_from_dict(RO)
+    bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    c = cams if kind in (0, 3, 4) else None
+    h = capi.Handle(0)
+    torch.cuda.synchronize(dev)
+    try:
+        h.estimate_batch_device(kind, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr() if kind == 0 else 0, t[3].data_ptr() if kind == 0 else 0, B, n, ro, bo, None, c, c, mask_t.data_ptr())
+        res = h.fetch_results(B)
+        mask = mask_t.cpu().numpy()
+    finally:
+        h.close()
+    ist, fst = ref["istats"], ref["fstats"]
+    assert np.array_equal(res["iterations"].astype(np.int64), ist[:, 1]) and np.array_equal(res["num_inliers"].astype(np.int64), ist[:, 2]), workload
+    assert np.array_equal(mask, np.unpackbits(ref["mask"], axis=1)[:, :n]), (workload, np.nonzero((mask != np.unpackbits(ref["mask"], axis=1)[:, :n]).any(axis=1))[0][:8])
+    sc_off = np.nonzero(~np.isclose(res["model_score"], fst[:, 1], rtol=1e-9, atol=0))[0]
+    assert sc_off.tolist() == SCORE_OFF_BASELINES.get(workload, []), (workload, {int(i): (float(res["model_score"][i]), float(fst[i, 1]), int(res["refinements"][i]), int(ist[i, 0]), int(ref["oracle_refinements"][i])) for i in sc_off})
+    worst = 0.0
+    for i in range(B):
+        m = capi.model_to_array(res[i]["model"])
+        r = ref["model"][i]
+        if kind == 0:
+            d = model_diff(m, r)
+        elif kind == 5:
+            d = _fund_diff(np.r_[m[:9]], r[:9])
+        else:
+            d = _pose_diff(m[:7], r[:7])
+            if kind == 4:
+                d = max(d, abs(m[10] - r[7]) / abs(r[7]))  # the shared focal length (mdrp_model.f1 | the fixture's 8th value)
+        worst = max(worst, d)
+        assert d < 1e-6, (workload, i, d)
+    expected = ref["oracle_refinements"].copy()
+    for k, v in GPU_MINUS_ORACLE_LO_BASELINES[workload].items():
+        expected[k] += v
+    got = res["refinements"].astype(np.int64)
+    wrong = np.nonzero(got != expected)[0]
+    assert len(wrong) == 0, (workload, {int(i): (int(got[i]), int(expected[i]), int(ist[i, 0])) for i in wrong})
+    off = np.nonzero(got != ist[:, 0])[0]
+    print(f"{workload} vs REFERENCE binary: {B} / {B} pairs identical (iterations, inliers, mask); worst model diff {worst:.2e}; LO count differs from the reference on {len(off)} pairs "
+          f"{dict(zip(off.tolist(), (got[off] - ist[off, 0]).tolist()))}")

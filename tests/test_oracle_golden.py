@@ -274,3 +274,31 @@ def test_dynamic_stopping_full_size_vs_reference_fixture(golden, name):
         assert (np.packbits(mask) == g[f"{name}_mask"][j]).all() and model_diff(m, g[f"{name}_model"][j]) < 1e-6, (name, j)
         lo_off += int(st.refinements != int(ist[j, 0]))
     assert lo_off <= 2, (name, lo_off)
+
+
+@pytest.mark.parametrize("workload,kind,pairs,outl,rf,lo_dev", [("relpose_5pt_n2000_i10k", 3, 1024, 0.5, None, 12), ("fundamental_7pt_n2000_i10k", 5, 1024, 0.5, None, 0),
+                                                               ("shared_6pt_n2000_i10k", 4, 256, 0.5, "shared", 7), ("calib_p3p_n2000_i10k_clean", 0, 1024, 0.0, None, 1)])
+def test_baseline_and_clean_headline_fixtures(golden, workload, kind, pairs, outl, rf, lo_dev):
+    """tests/golden/headline_ref_<workload>.npz (tests/tools/gen_golden_headline_ref_classic.py): the reference binary on every pair of the batches bench.py
+    times for the 5- / 6- / 7-point baselines and the outlier-free shape, with the oracle run beside it when the fixture was made: oracle result == reference
+    result (iterations, inliers, mask, model 1e-6) on EVERY pair; the LO count differs on 12 / 0 / 7 / 1 pairs.  One pair per workload is re-run now."""
+    import hashlib
+    from mdrp_amd import synth
+    g = golden(f"headline_ref_{workload}")
+    assert len(g["istats"]) == pairs and g["oracle_same"].all() and float(g["oracle_model_diff"].max()) < 1e-6
+    assert int((g["oracle_refinements"] != g["istats"][:, 0]).sum()) == lo_dev
+    i = 7
+    p = synth.make_pair(i, 2000, noise_px=0.5, depth_noise=0.02, outlier_frac=outl, random_focal=rf)
+    h = hashlib.sha256()
+    for key in ("x1", "x2", "d1", "d2"):
+        h.update(np.ascontiguousarray(p[key], dtype=np.float64).tobytes())
+    assert np.frombuffer(h.digest()[:8], dtype=np.uint64)[0] == g["digest"][i]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
+    if kind == 0:
+        ro = po.ransac_opt(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0, max_reproj_error=16.0)
+        m, st, mask = po.estimate(0, p["x1"], p["x2"], p["d1"], p["d2"], ro, po.bundle_opt(loss_type=4), cam, cam)
+    else:
+        ro = po.ransac_opt(max_iterations=10000, min_iterations=10000, max_epipolar_error=2.0)
+        m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], ro, po.bundle_opt(loss_type=4), cam if kind == 3 else None, cam if kind == 3 else None, pp=(0.0, 0.0))
+    assert (st.refinements, st.iterations, st.num_inliers) == (int(g["oracle_refinements"][i]), int(g["istats"][i, 1]), int(g["istats"][i, 2]))
+    assert (np.packbits(mask) == g["mask"][i]).all()
