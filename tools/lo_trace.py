@@ -51,6 +51,12 @@ elif len(sys.argv) > 1 and sys.argv[1] == "child":
     pos = ev[:, 1].astype(np.int64)
     print("duration by trigger ordinal within the pair (ordinal: problems, mean us, p90 us, mean LM iterations): " +
           ", ".join(f"{k}: {(pos == k).sum()}, {dur[pos == k].mean():.0f}, {np.percentile(dur[pos == k], 90):.0f}, {its[pos == k].mean():.1f}" for k in range(0, int(pos.max()) + 1) if (pos == k).sum() >= 20))
+    print("long problems by trigger ordinal (ordinal: share that ran all 25 iterations, p99 us, max us): " +
+          ", ".join(f"{k}: {(its[pos == k] >= 25).mean():.3f}, {np.percentile(dur[pos == k], 99):.0f}, {dur[pos == k].max():.0f}" for k in range(0, int(pos.max()) + 1) if (pos == k).sum() >= 20))
+    inl = ev[:, 2].astype(np.int64)
+    print("by inlier count of the triggering minimal model (range: problems, mean us, share at 25 iterations, max us): " +
+          ", ".join(f"{lo_}-{hi_}: {((inl >= lo_) & (inl < hi_)).sum()}, {dur[(inl >= lo_) & (inl < hi_)].mean():.0f}, {(its[(inl >= lo_) & (inl < hi_)] >= 25).mean():.3f}, {dur[(inl >= lo_) & (inl < hi_)].max():.0f}"
+                    for lo_, hi_ in ((0, 100), (100, 300), (300, 600), (600, 800), (800, 900), (900, 1000), (1000, 2001)) if ((inl >= lo_) & (inl < hi_)).sum() >= 20))
     try:
         fin = np.fromfile(trace + ".final", dtype=np.uint64).reshape(-1, 8)
         fin = fin[fin[:, 2] > 0]
