@@ -68,7 +68,10 @@ typedef struct {
     double max_epipolar_error;  /* 1.0 (pixels) */
     uint64_t seed;              /* 0 */
     int32_t monodepth_estimate_shift; /* calibrated estimator only; ignored elsewhere exactly like the reference */
-    float monodepth_weight_sampson;   /* 1.0 */
+    float monodepth_weight_sampson;   /* 1.0.  A float in the reference too (+0x4c); the wrappers hand max(ws, 0) on.  Away from 1 the reference's
+                                       * refiners are not self-consistent and the library reproduces them as they are: the Sampson term enters
+                                       * the LM COST as ws rho(r^2) but the normal equations as ws^2 w(.) J'J, with w evaluated at r^2 in the
+                                       * calibrated refiner and at ws r^2 in the two focal ones (tests/golden/refine_ws.npz). */
     int32_t score_initial_model;      /* 0.  RansacOptions +0x49, set by the binding when an initial pose is passed with it.  What the
                                        * reference then scores first is NOT the caller's pose: ransac_*_relpose reset it to the identity
                                        * (black-box: any initial pose gives the same result).  The reset model has E = 0: no inliers,
@@ -89,7 +92,11 @@ typedef struct {
 typedef struct {
     uint64_t max_iterations; /* 100 */
     int32_t loss_type;       /* 0 TRIVIAL 1 TRUNCATED 2 HUBER 3 CAUCHY 4 TRUNCATED_CAUCHY 5 TRUNCATED_LE_ZACH */
-    double loss_scale;       /* 1.0 */
+    double loss_scale;       /* 1.0.  Final refinement of the shared- / varying-focal estimators and of the 5- / 6- / 7-point baselines: divided by the
+                              * normalisation scale.  The calibrated monodepth estimator IGNORES it, as the reference does
+                              * (estimate_monodepth_relative_pose @0x224704): its final loss scale is half the normalised epipolar threshold,
+                              * (1/f1 + 1/f2) * max_epipolar_error / 4 — the same number as loss_scale = 1 at max_epipolar_error = 2, the
+                              * reference's own setting (tests/golden/options_ref.npz). */
     double gradient_tol;     /* 1e-10 */
     double step_tol;         /* 1e-8 */
     double initial_lambda;   /* 1e-3 */

@@ -530,7 +530,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     rp.batch = batch; rp.n_max = n_max;
     rp.max_iterations = ro->max_iterations; rp.min_iterations = ro->min_iterations;
     rp.dyn_mult = ro->dyn_num_trials_mult; rp.log_prob_missing = std::log(1.0 - ro->success_prob);
-    rp.weight_sampson = (double)ro->monodepth_weight_sampson;
+    rp.weight_sampson = ro->monodepth_weight_sampson > 0.0f ? (double)ro->monodepth_weight_sampson : 0.0; // the wrappers hand max(ws, 0) on (@0x2246e6)
     rp.final_max_it = (int)std::min<uint64_t>(bo->max_iterations, 1u << 30); rp.final_loss = bo->loss_type;
     rp.grad_tol = bo->gradient_tol; rp.step_tol = bo->step_tol; rp.lambda0 = bo->initial_lambda;
     rp.lambda_min = bo->min_lambda; rp.lambda_max = bo->max_lambda;

@@ -80,7 +80,7 @@ struct PairState {
     double sq_thr;      // eps^2
     double scale_reproj;
     double lo_loss_scale;   // loss_scale of the LO refinement (eps; 1.0 for varying focal — reference quirk)
-    double final_loss_scale; // user bundle loss_scale, normalised
+    double final_loss_scale; // focal estimators: user bundle loss_scale, normalised; calibrated: half the normalised epipolar threshold (k_prep)
     double norm;        // un-normalisation factor of the focals (1 for calibrated)
     double box[4];      // max |x1.x|, |x1.y|, |x2.x|, |x2.y| of the normalised correspondences (k_score's denominator bound)
     double cen[4];      // centroids subtracted by the 7-point baseline's normalisation (c1.x, c1.y, c2.x, c2.y); 0 otherwise
@@ -365,7 +365,10 @@ MDRP_GLOBAL __launch_bounds__(256) void k_prep(RunParams rp, const double *__res
         const double rep = max_reproj * k;
         s.scale_reproj = rep > 0.0 ? (s.eps * s.eps) / (rep * rep) : 0.0;
         s.lo_loss_scale = rp.kind == 2 ? 1.0 : s.eps;
-        s.final_loss_scale = bundle_loss_scale * k;
+        // the focal wrappers divide the caller's BundleOptions::loss_scale by the normalisation scale; the calibrated wrapper OVERWRITES it
+        // with half the normalised epipolar threshold, (1/f2 + 1/f1) * (max_epipolar_error * 0.25) (reference binary @0x224704; the
+        // two readings coincide at the reference's own settings, max_epipolar_error 2 and loss_scale 1)
+        s.final_loss_scale = rp.kind == 0 ? (1.0 / (0.5 * (fx2 + fy2)) + 1.0 / (0.5 * (fx1 + fy1))) * (max_epi * 0.25) : bundle_loss_scale * k;
         s.norm = norm;
         s.cen[0] = s.cen[1] = s.cen[2] = s.cen[3] = 0.0;
         s.best_min_cnt = 0; s.best_min_score = DBL_MAX;
@@ -1733,7 +1736,7 @@ __device__ __forceinline__ double lm_cost(const Model &m, const double *__restri
     const int loss = LOSS >= 0 ? LOSS : o.loss;
     const double lsc = o.loss_scale, mu = o.mu, t2 = lsc * lsc;
     const double *logtab = sh.logtab;
-    const bool ws_nz = ws != 0.0;
+    const bool ws_nz = ws * ws != 0.0; // the Sampson row's weight carries ws^2 (lm_accumulate_point)
     const unsigned long long lt = (1ull << lane) - 1ull;
     double cost = 0;
     int cnt = 0, evaluated = 0;
@@ -1775,19 +1778,22 @@ __device__ __forceinline__ double lm_cost(const Model &m, const double *__restri
             const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
             const int oki = cur.ok;
             fwd[u] = oki & (int)!(zf < 0); bwd[u] = oki & (int)!(zb < 0);
+            // The Sampson row's IRLS weight is ws^2 w(r^2) in the calibrated refiner and ws^2 w(ws r^2) in the two focal ones, while the COST
+            // carries ws rho(r^2) in all three (lm_accumulate_point): the work list follows the weight, so its argument is `ra`, not `rs`.
+            const double ra = KIND != 0 ? ws * rs : rs;
             if (LOSS == 1) { // TRUNCATED: min(r^2, t^2); IRLS weight 1 below the threshold, 0 at and above it (and for NaN)
-                const bool is = rs < t2, jf = rf < t2, jb = rb < t2;
+                const bool is = rs < t2, ia = KIND != 0 ? ra < t2 : is, jf = rf < t2, jb = rb < t2;
                 vs[u] = ws * (is ? rs : t2); vf[u] = jf ? rf : t2; vb[u] = jb ? rb : t2;
-                contrib[u] = ((oki & (int)is & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
+                contrib[u] = ((oki & (int)ia & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
             } else {
                 vs[u] = ws * loss_value_tab(loss, lsc, rs, logtab); vf[u] = loss_value_tab(loss, lsc, rf, logtab); vb[u] = loss_value_tab(loss, lsc, rb, logtab);
                 if (LOSS == 3 || LOSS == 4) {
                     // the Cauchy weights 1 / (1 + r^2 / t^2), floored at DBL_MIN, are never zero (NaN included: the floor takes it); TRUNCATED_CAUCHY's is
                     // zero exactly at and beyond the threshold — the same predicate as `loss_weight(...) != 0` without three reciprocal chains
-                    const bool is = LOSS == 3 || rs < t2, jf = LOSS == 3 || rf < t2, jb = LOSS == 3 || rb < t2;
-                    contrib[u] = ((oki & (int)is & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
+                    const bool ia = LOSS == 3 || ra < t2, jf = LOSS == 3 || rf < t2, jb = LOSS == 3 || rb < t2;
+                    contrib[u] = ((oki & (int)ia & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
                 } else
-                    contrib[u] = ((oki & (int)(ws * loss_weight(loss, lsc, rs, mu) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
+                    contrib[u] = ((oki & (int)(ws * ws * loss_weight(loss, lsc, ra, mu) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
                                   ((int)bwd[u] & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
             }
         }
@@ -1890,7 +1896,10 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
     {
         double r0, J0[LM_NPAR];
         lm_sampson_term<true, KIND != 0>(stt, p01.x, p01.y, p23.x, p23.y, r0, J0);
-        const double w = ws * loss_weight(loss, o.loss_scale, r0 * r0, o.mu);
+        // weight_sampson enters the normal equations SQUARED (the cost carries it to the first power), and the focal refiners evaluate the loss
+        // weight at ws r^2 where the calibrated one evaluates it at r^2: what the reference binary computes (oracle/orc_refine.c lm_accumulate,
+        // fitted against refine_monodepth_*relpose for ws = 0.3 ... 3 and all six losses); every form coincides at ws = 1
+        const double w = ws * ws * loss_weight(loss, o.loss_scale, KIND != 0 ? ws * (r0 * r0) : r0 * r0, o.mu);
         if (LOSS == 1) {
             if (w != 0.0) { lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); any_w = true; } // (ws is a run-time weight: its product stays)
             else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x1C0u>(J0, r0);

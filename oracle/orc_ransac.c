@@ -166,10 +166,18 @@ orc_ransac_stats orc_estimate(int kind, const double *x1, const double *x2, cons
     orc_ransac_opt ro = *ropt;
     orc_bundle_opt bo = *bopt;
     double norm = 1.0;
+    /* RansacOptions::monodepth_weight_sampson is a float (+0x4c); the wrappers hand max(ws, 0) on as a double (@0x2246e6) */
+    ro.weight_sampson = (double)(float)ropt->weight_sampson;
+    if (!(ro.weight_sampson > 0.0)) ro.weight_sampson = 0.0;
     if (kind == ORC_CALIB) {
         for (int k = 0; k < n; ++k) { cam_unproject(cam1, x1 + 2 * k, a1 + 2 * k); cam_unproject(cam2, x2 + 2 * k, a2 + 2 * k); }
         const double k = 0.5 * (1.0 / cam_focal(cam1) + 1.0 / cam_focal(cam2));
-        ro.max_epipolar_error *= k; ro.max_reproj_error *= k; bo.loss_scale *= k;
+        ro.max_epipolar_error *= k; ro.max_reproj_error *= k;
+        /* the calibrated wrapper does NOT scale the caller's BundleOptions::loss_scale: it overwrites it with half the
+         * normalised epipolar threshold, (1/f1 + 1/f2) * (max_epipolar_error * 0.25) (@0x224704 .. 0x2247a8); the two focal
+         * wrappers do divide the caller's value by the normalisation scale.  With the reference's own settings
+         * (max_epipolar_error 2, loss_scale 1: eval.py) the two readings coincide. */
+        bo.loss_scale = (1.0 / cam_focal(cam2) + 1.0 / cam_focal(cam1)) * (ropt->max_epipolar_error * 0.25);
     } else {
         /* normalize_points(..., normalize_scale=1, normalize_centroid=0, shared_scale=1) @0x4f6ae0 */
         double acc = 0.0;

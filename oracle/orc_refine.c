@@ -13,6 +13,7 @@
 #include "mdrp_oracle.h"
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* probing switches (kept so tools/probe_lm.py can re-run the discrimination; defaults = what the binary does) */
@@ -293,7 +294,13 @@ static void lm_accumulate(const lm_problem *pb, const orc_model *m, double *JtJ,
                 if (pb->kind == ORC_SHARED && pb->idx[p] == 9) J[row][p] += Jf[row][10];
             }
         const double pw = pb->weights ? pb->weights[k] : 1.0;
-        const double wS = pw * pb->ws * loss_weight(pb->loss_type, pb->thr, r[0] * r[0]);
+        /* weight_sampson enters the normal equations SQUARED while lm_cost() above carries it to the first power, and the two focal
+         * refiners evaluate the loss weight at ws * r^2 where the calibrated one evaluates it at r^2.  Neither is what a derivation
+         * from the cost gives; both are what the reference binary computes (fitted against refine_monodepth_relpose /
+         * refine_monodepth_{shared,varying}_focal_relpose for ws in {0.3, 0.5, 0.7, 1.3, 2, 3}, all six losses, with and without
+         * per-point weights: tests/test_refshim_parity.py::test_weight_sampson_in_the_refiners).  At ws = 1 all forms coincide. */
+        const double ws2 = pb->ws * pb->ws, rs2 = r[0] * r[0];
+        const double wS = pw * ws2 * loss_weight(pb->loss_type, pb->thr, pb->kind == ORC_CALIB ? rs2 : pb->ws * rs2);
         const double wF = (r[5] < 0) ? 0.0 : pw * loss_weight(pb->loss_type, pb->thr, r[1] * r[1] + r[2] * r[2]);
         const double wB = (r[6] < 0) ? 0.0 : pw * loss_weight(pb->loss_type, pb->thr, r[3] * r[3] + r[4] * r[4]);
         const double wr[5] = {wS, wF, wF, wB, wB};

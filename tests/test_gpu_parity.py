@@ -3,7 +3,8 @@ captured from the reference binary.  Needs an MI355X:  pytest -m gpu."""
 import numpy as np
 import pytest
 
-from helpers import KNOWN_LO_COUNT_DEVIATIONS, REFERENCE_NAN_SOLUTIONS, match_solution_sets, model_diff, widen
+from helpers import (KNOWN_LO_COUNT_DEVIATIONS, OPTIONS_GPU_MINUS_ORACLE_LO, OPTIONS_KINDS, OPTIONS_LO_DEVIATIONS, OPTIONS_MODEL_DEVIATIONS, OPTIONS_NAMES, REFERENCE_NAN_SOLUTIONS,
+                     match_solution_sets, model_diff, options_pair, widen)
 
 pytestmark = pytest.mark.gpu
 
@@ -179,7 +180,60 @@ def test_refine_vs_reference_golden(handle, capi, golden):
         assert cost[0] == pytest.approx(ref[14], rel=1e-8, abs=1e-18)
 
 
+def test_refine_weight_sampson_vs_reference_golden(handle, capi, golden):
+    """tests/golden/refine_ws.npz: the reference's three refiners at ws in {0.3 ... 3} — cost ws rho(r^2), normal equations ws^2 w(.), the loss weight at
+    r^2 (calibrated) or ws r^2 (focal) — on the 648 unweighted cases (the C ABI's refine entry point has no per-correspondence weights, like the
+    estimators' calls of it), model to 1e-6 and final cost to 1e-8."""
+    g, inp = golden("refine_ws"), golden("refine")
+    ran = 0
+    for case, ref in zip(g["cases"], g["out"]):
+        i, kind, es, ws, lt, its, weighted, thr = int(case[0]), int(case[1]), int(case[2]), case[3], int(case[4]), int(case[5]), int(case[6]), case[7]
+        if weighted:
+            continue
+        bo = capi.bundle_opt_from_dict({"max_iterations": its, "loss_type": lt, "loss_scale": thr, "gradient_tol": 1e-10})
+        m, cost = handle.refine_models(kind, capi.array_to_models(inp[f"model_{i}"]), inp[f"x1_{i}"], inp[f"x2_{i}"], inp[f"d1_{i}"], inp[f"d2_{i}"],
+                                       1 / 64.0, float(ws), bo, es)
+        assert model_diff(capi.model_to_array(m[0]), ref[:12]) < 1e-6, case
+        assert cost[0] == pytest.approx(ref[14], rel=1e-8, abs=1e-18), case
+        ran += 1
+    assert ran == 648
+
+
 # ---------------------------------------------------------------------------------------------- full estimators
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_randomised_options_vs_reference_fixture(golden, name):
+    """tests/golden/options_ref.npz through the drop-in module's single-pair entry points (option DICTS as the reference's scripts pass them): 96 cases per
+    estimator with size, outlier share, noise, both thresholds, the Sampson weight, seed, fixed / dynamic iteration budget, loss type, loss scale and
+    bundle iteration cap drawn at random.  Iterations, inlier count and mask identical to the REFERENCE BINARY on every case, model within 1e-6 (one
+    enumerated case 4e-6), LO count = the oracle's but for one enumerated tie (exact lists: helpers.OPTIONS_LO_DEVIATIONS, 5 cases oracle != reference; OPTIONS_GPU_MINUS_ORACLE_LO)."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi
+    g = golden("options_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+    loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
+    lo_dev, model_dev = OPTIONS_LO_DEVIATIONS.get(name, {}), OPTIONS_MODEL_DEVIATIONS.get(name, {})
+    for j, row in enumerate(g["cases"]):
+        n = int(row[0])
+        p = options_pair(name, j, row)
+        ro = {"max_iterations": int(row[7]), "min_iterations": int(row[8]), "max_epipolar_error": float(row[3]), "max_reproj_error": float(row[4]),
+              "seed": int(row[6]), "monodepth_estimate_shift": es, "monodepth_weight_sampson": float(row[5])}
+        bo = {"max_iterations": int(row[11]), "loss_type": loss_name[int(row[9])], "loss_scale": float(row[10]), "gradient_tol": 1e-10}
+        if kind == 0:
+            geom, info = poselib.estimate_monodepth_relative_pose(p["x1"], p["x2"], p["d1"], p["d2"], cam, cam, ro, bo)
+            m = np.r_[geom.pose.q, geom.pose.t, geom.scale, geom.shift1, geom.shift2, 1.0, 1.0]
+        else:
+            fn = poselib.estimate_monodepth_shared_focal_relative_pose if kind == 1 else poselib.estimate_monodepth_varying_focal_relative_pose
+            pair, info = fn(p["x1"], p["x2"], p["d1"], p["d2"], ro, bo)
+            geom = pair.geometry
+            m = np.r_[geom.pose.q, geom.pose.t, geom.scale, geom.shift1, geom.shift2, pair.camera1.focal(), pair.camera2.focal()]
+        ist = g[f"{name}_istats"][j]
+        assert (info["iterations"], info["num_inliers"]) == (int(ist[1]), int(ist[2])), (name, j, info["iterations"], info["num_inliers"], ist)
+        assert (np.asarray(info["inliers"], dtype=np.uint8) == np.unpackbits(g[f"{name}_mask"][j])[:n]).all(), (name, j)
+        assert model_diff(m, g[f"{name}_model"][j]) < model_dev.get(j, 1e-6), (name, j, model_diff(m, g[f"{name}_model"][j]))
+        assert info["refinements"] - int(ist[0]) == lo_dev.get(j, 0) + OPTIONS_GPU_MINUS_ORACLE_LO.get(name, {}).get(j, 0), (name, j, info["refinements"], int(ist[0]))
+
+
 def _run_estimate(capi, handle, kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None):
     def camrec(c):
         r = np.zeros(1, dtype=capi.CAMERA_DTYPE)

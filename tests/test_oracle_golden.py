@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import pyorc as po
-from helpers import INITIAL_ORACLE_DEVIATIONS, KNOWN_LO_COUNT_DEVIATIONS, REFERENCE_NAN_SOLUTIONS, match_solution_sets, model_diff, widen
+from helpers import (INITIAL_ORACLE_DEVIATIONS, KNOWN_LO_COUNT_DEVIATIONS, OPTIONS_KINDS, OPTIONS_LO_DEVIATIONS, OPTIONS_MODEL_DEVIATIONS, OPTIONS_NAMES,
+                     REFERENCE_NAN_SOLUTIONS, input_digest, match_solution_sets, model_diff, options_pair, refine_ws_weights, widen)
 
 
 def test_sampler_known_answers(golden):
@@ -72,6 +73,52 @@ def test_refine_matches_reference(golden):
         assert d < 1e-6, (case, d)
         assert abs(st.cost - ref[14]) <= 1e-9 * abs(ref[14]) + 1e-18
     assert worst < 1e-6
+
+
+def test_weight_sampson_in_the_refiners(golden):
+    """tests/golden/refine_ws.npz (tests/tools/gen_golden_refine_ws.py): the reference binary's three refiners at ws != 1 — cost ws rho(r^2), normal
+    equations ws^2 w(.), loss weight at r^2 (calibrated) or ws r^2 (focal) — on the nine problems of refine.npz, all six losses, with and without
+    per-correspondence weights: initial cost to 1e-12, model to 1e-6, final cost to 1e-9 on all 1296 cases."""
+    g, inp = golden("refine_ws"), golden("refine")
+    assert len(g["cases"]) == 1296
+    worst = 0.0
+    for case, ref in zip(g["cases"], g["out"]):
+        i, kind, es, ws, lt, its, weighted, thr = int(case[0]), int(case[1]), int(case[2]), case[3], int(case[4]), int(case[5]), int(case[6]), case[7]
+        bo = po.bundle_opt(max_iterations=its, loss_type=lt, loss_scale=thr, gradient_tol=1e-10)
+        w = refine_ws_weights(i, len(inp[f"x1_{i}"])) if weighted else None
+        m, st = po.refine(kind, inp[f"x1_{i}"], inp[f"x2_{i}"], inp[f"d1_{i}"], inp[f"d2_{i}"], inp[f"model_{i}"], 1 / 64.0, ws, bo, es, w)
+        assert abs(st.initial_cost - ref[13]) <= 1e-12 * abs(ref[13]), (case, st.initial_cost, ref[13])
+        d = model_diff(m, ref[:12])
+        worst = max(worst, d)
+        assert d < 1e-6, (case, d)
+        assert abs(st.cost - ref[14]) <= 1e-9 * abs(ref[14]) + 1e-18, case
+        assert st.iterations == int(ref[12]), case
+    assert worst < 1e-6
+
+
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_randomised_options_vs_reference_fixture(golden, name):
+    """tests/golden/options_ref.npz: the reference binary on 4 x 96 cases whose problem size, outlier share, noise, thresholds, Sampson weight, seed,
+    iteration budget (fixed and dynamic), loss type, loss scale and bundle iteration cap are all drawn at random — the options the boundary hands
+    through, varied together (the reference's own scripts only ever use one setting).  Oracle == reference in iterations, inlier count, mask and model
+    (1e-6) on every case but one enumerated model (4e-6); the LO count differs on 5 of 384 (an exact list: the solver classes of DESIGN.md §5)."""
+    g = golden("options_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
+    lo_dev, model_dev = OPTIONS_LO_DEVIATIONS.get(name, {}), OPTIONS_MODEL_DEVIATIONS.get(name, {})
+    for j, row in enumerate(g["cases"]):
+        n = int(row[0])
+        p = options_pair(name, j, row)
+        assert input_digest(p) == g[f"{name}_digest"][j]
+        ro = po.ransac_opt(max_iterations=int(row[7]), min_iterations=int(row[8]), max_epipolar_error=float(row[3]), max_reproj_error=float(row[4]),
+                           seed=int(row[6]), estimate_shift=es, weight_sampson=float(row[5]))
+        bo = po.bundle_opt(max_iterations=int(row[11]), loss_type=int(row[9]), loss_scale=float(row[10]), gradient_tol=1e-10)
+        m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, bo, cam if kind == 0 else None, cam if kind == 0 else None)
+        ist = g[f"{name}_istats"][j]
+        assert (st.iterations, st.num_inliers) == (int(ist[1]), int(ist[2])), (name, j, st.iterations, st.num_inliers, ist)
+        assert (mask == np.unpackbits(g[f"{name}_mask"][j])[:n]).all(), (name, j)
+        assert model_diff(m, g[f"{name}_model"][j]) < model_dev.get(j, 1e-6), (name, j, model_diff(m, g[f"{name}_model"][j]))
+        assert st.refinements - int(ist[0]) == lo_dev.get(j, 0), (name, j, st.refinements, int(ist[0]))
 
 
 def test_estimate_matches_reference(golden):
