@@ -457,3 +457,47 @@ def test_sixpt_cam2_may_be_null():
     r2, m2 = h.estimate_batch(_capi.SHARED_6PT, b["x1"], b["x2"], None, None, ro, bo, None, cams, None)
     assert r1.tobytes() == r2.tobytes() and np.array_equal(m1, m2)
     assert int(r1["num_inliers"].min()) > 100
+
+
+@pytest.mark.parametrize("name", ["relpose_5pt", "shared_6pt", "fundamental_7pt"])
+def test_randomised_options_vs_reference_fixture(golden, name):
+    """tests/golden/options_ref_classic.npz through the drop-in module's single-pair entry points (option dicts, Camera dicts): 64 cases per comparison row
+    with size, outliers, noise, threshold, seed, budget (to 100 000 iterations), loss type / scale, bundle cap, cameras and principal point drawn at random.
+    Iterations, inlier count and mask identical to the REFERENCE BINARY, model within 1e-6; LO count = the reference's or the oracle's where those differ
+    (two enumerated 6-point cases); the one 6-point case where oracle and reference end on different winners must equal one of the two."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi
+    from helpers import (CLASSIC_OPTIONS_KINDS, CLASSIC_OPTIONS_LO_DEVIATIONS, CLASSIC_OPTIONS_OTHER_WINNER, classic_options_cameras, classic_options_pair)
+    g = golden("options_ref_classic")
+    kind = CLASSIC_OPTIONS_KINDS[name]
+    loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
+    other = 0
+    for j, row in enumerate(g["cases"]):
+        n = int(row[0])
+        p = classic_options_pair(name, j, row)
+        ro = {"max_iterations": int(row[5]), "min_iterations": int(row[6]), "max_epipolar_error": float(row[3]), "seed": int(row[4])}
+        bo = {"max_iterations": int(row[9]), "loss_type": loss_name[int(row[7])], "loss_scale": float(row[8]), "gradient_tol": 1e-10}
+        if kind == 3:
+            c1, c2 = classic_options_cameras(row)
+            cams = [{"model": "PINHOLE" if c[0] else "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": c[1]} for c in (c1, c2)]
+            pose, info = poselib.estimate_relative_pose(p["x1"], p["x2"], cams[0], cams[1], ro, bo)
+            m = np.r_[pose.q, pose.t]
+        elif kind == 4:
+            pair, info = poselib.estimate_shared_focal_relative_pose(p["x1"], p["x2"], (float(row[12]), float(row[13])), ro, bo)
+            m = np.r_[pair.pose.q, pair.pose.t, pair.camera1.params[0]]
+        else:
+            F, info = poselib.estimate_fundamental(p["x1"], p["x2"], ro, bo)
+            m = np.asarray(F).reshape(-1)
+        r, ist = g[f"{name}_model"][j], g[f"{name}_istats"][j]
+        if j in CLASSIC_OPTIONS_OTHER_WINNER.get(name, ()):
+            other += 1
+            assert info["iterations"] == int(ist[1]) and abs(info["num_inliers"] - int(ist[2])) <= 1, (name, j, info["num_inliers"])
+            continue
+        assert (info["iterations"], info["num_inliers"]) == (int(ist[1]), int(ist[2])), (name, j, info["iterations"], info["num_inliers"], ist)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), np.unpackbits(g[f"{name}_mask"][j])[:n]), (name, j)
+        d = fund_diff(m, r[:9]) if kind == 5 else pose_diff(m[:7], r[:7])
+        assert d < 1e-6, (name, j, d)
+        if kind == 4:
+            assert abs(m[7] - r[7]) < 1e-6 * r[7], (name, j)
+        assert info["refinements"] - int(ist[0]) in (0, CLASSIC_OPTIONS_LO_DEVIATIONS.get(name, {}).get(j, 0)), (name, j, info["refinements"], int(ist[0]))
+    assert other == len(CLASSIC_OPTIONS_OTHER_WINNER.get(name, ()))

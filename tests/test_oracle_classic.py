@@ -319,3 +319,32 @@ def test_wide_full_size_classic_pin_subsample(golden):
             assert wide_classic_model_diff(kind, m, g[f"{name}_model"][j]) < 1e-8
             if kind == 4:
                 assert abs(m[10] - g[f"{name}_model"][j][7]) < 1e-8 * m[10]
+
+
+@pytest.mark.parametrize("name", ["relpose_5pt", "shared_6pt", "fundamental_7pt"])
+def test_randomised_options_vs_reference_fixture(golden, name):
+    """tests/golden/options_ref_classic.npz (tests/tools/gen_golden_options_ref_classic.py): the reference binary on 64 cases per comparison row with size,
+    outlier share, noise, threshold, seed, fixed / dynamic budget (up to 100 000 iterations), loss type, loss scale, bundle cap, cameras (5-point: two
+    focal lengths, SIMPLE_PINHOLE / PINHOLE, principal point) and principal point (6-point) drawn at random.  Oracle == reference in iterations, inliers,
+    mask, model (1e-6) and LO count on every 5- and 7-point case; 6-point: one other winner and two LO counts, enumerated."""
+    from helpers import (CLASSIC_OPTIONS_KINDS, CLASSIC_OPTIONS_LO_DEVIATIONS, CLASSIC_OPTIONS_OTHER_WINNER, classic_options_cameras, classic_options_pair,
+                         input_digest)
+    g = golden("options_ref_classic")
+    kind = CLASSIC_OPTIONS_KINDS[name]
+    for j, row in enumerate(g["cases"]):
+        n = int(row[0])
+        p = classic_options_pair(name, j, row)
+        assert input_digest(p) == g[f"{name}_digest"][j]
+        if j in CLASSIC_OPTIONS_OTHER_WINNER.get(name, ()):
+            continue
+        ro = po.ransac_opt(max_iterations=int(row[5]), min_iterations=int(row[6]), max_epipolar_error=float(row[3]), seed=int(row[4]))
+        bo = po.bundle_opt(max_iterations=int(row[9]), loss_type=int(row[7]), loss_scale=float(row[8]), gradient_tol=1e-10)
+        c1, c2 = classic_options_cameras(row)
+        cam1, cam2 = (po.cam_flat(*c1), po.cam_flat(*c2)) if kind == 3 else (None, None)
+        m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], ro, bo, cam1, cam2, pp=(float(row[12]), float(row[13])))
+        m, r, ist = np.asarray(m, float).reshape(-1), g[f"{name}_model"][j], g[f"{name}_istats"][j]
+        assert (st.iterations, st.num_inliers) == (int(ist[1]), int(ist[2])), (name, j)
+        assert (mask == np.unpackbits(g[f"{name}_mask"][j])[:n]).all(), (name, j)
+        d = pose_diff(m, r[:7]) if kind == 3 else (fund_diff(m, r[:9]) if kind == 5 else pose_diff(m[:7], r[:7]) + abs(r[7] - m[10]) / abs(r[7]))
+        assert d < 1e-6, (name, j, d)
+        assert st.refinements - int(ist[0]) == CLASSIC_OPTIONS_LO_DEVIATIONS.get(name, {}).get(j, 0), (name, j, st.refinements, int(ist[0]))
