@@ -1708,6 +1708,12 @@ __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
 #ifndef MDRP_LM_COST_UNROLL
 #define MDRP_LM_COST_UNROLL 1 // records per lane and trip of the cost sweep (lm_cost)
 #endif
+// IRLS weight of the Sampson row: ws^2 w(r^2) in the calibrated refiner, ws^2 w(ws r^2) in the two focal ones (the COST carries ws rho(r^2) in all
+// three) — see lm_accumulate_point.  The work lists of lm_cost and of the list engine (mdrp_lm.h) are built with the same expression.
+template <int KIND>
+__device__ __forceinline__ double sampson_row_weight(int loss, double lsc, double mu, double ws, double ws2, double rs) {
+    return ws2 * loss_weight(loss, lsc, KIND != 0 ? ws * rs : rs, mu);
+}
 // LOSS: the loss type when the caller knows it at compile time (1 = TRUNCATED: every LO refinement), -1 = o.loss.
 // Round 4: the loop body is straight-line — padding lanes evaluate a harmless record and every `if` of the round-3 body (record
 // valid, forward / backward depth positive, loss type) is a select on the three cost terms, added in the round-3 order, so the sums
@@ -1793,7 +1799,7 @@ __device__ __forceinline__ double lm_cost(const Model &m, const double *__restri
                     const bool ia = LOSS == 3 || ra < t2, jf = LOSS == 3 || rf < t2, jb = LOSS == 3 || rb < t2;
                     contrib[u] = ((oki & (int)ia & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
                 } else
-                    contrib[u] = ((oki & (int)(ws * ws * loss_weight(loss, lsc, ra, mu) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
+                    contrib[u] = ((oki & (int)(sampson_row_weight<KIND>(loss, lsc, mu, ws, ws * ws, rs) != 0.0)) | ((int)fwd[u] & (int)(loss_weight(loss, lsc, rf, mu) != 0.0)) |
                                   ((int)bwd[u] & (int)(loss_weight(loss, lsc, rb, mu) != 0.0))) != 0;
             }
         }
@@ -1889,7 +1895,7 @@ __device__ __forceinline__ double lm_zero_row_effect(const double *__restrict__ 
 // list of the list-based sweeps, so the dense sweeps must not let it act either.  Same sums bit for bit as the general path.
 template <int KIND, bool SHIFT, int LOSS = -1>
 __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 p01, double2 p23, double2 dd,
-                                                    double sqrt_sr, double ws, const LmOpt &o, double *acc) {
+                                                    double sqrt_sr, double ws, double ws2 /* ws * ws, uniform */, const LmOpt &o, double *acc) {
     const int loss = LOSS >= 0 ? LOSS : o.loss;
     double zero_rows = 0.0; // LOSS == 1: sum of the zero-weight rows' effects
     bool any_w = false;
@@ -1899,7 +1905,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         // weight_sampson enters the normal equations SQUARED (the cost carries it to the first power), and the focal refiners evaluate the loss
         // weight at ws r^2 where the calibrated one evaluates it at r^2: what the reference binary computes (oracle/orc_refine.c lm_accumulate,
         // fitted against refine_monodepth_*relpose for ws = 0.3 ... 3 and all six losses); every form coincides at ws = 1
-        const double w = ws * ws * loss_weight(loss, o.loss_scale, KIND != 0 ? ws * (r0 * r0) : r0 * r0, o.mu);
+        const double w = sampson_row_weight<KIND>(loss, o.loss_scale, o.mu, ws, ws2, r0 * r0);
         if (LOSS == 1) {
             if (w != 0.0) { lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); any_w = true; } // (ws is a run-time weight: its product stays)
             else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x1C0u>(J0, r0);
@@ -1946,7 +1952,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
 
 template <int KIND, bool SHIFT, int T, int LOSS = -1>
 __device__ __forceinline__ void lm_accumulate(const Model &m, const double *__restrict__ pts, const double *__restrict__ dep, int n,
-                              const uint8_t *__restrict__ mask, double sqrt_sr, double ws, const LmOpt &o, double *acc, LmShared &sh, int buf) {
+                              const uint8_t *__restrict__ mask, double sqrt_sr, double ws, double ws2, const LmOpt &o, double *acc, LmShared &sh, int buf) {
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NA = NP * (NP + 1) / 2 + NP;
     LmState stt;
@@ -1975,7 +1981,7 @@ __device__ __forceinline__ void lm_accumulate(const Model &m, const double *__re
         for (int k = lane; k < cnt; k += 64) {
             const double2 c01 = n01, c23 = n23, cdd = ndd;
             fetch(k + 64);
-            lm_accumulate_point<KIND, SHIFT, LOSS>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
+            lm_accumulate_point<KIND, SHIFT, LOSS>(stt, c01, c23, cdd, sqrt_sr, ws, ws2, o, acc);
         }
         if (sh.stats && lane == 0 && cnt) atomicAdd(&sh.ev[1], (unsigned long long)cnt);
     } else {
@@ -1983,7 +1989,7 @@ __device__ __forceinline__ void lm_accumulate(const Model &m, const double *__re
         for (int i = lo + lane; i < hi; i += 64)
             if (!mask || mask[i]) {
                 const double2 *P = reinterpret_cast<const double2 *>(pts + (size_t)i * PT_STRIDE);
-                lm_accumulate_point<KIND, SHIFT, LOSS>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i), sqrt_sr, ws, o, acc);
+                lm_accumulate_point<KIND, SHIFT, LOSS>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * (size_t)i), sqrt_sr, ws, ws2, o, acc);
             }
     }
     block_sum<NA, T>(acc, sh.scratch);
@@ -2021,6 +2027,7 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
     constexpr int NP = LmTraits<KIND, SHIFT>::NP;
     constexpr int NT = NP * (NP + 1) / 2;
     const double sqrt_sr = sqrt(scale_reproj);
+    const double ws2 = ws * ws; // the Sampson row's weight carries ws^2 (lm_accumulate_point)
     LmOpt o = o_in;
     o.mu = 0.5;
     int cur = 0; // list buffer that belongs to the current model
@@ -2065,7 +2072,7 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
         if (it >= o.max_it) break;
         if (recompute) {
             MDRP_TR(tr_t = wall_clock64(); ++tr_acc;)
-            lm_accumulate<KIND, SHIFT, T, LOSS>(m, pts, dep, n, mask, sqrt_sr, ws, o, acc, sh, cur);
+            lm_accumulate<KIND, SHIFT, T, LOSS>(m, pts, dep, n, mask, sqrt_sr, ws, ws2, o, acc, sh, cur);
             MDRP_TR(tr_a += wall_clock64() - tr_t;)
             double gn = 0;
             int idx = 0;
@@ -2188,11 +2195,25 @@ MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_lo_plan(int batch, const Pair
 __device__ __forceinline__ double coherent_f64(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// (uint64_t) of a double as the reference's x86-64 build computes it (comisd against 2^63; cvttsd2si; the high half via d - 2^63 and a flipped top
+// bit): what the dynamic iteration bound becomes when it leaves the range — success_prob = 1 gives +inf -> 0 (the search ends right after
+// min_iterations), NaN (success_prob > 1) gives 2^63 (never), a negative bound wraps.  v_cvt saturates instead.  tests/golden/edge_options_ref.npz
+__device__ __forceinline__ uint64_t f64_to_u64_x86(double d) {
+    const double t63 = 9223372036854775808.0;
+    if (d >= t63) {
+        const double e = d - t63;
+        return (e < t63 ? (uint64_t)(int64_t)e : 0x8000000000000000ull) ^ 0x8000000000000000ull;
+    }
+    return d >= -t63 ? (uint64_t)(int64_t)d : 0x8000000000000000ull; // (NaN fails both comparisons: cvttsd2si's "integer indefinite")
+}
 template <bool COHERENT = false>
 __device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__restrict__ models, const Trigger *trig /*of this pair*/,
                           size_t slot_base, uint64_t &need) {
     need = 0;
     if (!ps.active) return true;
+    // max_iterations = 0: the reference's loop head ends the search before a sample is drawn (ransac<>: iterations < max_iterations) — no record, no
+    // LO; the closing LO then runs on the reset identity model (tests/golden/edge_options_ref.npz)
+    if (rp.max_iterations == 0) { ps.iterations = 0; ps.active = 0; return true; }
     const uint64_t c0 = rp.chunk_start, c1 = rp.chunk_start + (uint64_t)rp.super_len;
     uint64_t it = c0; // iterations completed so far
     bool stopped = false;
@@ -2241,7 +2262,7 @@ __device__ bool walk_pair(const RunParams &rp, PairState &ps, const Model *__res
         else {
             // pow(ratio, sample size) of the reference: x * x * x for 3 (pinned against the binary), libm pow otherwise
             const double prob_outlier = 1.0 - (rp.sample_sz == 3 ? ps.inlier_ratio * ps.inlier_ratio * ps.inlier_ratio : pow(ps.inlier_ratio, (double)rp.sample_sz));
-            ps.dyn_max_iter = (uint64_t)ceil(rp.log_prob_missing / log(prob_outlier) * rp.dyn_mult);
+            ps.dyn_max_iter = f64_to_u64_x86(ceil(rp.log_prob_missing / log(prob_outlier) * rp.dyn_mult));
         }
         it = ti + 1;
         if (it >= rp.max_iterations || (it > rp.min_iterations && it > ps.dyn_max_iter)) { stopped = true; break; }
@@ -2484,8 +2505,9 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         block_score<T>(KIND, x, pp, ps.n, ps.sq_thr, scratch, sc, cn, mask); // get_inliers of the winner
         __syncthreads();
     }
-    // the estimator's inlier-only refinement with the user's BundleOptions
-    if (num_inliers > 3) {
+    // the estimator's inlier-only refinement with the user's BundleOptions: with more than 3 inliers in the calibrated (@0x224434) and shared-focal
+    // (@0x2235e6) wrappers, with more than 7 in the varying-focal one (@0x223d16)
+    if (num_inliers > (KIND == 2 ? 7u : 3u)) {
         LmOpt o;
         o.max_it = rp.final_max_it; o.loss = FLOSS >= 0 ? FLOSS : rp.final_loss; o.loss_scale = ps.final_loss_scale;
         o.grad_tol = rp.grad_tol; o.step_tol = rp.step_tol; o.lambda0 = rp.lambda0; o.lambda_min = rp.lambda_min; o.lambda_max = rp.lambda_max;

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
                 c += bwd ? loss_value(loss, lsc, rbk) : 0.0;
                 cost += ok[r] ? c : 0.0;
                 if (!DENSE)
-                    contrib[r] = ok[r] && ((ws * loss_weight(loss, lsc, rs, mu) != 0.0) || (fwd && loss_weight(loss, lsc, rf, mu) != 0.0) ||
+                    contrib[r] = ok[r] && ((sampson_row_weight<KIND>(loss, lsc, mu, ws, ws * ws, rs) != 0.0) || (fwd && loss_weight(loss, lsc, rf, mu) != 0.0) ||
                                            (bwd && loss_weight(loss, lsc, rbk, mu) != 0.0));
             }
             cost = wave_sum_swap(cost);
@@ -262,7 +262,7 @@ __device__ void lme_accumulate(const Model &m, const double *__restrict__ pts, c
         for (int k = wave * 64 + lane; k < total; k += 64 * LME_NW) {
             const double2 c01 = n01, c23 = n23, cdd = ndd;
             fetch(k + 64 * LME_NW);
-            lm_accumulate_point<KIND, SHIFT>(stt, c01, c23, cdd, sqrt_sr, ws, o, acc);
+            lm_accumulate_point<KIND, SHIFT>(stt, c01, c23, cdd, sqrt_sr, ws, ws * ws, o, acc);
         }
     } else {
         // large pairs: walk the segment lists directly (wavefront w takes segments w, w + 4, ...)
@@ -271,7 +271,7 @@ __device__ void lme_accumulate(const Model &m, const double *__restrict__ pts, c
             for (int e = lane; e < c; e += 64) {
                 const size_t i = (size_t)s * LME_SEG + lst[(size_t)s * LME_SEG + e];
                 const double2 *P = reinterpret_cast<const double2 *>(pts + i * PT_STRIDE);
-                lm_accumulate_point<KIND, SHIFT>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * i), sqrt_sr, ws, o, acc);
+                lm_accumulate_point<KIND, SHIFT>(stt, P[0], P[1], *reinterpret_cast<const double2 *>(dep + 2 * i), sqrt_sr, ws, ws * ws, o, acc);
             }
         }
     }
@@ -456,7 +456,7 @@ __global__ __launch_bounds__(64, MDRP_LME_MINWAVES) void k_lme_accum_seg(LmePhas
             for (int i = 0; i < NA; ++i) acc[i] = 0;
 #pragma unroll
             for (int r = 0; r < LME_RPT; ++r)
-                if (ok[r]) lm_accumulate_point<KIND, SHIFT, LOSS>(stt, r01[r], r23[r], rdd[r], sqrt_sr, ws, o, acc);
+                if (ok[r]) lm_accumulate_point<KIND, SHIFT, LOSS>(stt, r01[r], r23[r], rdd[r], sqrt_sr, ws, ws * ws, o, acc);
             wave_reduce_scatter<NA>(acc, ph.accpart + ((size_t)j * ph.nseg + seg) * MAX_ACC);
         }
     }
@@ -731,7 +731,7 @@ MDRP_GLOBAL void k_lme_fin_init2(LmePhase ph, RunParams rp, const PairState *__r
     const int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= rp.batch) return;
     const PairState &ps = st[pair];
-    if (ps.n < 3 || !(results[pair].num_inliers > 3)) return;
+    if (ps.n < 3 || !(results[pair].num_inliers > (rp.kind == 2 ? 7u : 3u))) return; // (the wrappers' thresholds: k_final)
     LmOpt f;
     f.max_it = rp.final_max_it; f.loss = rp.final_loss; f.loss_scale = ps.final_loss_scale;
     f.grad_tol = rp.grad_tol; f.step_tol = rp.step_tol; f.lambda0 = rp.lambda0; f.lambda_min = rp.lambda_min; f.lambda_max = rp.lambda_max;

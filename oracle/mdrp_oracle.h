@@ -53,6 +53,17 @@ enum { ORC_CALIB = 0, ORC_SHARED = 1, ORC_VARYING = 2 };
 /* a-3 sampler */
 int32_t orc_random_int(uint64_t *state);
 void orc_draw_sample(uint64_t n, uint64_t *state, uint64_t out[3]);
+/* (uint64_t)d as the reference's x86-64 (gcc) build computes it, spelled out so that the oracle does not depend on the compiler it is built with:
+ * d >= 2^63: cvttsd2si(d - 2^63) with the top bit flipped (+inf and d >= 2^64 -> 0); otherwise cvttsd2si(d) (NaN and d < -2^63 -> 2^63, negative d
+ * wraps).  Decides what the dynamic iteration bound is for success_prob >= 1 (tests/golden/edge_options_ref.npz). */
+static inline uint64_t orc_f64_to_u64(double d) {
+    const double t63 = 9223372036854775808.0;
+    if (d >= t63) {
+        const double e = d - t63;
+        return (e < t63 ? (uint64_t)(int64_t)e : 0x8000000000000000ull) ^ 0x8000000000000000ull;
+    }
+    return d >= -t63 ? (uint64_t)(int64_t)d : 0x8000000000000000ull;
+}
 
 /* geometry helpers */
 void orc_quat_to_rotmat(const double q[4], double R[9] /*row-major*/);

