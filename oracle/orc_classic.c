@@ -825,6 +825,7 @@ orc_ransac_stats orc_ransac_classic(int kind, const double *x1, const double *x2
     int pending_initial = opt->score_initial_model != 0;
     for (;;) {
         int nm;
+        if (!pending_initial && stats.iterations >= opt->max_iterations) break; /* max_iterations = 0: no sample is drawn (ransac<> loop head) */
         if (pending_initial) { models[0] = *best; nm = 1; }
         else nm = c_generate_models(&e, models);
         int best_ind = -1;

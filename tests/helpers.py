@@ -172,3 +172,24 @@ def edge_pair(name):
     from mdrp_amd import synth
     kind, es, rf = OPTIONS_KINDS[name]
     return synth.make_pair(51000, 300, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3, random_focal=rf, shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
+
+
+def classic_edge_cases():
+    """edge_cases() without the monodepth-only options"""
+    out = []
+    for rod, bod in edge_cases():
+        if rod.get("max_reproj_error") != 16.0 or rod.get("weight_sampson") != 1.0:
+            continue
+        out.append(({k: v for k, v in rod.items() if k not in ("max_reproj_error", "weight_sampson")}, bod))
+    return out
+
+
+def classic_edge_pair(name):
+    from mdrp_amd import synth
+    return synth.make_pair(52000, 300, noise_px=0.5, depth_noise=0.0, outlier_frac=0.3, random_focal="shared" if CLASSIC_OPTIONS_KINDS[name] == 4 else None)
+
+
+# edge cases whose winner is a tie: threshold 0 (every model scores 0: the first one scored stays, i.e. the solvers' solution ORDER decides; 6-point) and
+# oracle - reference in the LO count where only that differs (5-point at a threshold of 1e-3 px: 7 inliers)
+CLASSIC_EDGE_TIES = {"shared_6pt": ({"max_epipolar_error": 0.0},)}
+CLASSIC_EDGE_LO_DEVIATIONS = {"relpose_5pt": {"max_epipolar_error=0.001": -1}}

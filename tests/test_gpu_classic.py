@@ -501,3 +501,38 @@ def test_randomised_options_vs_reference_fixture(golden, name):
             assert abs(m[7] - r[7]) < 1e-6 * r[7], (name, j)
         assert info["refinements"] - int(ist[0]) in (0, CLASSIC_OPTIONS_LO_DEVIATIONS.get(name, {}).get(j, 0)), (name, j, info["refinements"], int(ist[0]))
     assert other == len(CLASSIC_OPTIONS_OTHER_WINNER.get(name, ()))
+
+
+@pytest.mark.parametrize("name", ["relpose_5pt", "shared_6pt", "fundamental_7pt"])
+def test_edge_options_vs_reference_fixture(golden, name):
+    """tests/golden/edge_options_ref_classic.npz through the drop-in module: max_iterations 0 / 1 / below min_iterations, success_prob 0 / 1,
+    dyn_num_trials_mult 0, thresholds 0 / 1e-3 / 100 px, a 41-bit seed, loss_scale 0, pinned damping, tolerances of 1.  Iterations, inlier count, mask and
+    model identical to the REFERENCE BINARY but for the enumerated ties; LO count = the reference's or the oracle's where those differ (one case)."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi
+    from helpers import CLASSIC_EDGE_LO_DEVIATIONS, CLASSIC_EDGE_TIES, CLASSIC_OPTIONS_KINDS, classic_edge_cases, classic_edge_pair
+    from test_oracle_classic import _classic_edge_model_equal
+    g = golden("edge_options_ref_classic")
+    kind = CLASSIC_OPTIONS_KINDS[name]
+    p = classic_edge_pair(name)
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+    loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
+    for j, (rod, bod) in enumerate(classic_edge_cases()):
+        bo = dict(bod, loss_type=loss_name[bod["loss_type"]])
+        if kind == 3:
+            pose, info = poselib.estimate_relative_pose(p["x1"], p["x2"], cam, cam, rod, bo)
+            m = np.r_[pose.q, pose.t]
+        elif kind == 4:
+            pair, info = poselib.estimate_shared_focal_relative_pose(p["x1"], p["x2"], (0.0, 0.0), rod, bo)
+            m = np.r_[pair.pose.q, pair.pose.t, 0.0, 0.0, 0.0, pair.camera1.params[0]]
+        else:
+            F, info = poselib.estimate_fundamental(p["x1"], p["x2"], rod, bo)
+            m = np.asarray(F).reshape(-1)
+        ref = g[f"{name}_stats"][j]
+        assert (info["iterations"], info["num_inliers"]) == (int(ref[1]), int(ref[2])), (name, j, rod, bod, info["iterations"], info["num_inliers"], ref)
+        lo = next((v for k, v in CLASSIC_EDGE_LO_DEVIATIONS.get(name, {}).items() if rod.get(k.split("=")[0]) == float(k.split("=")[1])), 0)
+        assert info["refinements"] - int(ref[0]) in (0, lo), (name, j, rod, info["refinements"], ref[0])
+        if any(all(rod.get(k) == v for k, v in tie.items()) for tie in CLASSIC_EDGE_TIES.get(name, ())):
+            continue
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), np.unpackbits(g[f"{name}_mask"][j])[:300]), (name, j)
+        assert _classic_edge_model_equal(kind, m, g[f"{name}_model"][j]), (name, j, rod, bod, m, g[f"{name}_model"][j])

@@ -348,3 +348,38 @@ def test_randomised_options_vs_reference_fixture(golden, name):
         d = pose_diff(m, r[:7]) if kind == 3 else (fund_diff(m, r[:9]) if kind == 5 else pose_diff(m[:7], r[:7]) + abs(r[7] - m[10]) / abs(r[7]))
         assert d < 1e-6, (name, j, d)
         assert st.refinements - int(ist[0]) == CLASSIC_OPTIONS_LO_DEVIATIONS.get(name, {}).get(j, 0), (name, j, st.refinements, int(ist[0]))
+
+
+def _classic_edge_model_equal(kind, m, r):
+    """m: our flat model (q, t [, ..., f at 10] or F), r: the reference's (q, t [, f at 7] or F).  Degenerate answers (the identity pose the search starts
+    from, NaN) must be equal as they stand; everything else to 1e-6 in the estimator's own gauge."""
+    m, r = np.asarray(m, float).reshape(-1), np.asarray(r, float).reshape(-1)
+    if kind == 5:
+        return np.array_equal(m[:9], r[:9], equal_nan=True) or fund_diff(m[:9], r[:9]) < 1e-6
+    f_ok = True if kind == 3 else abs(m[10] - r[7]) <= 1e-6 * abs(r[7])
+    if not np.linalg.norm(r[4:7]) > 0 or not np.linalg.norm(m[4:7]) > 0:
+        return bool(np.allclose(m[:7], r[:7], atol=1e-12, equal_nan=True) and f_ok)
+    return bool(pose_diff(m[:7], r[:7]) < 1e-6 and f_ok)
+
+
+@pytest.mark.parametrize("name", ["relpose_5pt", "shared_6pt", "fundamental_7pt"])
+def test_edge_options_vs_reference_fixture(golden, name):
+    """tests/golden/edge_options_ref_classic.npz: max_iterations 0 / 1 / below min_iterations, success_prob 0 / 1, dyn_num_trials_mult 0, thresholds 0 /
+    1e-3 / 100 px, a 41-bit seed, loss_scale 0, pinned damping, tolerances of 1 — stats, mask and model identical to the reference binary on every case
+    but the enumerated ties (threshold 0 with the 6-point solver: the first model scored stays; one LO count)."""
+    from helpers import CLASSIC_EDGE_LO_DEVIATIONS, CLASSIC_EDGE_TIES, CLASSIC_OPTIONS_KINDS, classic_edge_cases, classic_edge_pair, input_digest
+    g = golden("edge_options_ref_classic")
+    kind = CLASSIC_OPTIONS_KINDS[name]
+    p = classic_edge_pair(name)
+    assert input_digest(p) == g[f"{name}_digest"]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0]) if kind == 3 else None
+    for j, (rod, bod) in enumerate(classic_edge_cases()):
+        m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], po.ransac_opt(**rod), po.bundle_opt(**bod), cam, cam, pp=(0.0, 0.0))
+        ref = g[f"{name}_stats"][j]
+        assert (st.iterations, st.num_inliers) == (int(ref[1]), int(ref[2])), (name, j, rod, bod, st.iterations, st.num_inliers, ref)
+        lo = next((v for k, v in CLASSIC_EDGE_LO_DEVIATIONS.get(name, {}).items() if rod.get(k.split("=")[0]) == float(k.split("=")[1])), 0)
+        assert st.refinements - int(ref[0]) == lo, (name, j, rod, st.refinements, ref[0])
+        if any(all(rod.get(k) == v for k, v in tie.items()) for tie in CLASSIC_EDGE_TIES.get(name, ())):
+            continue
+        assert (mask == np.unpackbits(g[f"{name}_mask"][j])[:300]).all(), (name, j)
+        assert _classic_edge_model_equal(kind, m, g[f"{name}_model"][j]), (name, j, rod, bod, m, g[f"{name}_model"][j])
