@@ -516,6 +516,8 @@ def estimate_relative_pose(points2D_1, points2D_2, camera1, camera2, ransac_opt=
 def estimate_fundamental(points2D_1, points2D_2, ransac_opt={}, bundle_opt={}, initial_F=None):
     """Fundamental matrix estimation with non-linear refinement (_core.pyi:309-323; the 7-point baseline)."""
     if initial_F is not None:
+        # unlike ransac_*relpose, which reset the model they are handed (an initial pose only sets score_initial_model), the reference's
+        # ransac_fundamental scores the caller's F itself (DESIGN.md §9): not expressible through the flag, and no caller in the reference uses it
         raise NotImplementedError("estimate_fundamental with initial_F (score_initial_model on a caller's F) is not built")
     Fs, infos = estimate_fundamental_batch([_as_points(points2D_1)], [_as_points(points2D_2)], ransac_opt, bundle_opt)
     return Fs[0], infos[0]

@@ -547,6 +547,24 @@ def test_full_size_noisy_vs_oracle(handle, capi, po):
         assert model_diff(capi.model_to_array(res[i]["model"]), m) < 1e-6, i
 
 
+@pytest.mark.parametrize("kind,es,rf", [(0, False, None), (0, True, None), (1, False, "shared"), (2, False, "varying")])
+def test_sizes_beyond_the_sixteen_bit_lists_vs_oracle(handle, capi, po, kind, es, rf):
+    """N = 70 001 correspondences in one pair (past every u16 index and LDS work list of the LM sweeps, and not a multiple of any tile): stats and
+    mask identical to the oracle, model to 1e-6."""
+    from mdrp_amd import synth
+    n = 70001
+    p = synth.make_pair(88000 + kind + int(es), n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4, random_focal=rf, shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
+    ro = dict(max_iterations=300, min_iterations=300, max_epipolar_error=2.0, max_reproj_error=16.0, seed=1)
+    cams = np.zeros(1, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    res, mask = handle.estimate_batch(kind, p["x1"][None], p["x2"][None], p["d1"][None], p["d2"][None], capi.ransac_opt_from_dict(dict(ro, monodepth_estimate_shift=es)),
+                                      capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"}), None, cams if kind == 0 else None, cams if kind == 0 else None)
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0]) if kind == 0 else None
+    m, st, mk = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], po.ransac_opt(estimate_shift=es, **ro), po.bundle_opt(loss_type=4), cam, cam)
+    r = res[0]
+    assert (int(r["refinements"]), int(r["iterations"]), int(r["num_inliers"])) == (st.refinements, st.iterations, st.num_inliers)
+    assert (mask[0][:n] == mk).all() and model_diff(capi.model_to_array(r["model"]), m) < 1e-6
+
+
 def test_full_size_properties(handle, capi):
     """BASELINE config 2 shape (N=2000, 10k iterations) on a few pairs: size-independent properties —
     noise-free pairs recover ground truth to 1e-6; every true inlier is flagged; duplicating a pair gives
