@@ -536,3 +536,51 @@ def test_edge_options_vs_reference_fixture(golden, name):
             continue
         assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), np.unpackbits(g[f"{name}_mask"][j])[:300]), (name, j)
         assert _classic_edge_model_equal(kind, m, g[f"{name}_model"][j]), (name, j, rod, bod, m, g[f"{name}_model"][j])
+
+
+@pytest.mark.parametrize("name", ["relpose_5pt", "shared_6pt", "fundamental_7pt"])
+def test_batched_ragged_calls_under_random_options_vs_oracle(golden, name):
+    """The first 8 option sets of tests/golden/options_ref_classic.npz, each driving ONE batched call of the drop-in module over 10 ragged pairs (N = 40 ...
+    1500; 5-point: a camera pair of its own per image pair): every pair's iterations, inlier count and mask = the oracle's, model within 2e-6, LO count
+    equal (+-1 below N = 100, where scores tie; the 6-point solver's solution-order ties: +-2)."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi, synth
+    from helpers import CLASSIC_OPTIONS_KINDS
+    g = golden("options_ref_classic")
+    kind = CLASSIC_OPTIONS_KINDS[name]
+    loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
+    sizes = [40, 63, 64, 65, 150, 257, 512, 900, 1024, 1500]
+    focals = [500.0, 800.0, 1400.0]
+    for j in range(8):
+        row = g["cases"][j]
+        ro = {"max_iterations": int(row[5]), "min_iterations": int(row[6]), "max_epipolar_error": float(row[3]), "seed": int(row[4])}
+        bo = {"max_iterations": int(row[9]), "loss_type": loss_name[int(row[7])], "loss_scale": float(row[8]), "gradient_tol": 1e-10}
+        pairs, cams1, cams2 = [], [], []
+        for i, n in enumerate(sizes):
+            f1, f2 = focals[i % 3], focals[(i + j) % 3]
+            kw = dict(noise_px=float(row[2]), depth_noise=0.0, outlier_frac=[0.0, 0.3, 0.5][(i + j) % 3], pp=(3.0, -2.0))
+            pairs.append(synth.make_pair(98000 + 100 * j + i, n, random_focal="shared", **kw) if kind == 4 else synth.make_pair(98000 + 100 * j + i, n, f1=f1, f2=f2, **kw))
+            cams1.append({"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [f1, 3.0, -2.0]})
+            cams2.append({"model": "PINHOLE", "width": 1600, "height": 1200, "params": [f2 * 1.01, f2 * 0.99, 3.0, -2.0]})
+        x1, x2 = [p["x1"] for p in pairs], [p["x2"] for p in pairs]
+        if kind == 3:
+            models, infos = poselib.estimate_relative_pose_batch(x1, x2, cams1, cams2, ro, bo)
+            rows = [np.r_[m.q, m.t] for m in models]
+        elif kind == 4:
+            models, infos = poselib.estimate_shared_focal_relative_pose_batch(x1, x2, (3.0, -2.0), ro, bo)
+            rows = [np.r_[m.pose.q, m.pose.t, m.camera1.params[0]] for m in models]
+        else:
+            models, infos = poselib.estimate_fundamental_batch(x1, x2, ro, bo)
+            rows = [np.asarray(m).reshape(-1) for m in models]
+        oro = po.ransac_opt(**ro)
+        obo = po.bundle_opt(max_iterations=int(row[9]), loss_type=int(row[7]), loss_scale=float(row[8]), gradient_tol=1e-10)
+        for i, n in enumerate(sizes):
+            c1 = po.cam_flat(0, cams1[i]["params"]) if kind == 3 else None
+            c2 = po.cam_flat(1, cams2[i]["params"]) if kind == 3 else None
+            m, st, mask = po.estimate_classic(kind, x1[i], x2[i], oro, obo, c1, c2, pp=(3.0, -2.0))
+            m, info, where = np.asarray(m, float).reshape(-1), infos[i], (name, j, i, n)
+            assert (info["iterations"], info["num_inliers"]) == (st.iterations, st.num_inliers), where
+            assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask), where
+            d = fund_diff(rows[i], m[:9]) if kind == 5 else pose_diff(rows[i][:7], m[:7])
+            assert d < 2e-6 and (kind != 4 or abs(rows[i][7] - m[10]) < 2e-6 * m[10]), (where, d)
+            assert abs(info["refinements"] - st.refinements) <= ((2 if kind == 4 else 1) if n < 100 else (2 if kind == 4 else 0)), (where, info["refinements"], st.refinements)
