@@ -495,10 +495,10 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     if (!ps.active) return;
     const bool live = it < it_end;
     int n = 0;
+    bool nan_model = false;
     Model out[4];
-    if (live) {
+    auto load_sample = [&](Sample3 &s) {
         const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it) * 3;
-        Sample3 s;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const size_t idx = (size_t)pair * rp.n_max + sm[k];
@@ -506,9 +506,25 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
             s.x1[k][0] = p[0]; s.x1[k][1] = p[1]; s.x2[k][0] = p[2]; s.x2[k][1] = p[3];
             s.d1[k] = dep[2 * idx]; s.d2[k] = dep[2 * idx + 1];
         }
+    };
+    if (live) {
+        Sample3 s;
+        load_sample(s);
         n = run_solver(SOLVER, s, out);
-        // a NaN hypothesis can never become a record (its score is N*thr, count 0) except as the very first model;
-        // drop it (the reference's own P3P emits NaN poses for ~2% of garbage samples)
+        // The reference's P3P emits NaN poses for ~3 % of the samples (p3p_reference_nan: exactly predictable).  A NaN hypothesis scores N * thr with
+        // no inlier: it can only be a record while nothing has been scored yet — then it costs the reference one LO, and it is the run's answer if no
+        // sample ever gives a real pose.  It needs no sweep: slot state -3 tells k_scan its (count, score) = (0, N * thr); it is not on the tag list.
+    }
+    if (SOLVER == SOLVER_P3P) {
+        // ... and it only matters BEFORE the first real pose of the run: a lane asks only if no earlier iteration of its own wavefront has one
+        // (k_scan decides exactly; this merely keeps ~80 % of the wavefronts — those whose first sample has a pose — out of the predicate)
+        const unsigned long long valid = __ballot(live && n > 0);
+        const int first_valid = valid ? __ffsll((long long)valid) - 1 : 64;
+        if (live && (int)(threadIdx.x & 63) < first_valid) {
+            Sample3 s; // read again (L2): kept live across the solver it would cost the kernel its third wavefront per SIMD
+            load_sample(s);
+            nan_model = p3p_reference_nan(s);
+        }
     }
     // wave-aggregated append to the pair's tag list: one atomic per wave (k_sort_tags orders and classifies the list)
     const int lane = threadIdx.x & 63;
@@ -528,7 +544,14 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     const size_t tag_base = (size_t)pair * rp.slot_stride;
     // slot states of the iteration in one 16-byte store: -1 = empty, -2 = "no record" — the default of every live slot:
     // k_count / k_bound retire most hypotheses without touching their slots again, k_score overwrites the survivors'
-    *reinterpret_cast<int4 *>(slot_inl + slot0) = make_int4(n > 0 ? -2 : -1, n > 1 ? -2 : -1, n > 2 ? -2 : -1, n > 3 ? -2 : -1);
+    *reinterpret_cast<int4 *>(slot_inl + slot0) = make_int4(nan_model ? -3 : (n > 0 ? -2 : -1), n > 1 ? -2 : -1, n > 2 ? -2 : -1, n > 3 ? -2 : -1);
+    if (nan_model) {
+        Model m;
+        model_identity(m);
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        m.q[0] = m.q[1] = m.q[2] = m.q[3] = m.t[0] = m.t[1] = m.t[2] = m.scale = qnan;
+        models[slot0] = m;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k < n) {
@@ -1530,6 +1553,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     if (lane == 0 && evals) atomicAdd(evals, (unsigned long long)(model_count[2 * pair] + model_count[2 * pair + 1]) * (unsigned long long)ps.n); // survivors handed to the fp64 sweep
     long long run_cnt = (long long)ps.best_min_cnt;
     double run_score = ps.best_min_score;
+    const double nan_score = (double)ps.n * ps.sq_thr;
     int ntrig = rp.chunk_off > 0 ? ps.n_triggers : 0; // later chunks of a super-chunk append to its trigger list
     static_assert(MPS % 4 == 0, "slots of an iteration are read as 16-byte groups");
     constexpr int NG = MPS / 4;
@@ -1563,6 +1587,7 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
             s[4 * g] = c[4 * g] >= 0 ? cur.s01[g].x : DBL_MAX; s[4 * g + 1] = c[4 * g + 1] >= 0 ? cur.s01[g].y : DBL_MAX;
             s[4 * g + 2] = c[4 * g + 2] >= 0 ? cur.s23[g].x : DBL_MAX; s[4 * g + 3] = c[4 * g + 3] >= 0 ? cur.s23[g].y : DBL_MAX;
         }
+        if (c[0] == -3) { c[0] = 0; s[0] = nan_score; } // k_solve's NaN model of the iteration (the reference's P3P): no inlier, every residual counts thr
         long long lc = -1;
         double ls = DBL_MAX;
 #pragma unroll
@@ -2390,7 +2415,8 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
 #ifdef MDRP_LO_TRACE
     const unsigned long long t_start = wall_clock64();
 #endif
-    lm_refine<KIND, SHIFT, T, 1>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // refine_model: always TRUNCATED
+    // (a NaN model — the reference's P3P, k_solve — has a NaN cost: no step can be accepted, it comes back as it is)
+    if (m.q[0] == m.q[0]) lm_refine<KIND, SHIFT, T, 1>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // refine_model: always TRUNCATED
     double sc;
     int cn;
     block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
@@ -2489,7 +2515,7 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         LmOpt o;
         o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
         o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-        lm_refine<KIND, SHIFT, T, 1>(x, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh);
+        if (x.q[0] == x.q[0]) lm_refine<KIND, SHIFT, T, 1>(x, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // (NaN model: lo_problem)
     }
 #ifdef MDRP_LO_TRACE
     if (threadIdx.x == 0) tf_it |= (sh.ph[3] & 0xFFFFull) << 32;

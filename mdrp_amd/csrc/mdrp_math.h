@@ -464,6 +464,58 @@ MDRP_HD int solver_calib_p3p(const Sample3 &s, Model out[4]) {
     return n;
 }
 
+// Does the reference's P3P hand back NaN poses for this sample?  Its p3p() (Ding et al.: one real root s of a cubic — the largest when there are
+// three —, the degenerate conic C(s) of the pencil split into two lines) takes the square root of the largest diagonal entry of -adj(C) without a
+// sign test; where C(s) is a POINT conic all three are negative, both lines are NaN, every test that would discard a solution is a comparison with NaN,
+// and four NaN poses come out (black-box: exactly the 398 of 12 000 noisy samples where this predicate holds; our solver, rightly, finds no real pose
+// on any of them).  A NaN model scores N * thr with no inlier: a record while nothing has been scored yet, one LO that cannot change anything, and
+// the run's answer if no sample ever gives a real pose.  Only reachable with three real roots (a single real root's conic is a real line pair), so
+// the trigonometric branch below runs for ~5 % of the samples.  Same arithmetic as oracle/orc_solvers.c orc_p3p_reference_nan.
+MDRP_HD bool p3p_reference_nan(const Sample3 &sm) {
+    double xs[3][3], X[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double inv = sv_rsqrt(sm.x2[i][0] * sm.x2[i][0] + sm.x2[i][1] * sm.x2[i][1] + 1.0);
+        X[i][0] = sm.d1[i] * sm.x1[i][0]; X[i][1] = sm.d1[i] * sm.x1[i][1]; X[i][2] = sm.d1[i];
+        xs[i][0] = sm.x2[i][0] * inv; xs[i][1] = sm.x2[i][1] * inv; xs[i][2] = inv;
+    }
+    double a01 = 0, a02 = 0, a12 = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        a01 += (X[0][k] - X[1][k]) * (X[0][k] - X[1][k]); a02 += (X[0][k] - X[2][k]) * (X[0][k] - X[2][k]); a12 += (X[1][k] - X[2][k]) * (X[1][k] - X[2][k]);
+    }
+    // the largest of the three distances becomes "12": swap bearing 0 with 2 (or 1) — as selects, no divergent copies
+    const bool sw02 = a01 > a02 && a01 > a12, sw01 = !(a01 > a02) && a02 > a12;
+    double x0[3], x1v[3], x2v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        x0[k] = sw02 ? xs[2][k] : (sw01 ? xs[1][k] : xs[0][k]);
+        x1v[k] = sw01 ? xs[0][k] : xs[1][k];
+        x2v[k] = sw02 ? xs[0][k] : xs[2][k];
+    }
+    if (sw02) { const double t = a01; a01 = a12; a12 = t; }
+    if (sw01) { const double t = a02; a02 = a12; a12 = t; }
+    const double a12d = 1.0 / a12, a = a01 * a12d, b = a02 * a12d;
+    const double m01 = dot3(x0, x1v), m02 = dot3(x0, x2v), m12 = dot3(x1v, x2v);
+    const double m12sq = -m12 * m12 + 1.0, m02sq = -1.0 + m02 * m02, m01sq = -1.0 + m01 * m01;
+    const double ab = a * b, bsq = b * b, asq = a * a, m013 = -2.0 + 2.0 * m01 * m02 * m12;
+    const double bsqm12sq = bsq * m12sq, asqm12sq = asq * m12sq, abm12sq = 2.0 * ab * m12sq;
+    const double k3i = 1.0 / (bsqm12sq + b * m02sq);
+    const double k2 = k3i * ((-1.0 + a) * m02sq + abm12sq + bsqm12sq + b * m013);
+    const double k1 = k3i * (asqm12sq + abm12sq + a * m013 + (-1.0 + b) * m01sq);
+    const double k0 = k3i * (asqm12sq + a * m01sq);
+    const double ca = k1 - k2 * k2 / 3.0;
+    const double cb = (2.0 * k2 * k2 * k2 - 9.0 * k2 * k1) / 27.0 + k0;
+    const double cc = cb * cb / 4.0 + ca * ca * ca / 27.0;
+    if (!(cc < 0)) return false; // one real root (or the degenerate cc == 0 / NaN cases): never a point conic
+    const double arg = 3.0 * cb / (2.0 * ca) * sqrt(-3.0 / ca);
+    const double s = 2.0 * sqrt(-ca / 3.0) * cos(acos(arg) / 3.0) - k2 / 3.0;
+    const double C00 = -a + s * (1 - b), C01 = -m02 * s, C02 = a * m12 + b * m12 * s, C11 = s + 1, C12 = -m01, C22 = -a - b * s + 1;
+    const double A0 = C12 * C12 - C11 * C22, A1 = C02 * C02 - C00 * C22, A2 = C01 * C01 - C00 * C11;
+    const double mx = A0 > A1 ? (A0 > A2 ? A0 : A2) : (A1 > A2 ? A1 : A2);
+    return mx < 0;
+}
+
 // a-4: scale + two shifts.  |(d1_i+u) x1_i - (d1_j+u) x1_j|^2 = s^2 |(d2_i+v) x2_i - (d2_j+v) x2_j|^2 for the 3
 // pairs: linear in (a,b,c) = (s^2, s^2 v, s^2 v^2), quadratic in u; a c = b^2 -> quartic in u.
 MDRP_HD int solver_calib_shift(const Sample3 &s, Model out[4]) {

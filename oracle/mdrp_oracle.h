@@ -52,6 +52,7 @@ enum { ORC_CALIB = 0, ORC_SHARED = 1, ORC_VARYING = 2 };
 
 /* a-3 sampler */
 int32_t orc_random_int(uint64_t *state);
+int orc_p3p_reference_nan(const double xb[9], const double X[9]); /* does the reference's P3P return NaN poses for this sample? (orc_solvers.c) */
 void orc_draw_sample(uint64_t n, uint64_t *state, uint64_t out[3]);
 /* (uint64_t)d as the reference's x86-64 (gcc) build computes it, spelled out so that the oracle does not depend on the compiler it is built with:
  * d >= 2^63: cvttsd2si(d - 2^63) with the top bit flipped (+inf and d >= 2^64 -> 0); otherwise cvttsd2si(d) (NaN and d < -2^63 -> 2^63, negative d

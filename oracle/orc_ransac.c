@@ -32,7 +32,23 @@ static int generate_models(estimator *e, orc_model out[4]) {
     }
     switch (e->kind) {
     case ORC_CALIB:
-        return e->opt->estimate_shift ? orc_solver_calib_shift(x1h, x2h, d1, d2, out) : orc_solver_calib_p3p(x1h, x2h, d1, d2, out);
+        if (e->opt->estimate_shift) return orc_solver_calib_shift(x1h, x2h, d1, d2, out);
+        {
+            /* the reference's P3P returns NaN poses where its degenerate conic is a point conic (orc_p3p_reference_nan): four of them, each scoring
+             * N * thr with no inlier — one is enough to reproduce what they do to the records */
+            double X[9], xb[9];
+            for (int i = 0; i < 3; ++i) {
+                const double nrm = sqrt(x2h[3 * i] * x2h[3 * i] + x2h[3 * i + 1] * x2h[3 * i + 1] + x2h[3 * i + 2] * x2h[3 * i + 2]);
+                for (int k = 0; k < 3; ++k) { X[3 * i + k] = d1[i] * x1h[3 * i + k]; xb[3 * i + k] = x2h[3 * i + k] / nrm; }
+            }
+            if (orc_p3p_reference_nan(xb, X)) {
+                memset(&out[0], 0, sizeof out[0]);
+                out[0].q[0] = out[0].q[1] = out[0].q[2] = out[0].q[3] = out[0].t[0] = out[0].t[1] = out[0].t[2] = out[0].scale = NAN;
+                out[0].f1 = out[0].f2 = 1.0;
+                return 1;
+            }
+        }
+        return orc_solver_calib_p3p(x1h, x2h, d1, d2, out);
     case ORC_SHARED: return orc_solver_shared(x1h, x2h, d1, d2, out);
     default: return orc_solver_varying(x1h, x2h, d1, d2, out);
     }

@@ -228,6 +228,49 @@ int orc_solver_calib_p3p(const double x1h[9], const double x2h[9], const double 
     return n;
 }
 
+/* When does the reference's P3P hand back NaN poses?  Its p3p() (Ding et al., "Revisiting the P3P problem": one real root s of a cubic, the degenerate
+ * conic C(s) of the pencil split into two lines p, q) takes sqrt of the largest diagonal entry of -adj(C) without testing its sign.  Where C(s) is a
+ * POINT conic (complex line pair) all three are negative: the root is NaN, both "lines" are NaN, every test that would discard a solution is a
+ * comparison with NaN (false), and 2 x 2 NaN poses come out.  Black-box on 12 000 samples of noisy pairs: the binary returns 4 NaN poses on exactly the
+ * 398 samples where this predicate holds (on all of them our solver, rightly, finds no real pose) and never otherwise.  A NaN model scores N * thr
+ * with 0 inliers — a record while no model has been scored yet — and costs the reference one LO (DESIGN.md §5 class i): generate_models() below
+ * reproduces that.  x: unit bearings in image 2, X: points of image 1 (d1 * x1h). */
+int orc_p3p_reference_nan(const double x[9], const double X[9]) {
+    double xs[3][3], a01 = 0, a02 = 0, a12 = 0;
+    for (int k = 0; k < 3; ++k) {
+        for (int i = 0; i < 3; ++i) xs[i][k] = x[3 * i + k];
+        a01 += (X[k] - X[3 + k]) * (X[k] - X[3 + k]); a02 += (X[k] - X[6 + k]) * (X[k] - X[6 + k]); a12 += (X[3 + k] - X[6 + k]) * (X[3 + k] - X[6 + k]);
+    }
+    /* the largest of the three distances becomes "12" */
+    if (a01 > a02) {
+        if (a01 > a12) { for (int k = 0; k < 3; ++k) { const double t = xs[0][k]; xs[0][k] = xs[2][k]; xs[2][k] = t; } const double t = a01; a01 = a12; a12 = t; }
+    } else if (a02 > a12) { for (int k = 0; k < 3; ++k) { const double t = xs[0][k]; xs[0][k] = xs[1][k]; xs[1][k] = t; } const double t = a02; a02 = a12; a12 = t; }
+    const double a12d = 1.0 / a12, a = a01 * a12d, b = a02 * a12d;
+    const double m01 = dot3(xs[0], xs[1]), m02 = dot3(xs[0], xs[2]), m12 = dot3(xs[1], xs[2]);
+    const double m12sq = -m12 * m12 + 1.0, m02sq = -1.0 + m02 * m02, m01sq = -1.0 + m01 * m01;
+    const double ab = a * b, bsq = b * b, asq = a * a, m013 = -2.0 + 2.0 * m01 * m02 * m12;
+    const double bsqm12sq = bsq * m12sq, asqm12sq = asq * m12sq, abm12sq = 2.0 * ab * m12sq;
+    const double k3i = 1.0 / (bsqm12sq + b * m02sq);
+    const double k2 = k3i * ((-1.0 + a) * m02sq + abm12sq + bsqm12sq + b * m013);
+    const double k1 = k3i * (asqm12sq + abm12sq + a * m013 + (-1.0 + b) * m01sq);
+    const double k0 = k3i * (asqm12sq + a * m01sq);
+    /* solve_cubic_single_real: the real root if there is one, the largest of three otherwise */
+    double s;
+    {
+        const double ca = k1 - k2 * k2 / 3.0;
+        double cb = (2.0 * k2 * k2 * k2 - 9.0 * k2 * k1) / 27.0 + k0;
+        double cc = cb * cb / 4.0 + ca * ca * ca / 27.0;
+        if (cc != 0) {
+            if (cc > 0) { cc = sqrt(cc); cb *= -0.5; s = cbrt(cb + cc) + cbrt(cb - cc) - k2 / 3.0; }
+            else { cc = 3.0 * cb / (2.0 * ca) * sqrt(-3.0 / ca); s = 2.0 * sqrt(-ca / 3.0) * cos(acos(cc) / 3.0) - k2 / 3.0; }
+        } else s = -k2 / 3.0 + (ca != 0 ? (3.0 * cb / ca) : 0);
+    }
+    const double C00 = -a + s * (1 - b), C01 = -m02 * s, C02 = a * m12 + b * m12 * s, C11 = s + 1, C12 = -m01, C22 = -a - b * s + 1;
+    const double A0 = C12 * C12 - C11 * C22, A1 = C02 * C02 - C00 * C22, A2 = C01 * C01 - C00 * C11;
+    const double mx = A0 > A1 ? (A0 > A2 ? A0 : A2) : (A1 > A2 ? A1 : A2);
+    return mx < 0;
+}
+
 /* ---------- univariate helpers ---------- */
 /* real roots of x^4 + b x^3 + c x^2 + d x + e (Ferrari via the resolvent cubic), Newton-polished */
 static int solve_quartic_real(double b, double c, double d, double e, double roots[4]) {

@@ -48,13 +48,11 @@ REFERENCE_NAN_SOLUTIONS = {"p3p": (), "calib_shift": (21,), "shared": (), "varyi
 
 # tests/golden/estimate_full.npz: our LO count minus the reference's.  Found with the per-iteration replay of both
 # sides' minimal models (tests/tools/diag_lo_count.py):
-#   case 1 (calibrated P3P, pair 1): the reference's P3P returns four NaN poses for the sample of iteration 0; a NaN model
-#           scores N * eps^2 < DBL_MAX, so it is the run's first "record" and costs the reference one LO that cannot
-#           change the result; ours returns the empty set.
 #   case 4 (calibrated + shift, pair 1): at iteration 2827 the reference's relpose_monodepth_3pt misses a true root
 #           that ours finds; that model has 993 inliers, sets a record and costs us one LO.
-# Iterations, inliers, score, mask and model are identical in both cases.
-KNOWN_LO_COUNT_DEVIATIONS = {1: -1, 4: +1}
+# Iterations, inliers, score, mask and model are identical.  (Case 1 — the reference's P3P returns four NaN poses for the sample of
+# iteration 0, one LO that cannot change anything — was a deviation until the second half of round 5: the NaN poses are reproduced now.)
+KNOWN_LO_COUNT_DEVIATIONS = {4: +1}
 
 # tests/golden/initial.npz: case 11 (varying focal, ALL correspondences identical, score_initial_model) was an oracle-only deviation up to round 5: the LO
 # that starts from the reset identity pose (E = 0: every Sampson residual 0/0) moved in our LM and stays put in the reference's.  Cause: the reference's
@@ -71,7 +69,7 @@ OPTIONS_COLS = ("n", "outlier_frac", "noise_px", "max_epipolar_error", "max_repr
 OPTIONS_FIRST = 30000
 # oracle - reference in the LO count on the 384 cases (everything else identical there): the solver classes of DESIGN.md §5
 # (shared 16: the reference's action-matrix solver returns the real part of a complex root pair 0.4326 +- 0.0321i as a double root at iteration 1)
-OPTIONS_LO_DEVIATIONS = {"calib_p3p": {14: -1, 59: -1, 68: -1}, "calib_shift": {67: +1}, "shared": {16: +3}, "varying": {58: +1, 69: -1, 87: +1}}
+OPTIONS_LO_DEVIATIONS = {"calib_p3p": {}, "calib_shift": {67: +1}, "shared": {16: +3}, "varying": {58: +1, 69: -1, 87: +1}}
 # HIP path - oracle in the LO count (score ties decided by the last bits)
 OPTIONS_GPU_MINUS_ORACLE_LO = {"varying": {58: -1, 69: +1}}  # (= the reference on both)
 # another RANSAC winner than the reference's (230 against 227 inliers, 7 mask bits, model 2.7e-3; the shift solver's missed roots): the HIP path must
