@@ -154,7 +154,9 @@ EDGE_RANSAC = [dict(max_reproj_error=0.0), dict(weight_sampson=0.0), dict(weight
                dict(max_iterations=0, min_iterations=0), dict(max_iterations=1, min_iterations=0), dict(max_iterations=2, min_iterations=5),
                dict(max_iterations=5000, min_iterations=0), dict(success_prob=1.0, max_iterations=3000, min_iterations=100),
                dict(success_prob=0.0, max_iterations=3000, min_iterations=100), dict(dyn_num_trials_mult=0.0, max_iterations=3000, min_iterations=100),
-               dict(max_epipolar_error=0.0), dict(max_epipolar_error=1e-3), dict(max_epipolar_error=100.0), dict(seed=2 ** 40 + 7)]
+               dict(max_epipolar_error=0.0), dict(max_epipolar_error=1e-3), dict(max_epipolar_error=100.0), dict(seed=2 ** 40 + 7),
+               # calibrated P3P: the only sample(s) of the run are ones on which the reference's p3p() returns NaN poses -> the answer is a NaN pose
+               dict(max_iterations=1, min_iterations=0, seed=12), dict(max_iterations=2, min_iterations=0, seed=171)]
 EDGE_BUNDLE = [dict(loss_scale=0.0), dict(max_iterations=1), dict(initial_lambda=0.0), dict(min_lambda=1.0, max_lambda=1.0), dict(gradient_tol=1.0), dict(step_tol=1.0),
                dict(loss_type=0, max_iterations=3), dict(loss_type=5, max_iterations=200)]
 
@@ -191,3 +193,12 @@ def classic_edge_pair(name):
 # oracle - reference in the LO count where only that differs (5-point at a threshold of 1e-3 px: 7 inliers)
 CLASSIC_EDGE_TIES = {"shared_6pt": ({"max_epipolar_error": 0.0},)}
 CLASSIC_EDGE_LO_DEVIATIONS = {"relpose_5pt": {"max_epipolar_error=0.001": -1}}
+
+
+def same_model(m, ref, tol=1e-6):
+    """model_diff < tol, or — where the reference's answer is a NaN pose — NaN in exactly the same components and the rest equal"""
+    import numpy as np
+    m, ref = np.asarray(m, float), np.asarray(ref, float)
+    if np.isnan(ref).any() or np.isnan(m).any():
+        return bool(np.array_equal(np.isnan(m), np.isnan(ref)) and np.allclose(np.nan_to_num(m), np.nan_to_num(ref), rtol=1e-9, atol=1e-12))
+    return bool(model_diff(m, ref) < tol)

@@ -246,10 +246,10 @@ def test_randomised_options_vs_reference_fixture(golden, po, name):
 def test_edge_options_vs_reference_fixture(golden, name):
     """tests/golden/edge_options_ref.npz through the drop-in module: one option at an edge of its range per case — max_iterations 0 / 1 / below
     min_iterations, success_prob 0 / 1, dyn_num_trials_mult 0, thresholds 0 / 1e-3 / 100 px, reprojection off, weight_sampson 0 / negative, a 41-bit
-    seed, loss_scale 0, pinned damping, tolerances of 1.  Stats, mask and model identical to the REFERENCE BINARY on all 4 x 23 cases."""
+    seed, loss_scale 0, pinned damping, tolerances of 1.  Stats, mask and model identical to the REFERENCE BINARY on all 4 x 25 cases (two of them, for the calibrated P3P estimator, runs whose only samples make the reference's p3p() return NaN poses: the answer is that NaN pose)."""
     import mdrp_amd.poselib as poselib
     from mdrp_amd import _capi
-    from helpers import edge_cases, edge_pair
+    from helpers import edge_cases, edge_pair, same_model
     g = golden("edge_options_ref")
     kind, es, rf = OPTIONS_KINDS[name]
     p = edge_pair(name)
@@ -270,7 +270,7 @@ def test_edge_options_vs_reference_fixture(golden, name):
         ref = g[f"{name}_stats"][j]
         assert (info["refinements"], info["iterations"], info["num_inliers"]) == tuple(int(v) for v in ref[:3]), (name, j, rod, bod, info["refinements"], info["iterations"], info["num_inliers"], ref)
         assert (np.asarray(info["inliers"], dtype=np.uint8) == np.unpackbits(g[f"{name}_mask"][j])[:300]).all(), (name, j)
-        assert model_diff(m, g[f"{name}_model"][j]) < 1e-6, (name, j, rod, bod)
+        assert same_model(m, g[f"{name}_model"][j]), (name, j, rod, bod, m, g[f"{name}_model"][j])
         assert info["model_score"] == ref[4] or abs(info["model_score"] - ref[4]) <= 1e-9 * abs(ref[4]), (name, j)
 
 
