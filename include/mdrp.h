@@ -112,7 +112,9 @@ typedef struct {
     double params[4];
 } mdrp_camera;
 
-/* One record per image pair: the estimator's return value + RansacStats */
+/* One record per image pair: the estimator's return value + RansacStats.  As in the reference, the model of MDRP_CALIB without the shift flag can be a
+ * NaN pose (num_inliers 0, model_score N * eps^2) when no sample of the run gave a real pose: the reference's p3p() emits NaN poses for ~3 % of the
+ * samples, and such a model is the record until a real one is scored. */
 typedef struct {
     mdrp_model model;
     uint64_t refinements, iterations, num_inliers;

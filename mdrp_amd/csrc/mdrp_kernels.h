@@ -1808,12 +1808,14 @@ __device__ __forceinline__ double lm_cost(const Model &m, const double *__restri
             point_residuals<false, KIND != 0>(stt, sqrt_sr, cur.a, cur.b, cur.c, cur.d, cur.e1, cur.e2, r, zf, zb, nullptr);
             const double rs = r[0] * r[0], rf = r[1] * r[1] + r[2] * r[2], rb = r[3] * r[3] + r[4] * r[4];
             const int oki = cur.ok;
-            fwd[u] = oki & (int)!(zf < 0); bwd[u] = oki & (int)!(zb < 0);
+            fwd[u] = oki & (int)(zf > 0); bwd[u] = oki & (int)(zb > 0); // positive depth of the transferred point: NaN depths drop the term like negative ones (reference)
             // The Sampson row's IRLS weight is ws^2 w(r^2) in the calibrated refiner and ws^2 w(ws r^2) in the two focal ones, while the COST
             // carries ws rho(r^2) in all three (lm_accumulate_point): the work list follows the weight, so its argument is `ra`, not `rs`.
             const double ra = KIND != 0 ? ws * rs : rs;
             if (LOSS == 1) { // TRUNCATED: min(r^2, t^2); IRLS weight 1 below the threshold, 0 at and above it (and for NaN)
-                const bool is = rs < t2, ia = KIND != 0 ? ra < t2 : is, jf = rf < t2, jb = rb < t2;
+                // value: std::min(r^2, t^2) as the reference evaluates it — a NaN residual comes back NaN and makes the cost NaN (the LM then accepts
+                // nothing).  One predicate serves the value and the work list: a NaN row on the list has weight 0 in the accumulate sweep.
+                const bool is = !(rs >= t2), ia = KIND != 0 ? !(ra >= t2) : is, jf = !(rf >= t2), jb = !(rb >= t2);
                 vs[u] = ws * (is ? rs : t2); vf[u] = jf ? rf : t2; vb[u] = jb ? rb : t2;
                 contrib[u] = ((oki & (int)ia & (int)ws_nz) | ((int)fwd[u] & (int)jf) | ((int)bwd[u] & (int)jb)) != 0;
             } else {
@@ -1896,34 +1898,16 @@ __device__ __forceinline__ void lm_accumulate_row(const double *__restrict__ Jro
 
 // One correspondence of the accumulate sweep, term by term: each term's Jacobian rows are folded into the accumulators
 // before the next term is computed, so at most two rows need to be live beside the NP (NP + 3) / 2 accumulators.
-// what a row of weight ZERO does to the sums in lm_accumulate_row: acc += (0 * J_a) * J_b and (0 * J_a) * r add +-0 — or NaN when an
-// entry of the row or its residual is not finite (the Sampson row of E = 0, a point at depth zero), and one NaN in J'J | J'r stalls the
-// whole LM (no step is ever accepted: the model comes back unchanged).  The reference shows exactly that behaviour on
-// tests/golden/initial.npz case 11, so skipping a zero-weight row must keep it: `0 * (r + sum of the row's entries)` is +-0 for a finite
-// row and NaN otherwise.
-template <int KIND, bool SHIFT, unsigned ZMASK>
-__device__ __forceinline__ double lm_zero_row_effect(const double *__restrict__ Jrow, double r) {
-    constexpr int NP = LmTraits<KIND, SHIFT>::NP;
-    double s = r;
-#pragma unroll
-    for (int q = 0; q < NP; ++q) {
-        const int col = lm_col<KIND, SHIFT>(q);
-        if (!((ZMASK >> col) & 1u)) s += Jrow[col];
-        if (KIND == 1 && q == 7 && !((ZMASK >> 10) & 1u)) s += Jrow[10];
-    }
-    return 0.0 * s;
-}
-
+// A row of weight ZERO is skipped, as the reference's accumulators do (`if (weight == 0.0) continue`): a non-finite Jacobian row of a dropped term (the
+// backward term of a model whose scale is NaN, a NaN depth) must not reach the sums as 0 * NaN.  (Rounds 3-5 added `0 * (r + sum of the row)` for such
+// rows to reproduce the stalled LM of tests/golden/initial.npz case 11; what stalls the reference there is its NaN COST — lm_cost hands NaN residuals on
+// now — and the reference does refine models with a NaN scale, tests/golden/bad_inputs_ref.npz.)
 // LOSS == 1 (TRUNCATED, known at compile time: every LO refinement): the weights of the reprojection terms are exactly 0 or 1.  A row
-// of weight 1 is accumulated without the NP products by the weight (w J = J bit for bit); a row of weight 0 only leaves its NaN-or-zero
-// effect (above) — and only if the correspondence has a non-zero weight at all: one whose three weights are all zero is not on the work
-// list of the list-based sweeps, so the dense sweeps must not let it act either.  Same sums bit for bit as the general path.
+// of weight 1 is accumulated without the NP products by the weight (w J = J bit for bit).  Same sums bit for bit as the general path.
 template <int KIND, bool SHIFT, int LOSS = -1>
 __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 p01, double2 p23, double2 dd,
                                                     double sqrt_sr, double ws, double ws2 /* ws * ws, uniform */, const LmOpt &o, double *acc) {
     const int loss = LOSS >= 0 ? LOSS : o.loss;
-    double zero_rows = 0.0; // LOSS == 1: sum of the zero-weight rows' effects
-    bool any_w = false;
     {
         double r0, J0[LM_NPAR];
         lm_sampson_term<true, KIND != 0>(stt, p01.x, p01.y, p23.x, p23.y, r0, J0);
@@ -1931,10 +1915,7 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         // weight at ws r^2 where the calibrated one evaluates it at r^2: what the reference binary computes (oracle/orc_refine.c lm_accumulate,
         // fitted against refine_monodepth_*relpose for ws = 0.3 ... 3 and all six losses); every form coincides at ws = 1
         const double w = sampson_row_weight<KIND>(loss, o.loss_scale, o.mu, ws, ws2, r0 * r0);
-        if (LOSS == 1) {
-            if (w != 0.0) { lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); any_w = true; } // (ws is a run-time weight: its product stays)
-            else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x1C0u>(J0, r0);
-        } else lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); // no scale / shift dependence
+        if (w != 0.0) lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); // no scale / shift dependence (ws is a run-time weight: its product stays)
     }
 #ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
     __builtin_amdgcn_sched_barrier(0);
@@ -1942,16 +1923,11 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
     {
         double r1, r2, zf, J1[LM_NPAR], J2[LM_NPAR];
         lm_forward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.x, r1, r2, zf, J1, J2);
-        const double w = (zf < 0) ? 0.0 : loss_weight(loss, o.loss_scale, r1 * r1 + r2 * r2, o.mu);
-        if (LOSS == 1) {
-            if (w != 0.0) {
-                lm_accumulate_row<KIND, SHIFT, 0x150u, true>(J1, r1, w, acc);
-                lm_accumulate_row<KIND, SHIFT, 0x148u, true>(J2, r2, w, acc);
-                any_w = true;
-            } else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x150u>(J1, r1) + lm_zero_row_effect<KIND, SHIFT, 0x148u>(J2, r2);
-        } else {
-            lm_accumulate_row<KIND, SHIFT, 0x150u>(J1, r1, w, acc); // t.y, scale, shift2
-            lm_accumulate_row<KIND, SHIFT, 0x148u>(J2, r2, w, acc); // t.x, scale, shift2
+        // positive depth of the transferred point: a NaN depth drops the term like a non-positive one (reference; the cost sweep does the same)
+        const double w = !(zf > 0) ? 0.0 : loss_weight(loss, o.loss_scale, r1 * r1 + r2 * r2, o.mu);
+        if (w != 0.0) {
+            lm_accumulate_row<KIND, SHIFT, 0x150u, LOSS == 1>(J1, r1, w, acc); // t.y, scale, shift2
+            lm_accumulate_row<KIND, SHIFT, 0x148u, LOSS == 1>(J2, r2, w, acc); // t.x, scale, shift2
         }
     }
 #ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
@@ -1960,19 +1936,12 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
     {
         double r3, r4, zb, J3[LM_NPAR], J4[LM_NPAR];
         lm_backward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.y, r3, r4, zb, J3, J4);
-        const double w = (zb < 0) ? 0.0 : loss_weight(loss, o.loss_scale, r3 * r3 + r4 * r4, o.mu);
-        if (LOSS == 1) {
-            if (w != 0.0) {
-                lm_accumulate_row<KIND, SHIFT, 0x080u, true>(J3, r3, w, acc);
-                lm_accumulate_row<KIND, SHIFT, 0x080u, true>(J4, r4, w, acc);
-                any_w = true;
-            } else zero_rows += lm_zero_row_effect<KIND, SHIFT, 0x080u>(J3, r3) + lm_zero_row_effect<KIND, SHIFT, 0x080u>(J4, r4);
-        } else {
-            lm_accumulate_row<KIND, SHIFT, 0x080u>(J3, r3, w, acc); // shift1
-            lm_accumulate_row<KIND, SHIFT, 0x080u>(J4, r4, w, acc); // shift1
+        const double w = !(zb > 0) ? 0.0 : loss_weight(loss, o.loss_scale, r3 * r3 + r4 * r4, o.mu);
+        if (w != 0.0) {
+            lm_accumulate_row<KIND, SHIFT, 0x080u, LOSS == 1>(J3, r3, w, acc); // shift1
+            lm_accumulate_row<KIND, SHIFT, 0x080u, LOSS == 1>(J4, r4, w, acc); // shift1
         }
     }
-    if (LOSS == 1 && any_w) acc[0] += zero_rows; // (+-0, or NaN: see lm_zero_row_effect; acc[0] takes part in every row)
 }
 
 template <int KIND, bool SHIFT, int T, int LOSS = -1>

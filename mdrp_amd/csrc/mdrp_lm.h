@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void k_lme_cost(LmePhase ph, const PairState *_
                 double res[5], zf, zb;
                 point_residuals<false, KIND != 0>(stt, sqrt_sr, ra[r], rb[r], rc[r], rd[r], e1[r], e2[r], res, zf, zb, nullptr);
                 const double rs = res[0] * res[0], rf = res[1] * res[1] + res[2] * res[2], rbk = res[3] * res[3] + res[4] * res[4];
-                const bool fwd = !(zf < 0), bwd = !(zb < 0);
+                const bool fwd = zf > 0, bwd = zb > 0;
                 double c = ws * loss_value(loss, lsc, rs);
                 c += fwd ? loss_value(loss, lsc, rf) : 0.0;
                 c += bwd ? loss_value(loss, lsc, rbk) : 0.0;

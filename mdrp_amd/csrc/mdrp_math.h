@@ -763,14 +763,15 @@ MDRP_HD double lm_rsqrt(double x) {
 MDRP_HD double loss_value(int type, double thr, double r2) {
     const double t2 = thr * thr;
     switch (type) {
-    case 1: case 5: return r2 < t2 ? r2 : t2;
+    // the truncated losses are std::min(r2, t2) = (t2 < r2) ? t2 : r2 in the reference: a NaN residual makes the COST NaN (no LM step is ever accepted)
+    case 1: case 5: return t2 < r2 ? t2 : r2;
     case 2: { const double r = sqrt(r2); return r <= thr ? r2 : thr * (2.0 * r - thr); }
 #if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV // (1 / t^2 is invariant over a sweep: one reciprocal, products per record)
     case 3: return t2 * log1p(r2 * lm_rcp(t2));
-    case 4: return t2 * log1p((r2 < t2 ? r2 : t2) * lm_rcp(t2));
+    case 4: return t2 * log1p((t2 < r2 ? t2 : r2) * lm_rcp(t2));
 #else
     case 3: return t2 * log1p(r2 / t2);
-    case 4: return t2 * log1p((r2 < t2 ? r2 : t2) / t2);
+    case 4: return t2 * log1p((t2 < r2 ? t2 : r2) / t2);
 #endif
     default: return r2;
     }
@@ -810,7 +811,7 @@ __device__ __forceinline__ double lm_log1p(double x, const double *tab_lds) {
 __device__ __forceinline__ double loss_value_tab(int type, double thr, double r2, const double *tab_lds) {
     if (!tab_lds || (type != 3 && type != 4)) return loss_value(type, thr, r2);
     const double t2 = thr * thr;
-    const double x = (type == 4 ? (r2 < t2 ? r2 : t2) : r2) * lm_rcp(t2);
+    const double x = (type == 4 ? (t2 < r2 ? t2 : r2) : r2) * lm_rcp(t2);
     return t2 * lm_log1p(x, tab_lds);
 }
 #endif

@@ -276,8 +276,10 @@ static double lm_cost(const lm_problem *pb, const orc_model *m) {
         point_residuals(&st, pb->sqrt_sr, pb->x1 + 2 * k, pb->x2 + 2 * k, pb->d1[k], pb->d2[k], r, NULL);
         const double w = pb->weights ? pb->weights[k] : 1.0;
         cost += w * pb->ws * loss_value(pb->loss_type, pb->thr, r[0] * r[0]);
-        if (!(r[5] < 0)) cost += w * loss_value(pb->loss_type, pb->thr, r[1] * r[1] + r[2] * r[2]);
-        if (!(r[6] < 0)) cost += w * loss_value(pb->loss_type, pb->thr, r[3] * r[3] + r[4] * r[4]);
+        /* a reprojection term takes part only with a POSITIVE depth of the transferred point: a NaN depth (NaN in d1 / d2) drops the term like a negative
+         * one does (black-box: refine_* with NaN depths have the finite cost of the same data with those depths negated), it does not poison the cost */
+        if (r[5] > 0) cost += w * loss_value(pb->loss_type, pb->thr, r[1] * r[1] + r[2] * r[2]);
+        if (r[6] > 0) cost += w * loss_value(pb->loss_type, pb->thr, r[3] * r[3] + r[4] * r[4]);
     }
     return cost;
 }
@@ -304,8 +306,8 @@ static void lm_accumulate(const lm_problem *pb, const orc_model *m, double *JtJ,
          * per-point weights: tests/test_refshim_parity.py::test_weight_sampson_in_the_refiners).  At ws = 1 all forms coincide. */
         const double ws2 = pb->ws * pb->ws, rs2 = r[0] * r[0];
         const double wS = pw * ws2 * loss_weight(pb->loss_type, pb->thr, pb->kind == ORC_CALIB ? rs2 : pb->ws * rs2);
-        const double wF = (r[5] < 0) ? 0.0 : pw * loss_weight(pb->loss_type, pb->thr, r[1] * r[1] + r[2] * r[2]);
-        const double wB = (r[6] < 0) ? 0.0 : pw * loss_weight(pb->loss_type, pb->thr, r[3] * r[3] + r[4] * r[4]);
+        const double wF = !(r[5] > 0) ? 0.0 : pw * loss_weight(pb->loss_type, pb->thr, r[1] * r[1] + r[2] * r[2]);
+        const double wB = !(r[6] > 0) ? 0.0 : pw * loss_weight(pb->loss_type, pb->thr, r[3] * r[3] + r[4] * r[4]);
         const double wr[5] = {wS, wF, wF, wB, wB};
         for (int row = 0; row < 5; ++row) {
             if (wr[row] == 0.0) continue;

@@ -202,3 +202,33 @@ def same_model(m, ref, tol=1e-6):
     if np.isnan(ref).any() or np.isnan(m).any():
         return bool(np.array_equal(np.isnan(m), np.isnan(ref)) and np.allclose(np.nan_to_num(m), np.nan_to_num(ref), rtol=1e-9, atol=1e-12))
     return bool(model_diff(m, ref) < tol)
+
+
+# ---- corrupted inputs against the reference binary (tests/golden/bad_inputs_ref.npz, tests/tools/gen_golden_bad_inputs_ref.py) ----------------------------
+BAD_INPUT_MODES = ("zero_depth", "neg_depth", "nan_depth", "nan_depth2", "nan_point", "inf_point", "dup_points")
+
+
+def bad_input_pair(name, mode):
+    """N = 300 pair of the estimator with a tenth of its correspondences corrupted: depths 0 / negated / NaN (image 1, image 2), NaN / inf coordinates
+    (5 points), 30 identical correspondences"""
+    import numpy as np
+    from mdrp_amd import synth
+    kind, es, rf = OPTIONS_KINDS[name]
+    p0 = synth.make_pair(53000, 300, noise_px=0.5, depth_noise=0.02, outlier_frac=0.3, random_focal=rf, shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
+    p = {k: np.array(p0[k], copy=True) for k in ("x1", "x2", "d1", "d2")}
+    idx = np.random.default_rng(5).choice(300, 30, replace=False)
+    if mode == "zero_depth": p["d1"][idx] = 0.0
+    elif mode == "neg_depth": p["d2"][idx] = -p["d2"][idx]
+    elif mode == "nan_depth": p["d1"][idx[:5]] = np.nan
+    elif mode == "nan_depth2": p["d2"][idx[:5]] = np.nan
+    elif mode == "nan_point": p["x2"][idx[:5], 0] = np.nan
+    elif mode == "inf_point": p["x1"][idx[:5], 1] = np.inf
+    elif mode == "dup_points":
+        for k in ("x1", "x2", "d1", "d2"): p[k][idx] = p[k][idx[0]]
+    return p
+
+
+# not compared: shared focal with inf coordinates — the normalisation scale is inf, every point becomes 0 (or NaN), the threshold 0; the reference's
+# generated solver returns a NaN model for the all-zero samples (which then is the answer: any score is 0), ours returns none (identity, f = inf)
+BAD_INPUT_SKIP = {("shared", "inf_point")}
+BAD_INPUT_LO_DEVIATIONS = {}

@@ -274,6 +274,29 @@ def test_edge_options_vs_reference_fixture(golden, name):
         assert info["model_score"] == ref[4] or abs(info["model_score"] - ref[4]) <= 1e-9 * abs(ref[4]), (name, j)
 
 
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_corrupted_inputs_vs_reference_fixture(handle, capi, golden, name):
+    """tests/golden/bad_inputs_ref.npz: a tenth of the correspondences with zero / negative / NaN depths (either image), NaN / inf coordinates, or all
+    identical — stats, mask and model identical to the REFERENCE BINARY on 27 of the 4 x 7 cases (the other one, garbage in both, is not compared: helpers.BAD_INPUT_SKIP): non-positive and NaN depths drop the reprojection terms, NaN / inf correspondences are never inliers, a NaN coordinate
+    poisons the focal estimators' normalisation (0 inliers, NaN model)."""
+    from helpers import BAD_INPUT_LO_DEVIATIONS, BAD_INPUT_MODES, BAD_INPUT_SKIP, bad_input_pair, same_model
+    g = golden("bad_inputs_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    cams = np.zeros(1, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ro = capi.ransac_opt_from_dict({"max_iterations": 500, "min_iterations": 500, "max_epipolar_error": 2.0, "max_reproj_error": 16.0, "seed": 2, "monodepth_estimate_shift": es})
+    bo = capi.bundle_opt_from_dict({"max_iterations": 100, "loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.0, "gradient_tol": 1e-10})
+    for j, mode in enumerate(BAD_INPUT_MODES):
+        if (name, mode) in BAD_INPUT_SKIP:
+            continue
+        p = bad_input_pair(name, mode)
+        res, mask = handle.estimate_batch(kind, p["x1"][None], p["x2"][None], p["d1"][None], p["d2"][None], ro, bo, None, cams if kind == 0 else None, cams if kind == 0 else None)
+        r, ref = res[0], g[f"{name}_stats"][j]
+        assert (int(r["iterations"]), int(r["num_inliers"])) == (int(ref[1]), int(ref[2])), (name, mode, int(r["iterations"]), int(r["num_inliers"]), ref)
+        assert int(r["refinements"]) - int(ref[0]) in (0, BAD_INPUT_LO_DEVIATIONS.get((name, mode), 0)), (name, mode, int(r["refinements"]), ref[0])
+        assert (mask[0] == np.unpackbits(g[f"{name}_mask"][j])[:300]).all(), (name, mode)
+        assert same_model(capi.model_to_array(r["model"]), g[f"{name}_model"][j]), (name, mode, capi.model_to_array(r["model"]), g[f"{name}_model"][j])
+
+
 def _run_estimate(capi, handle, kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None):
     def camrec(c):
         r = np.zeros(1, dtype=capi.CAMERA_DTYPE)

@@ -145,6 +145,29 @@ def test_edge_options_vs_reference_fixture(golden, name):
         assert st.model_score == ref[4] or abs(st.model_score - ref[4]) <= 1e-9 * abs(ref[4]), (name, j)
 
 
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_corrupted_inputs_vs_reference_fixture(golden, name):
+    """tests/golden/bad_inputs_ref.npz: a tenth of the correspondences with zero / negative / NaN depths (either image), NaN / inf coordinates, or all
+    identical.  The reference drops the reprojection terms of non-positive AND of NaN depths (the LM cost stays finite), never counts a NaN / inf
+    correspondence as an inlier, and lets a NaN coordinate poison the focal estimators' normalisation scale (0 inliers, NaN model).  Stats, mask and
+    model identical on 27 of the 4 x 7 cases (the other one, garbage in both, is not compared: helpers.BAD_INPUT_SKIP)."""
+    from helpers import BAD_INPUT_LO_DEVIATIONS, BAD_INPUT_MODES, BAD_INPUT_SKIP, bad_input_pair, same_model
+    g = golden("bad_inputs_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0]) if kind == 0 else None
+    for j, mode in enumerate(BAD_INPUT_MODES):
+        if (name, mode) in BAD_INPUT_SKIP:
+            continue
+        p = bad_input_pair(name, mode)
+        ro = po.ransac_opt(max_iterations=500, min_iterations=500, max_epipolar_error=2.0, max_reproj_error=16.0, seed=2, estimate_shift=es)
+        m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, po.bundle_opt(max_iterations=100, loss_type=4, loss_scale=1.0, gradient_tol=1e-10), cam, cam)
+        ref = g[f"{name}_stats"][j]
+        assert (st.iterations, st.num_inliers) == (int(ref[1]), int(ref[2])), (name, mode, st.iterations, st.num_inliers, ref)
+        assert st.refinements - int(ref[0]) == BAD_INPUT_LO_DEVIATIONS.get((name, mode), 0), (name, mode, st.refinements, ref[0])
+        assert (mask == np.unpackbits(g[f"{name}_mask"][j])[:300]).all(), (name, mode)
+        assert same_model(m, g[f"{name}_model"][j]), (name, mode, m, g[f"{name}_model"][j])
+
+
 def test_estimate_matches_reference(golden):
     g = golden("estimate")
     for case in g["cases"]:
