@@ -2386,6 +2386,9 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
 #endif
     // (a NaN model — the reference's P3P, k_solve — has a NaN cost: no step can be accepted, it comes back as it is)
     if (m.q[0] == m.q[0]) lm_refine<KIND, SHIFT, T, 1>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // refine_model: always TRUNCATED
+#ifdef MDRP_LO_TRACE
+    else if (threadIdx.x == 0) sh.ph[0] = sh.ph[1] = sh.ph[2] = sh.ph[3] = 0; // (no LM ran: nothing to attribute)
+#endif
     double sc;
     int cn;
     block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
