@@ -232,3 +232,37 @@ def bad_input_pair(name, mode):
 # generated solver returns a NaN model for the all-zero samples (which then is the answer: any score is 0), ours returns none (identity, f = inf)
 BAD_INPUT_SKIP = {("shared", "inf_point")}
 BAD_INPUT_LO_DEVIATIONS = {}
+
+
+# ---- degenerate geometry against the reference binary (tests/golden/degenerate_ref.npz, tests/tools/gen_golden_degenerate_ref.py) ---------------------------
+DEGENERATE_MODES = ("pure_rotation", "planar", "tiny_baseline", "forward")
+DEGENERATE_SEEDS = 6
+# shared focal under pure rotation: the focal length is unobservable, the refinements stop 5e-6 apart (iterations, inliers, mask, LO count identical)
+DEGENERATE_MODEL_TOL = {("shared", "pure_rotation", 4): 1e-5}
+# HIP path only: with the shift solver under pure rotation the two depth shifts are unobservable (they end at 16.6 and 10.4 here) and the last LM steps
+# amplify the summation order (iterations, inliers, mask identical)
+DEGENERATE_GPU_MODEL_TOL = {("calib_shift", "pure_rotation", 5): 1e-3}
+
+
+def degenerate_pair(name, mode, seed):
+    """N = 400 correspondences, 25 % outliers, 0.5 px noise, of a scene that is degenerate for epipolar geometry: pure rotation (t = 0), a plane,
+    a baseline of 1e-4 scene units, motion along the optical axis"""
+    import numpy as np
+    from mdrp_amd import synth
+    kind, es, rf = OPTIONS_KINDS[name]
+    rng = np.random.default_rng(seed)
+    n = 400
+    f1 = f2 = 800.0
+    if rf == "shared": f1 = f2 = rng.uniform(400, 1500)
+    if rf == "varying": f1, f2 = rng.uniform(400, 1500, 2)
+    R = synth.rodrigues(rng.normal(0, 0.2, 3)); t = rng.normal(0, 0.5, 3); scale = rng.uniform(0.5, 2)
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(3, 8, n)], 1)
+    if mode == "pure_rotation": t = np.zeros(3)
+    if mode == "planar": X[:, 2] = 5.0 + 0.3 * X[:, 0]
+    if mode == "tiny_baseline": t = t * 1e-4
+    if mode == "forward": t = np.array([0, 0, 0.7])
+    X2 = X @ R.T + t
+    x1 = f1 * X[:, :2] / X[:, 2:3] + rng.normal(0, 0.5, (n, 2)); x2 = f2 * X2[:, :2] / X2[:, 2:3] + rng.normal(0, 0.5, (n, 2))
+    d1 = X[:, 2] * (1 + rng.normal(0, 0.02, n)) - (0.2 if es else 0); d2 = X2[:, 2] / scale * (1 + rng.normal(0, 0.02, n)) - (-0.1 if es else 0)
+    o = rng.choice(n, n // 4, replace=False); x2[o] = rng.uniform(-600, 600, (len(o), 2))
+    return {"x1": x1, "x2": x2, "d1": d1, "d2": d2}

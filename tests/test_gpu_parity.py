@@ -297,6 +297,35 @@ def test_corrupted_inputs_vs_reference_fixture(handle, capi, golden, name):
         assert same_model(capi.model_to_array(r["model"]), g[f"{name}_model"][j]), (name, mode, capi.model_to_array(r["model"]), g[f"{name}_model"][j])
 
 
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_degenerate_geometry_vs_reference_fixture(handle, capi, golden, name):
+    """tests/golden/degenerate_ref.npz as ONE batched call per estimator: pure rotation, a planar scene, a baseline of 1e-4, motion along the optical axis
+    (6 seeds each — the seed is an option of the call, so one call per seed over the four scene types): iterations, inlier count and mask identical to
+    the REFERENCE BINARY on all 24 cases, model within 1e-6 (one enumerated: 1e-5), LO count equal or one apart (rounding ties on degenerate data)."""
+    from helpers import DEGENERATE_GPU_MODEL_TOL, DEGENERATE_MODEL_TOL, DEGENERATE_MODES, DEGENERATE_SEEDS, degenerate_pair, same_model
+    g = golden("degenerate_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    B = len(DEGENERATE_MODES)
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    bo = capi.bundle_opt_from_dict({"max_iterations": 100, "loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.0, "gradient_tol": 1e-10})
+    lo_off = 0
+    for seed in range(DEGENERATE_SEEDS):
+        pairs = [degenerate_pair(name, mode, seed) for mode in DEGENERATE_MODES]
+        ro = capi.ransac_opt_from_dict({"max_iterations": 1000, "min_iterations": 1000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0, "seed": seed, "monodepth_estimate_shift": es})
+        res, mask = handle.estimate_batch(kind, np.stack([p["x1"] for p in pairs]), np.stack([p["x2"] for p in pairs]), np.stack([p["d1"] for p in pairs]),
+                                          np.stack([p["d2"] for p in pairs]), ro, bo, None, cams if kind == 0 else None, cams if kind == 0 else None)
+        for i, mode in enumerate(DEGENERATE_MODES):
+            k = i * DEGENERATE_SEEDS + seed
+            r, ref = res[i], g[f"{name}_stats"][k]
+            assert (int(r["iterations"]), int(r["num_inliers"])) == (int(ref[1]), int(ref[2])), (name, mode, seed, int(r["num_inliers"]), ref)
+            assert (mask[i] == np.unpackbits(g[f"{name}_mask"][k])[:400]).all(), (name, mode, seed)
+            tol = DEGENERATE_GPU_MODEL_TOL.get((name, mode, seed), DEGENERATE_MODEL_TOL.get((name, mode, seed), 1e-6))
+            assert same_model(capi.model_to_array(r["model"]), g[f"{name}_model"][k], tol), (name, mode, seed, model_diff(capi.model_to_array(r["model"]), g[f"{name}_model"][k]))
+            assert abs(int(r["refinements"]) - int(ref[0])) <= 1, (name, mode, seed, int(r["refinements"]), ref[0])
+            lo_off += int(r["refinements"]) != int(ref[0])
+    assert lo_off <= 2, lo_off
+
+
 def _run_estimate(capi, handle, kind, x1, x2, d1, d2, ro, bo, cam1=None, cam2=None):
     def camrec(c):
         r = np.zeros(1, dtype=capi.CAMERA_DTYPE)

@@ -168,6 +168,28 @@ def test_corrupted_inputs_vs_reference_fixture(golden, name):
         assert same_model(m, g[f"{name}_model"][j]), (name, mode, m, g[f"{name}_model"][j])
 
 
+@pytest.mark.parametrize("name", list(OPTIONS_NAMES))
+def test_degenerate_geometry_vs_reference_fixture(golden, name):
+    """tests/golden/degenerate_ref.npz: pure rotation, a planar scene, a baseline of 1e-4, motion along the optical axis (6 seeds each; 25 % outliers):
+    stats (LO count included), mask and model identical to the reference binary on all 24 cases per estimator (one model 5e-6, enumerated)."""
+    from helpers import DEGENERATE_MODEL_TOL, DEGENERATE_MODES, DEGENERATE_SEEDS, degenerate_pair, same_model
+    g = golden("degenerate_ref")
+    kind, es, rf = OPTIONS_KINDS[name]
+    cam = po.cam_flat(0, [800.0, 0.0, 0.0]) if kind == 0 else None
+    k = 0
+    for mode in DEGENERATE_MODES:
+        for seed in range(DEGENERATE_SEEDS):
+            p = degenerate_pair(name, mode, seed)
+            assert input_digest(p) == g[f"{name}_digest"][k]
+            ro = po.ransac_opt(max_iterations=1000, min_iterations=1000, max_epipolar_error=2.0, max_reproj_error=16.0, seed=seed, estimate_shift=es)
+            m, st, mask = po.estimate(kind, p["x1"], p["x2"], p["d1"], p["d2"], ro, po.bundle_opt(max_iterations=100, loss_type=4, loss_scale=1.0, gradient_tol=1e-10), cam, cam)
+            ref = g[f"{name}_stats"][k]
+            assert (st.refinements, st.iterations, st.num_inliers) == tuple(int(v) for v in ref[:3]), (name, mode, seed, st.refinements, st.num_inliers, ref)
+            assert (mask == np.unpackbits(g[f"{name}_mask"][k])[:400]).all(), (name, mode, seed)
+            assert same_model(m, g[f"{name}_model"][k], DEGENERATE_MODEL_TOL.get((name, mode, seed), 1e-6)), (name, mode, seed)
+            k += 1
+
+
 def test_estimate_matches_reference(golden):
     g = golden("estimate")
     for case in g["cases"]:
