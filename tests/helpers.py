@@ -12,8 +12,9 @@ def quat_to_R(q):
 def model_diff(a, b):
     """max of |dR| and relative difference of (t, scale, shifts, focals); a, b are 12-wide models."""
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
-    dR = np.abs(quat_to_R(a[:4]) - quat_to_R(b[:4])).max()
-    rest = np.abs((a[4:] - b[4:]) / (1.0 + np.abs(b[4:]))).max()
+    with np.errstate(invalid="ignore"):  # (inf - inf in models of corrupted inputs: the NaN travels to the caller's comparison)
+        dR = np.abs(quat_to_R(a[:4]) - quat_to_R(b[:4])).max()
+        rest = np.abs((a[4:] - b[4:]) / (1.0 + np.abs(b[4:]))).max()
     return max(dR, rest)
 
 
