@@ -584,3 +584,46 @@ def test_batched_ragged_calls_under_random_options_vs_oracle(golden, name):
             d = fund_diff(rows[i], m[:9]) if kind == 5 else pose_diff(rows[i][:7], m[:7])
             assert d < 2e-6 and (kind != 4 or abs(rows[i][7] - m[10]) < 2e-6 * m[10]), (where, d)
             assert abs(info["refinements"] - st.refinements) <= ((2 if kind == 4 else 1) if n < 100 else (2 if kind == 4 else 0)), (where, info["refinements"], st.refinements)
+
+
+@pytest.mark.parametrize("name", ["relpose_5pt", "shared_6pt", "fundamental_7pt"])
+def test_corrupted_inputs_vs_oracle(name):
+    """NaN / inf coordinates (5 of 300 correspondences), 30 identical correspondences, 20 inliers among 280 random matches: the comparison rows through
+    the drop-in module against the oracle (which a one-off probe against the reference binary found identical on these inputs for the 5- and 7-point
+    estimators): iterations, inlier count, mask, LO count; model to 1e-6 or non-finite in the same places."""
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import synth
+    from helpers import CLASSIC_OPTIONS_KINDS
+    kind = CLASSIC_OPTIONS_KINDS[name]
+    cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
+    ro = {"max_iterations": 500, "min_iterations": 500, "max_epipolar_error": 2.0, "seed": 2}
+    bo = {"max_iterations": 100, "loss_type": "TRUNCATED_CAUCHY", "loss_scale": 1.0, "gradient_tol": 1e-10}
+    for mode in ("nan_point", "inf_point", "dup_points", "few_inliers"):
+        p0 = synth.make_pair(54000, 300, noise_px=0.5, depth_noise=0.0, outlier_frac=0.3, random_focal="shared" if kind == 4 else None)
+        x1, x2 = np.array(p0["x1"], copy=True), np.array(p0["x2"], copy=True)
+        idx = np.random.default_rng(5).choice(300, 30, replace=False)
+        if mode == "nan_point": x2[idx[:5], 0] = np.nan
+        if mode == "inf_point": x1[idx[:5], 1] = np.inf
+        if mode == "dup_points": x1[idx] = x1[idx[0]]; x2[idx] = x2[idx[0]]
+        if mode == "few_inliers": x2[20:] = np.random.default_rng(6).uniform(-500, 500, (280, 2))
+        if kind == 3:
+            pose, info = poselib.estimate_relative_pose(x1, x2, cam, cam, ro, bo)
+            mine = np.r_[pose.q, pose.t]
+        elif kind == 4:
+            pair, info = poselib.estimate_shared_focal_relative_pose(x1, x2, (0.0, 0.0), ro, bo)
+            mine = np.r_[pair.pose.q, pair.pose.t, pair.camera1.params[0]]
+        else:
+            F, info = poselib.estimate_fundamental(x1, x2, ro, bo)
+            mine = np.asarray(F).reshape(-1)
+        c = po.cam_flat(0, [800.0, 0.0, 0.0]) if kind == 3 else None
+        m, st, mask = po.estimate_classic(kind, x1, x2, po.ransac_opt(**ro), po.bundle_opt(max_iterations=100, loss_type=4, loss_scale=1.0, gradient_tol=1e-10), c, c, pp=(0.0, 0.0))
+        m = np.asarray(m, float).reshape(-1)
+        want = m[:7] if kind == 3 else (np.r_[m[:7], m[10]] if kind == 4 else m[:9])
+        where = (name, mode)
+        assert (info["iterations"], info["num_inliers"], info["refinements"]) == (st.iterations, st.num_inliers, st.refinements), (where, info["refinements"], st.refinements)
+        assert np.array_equal(np.array(info["inliers"], dtype=np.uint8), mask), where
+        if np.isfinite(want).all() and np.linalg.norm(want[4:7] if kind != 5 else want) > 0:
+            d = fund_diff(mine, want) if kind == 5 else pose_diff(mine[:7], want[:7])
+            assert d < 1e-6 and (kind != 4 or abs(mine[7] - want[7]) < 1e-6 * abs(want[7])), (where, d)
+        else:
+            assert np.array_equal(np.isfinite(mine), np.isfinite(want)) and np.allclose(np.nan_to_num(mine, posinf=0, neginf=0), np.nan_to_num(want, posinf=0, neginf=0), atol=1e-9), (where, mine, want)
