@@ -16,6 +16,7 @@ MDRP_STRESS_KINDS=4 timeout 600 python tests/tools/stress_parity_classic.py 32 >
 MDRP_FUSE_TAIL=0 timeout 300 python tools/lo_trace.py > gpurun_out/r05_lo_trace.txt 2>&1
 MDRP_FUSE_TAIL=0 timeout 300 python tools/lo_trace.py varying_n5000_i10k > gpurun_out/r05_lo_trace_varying.txt 2>&1
 (MDRP_PIPELINE_MIN=1000000 timeout 120 python tools/entry_rate.py 2048 3; MDRP_PIPELINE_MIN=1000000 timeout 120 python tools/entry_rate.py 4096 3; timeout 200 python tools/entry_rate.py 8192 3; timeout 300 python tools/entry_rate.py 16384 2) 2>&1 | grep "^B " > gpurun_out/r05_python_entry_points.txt
+timeout 600 python tests/tools/stress_options.py 512 777 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_stress_options.txt
 timeout 900 python -m pytest tests -q -m gpu -s 2>&1 | grep -E "passed|failed|^FAILED|pairs identical|pairs/s|REFERENCE" > gpurun_out/r05_pytest_gpu.txt
 mkdir -p gpurun_out/profiles_r05; cp profiles/r05_* gpurun_out/profiles_r05/ 2>/dev/null
 ls gpurun_out/profiles_r05 | wc -l
