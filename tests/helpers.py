@@ -15,7 +15,9 @@ def model_diff(a, b):
     with np.errstate(invalid="ignore"):  # (inf - inf in models of corrupted inputs: the NaN travels to the caller's comparison)
         dR = np.abs(quat_to_R(a[:4]) - quat_to_R(b[:4])).max()
         rest = np.abs((a[4:] - b[4:]) / (1.0 + np.abs(b[4:]))).max()
-    return max(dR, rest)
+    # np.max propagates NaN where Python's max(0.1, nan) is 0.1: a NaN translation / scale / shift / focal against a finite reference must not pass
+    # a `model_diff(...) < tol` assertion just because the rotation is finite
+    return float(np.max([dR, rest]))
 
 
 def match_solution_sets(A, B, tol=1e-6):

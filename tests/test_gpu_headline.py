@@ -302,6 +302,75 @@ def test_emulated_eight_way_split_equals_one_call_and_the_reference(capi, golden
         assert model_diff(capi.model_to_array(sharded[i]["model"]), ref["model"][j]) < 1e-6, i
 
 
+def test_one_rank_share_of_configs4_12500_pairs_vs_the_reference(capi, golden):
+    """VERDICT r05 item 1 — BASELINE configs[4] at the size ONE rank sees: 100 000 pairs over 8 GPUs = 12 500 pairs per rank.  The 1024-pair headline
+    batch tiled to 12 500 pairs goes through `dist.estimate_local_shard_device(force_collective=True)` — device-resident inputs, ONE
+    mdrp_estimate_batch_async call (one pass, ~66 GB of scratch), mdrp_copy_results_device into the rank's slot, all_gather_into_tensor over RCCL
+    (a one-rank `nccl` group, the collective forced): exactly what `bench.py --gpus 8 --total-pairs 100000` runs on each rank — and EVERY pair is
+    compared with the reference binary's fixture by index modulo 1024: iterations, inlier count, mask identical, model within 1e-6."""
+    import socket
+    import time
+    import torch
+    import torch.distributed as tdist
+    from mdrp_amd import dist as mdist, synth
+    ref = golden("headline_ref_calib_p3p_n2000_i10k")
+    total, n = 12500, 2000
+    b = synth.make_batch(0, 1024, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
+    for i in range(0, 1024, 97):
+        assert _digest(b, i) == ref["digest"][i], "synthetic generator drifted"
+    idx = np.arange(total) % 1024
+    dev = torch.device("cuda", 0)
+    base = [torch.from_numpy(b[k]).to(dev) for k in ("x1", "x2", "d1", "d2")]
+    tidx = torch.from_numpy(idx).to(dev)
+    t = [x.index_select(0, tidx).contiguous() for x in base]  # tiled on the device: 1.2 GB of inputs, no 12x host copy
+    del base
+    mask = torch.zeros((total, n), dtype=torch.uint8, device=dev)
+    cams = np.zeros(total, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ro = capi.ransac_opt_from_dict(RO); bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    created = False
+    if not tdist.is_initialized():
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tdist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        created = True
+    h = capi.Handle(0)
+    try:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = mdist.estimate_local_shard_device(0, total, *t, ro, bo, None, cams, cams, handle=h, mask=mask, force_collective=True)
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out2 = mdist.estimate_local_shard_device(0, total, *t, ro, bo, None, cams, cams, handle=h, mask=mask, force_collective=True)
+        dt2 = time.perf_counter() - t0
+        st = h.last_stats()
+    finally:
+        h.close()
+        if created:
+            tdist.destroy_process_group()
+    assert len(out) == total and out.tobytes() == out2.tobytes()
+    ist = ref["istats"][idx]
+    assert np.array_equal(out["iterations"].astype(np.int64), ist[:, 1]) and np.array_equal(out["num_inliers"].astype(np.int64), ist[:, 2])
+    ref_mask = np.unpackbits(ref["mask"], axis=1)[:, :n]
+    m = mask.cpu().numpy()
+    for r0 in range(0, total, 1024):  # block by block: the comparison array stays at 2 MB
+        blk = m[r0:r0 + 1024]
+        assert np.array_equal(blk, ref_mask[:len(blk)]), r0
+    worst = 0.0
+    for i in range(total):
+        d = model_diff(capi.model_to_array(out[i]["model"]), ref["model"][idx[i]])
+        worst = max(worst, d)
+        assert d < 1e-6, (i, d)
+    # every copy of a pair gets the same record whatever its place in the batch
+    first = out[:1024]
+    for r0 in range(1024, total, 1024):
+        blk = out[r0:r0 + 1024]
+        assert blk.tobytes() == first[:len(blk)].tobytes(), r0
+    print(f"one rank's share of BASELINE configs[4]: {total} pairs in one call through estimate_local_shard_device (collective forced): every pair = reference fixture "
+          f"(iterations, inliers, mask; worst model diff {worst:.2e}); {total / dt2:.0f} pairs/s incl. the gather and the host copy of the records "
+          f"(first call with scratch allocation {total / dt:.0f}); fused-tail time-outs {st.get('fuse_timeouts', 0)}")
+
+
 @pytest.mark.parametrize("name", ["calib_p3p", "calib_shift", "shared", "varying"])
 def test_dynamic_stopping_full_size_vs_reference_fixture(capi, golden, name):
     """Round 5: ransac<>'s DYNAMIC stopping rule at full size against the reference binary (tests/golden/dynamic_ref.npz,

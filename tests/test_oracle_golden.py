@@ -418,3 +418,16 @@ def test_baseline_and_clean_headline_fixtures(golden, workload, kind, pairs, out
         m, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], ro, po.bundle_opt(loss_type=4), cam if kind == 3 else None, cam if kind == 3 else None, pp=(0.0, 0.0))
     assert (st.refinements, st.iterations, st.num_inliers) == (int(g["oracle_refinements"][i]), int(g["istats"][i, 1]), int(g["istats"][i, 2]))
     assert (np.packbits(mask) == g["mask"][i]).all()
+
+
+def test_model_diff_propagates_nan_in_any_component():
+    """NaN poses / NaN scales are legitimate outputs (the reference's P3P); a GPU model with a NaN translation, scale, shift or
+    focal must never compare as `< tol` against a finite reference just because its rotation is finite — and the other way round."""
+    import numpy as np
+    from helpers import model_diff
+    ref = np.array([1.0, 0, 0, 0, 0.1, 0.2, 0.3, 1.0, 0.0, 0.0, 1.0, 1.0])
+    assert model_diff(ref, ref) == 0.0
+    for col in range(12):
+        bad = ref.copy(); bad[col] = np.nan
+        assert not (model_diff(bad, ref) < 1e-6), col
+        assert not (model_diff(ref, bad) < 1e-6), col
