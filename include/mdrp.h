@@ -124,21 +124,27 @@ typedef struct {
 typedef struct mdrp_handle mdrp_handle;
 
 /* Library/handle management.  device = HIP device ordinal.  stream = a hipStream_t created by the caller or NULL to
- * let the handle create its own (non-blocking) stream. */
-int mdrp_create(int device, void *stream, mdrp_handle **out);
+ * let the handle create its own (non-blocking) stream.
+ * mdrp_create / mdrp_create_on_stream are MACROS over the exported mdrp_create_ / mdrp_create_on_stream_ (the zlib deflateInit pattern): they hand the
+ * ABI version and the size of mdrp_ransac_opt of the header the HOST was compiled against to the library, which refuses a mismatch
+ * (MDRP_ERR_INVALID, mdrp_last_error() names both versions) instead of reading option fields past the end of a smaller struct.  A host built
+ * against ABI 0.4 or older, which imported the plain symbols, no longer loads against this library: it must be recompiled. */
+int mdrp_create_(int device, void *stream, mdrp_handle **out, int abi_version, int ransac_opt_bytes);
 /* Same, but `stream` is used exactly as given: NULL means the device's legacy default (null) stream — which is what
  * torch.cuda.current_stream().cuda_stream is (0) unless the caller switched streams.  Work of the handle is then
  * ordered with everything else queued on that stream (inputs produced by earlier kernels, consumers of the mask). */
-int mdrp_create_on_stream(int device, void *stream, mdrp_handle **out);
+int mdrp_create_on_stream_(int device, void *stream, mdrp_handle **out, int abi_version, int ransac_opt_bytes);
+#define mdrp_create(device, stream, out) mdrp_create_((device), (stream), (out), MDRP_ABI_VERSION, (int)sizeof(mdrp_ransac_opt))
+#define mdrp_create_on_stream(device, stream, out) mdrp_create_on_stream_((device), (stream), (out), MDRP_ABI_VERSION, (int)sizeof(mdrp_ransac_opt))
 void mdrp_destroy(mdrp_handle *h);
 const char *mdrp_last_error(void);
 /* "mdrp-hip <ver> (gfx950) MDRP_SRC_HASH=<16 hex digits>": the hash covers mdrp_capi.hip, mdrp_kernels.h, mdrp_math.h,
  * mdrp_classic.h, mdrp_classic_math.h and this header as they were when the library was built (mdrp_amd/build.py source_hash()) */
 const char *mdrp_version(void);
-/* ABI 0.4: (major << 16) | minor of the structs and entry points in this header = 0x00000004.  Within one major, minors only append
- * (fields behind the existing ones, new entry points); mdrp_ransac_opt grew from 72 to 88 bytes in 0.4, so a host built against 0.3
- * must be recompiled — compare this with MDRP_ABI_VERSION of the header it was compiled against. */
-#define MDRP_ABI_VERSION 0x00000004
+/* ABI 0.5: (major << 16) | minor of the structs and entry points in this header = 0x00000005.  mdrp_ransac_opt grew from 72 to 88 bytes in
+ * 0.4; 0.5 makes the version check involuntary: handles are created through mdrp_create_ / mdrp_create_on_stream_, which take the host's
+ * MDRP_ABI_VERSION and sizeof(mdrp_ransac_opt) (the macros above pass them) and refuse another ABI. */
+#define MDRP_ABI_VERSION 0x00000005
 int mdrp_abi_version(void);
 /* HIP_VERSION (major * 10^7 + minor * 10^5 + patch) of the toolchain the library was compiled with.  The library carries no HIP
  * runtime of its own (it binds to the host process's libamdhip64 when it is loaded): a host compares this with

@@ -18,7 +18,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 SOLVER_P3P, SOLVER_SHIFT, SOLVER_SHARED, SOLVER_VARYING = 0, 1, 2, 3
 
 EXPORTS = (
-    "mdrp_create", "mdrp_create_on_stream", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_abi_version", "mdrp_hip_build_version", "mdrp_synchronize", "mdrp_estimate_batch",
+    "mdrp_create_", "mdrp_create_on_stream_", "mdrp_destroy", "mdrp_last_error", "mdrp_version", "mdrp_abi_version", "mdrp_hip_build_version", "mdrp_synchronize", "mdrp_estimate_batch",
     "mdrp_estimate_batch_async", "mdrp_fetch_results", "mdrp_copy_results_device", "mdrp_solver_batch", "mdrp_score_models", "mdrp_count_candidates", "mdrp_bound_models", "mdrp_refine_models",
     "mdrp_last_sweep_stats", "mdrp_last_stats", "mdrp_last_stats_sized", "mdrp_classic_solver_batch",
 )
@@ -89,11 +89,14 @@ def load_library():
         vp, dp, ip = C.c_void_p, C.c_void_p, C.c_void_p
         lib.mdrp_last_error.restype = C.c_char_p
         lib.mdrp_version.restype = C.c_char_p
-        lib.mdrp_abi_version.restype = C.c_int
-        if lib.mdrp_abi_version() != ABI_VERSION:
-            raise MdrpError(f"{LIB_PATH} speaks ABI {lib.mdrp_abi_version():#x}, this binding {ABI_VERSION:#x}: rebuild (mdrp_amd/build.py)")
-        lib.mdrp_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
-        lib.mdrp_create_on_stream.argtypes = [C.c_int, vp, C.POINTER(vp)]
+        abi = getattr(lib, "mdrp_abi_version", None)  # (a library from before ABI 0.4, e.g. through MDRP_LIB, has no such symbol)
+        if abi is None or getattr(lib, "mdrp_create_", None) is None:
+            raise MdrpError(f"{LIB_PATH} predates ABI {ABI_VERSION:#x} (no mdrp_abi_version / mdrp_create_): rebuild (mdrp_amd/build.py)")
+        abi.restype = C.c_int
+        if abi() != ABI_VERSION:
+            raise MdrpError(f"{LIB_PATH} speaks ABI {abi():#x}, this binding {ABI_VERSION:#x}: rebuild (mdrp_amd/build.py)")
+        lib.mdrp_create_.argtypes = [C.c_int, vp, C.POINTER(vp), C.c_int, C.c_int]
+        lib.mdrp_create_on_stream_.argtypes = [C.c_int, vp, C.POINTER(vp), C.c_int, C.c_int]
         lib.mdrp_destroy.argtypes = [vp]
         lib.mdrp_destroy.restype = None
         lib.mdrp_synchronize.argtypes = [vp]
@@ -117,7 +120,7 @@ def load_library():
         return lib
 
 
-ABI_VERSION = 0x00000004  # include/mdrp.h MDRP_ABI_VERSION
+ABI_VERSION = 0x00000005  # include/mdrp.h MDRP_ABI_VERSION
 ERR_UNSUPPORTED = 4  # include/mdrp.h MDRP_ERR_UNSUPPORTED: a reference option that selects behaviour the library does not build
 
 
@@ -256,9 +259,9 @@ class Handle:
         self._lib = load_library()
         h = C.c_void_p()
         if stream is None:
-            _check(self._lib, self._lib.mdrp_create(int(device), None, C.byref(h)))
+            _check(self._lib, self._lib.mdrp_create_(int(device), None, C.byref(h), ABI_VERSION, C.sizeof(RansacOpt)))
         else:
-            _check(self._lib, self._lib.mdrp_create_on_stream(int(device), C.c_void_p(int(stream)) if stream else None, C.byref(h)))
+            _check(self._lib, self._lib.mdrp_create_on_stream_(int(device), C.c_void_p(int(stream)) if stream else None, C.byref(h), ABI_VERSION, C.sizeof(RansacOpt)))
         self._h = h
         self.device = int(device)
         self.stream = stream

@@ -15,7 +15,7 @@ SRC_TU = os.path.join(HERE, "csrc", "mdrp_tu.hip")  # secondary translation unit
 TU_GROUPS = (1, 2, 3)                                # k_final at 64 lanes | k_final at 256 lanes | 5- / 6- / 7-point baselines (mdrp_instances.h)
 DEPS = [SRC, SRC_TU, os.path.join(HERE, "csrc", "mdrp_kernels.h"), os.path.join(HERE, "csrc", "mdrp_math.h"),
         os.path.join(HERE, "csrc", "mdrp_classic.h"), os.path.join(HERE, "csrc", "mdrp_classic_math.h"),
-        os.path.join(HERE, "csrc", "mdrp_lm.h"), os.path.join(HERE, "csrc", "mdrp_logtab.h"), os.path.join(HERE, "csrc", "mdrp_instances.h"),
+        os.path.join(HERE, "csrc", "mdrp_logtab.h"), os.path.join(HERE, "csrc", "mdrp_instances.h"),
         os.path.join(HERE, "..", "include", "mdrp.h")]
 OUT = os.path.join(HERE, "libmdrp_hip.so")
 _MARK = b"MDRP_SRC_HASH="

@@ -4,7 +4,6 @@
 #include "../../include/mdrp.h"
 #include "mdrp_kernels.h"
 #include "mdrp_classic.h"
-#include "mdrp_lm.h"
 // MDRP_SPLIT_TU (the default build): the k_final family and the baselines' kernels are instantiated in mdrp_tu.hip, compiled in parallel with
 // this file; a single-unit build (experiment builds with -D switches: mdrp_amd/build.py single=True) instantiates them here, implicitly.
 #ifdef MDRP_SPLIT_TU
@@ -78,7 +77,7 @@ struct Progress {
 };
 constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
 constexpr int CNT_XCD_HEAD = 32; // int32 index of the per-XCD LO queue heads: [chunk][8] at LO_XCD_STRIDE ints (lo_take, mdrp_kernels.h)
-constexpr size_t COUNTERS_BYTES = sizeof(int32_t) * (CNT_XCD_HEAD + 8 /*NC_MAX*/ * 8 * LO_XCD_STRIDE);
+constexpr size_t COUNTERS_BYTES = sizeof(int32_t) * (CNT_XCD_HEAD + 8 * LO_XCD_STRIDE);
 constexpr size_t LM_STATS_BYTES = 6 * sizeof(unsigned long long); // mdrp_handle::lm_stats
 
 // Every entry point runs on the handle's device and puts the caller's current device back on return (the caller is
@@ -107,10 +106,7 @@ struct mdrp_handle {
     hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
     DevBuf fuse;                       // fused tail: control words (64 B) | done_cnt[batch] | fin_done[batch] | ready[batch]
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
-    hipEvent_t ev_lo = nullptr, ev_counted = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
-    static constexpr int PARTS_MAX = 4; // sub-ranges of one chunk's solver launch (k_count of part i runs beside the solver of part i + 1)
-    hipEvent_t ev_part[2][PARTS_MAX] = {};
-    DevBuf tag_snap;                   // [2 (chunk parity)][PARTS_MAX - 1][2 batch] tag counts after each solver part
+    hipEvent_t ev_lo = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
     int num_cu = 256;
     // persistent device buffers
     DevBuf pts, dep, st, samples;
@@ -125,18 +121,13 @@ struct mdrp_handle {
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
-    // phase-batched LM engine (mdrp_lm.h): problem table, per (problem, segment) partials, work lists, round counters
-    DevBuf lme_probs, lme_part, lme_ipart, lme_list, lme_cnt, lme_ctl, lme_iota, lme_pair_live, lme_accpart;
-    int lme_mode = 0;                  // LO phases: 1 = list engine (k_lme_accum), 2 = segment engine (dense sweeps: k_lme_decide / k_lme_accum_seg / k_lme_reduce)
-    int lme_mode_final = 0;            // the final phase (one problem per pair, an inlier mask in its second half): 1 or 2
-    bool lme_trace = false;
-    int32_t *lme_live_host = nullptr; // pinned: problems still iterating, read back every few rounds of an open-ended phase
     DevBuf lm_stats;                  // six u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel |
                                       // fused tail: gate time-outs | final-refinement wait time-outs
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
     int64_t fuse_gate_timeouts = 0, fuse_wait_timeouts = 0; // of the last call
     bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, run unfused ...
-    int fuse_retry_in = 0;            // ... for this many calls, then try the fused tail again (a busy moment on a shared GPU is not a profiler)
+    int fuse_retry_in = 0;            // ... for this many API calls, then try the fused tail again (a busy moment on a shared GPU is not a profiler)
+    int fuse_backoff = 64;            // ... doubled after every consecutive expired wait (capped), reset by a call whose fused tail ran through
     DevBuf in_x1, in_x2, in_d1, in_d2; // staging when the caller passes host memory
     DevBuf unit_a, unit_b, unit_c, unit_d, unit_e, unit_f;
     Progress *progress_host = nullptr; // pinned
@@ -156,10 +147,6 @@ struct mdrp_handle {
 namespace {
 
 // one LM instantiation per kernel: dispatch (kind, estimate_shift) on the host
-#ifdef MDRP_FAST_BUILD // experiments: only the calibrated, no-shift LM is instantiated (16 s instead of 60 s)
-#define MDRP_LM_DISPATCH_T(KERNEL, T, kind, shift, grid, smem, stream, ...) \
-    hipLaunchKernelGGL((KERNEL<0, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__)
-#else
 #define MDRP_LM_DISPATCH_T(KERNEL, T, kind, shift, grid, smem, stream, ...)                                          \
     do {                                                                                                             \
         if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true, T>), grid, dim3(T), smem, stream, __VA_ARGS__);  \
@@ -167,7 +154,6 @@ namespace {
         else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((KERNEL<2, false, T>), grid, dim3(T), smem, stream, __VA_ARGS__);                        \
     } while (0)
-#endif
 // threads per LM problem: one wavefront (64) when problems outnumber SIMDs, a 256-thread workgroup otherwise
 #define MDRP_LM_DISPATCH(KERNEL, threads, kind, shift, grid, smem, stream, ...)                                      \
     do {                                                                                                             \
@@ -177,9 +163,6 @@ namespace {
 
 // k_final: the user's loss type of the inlier-only refinement is a template parameter as well (rp.final_loss): one instantiation per loss type of
 // BundleOptions (an unknown type is the TRIVIAL loss, as in loss_value)
-#ifdef MDRP_FAST_BUILD
-#define MDRP_FINAL_DISPATCH_L(T, FL, kind, shift, grid, smem, stream, ...) hipLaunchKernelGGL((k_final<0, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__)
-#else
 #define MDRP_FINAL_DISPATCH_L(T, FL, kind, shift, grid, smem, stream, ...)                                                  \
     do {                                                                                                                   \
         if ((kind) == 0 && (shift)) hipLaunchKernelGGL((k_final<0, true, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);  \
@@ -187,7 +170,6 @@ namespace {
         else if ((kind) == 1) hipLaunchKernelGGL((k_final<1, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL((k_final<2, false, T, FL>), grid, dim3(T), smem, stream, __VA_ARGS__);                        \
     } while (0)
-#endif
 #define MDRP_FINAL_DISPATCH_T(T, floss, kind, shift, grid, smem, stream, ...)                                               \
     do {                                                                                                                   \
         switch (floss) {                                                                                                   \
@@ -256,191 +238,6 @@ int solver_for(int kind, int est_shift) {
     return kind == MDRP_SHARED_FOCAL ? SOLVER_SHARED : SOLVER_VARYING;
 }
 
-// ---------------------------------------------------------------------------------------------- LM engine (mdrp_lm.h)
-#ifdef MDRP_FAST_BUILD
-#define MDRP_LME_LM(KERNEL, kind, shift, grid, block, smem, stream, ...) hipLaunchKernelGGL((KERNEL<0, false>), grid, block, smem, stream, __VA_ARGS__)
-#define MDRP_LME_ACCUM(kind, shift, loss, grid, smem, stream, ...)                                                         \
-    do {                                                                                                                 \
-        if ((loss) == 1) hipLaunchKernelGGL((k_lme_accum<0, false, 1>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);     \
-        else hipLaunchKernelGGL((k_lme_accum<0, false, -1>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);                \
-    } while (0)
-#else
-#define MDRP_LME_LM(KERNEL, kind, shift, grid, block, smem, stream, ...)                                                  \
-    do {                                                                                                                 \
-        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((KERNEL<0, true>), grid, block, smem, stream, __VA_ARGS__);        \
-        else if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0, false>), grid, block, smem, stream, __VA_ARGS__);             \
-        else if ((kind) == 1) hipLaunchKernelGGL((KERNEL<1, false>), grid, block, smem, stream, __VA_ARGS__);             \
-        else hipLaunchKernelGGL((KERNEL<2, false>), grid, block, smem, stream, __VA_ARGS__);                              \
-    } while (0)
-#define MDRP_LME_ACCUM_L(L, kind, shift, grid, smem, stream, ...)                                                          \
-    do {                                                                                                                 \
-        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((k_lme_accum<0, true, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);  \
-        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_accum<0, false, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);       \
-        else if ((kind) == 1) hipLaunchKernelGGL((k_lme_accum<1, false, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((k_lme_accum<2, false, L>), grid, dim3(LME_T), smem, stream, __VA_ARGS__);                        \
-    } while (0)
-// the LO refinements are always TRUNCATED (loss 1): their kernels carry the loss as a compile-time constant
-#define MDRP_LME_ACCUM(kind, shift, loss, grid, smem, stream, ...)                                                         \
-    do {                                                                                                                 \
-        if ((loss) == 1) MDRP_LME_ACCUM_L(1, kind, shift, grid, smem, stream, __VA_ARGS__);                               \
-        else MDRP_LME_ACCUM_L(-1, kind, shift, grid, smem, stream, __VA_ARGS__);                                          \
-    } while (0)
-#endif
-// cost / score sweeps: the calibrated estimator folds f1 = f2 = 1 away (KIND 0), the focal ones share one instantiation
-#define MDRP_LME_SWEEP(KERNEL, kind, grid, stream, ...)                                                                  \
-    do {                                                                                                                 \
-        if ((kind) == 0) hipLaunchKernelGGL((KERNEL<0>), grid, dim3(64), 0, stream, __VA_ARGS__);                        \
-        else hipLaunchKernelGGL((KERNEL<1>), grid, dim3(64), 0, stream, __VA_ARGS__);                                    \
-    } while (0)
-#define MDRP_LME_COST_D(DENSE, kind, loss, grid, stream, ...)                                                            \
-    do {                                                                                                                 \
-        if ((kind) == 0 && (loss) == 1) hipLaunchKernelGGL((k_lme_cost<0, 1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);   \
-        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_cost<0, -1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);            \
-        else if ((loss) == 1) hipLaunchKernelGGL((k_lme_cost<1, 1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);             \
-        else hipLaunchKernelGGL((k_lme_cost<1, -1, DENSE>), grid, dim3(64), 0, stream, __VA_ARGS__);                             \
-    } while (0)
-#define MDRP_LME_COST(dense, kind, loss, grid, stream, ...)                                                              \
-    do {                                                                                                                 \
-        if (dense) MDRP_LME_COST_D(true, kind, loss, grid, stream, __VA_ARGS__);                                         \
-        else MDRP_LME_COST_D(false, kind, loss, grid, stream, __VA_ARGS__);                                              \
-    } while (0)
-// segment engine: normal equations per (pair, segment), the segments of a problem added in order
-#ifdef MDRP_FAST_BUILD
-#define MDRP_LME_ACCUM_SEG(kind, shift, loss, grid, stream, ...)                                                          \
-    do {                                                                                                                 \
-        if ((loss) == 1) hipLaunchKernelGGL((k_lme_accum_seg<0, false, 1>), grid, dim3(64), 0, stream, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((k_lme_accum_seg<0, false, -1>), grid, dim3(64), 0, stream, __VA_ARGS__);                  \
-    } while (0)
-#else
-#define MDRP_LME_ACCUM_SEG_L(L, kind, shift, grid, stream, ...)                                                           \
-    do {                                                                                                                 \
-        if ((kind) == 0 && (shift)) hipLaunchKernelGGL((k_lme_accum_seg<0, true, L>), grid, dim3(64), 0, stream, __VA_ARGS__);  \
-        else if ((kind) == 0) hipLaunchKernelGGL((k_lme_accum_seg<0, false, L>), grid, dim3(64), 0, stream, __VA_ARGS__);       \
-        else if ((kind) == 1) hipLaunchKernelGGL((k_lme_accum_seg<1, false, L>), grid, dim3(64), 0, stream, __VA_ARGS__);       \
-        else hipLaunchKernelGGL((k_lme_accum_seg<2, false, L>), grid, dim3(64), 0, stream, __VA_ARGS__);                        \
-    } while (0)
-#define MDRP_LME_ACCUM_SEG(kind, shift, loss, grid, stream, ...)                                                          \
-    do {                                                                                                                 \
-        if ((loss) == 1) MDRP_LME_ACCUM_SEG_L(1, kind, shift, grid, stream, __VA_ARGS__);                                 \
-        else MDRP_LME_ACCUM_SEG_L(-1, kind, shift, grid, stream, __VA_ARGS__);                                            \
-    } while (0)
-#endif
-
-constexpr int LME_CTL_INTS = LME_RING + 8; // live ring | total | pad
-int lme_nseg(int n_max) { return std::max(1, (n_max + LME_SEG - 1) / LME_SEG); }
-size_t lme_bytes_per_problem(int n_max) {
-    const size_t nseg = (size_t)lme_nseg(n_max);
-    // work lists (list engine) or normal-equation partials (segment engine), whichever is larger
-    return sizeof(LmProb) + nseg * (sizeof(double) + sizeof(int32_t)) + std::max<size_t>(2 * nseg * LME_SEG + 2 * nseg * sizeof(uint16_t), nseg * MAX_ACC * sizeof(double)) + 16;
-}
-
-int lme_ensure(mdrp_handle *h, int cap, int batch, int n_max) {
-    const size_t nseg = (size_t)lme_nseg(n_max), c = (size_t)std::max(cap, 1);
-    // work lists for the phases that run on the list engine, normal-equation partials for those on the segment engine (dense sweeps)
-    const size_t c_list = h->lme_mode == 1 ? c : (h->lme_mode_final == 1 ? (size_t)std::max(batch, 1) : 0);
-    const size_t c_seg = h->lme_mode == 2 ? c : (h->lme_mode_final == 2 ? (size_t)std::max(batch, 1) : 0);
-    int rc;
-    if ((rc = h->lme_probs.ensure(sizeof(LmProb) * c)) || (rc = h->lme_part.ensure(sizeof(double) * c * nseg)) ||
-        (rc = h->lme_ipart.ensure(sizeof(int32_t) * c * nseg)) || (c_list && (rc = h->lme_list.ensure(c_list * 2 * nseg * LME_SEG))) ||
-        (c_list && (rc = h->lme_cnt.ensure(sizeof(uint16_t) * c_list * 2 * nseg))) || (rc = h->lme_ctl.ensure(sizeof(int32_t) * LME_CTL_INTS)) ||
-        (c_seg && (rc = h->lme_accpart.ensure(sizeof(double) * c_seg * nseg * MAX_ACC))) ||
-        (rc = h->lme_iota.ensure(sizeof(int32_t) * ((size_t)batch + 2))) || (rc = h->lme_pair_live.ensure(sizeof(int32_t) * 4 * (size_t)std::max(batch, 1))))
-        return rc;
-    return MDRP_OK;
-}
-
-LmePhase lme_phase(mdrp_handle *h, int batch, int n_max, const int32_t *pfx, const int32_t *total, int first, int cap, const uint8_t *mask) {
-    LmePhase ph;
-    ph.probs = h->lme_probs.as<LmProb>(); ph.part = h->lme_part.as<double>(); ph.ipart = h->lme_ipart.as<int32_t>();
-    ph.list = h->lme_list.as<uint8_t>(); ph.list_cnt = h->lme_cnt.as<uint16_t>();
-    ph.pfx = pfx; ph.total = total;
-    ph.live = h->lme_ctl.as<int32_t>(); ph.pair_live = h->lme_pair_live.as<int32_t>();
-    ph.pair_acc = ph.pair_live + 2 * (size_t)std::max(batch, 1); ph.accpart = h->lme_accpart.as<double>();
-    ph.first = first; ph.cap = cap; ph.batch = batch; ph.n_max = n_max; ph.nseg = lme_nseg(n_max);
-    ph.mask = mask;
-    return ph;
-}
-
-// The rounds of one phase on `stream`: cost of the initial models, then (accept + normal equations, solve, cost) per LM
-// iteration.  max_it <= 25 (the LO refinements) is launched blind; an open-ended phase (the user's BundleOptions) reads the live
-// counter back every `poll_every` rounds from round `poll_from` on and stops when nothing iterates any more.
-int lme_run(mdrp_handle *h, hipStream_t stream, const LmePhase &ph, int kind, int est_shift, int loss, int max_it, int accum_blocks, int problems_bound,
-            int poll_from, int poll_every, bool seg /*segment engine (dense sweeps) instead of the list engine*/) {
-    HIPCHK(hipMemsetAsync(ph.live, 0, sizeof(int32_t) * LME_RING, stream));
-    HIPCHK(hipMemsetAsync(ph.pair_live, 0, sizeof(int32_t) * 4 * (size_t)std::max(ph.batch, 1), stream)); // pair_live | pair_acc
-    const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
-    const int dense_cap = ph.n_max <= LM_LIST_MAX_N ? ((ph.n_max + 63) / 64) * 64 : 0;
-    const size_t smem = sizeof(int32_t) * ((size_t)ph.nseg + 1) + sizeof(uint16_t) * (size_t)dense_cap + 8;
-    const dim3 solve_grid((unsigned)(std::max(problems_bound, 1) + 63) / 64);
-    const dim3 lane_grid((unsigned)(std::max(problems_bound, 1) + 255) / 256), reduce_grid((unsigned)std::min((std::max(problems_bound, 1) + 3) / 4, h->num_cu * 32));
-    const int cost_seg = seg ? 64 * LME_RPT_DENSE : LME_SEG; // the dense cost sweep holds 8 records per lane
-    const dim3 cost_grid((unsigned)std::max(1, (ph.n_max + cost_seg - 1) / cost_seg), (unsigned)ph.batch);
-    MDRP_LME_COST(seg, kind, loss, cost_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), -1);
-    for (int r = 0; r <= max_it; ++r) {
-        if (seg) {
-            hipLaunchKernelGGL(k_lme_decide, lane_grid, dim3(256), 0, stream, ph, r, cost_seg);
-            if (r < max_it) { // (the closing round only decides: every problem is done)
-                MDRP_LME_ACCUM_SEG(kind, est_shift, loss, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r);
-                MDRP_LME_LM(k_lme_reduce, kind, est_shift, reduce_grid, dim3(256), 0, stream, ph);
-            }
-        } else
-        MDRP_LME_ACCUM(kind, est_shift, loss, dim3((unsigned)std::max(accum_blocks, 1)), smem, stream, ph, h->pts.as<double>(),
-                       h->dep.as<double>(), r, dense_cap);
-        if (r == max_it) break;
-        MDRP_LME_LM(k_lme_solve, kind, est_shift, solve_grid, dim3(64), 0, stream, ph, r);
-        if (poll_every > 0 && r >= poll_from && (r - poll_from) % poll_every == 0) {
-            HIPCHK(hipMemcpyAsync(h->lme_live_host, ph.live + (r & (LME_RING - 1)), sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            if (h->lme_trace) std::fprintf(stderr, "[mdrp] lme round %d: %d live\n", r, *h->lme_live_host); // MDRP_LME_TRACE=1
-            if (*h->lme_live_host == 0) break;
-        }
-        MDRP_LME_COST(seg, kind, loss, cost_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), r & 1);
-    }
-    HIPCHK(hipGetLastError());
-    return MDRP_OK;
-}
-
-// LO of one chunk's triggers (refine_model @0x4fa550 / @0x4fad60 / @0x4fb0a0 + score_model of the refined model)
-int lme_lo(mdrp_handle *h, hipStream_t stream, const RunParams &rp, int kind, int est_shift, const int32_t *lo_plan, int trig_cap, int first, int cap) {
-    const int32_t *total = lo_plan + 3 * (size_t)rp.batch + 1;
-    const LmePhase ph = lme_phase(h, rp.batch, rp.n_max, lo_plan /*prefix*/, total, first, cap, nullptr);
-    hipLaunchKernelGGL(k_lme_lo_init, dim3((cap + 255) / 256), dim3(256), 0, stream, ph, rp, h->st.as<PairState>(), h->models.as<Model>(),
-                       h->triggers.as<Trigger>(), trig_cap, lo_plan);
-    int rc = lme_run(h, stream, ph, kind, est_shift, 1, 25, h->num_cu * 8, cap, 0, 0, h->lme_mode == 2);
-    if (rc) return rc;
-    const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)ph.batch);
-    MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, stream, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
-    hipLaunchKernelGGL(k_lme_lo_finish, dim3((cap + 255) / 256), dim3(256), 0, stream, ph, rp, h->st.as<PairState>(), h->triggers.as<Trigger>(),
-                       trig_cap, lo_plan, h->lm_stats.as<unsigned long long>());
-    HIPCHK(hipGetLastError());
-    return MDRP_OK;
-}
-
-// ransac<> tail, inlier mask, inlier-only refinement, result records: one problem per pair
-int lme_final(mdrp_handle *h, hipStream_t s, const RunParams &rp, int kind, int est_shift, uint8_t *mask_dev, ResultDev *results_dev) {
-    const int batch = rp.batch;
-    int32_t *iota = h->lme_iota.as<int32_t>(), *total = h->lme_ctl.as<int32_t>() + LME_RING;
-    hipLaunchKernelGGL(k_lme_iota, dim3((batch + 1 + 255) / 256), dim3(256), 0, s, iota, batch + 1, total, batch, -1);
-    LmePhase ph = lme_phase(h, batch, rp.n_max, iota, total, 0, batch, nullptr);
-    const dim3 sweep_grid((unsigned)ph.nseg, (unsigned)batch), pair_grid((unsigned)(batch + 255) / 256);
-    hipLaunchKernelGGL(k_lme_fin_init, dim3(batch), dim3(64), 0, s, ph, rp, h->st.as<PairState>(), mask_dev, results_dev);
-    const int step_blocks = std::min(batch, h->num_cu * 8);
-    const bool seg = h->lme_mode_final == 2;
-    int rc = lme_run(h, s, ph, kind, est_shift, 1, 25, step_blocks, batch, env_int("MDRP_LME_POLL_FROM", 3), env_int("MDRP_LME_POLL_EVERY", 4), seg);
-    if (rc) return rc;
-    MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, s, ph, h->st.as<PairState>(), h->pts.as<double>(), (uint8_t *)nullptr);
-    hipLaunchKernelGGL(k_lme_fin_select, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
-    MDRP_LME_SWEEP(k_lme_score, kind, sweep_grid, s, ph, h->st.as<PairState>(), h->pts.as<double>(), mask_dev);
-    hipLaunchKernelGGL(k_lme_fin_init2, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev);
-    ph.mask = mask_dev;
-    rc = lme_run(h, s, ph, kind, est_shift, rp.final_loss, rp.final_max_it, step_blocks, batch, env_int("MDRP_LME_POLL_FROM2", 8), env_int("MDRP_LME_POLL_EVERY", 4), seg);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_lme_fin_write, pair_grid, dim3(256), 0, s, ph, rp, h->st.as<PairState>(), results_dev,
-                       h->lm_stats.as<unsigned long long>() + 2);
-    HIPCHK(hipGetLastError());
-    return MDRP_OK;
-}
-
 // one pass = a contiguous range of pairs that fits the scratch budget
 int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
              int n_max, const int32_t *n_host, const mdrp_camera *cam1, const mdrp_camera *cam2, const mdrp_ransac_opt *ro,
@@ -500,12 +297,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
     if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
     if ((rc = h->surv2_count.ensure(sizeof(int32_t) * batch))) return rc;
-    if ((rc = h->tag_snap.ensure(sizeof(int32_t) * 2 * (mdrp_handle::PARTS_MAX - 1) * 2 * (size_t)batch))) return rc;
     const size_t groups_max = ((size_t)n_max + 15) / 16;
     if ((rc = h->rfrag.ensure(std::max<size_t>(1024, (size_t)batch * groups_max * 1024)))) return rc;
     const int trig_cap = chunk_cap;
     if ((rc = h->triggers.ensure(sizeof(Trigger) * (size_t)batch * trig_cap))) return rc;
-    if ((rc = h->work_pair.ensure(sizeof(int32_t) * mdrp_handle::NC_MAX * (3 * (size_t)batch + 2)))) return rc; // LO plan per chunk: prefix | begin | end | total
+    if ((rc = h->work_pair.ensure(sizeof(int32_t) * (3 * (size_t)batch + 2)))) return rc; // LO plan of a super-chunk: prefix | begin | end | total
     if ((rc = h->counters.ensure(COUNTERS_BYTES))) return rc;
     if ((rc = h->plan.ensure(sizeof(int32_t) * (2 * (size_t)batch + 2 + 4 + 16)))) return rc; // two prefix arrays + {dense, total, head} // [2] n_active, [4..5] max_needed (u64), [6..7] evals (u64), [8], [9] LO queue heads of the two chunks
 
@@ -548,25 +344,17 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                            h->rfrag.as<uint4>());
     HIPCHK(hipGetLastError());
 
-    // LO problems per chunk ~ 10 x batch, final LMs = batch: one wavefront per problem once they outnumber the 1024 SIMDs
-    const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0;
-    const int lo_overlap_waves = env_int("MDRP_LO_OVERLAP_WAVES", 8); // LO wavefronts per CU while it shares the chip
-    const bool lo_after_solve = env_int("MDRP_LO_AFTER_SOLVE", 1) != 0; // LO of chunk c starts when chunk c + 1 is solved (the solver is on the critical path)
-    // ... and counted: LO then runs beside k_bound / k_score instead of beside k_count.  Same step time either way (12.2 ms both:
-    // the chip is throughput-bound in aggregate), but the MFMA kernel keeps the chip to itself (1.9-2.2 ms instead of 3.7)
-    const bool lo_after_count = env_int("MDRP_LO_AFTER_COUNT", 1) != 0;
-    const int score_blocks_per_cu = env_int("MDRP_SCORE_BLOCKS_PER_CU", 0);
-    const bool use_bound = env_int("MDRP_BOUND", 1) != 0; // fp32 lower-bound stage between k_count and the fp64 sweep
-    const bool lo_xcd = env_int("MDRP_LO_XCD", 1) != 0; // one LO queue per XCD (lo_take) instead of one for the chip
+    // Run-time knobs (DESIGN.md 10 lists all of them): the stream pipeline, the fp32 bound stage, lanes per LM problem.
+    const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0; // three-stream pipeline; 0 = every kernel on the handle's stream
+    const bool use_bound = env_int("MDRP_BOUND", 1) != 0;       // fp32 lower-bound stage between k_count and the fp64 sweep
     // lanes per LO problem: one wavefront when there are many short problems; four when the batch is small or the pairs are large (N = 5000:
     // a one-wavefront problem is 4 ms long and the launch ends with its stragglers — 45.6 against 43.9 ms per 1024 varying-focal pairs)
     const int lo_threads = env_int("MDRP_LO_THREADS", (batch >= 128 && n_max < 4096) ? 64 : 256);
-    const int lo_threads_last = env_int("MDRP_LO_THREADS_LAST", lo_threads); // LO of a super-chunk's last chunk (nothing runs beside it)
     const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
-    // the inlier-only final refinement walks a compacted index of the inliers instead of masking every record (MDRP_FINAL_MASK_INDEX=0: off)
-    const int mask_index = env_int("MDRP_FINAL_MASK_INDEX", 1) ? lm_mask_index_on(n_max) : 0;
-    // work lists of the classic LM (mdrp_classic.h ClmList; MDRP_CLASSIC_LISTS=0: every sweep visits every record)
-    const int clm_list_stride = env_int("MDRP_CLASSIC_LISTS", 1) ? lm_list_stride(n_max) : 0;
+    // the inlier-only final refinement walks a compacted index of the inliers instead of masking every record (where the three lists fit 32 KiB of LDS)
+    const int mask_index = lm_mask_index_on(n_max);
+    // work lists of the classic LM (mdrp_classic.h ClmList)
+    const int clm_list_stride = lm_list_stride(n_max);
     const size_t clm_list_bytes = (size_t)2 * clm_list_stride * sizeof(uint16_t);
     // Fused tail (mdrp_kernels.h FuseTail): when the end of the run is known on the host (the super-chunk reaches max_iterations), the
     // last LO launch replays each pair as its last trigger is refined (no k_walk launch), and k_final starts - on the main stream,
@@ -576,48 +364,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // with the shift solver's 9-parameter LM the final refinements are 1.5x the LO's tail and gain nothing (12.75 -> 12.9 ms): off there.
     // After a bounded wait expired on this handle (kernels of two streams do not run side by side here: serialising profiler,
     // AMD_SERIALIZE_KERNEL, a busy shared GPU) the handle stays unfused, unless MDRP_FUSE_TAIL is set explicitly.
-    if (h->fuse_disabled && --h->fuse_retry_in <= 0) h->fuse_disabled = false; // re-armed: one expired wait costs FUSE_RETRY_CALLS unfused calls, not the handle's lifetime
+    // (fuse_disabled / fuse_retry_in are advanced once per API call in estimate_device, not per pass)
     const bool fuse_env = env_int("MDRP_FUSE_TAIL", ((kind == MDRP_CALIB && est_shift) || h->fuse_disabled) ? 0 : 1) != 0;
     bool final_done = false;
-    // phase-batched LM engine (mdrp_lm.h) for the monodepth LO and final refinements; its problem table holds lme_cap triggers
-    // per chunk and pass (a run finds ~6 per pair and chunk; more than lme_cap are refined in further passes, see k_walk)
-    // Default since round 4: off.  The engines were built for the varying-focal estimator, whose LO leaves loss_scale at 1.0 (reference
-    // quirk): nothing is truncated, every sweep of every problem covers all N correspondences, and with the round-2/3 sweeps the
-    // round structure won there (N = 5000: 53.5 vs 57.1 ms per 1024 pairs in round 3, 48.6 with the segment engine in round 4).  With the
-    // round-4 sweeps (no division chains, LDS work lists written as LDS) the persistent kernels are ahead on every shape: varying focal
-    // N = 5000 41.7 ms with 256 lanes per LO problem (MDRP_LO_THREADS, chosen by N below) against 48.6; calibrated / shared focal 9.5 vs 14.5.
-    // MDRP_LM_ENGINE: 0 = persistent kernels, 1 = list engine, 2 = segment engine (dense sweeps per (pair, segment), mdrp_lm.h)
-    const int lme_mode = classic ? 0 : env_int("MDRP_LM_ENGINE", 0);
-    const bool use_lme = lme_mode != 0;
-    h->lme_mode = lme_mode;
-    // The final phase has one problem per pair and, in its second half, an inlier mask: dense sweeps waste the masked lanes and its
-    // ~100 rounds pay five launches each instead of three — it stays on the list engine (varying focal, 1024 x 5000: 14.8 against 19.4 ms)
-    h->lme_mode_final = use_lme ? env_int("MDRP_LM_ENGINE_FINAL", 1) : 0;
-    h->lme_trace = env_int("MDRP_LME_TRACE", 0) != 0;
-    const int lme_cap = std::max(batch, env_int("MDRP_LME_CAP", batch * 48 + 2048));
-    if (use_lme && (rc = lme_ensure(h, lme_cap, batch, n_max))) return rc;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
-    const size_t lo_mask_rows = (size_t)h->num_cu * (size_t)std::max(lo_overlap_waves, 8); // kc_lo launches num_cu * max(overlap waves, 8 | 2) workgroups
-    if ((kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) && (rc = h->lo_mask.ensure(lo_mask_rows * mdrp_handle::NC_MAX * (size_t)std::max(n_max, 1)))) return rc;
+    const size_t lo_mask_rows = (size_t)h->num_cu * 8; // kc_lo launches num_cu * (8 | 2) workgroups
+    if ((kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) && (rc = h->lo_mask.ensure(lo_mask_rows * (size_t)std::max(n_max, 1)))) return rc;
     int32_t *cnt = h->counters.as<int32_t>();
     const size_t tile_bytes = SCORE_TILE_BYTES;
-    int64_t sum_n = 0;
-    for (int i = 0; i < batch; ++i) sum_n += n_host[i] >= 3 ? n_host[i] : 0;
-    (void)sum_n;
 
-#ifdef MDRP_LO_TRACE
-    if (getenv("MDRP_LO_TRACE_FILE")) {
-        static unsigned long long *trace_buf = nullptr;
-        if (!trace_buf) HIPCHK(hipMalloc(&trace_buf, 64ull << 20));
-        const unsigned int zero = 0;
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace), &trace_buf, sizeof trace_buf));
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace_n), &zero, sizeof zero));
-        static unsigned long long *fin_buf = nullptr;
-        if (!fin_buf) HIPCHK(hipMalloc(&fin_buf, 64ull * 65536));
-        HIPCHK(hipMemset(fin_buf, 0, 64ull * std::min(batch, 65536)));
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fin_trace), &fin_buf, sizeof fin_buf));
-    }
-#endif
     uint64_t it0 = 0;
     // iterations that certainly run: the reference cannot stop before min_iterations + 1 (or max_iterations)
     const uint64_t certain = ro->max_iterations == 0 ? 1 : std::min<uint64_t>(ro->max_iterations, ro->min_iterations + 1);
@@ -645,7 +400,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     }
     uint64_t max_needed = 0;
     rp.slot_stride = chunk_cap * mps;
-    const size_t lo_plan_ints = 3 * (size_t)batch + 2;
     while (true) {
         uint64_t lens[mdrp_handle::NC_MAX] = {0};
         int n_chunks = 1;
@@ -666,16 +420,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         for (int c = 0; c < n_chunks; ++c) super_len += lens[c];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
         HIPCHK(hipMemsetAsync(h->counters.p, 0, COUNTERS_BYTES, s));
-        // Three-stream pipeline over the chunks of a super-chunk (the benchmark shape: 512 | 9488 iterations):
-        //   main:  solve 0 | score 0, scan 0 | score 1, scan 1 | ... | walk
-        //   aux :            solve 1         | solve 2 ...
-        //   aux2:                              lo 0             | lo 1 ...
-        // The solver (gathers, divergent roots) and the LO refinements (dependent fp64 latency at 2 waves/SIMD) leave most
-        // issue slots idle; the sweep (VALU-bound, short workgroups) fills them.  Chunk c + 1 is solved while chunk c is
-        // swept, and chunk c's triggers are refined while chunk c + 1 is swept.  Chunks alternate between two sets of tag
-        // lists / model counters / sample tables; slots, triggers and LO plans of different chunks are disjoint.
+        // Three-stream pipeline over the chunks of a super-chunk (the benchmark shape: 128 | 9872 iterations):
+        //   main:  prep solve0 count0 sort0 score0 scan0 | (wait solve1) count1 bound1 sort1 score1 scan1 | gate, final refinements (fused tail) | walk
+        //   aux :       (after solve0) solve1 ...
+        //   aux2:  samples0 samples1 (beside prep)                                                        | (after the last scan) LO: ALL triggers of the super-chunk
+        // Chunk c + 1 is solved while chunk c is swept.  Chunks alternate between two sets of tag lists / model counters / sample tables; slots
+        // and triggers of different chunks are disjoint.  A super-chunk has ONE LO launch, behind its last scan (round 5: two launches, each with
+        // its own tail of long problems, cost 4.3 ms where one costs 2.7; LO problems are independent of each other, so results are bit-identical).
         const bool piped = n_chunks > 1 && lo_overlap;
-        const bool fuse_tail = fuse_env && piped && !use_lme && it0 + super_len >= ro->max_iterations;
+        const bool fuse_tail = fuse_env && piped && it0 + super_len >= ro->max_iterations;
         int32_t *fz_ctl = nullptr, *fz_done = nullptr, *fz_fin = nullptr, *fz_ready = nullptr;
         if (fuse_tail) {
             if ((rc = h->fuse.ensure(64 + 3 * sizeof(int32_t) * (size_t)batch))) return rc;
@@ -685,7 +438,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         int offs[mdrp_handle::NC_MAX] = {0};
         for (int c = 1; c < n_chunks; ++c) offs[c] = offs[c - 1] + (int)lens[c - 1];
         // The sample tables of the first two chunks do not depend on anything but (seed, N): they are drawn on the (still idle)
-        // LO stream while k_prep runs, so the one-wavefront-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
+        // LO stream while k_prep runs, so the one-workgroup-per-table sampler (0.18 ms for 10^4 samples) is off the solver's path.
         const int samp_threads = env_int("MDRP_SAMPLE_THREADS", ssz == 3 ? SAMP_THREADS : (ssz == 5 ? 512 : 256)); // ~ samples between two rejections
         auto launch_samples = [&](hipStream_t st_, int len_, uint32_t *smp_) {
             if (ssz == 6) hipLaunchKernelGGL(kc_samples<6>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
@@ -693,11 +446,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             else if (ssz == 7) hipLaunchKernelGGL(kc_samples<7>, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
             else hipLaunchKernelGGL(k_samples, dim3(n_tables), dim3(samp_threads), 0, st_, n_tables, d_table_n, d_table_state, len_, smp_);
         };
-        // solver sub-ranges: only where the solver of a long chunk has the chip to itself (piped schedule, not the run's first chunk)
-        // Measured (1024 x 2000, 10^4 iterations): 1 part 10.61 ms, 2 parts 10.72, 3: 10.80, 4: 10.90 — the solver (fp64 VALU) and k_count (MFMA + 8 fp32
-        // VALU instructions per tile) compete for the same issue ports, overlap creates no slots; default 1 (off).
-        const int solve_parts_env = std::min(std::max(env_int("MDRP_SOLVE_PARTS", 1), 1), (int)mdrp_handle::PARTS_MAX);
-        auto parts_of = [&](int c) { return (piped && !classic && c >= 1 && lens[c] >= 2048) ? solve_parts_env : 1; };
         bool presampled[2] = {false, false};
         if (piped && it0 == 0) {
             HIPCHK(hipStreamWaitEvent(aux2, h->ev_tables, 0));
@@ -707,7 +455,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 presampled[c] = true;
             }
         }
-        auto issue_solve = [&](int c, hipStream_t st_, int parts = 1) -> int {
+        auto issue_solve = [&](int c, hipStream_t st_) -> int {
             RunParams r = rp;
             r.chunk_len = (int)lens[c]; r.chunk_off = offs[c];
             const bool odd = c & 1;
@@ -736,88 +484,51 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 return MDRP_OK;
             }
 #define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
-    hipLaunchKernelGGL(k_solve<S>, dim3((sub_e - sub_b + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp, \
-                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc, sub_b, sub_e)
-            // Sub-ranges (round 4): the solver of a big chunk runs alone on the chip for ~0.8 ms (the chunk before it is short).  Solved
-            // as `parts` launches over consecutive iteration ranges, with the tag counts snapshotted in between, k_count of the first
-            // range runs on the matrix cores beside the solver of the second (same retirement bar: results are unchanged).
-            for (int part = 0; part < parts; ++part) {
-                const int sub_b = (int)((long long)r.chunk_len * part / parts), sub_e = (int)((long long)r.chunk_len * (part + 1) / parts);
-                switch (r.solver) {
-                case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
-                case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;
-                case SOLVER_SHARED: MDRP_SOLVE_LAUNCH(SOLVER_SHARED); break;
-                default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
-                }
-                if (part + 1 < parts) { // the tag counts after this part = where the next part's tags begin
-                    HIPCHK(hipMemcpyAsync(h->tag_snap.as<int32_t>() + ((size_t)(c & 1) * (mdrp_handle::PARTS_MAX - 1) + part) * 2 * batch, mc, sizeof(int32_t) * 2 * batch,
-                                          hipMemcpyDeviceToDevice, st_));
-                    HIPCHK(hipEventRecord(h->ev_part[c & 1][part], st_));
-                }
+    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp,   \
+                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc, 0, r.chunk_len)
+            switch (r.solver) {
+            case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
+            case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;
+            case SOLVER_SHARED: MDRP_SOLVE_LAUNCH(SOLVER_SHARED); break;
+            default: MDRP_SOLVE_LAUNCH(SOLVER_VARYING); break;
             }
 #undef MDRP_SOLVE_LAUNCH
             return MDRP_OK;
         };
         if ((rc = issue_solve(0, s))) return rc;
         if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
-        std::function<int()> pending_lo; // LO of the previous chunk, held back until this chunk's k_count is queued (MDRP_LO_AFTER_COUNT)
-        // ONE LO launch per super-chunk (round 5).  MDRP_LO_MERGE = m: the first m chunks of a schedule launch no LO of their own; their triggers are
-        // refined by the next launch (its plan starts where the last LAUNCHED plan ended).  Default: every chunk but the last, i.e. all of a
-        // super-chunk's triggers in one launch behind its last scan.  Rounds 2-4 launched the first chunk's LO beside the second chunk's sweeps: two
-        // persistent launches, each ending with its own tail of long problems (makespan 2.1 + 1.5 ms for 1.1 + 0.9 ms of balanced work per slot), the
-        // first one holding every wavefront slot while k_sort_tags / k_score waited.  One launch has one tail, twice the problems to balance it with,
-        // and the fused final refinements in its shadow: k_lo 4.32 -> 2.67 ms event-timed, headline 8.72 -> 8.58 ms, shared focal 8.63 -> 8.35,
-        // varying focal 36.6 -> 36.1 (k_lo 25.0 -> 21.7).  LO problems are independent of each other: results are bit-identical.  MDRP_LO_MERGE=0
-        // restores a launch per chunk.
-        const int lo_merge = (piped && !use_lme) ? env_int("MDRP_LO_MERGE", n_chunks - 1) : 0;
-        int last_lo_chunk = -1;
         for (int c = 0; c < n_chunks; ++c) {
             const int len = (int)lens[c];
             rp.chunk_len = len; rp.chunk_off = offs[c];
             const bool odd = c & 1;
             uint32_t *tags_sc = (odd ? h->tags2_s : h->tags_s).as<uint32_t>();
             int32_t *mcount_c = (odd ? h->model_count2 : h->model_count).as<int32_t>();
-            if (c + 1 < n_chunks) {
-                if (piped) {
-                    // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
-                    HIPCHK(hipStreamWaitEvent(aux, c == 0 ? h->ev_solved[0] : h->ev_scanned[c - 1], 0));
-                    if ((rc = issue_solve(c + 1, aux, parts_of(c + 1)))) return rc;
-                    HIPCHK(hipEventRecord(h->ev_solved[c + 1], aux));
-                }
+            if (piped && c + 1 < n_chunks) {
+                // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
+                HIPCHK(hipStreamWaitEvent(aux, c == 0 ? h->ev_solved[0] : h->ev_scanned[c - 1], 0));
+                if ((rc = issue_solve(c + 1, aux))) return rc;
+                HIPCHK(hipEventRecord(h->ev_solved[c + 1], aux));
             }
-            const int parts_c = parts_of(c);
-            if (piped && c > 0 && parts_c == 1) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
+            if (piped && c > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
             if (!piped && c > 0 && (rc = issue_solve(c, s))) return rc;
             {
                 hipEvent_t e0, e1;
                 if ((rc = get_events(h, &e0, &e1, 0))) return rc;
-                // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on.
-                // One launch per solver part: part i is counted while the solver works on part i + 1 (tags [snap[i-1], snap[i]) per pair).
+                // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
                 const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
                 unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
-                for (int part = 0; part < parts_c; ++part) {
+                {
                     hipEvent_t c0, c1;
                     if ((rc = get_events(h, &c0, &c1, 1))) return rc;
-                    if (parts_c > 1) HIPCHK(hipStreamWaitEvent(s, part + 1 < parts_c ? h->ev_part[c & 1][part] : h->ev_solved[c], 0));
-                    const int32_t *snap = h->tag_snap.as<int32_t>() + (size_t)(c & 1) * (mdrp_handle::PARTS_MAX - 1) * 2 * batch;
-                    const int32_t *t_begin = part == 0 ? nullptr : snap + (size_t)(part - 1) * 2 * batch;
-                    const int32_t *t_end = part + 1 < parts_c ? snap + (size_t)part * 2 * batch : mcount_c;
-                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), t_end, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
-                                       part == 0 ? h->surv_count.as<int32_t>() : (int32_t *)nullptr, t_begin); // (part 0 also clears the survivor counters k_count appends to)
-                    const int part_len = (int)((long long)len * (part + 1) / parts_c) - (int)((long long)len * part / parts_c);
-                    const dim3 cgrid((unsigned)batch * (unsigned)((part_len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
+                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
+                                       h->surv_count.as<int32_t>(), (const int32_t *)nullptr); // (also clears the survivor counters k_count appends to)
+                    const dim3 cgrid((unsigned)batch * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                     HIPCHK(hipEventRecord(c0, s));
                     MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                                        tags_c, t_end, h->cplan.as<int32_t>(), h->tags_v.as<uint32_t>(),
-                                        h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr, t_begin);
+                                        tags_c, mcount_c, h->cplan.as<int32_t>(), h->tags_v.as<uint32_t>(),
+                                        h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr, (const int32_t *)nullptr);
                     HIPCHK(hipEventRecord(c1, s));
                     h->count_launches++;
-                }
-                if (pending_lo) {
-                    HIPCHK(hipEventRecord(h->ev_counted, s));
-                    HIPCHK(hipStreamWaitEvent(aux2, h->ev_counted, 0));
-                    if ((rc = pending_lo())) return rc;
-                    pending_lo = nullptr;
                 }
                 const uint32_t *surv_tags = h->tags_v.as<uint32_t>();
                 const int32_t *surv_cnt = h->surv_count.as<int32_t>();
@@ -825,7 +536,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     // fp32 lower bound of the score for k_count's survivors; its survivors go back into the chunk's tag list
                     uint32_t *tags_b = (odd ? h->tags2 : h->tags).as<uint32_t>();
                     hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1,
-                                       BND_THREADS, h->cplan.as<int32_t>(), h->surv2_count.as<int32_t>());
+                                       BND_THREADS, h->cplan.as<int32_t>(), h->surv2_count.as<int32_t>(), (const int32_t *)nullptr);
                     const dim3 bgrid((unsigned)batch * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
                     unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
                     hipEvent_t b0, b1;
@@ -841,8 +552,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
                 hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, mcount_c, plan, totals);
                 HIPCHK(hipEventRecord(e0, s));
-                const dim3 grid(score_blocks_per_cu > 0 ? (unsigned)(h->num_cu * score_blocks_per_cu)
-                                                        : (unsigned)batch * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
+                const dim3 grid((unsigned)batch * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
                 MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
                                     h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
                 HIPCHK(hipEventRecord(e1, s));
@@ -860,66 +570,46 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 hipLaunchKernelGGL(k_scan<4>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
                                    h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
                                    reinterpret_cast<unsigned long long *>(cnt + 10));
-            // LO of this chunk's triggers (the plan freezes begin/end per pair, later scans only append)
-            const bool skip_lo = c < lo_merge && c + 1 < n_chunks;
-            if (skip_lo) { // (the solver of chunk c + 2 still waits for this chunk's scan)
+            if (c + 1 < n_chunks) { // (the solver of chunk c + 2 waits for this chunk's scan: it reuses this chunk's lists)
                 if (piped) HIPCHK(hipEventRecord(h->ev_scanned[c], s));
                 continue;
             }
-            int32_t *lo_plan = h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints;
-            const int32_t *prev_plan = last_lo_chunk < 0 ? nullptr : h->work_pair.as<int32_t>() + (size_t)last_lo_chunk * lo_plan_ints;
-            last_lo_chunk = c;
-            hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), prev_plan, lo_plan);
-            const bool fuse_here = fuse_tail && c + 1 == n_chunks;
-            if (fuse_here) {
+            // ---- behind the super-chunk's last scan: the LO of ALL its triggers, one persistent launch
+            int32_t *lo_plan = h->work_pair.as<int32_t>();
+            hipLaunchKernelGGL(k_lo_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), (const int32_t *)nullptr, lo_plan);
+            if (fuse_tail) {
                 HIPCHK(hipMemsetAsync(fz_ctl, 0, 64 + 2 * sizeof(int32_t) * (size_t)batch, s));
                 HIPCHK(hipMemsetAsync(fz_ready, 0xFF, sizeof(int32_t) * (size_t)batch, s));
             }
             if (piped) { HIPCHK(hipEventRecord(h->ev_scanned[c], s)); HIPCHK(hipStreamWaitEvent(aux2, h->ev_scanned[c], 0)); }
-            // LO beside the solver wastes both (two latency-bound kernels share a SIMD); LO beside the sweep does not
-            if (piped && lo_after_solve && c + 1 < n_chunks) HIPCHK(hipStreamWaitEvent(aux2, h->ev_solved[c + 1], 0));
-            const int lo_waves_c = (piped && c + 1 < n_chunks) ? lo_overlap_waves : 8; // the last chunk's LO has the chip to itself
-            const int lo_threads_c = (c + 1 == n_chunks) ? lo_threads_last : lo_threads;
-            const int lo_blocks = h->num_cu * (lo_threads_c == 64 ? lo_waves_c : 2);
-            const FuseTail fz = fuse_here ? FuseTail{fz_done, fz_ready, fz_ctl, h->st.as<PairState>()} : FuseTail{nullptr, nullptr, nullptr, nullptr};
-            const RunParams rp_lo = rp;
+            const int lo_blocks = h->num_cu * (lo_threads == 64 ? 8 : 2);
+            const FuseTail fz = fuse_tail ? FuseTail{fz_done, fz_ready, fz_ctl, h->st.as<PairState>()} : FuseTail{nullptr, nullptr, nullptr, nullptr};
             unsigned long long *lm_stats = h->lm_stats.as<unsigned long long>();
-            int32_t *xheads_c = lo_xcd ? cnt + CNT_XCD_HEAD + (size_t)c * 8 * LO_XCD_STRIDE : nullptr;
-            auto launch_lo_kernels = [=]() -> int {
-                if (use_lme) return lme_lo(h, aux2, rp_lo, kind, est_shift, lo_plan, trig_cap, 0, lme_cap);
-                if (classic) {
-                    MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads_c, kind, dim3(lo_blocks), clm_list_bytes, aux2, rp_lo, h->st.as<PairState>(), h->pts.as<double>(),
-                                             h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, xheads_c,
-                                             h->lo_mask.as<uint8_t>() + (size_t)c * lo_mask_rows * n_max, clm_list_stride, fz);
-                    return MDRP_OK;
-                }
-                MDRP_LM_DISPATCH(k_lo, lo_threads_c, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp_lo,
+            int32_t *xheads = cnt + CNT_XCD_HEAD; // one LO queue per XCD (lo_take)
+            hipEvent_t l0, l1; // HIP events on the stream the LO runs on (mdrp_stats::lo_ms)
+            if ((rc = get_events(h, &l0, &l1, 2))) return rc;
+            HIPCHK(hipEventRecord(l0, aux2));
+            if (classic)
+                MDRP_CLASSIC_LM_DISPATCH(kc_lo, lo_threads, kind, dim3(lo_blocks), clm_list_bytes, aux2, rp, h->st.as<PairState>(), h->pts.as<double>(),
+                                         h->models.as<Model>(), h->triggers.as<Trigger>(), trig_cap, lo_plan, cnt + CNT_LO_HEAD, xheads,
+                                         h->lo_mask.as<uint8_t>(), clm_list_stride, fz);
+            else
+                MDRP_LM_DISPATCH(k_lo, lo_threads, kind, est_shift, dim3(lo_blocks), lm_list_bytes(n_max), aux2, rp,
                                  h->st.as<PairState>(), h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->triggers.as<Trigger>(),
-                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD + c, xheads_c, lm_list_stride(n_max), lm_stats, fz);
-                return MDRP_OK;
-            };
-            auto launch_lo = [=]() -> int { // bracketed by HIP events on the stream the LO runs on (mdrp_stats::lo_ms)
-                hipEvent_t l0, l1;
-                int rc_;
-                if ((rc_ = get_events(h, &l0, &l1, 2))) return rc_;
-                HIPCHK(hipEventRecord(l0, aux2));
-                if ((rc_ = launch_lo_kernels())) return rc_;
-                HIPCHK(hipEventRecord(l1, aux2));
-                return MDRP_OK;
-            };
-            if (piped && lo_after_count && c + 1 < n_chunks) pending_lo = launch_lo;
-            else if ((rc = launch_lo())) return rc;
+                                 trig_cap, lo_plan, cnt + CNT_LO_HEAD, xheads, lm_list_stride(n_max), lm_stats, fz);
+            HIPCHK(hipEventRecord(l1, aux2));
         }
         if (fuse_tail) { // final refinements on the main stream, released when the last LO launch's queue is empty
-            const int cl = n_chunks - 1;
-            const int32_t *plan_l = h->work_pair.as<int32_t>() + (size_t)cl * lo_plan_ints;
-            const int lo_blocks_l = h->num_cu * (lo_threads_last == 64 ? 8 : 2); // = lo_blocks of the last chunk's launch above
+            const int32_t *plan_l = h->work_pair.as<int32_t>();
+            const int lo_blocks_l = h->num_cu * (lo_threads == 64 ? 8 : 2); // = lo_blocks of the launch above
             // bounded waits (k_gate): far beyond anything a healthy run needs (the LO queue of 1024 pairs is empty after ~1 ms)
             // ... and scaled with the problem size: one LO problem is ~0.4 ms at N = 2000 and grows linearly with N (4 ms at 5000 on one wavefront)
-            const int n_scale = std::max(1, (n_max + 1999) / 2000);
-            const unsigned long long gate_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_GATE_US", (50000 + 40 * batch) * n_scale);
-            const unsigned long long wait_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_WAIT_US", (20000 + 4 * batch) * n_scale);
-            hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const int32_t *)(cnt + CNT_LO_HEAD + cl), plan_l + 3 * (size_t)batch + 1,
+            // ... capped at 200 ms / 100 ms: under persistently serialised dispatch (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL, a debugger) every re-try of the
+            // fused tail pays these in full (3.3 s at N = 70001 before the cap)
+            const long long n_scale = std::max(1, (n_max + 1999) / 2000);
+            const unsigned long long gate_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_GATE_US", (int)std::min<long long>((50000 + 40ll * batch) * n_scale, 200000));
+            const unsigned long long wait_ticks = 100ull * (unsigned long long)env_int("MDRP_FUSE_WAIT_US", (int)std::min<long long>((20000 + 4ll * batch) * n_scale, 100000));
+            hipLaunchKernelGGL(k_gate, dim3(1), dim3(1), 0, s, (const int32_t *)(cnt + CNT_LO_HEAD), plan_l + 3 * (size_t)batch + 1,
                                (const int32_t *)fz_ctl, lo_blocks_l, gate_ticks, h->lm_stats.as<unsigned long long>() + 4);
             hipEvent_t g0, g1;
             if ((rc = get_events(h, &g0, &g1, 3))) return rc;
@@ -948,59 +638,20 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         if (!fuse_tail)
             hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
                                h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
-                               h->work_pair.as<int32_t>(), use_lme ? n_chunks : 0, (int)lo_plan_ints, lme_cap);
+                               (const int32_t *)nullptr, 0, 0, 0);
         HIPCHK(hipGetLastError());
         // progress record: pairs still iterating, iterations they still need, evaluations swept (sum over pairs of models * n)
         HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        if (use_lme && h->progress_host->lo_overflow) {
-            // a chunk found more triggers than one pass of the LM engine holds: refine the rest, pass by pass, then replay
-            std::vector<int32_t> totals(n_chunks);
-            for (int c = 0; c < n_chunks; ++c)
-                HIPCHK(hipMemcpy(&totals[c], h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints + 3 * (size_t)batch + 1, sizeof(int32_t), hipMemcpyDeviceToHost));
-            for (int c = 0; c < n_chunks; ++c)
-                for (int first = lme_cap; first < totals[c]; first += lme_cap)
-                    if ((rc = lme_lo(h, s, rp, kind, est_shift, h->work_pair.as<int32_t>() + (size_t)c * lo_plan_ints, trig_cap, first, lme_cap))) return rc;
-            HIPCHK(hipMemsetAsync(cnt + 3, 0, sizeof(int32_t), s));
-            hipLaunchKernelGGL(k_walk, dim3((batch + 63) / 64), dim3(64), 0, s, rp, h->st.as<PairState>(), h->models.as<Model>(),
-                               h->triggers.as<Trigger>(), trig_cap, cnt + 2, reinterpret_cast<unsigned long long *>(cnt + 4),
-                               (const int32_t *)nullptr, 0, 0, 0);
-            HIPCHK(hipMemcpyAsync(h->progress_host, cnt + 2, sizeof(Progress), hipMemcpyDeviceToHost, s));
-            HIPCHK(hipStreamSynchronize(s));
-        }
         h->sweep_evals += (int64_t)h->progress_host->evals;
         h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
         h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
         h->bound_evals += (int64_t)h->progress_host->evals_bound;
-#ifdef MDRP_EXP_STATS
-        {
-            unsigned long long st8[8];
-            HIPCHK(hipMemcpy(st8, h->plan.as<int32_t>() + 2 * (size_t)batch + 2 + 4, sizeof(st8), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[mdrp] sparse stats: candidates %llu wave-iterations %llu wave-windows %llu live-lane-windows %llu exact-candidates %llu\n",
-                    st8[0], st8[1], st8[2], st8[3], st8[4]);
-            HIPCHK(hipMemset(h->plan.as<int32_t>() + 2 * (size_t)batch + 2 + 4, 0, sizeof(st8)));
-        }
-#endif
         if (getenv("MDRP_DEBUG"))
             fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu (mfma %llu, fp32 bound %llu, fp64 sweep %llu = %.2f %%) active %d max_needed %llu\n",
                     (unsigned long long)it0, (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->evals_mfma,
                     h->progress_host->evals_bound, h->progress_host->evals_sweep, 100.0 * (double)h->progress_host->evals_sweep / (double)std::max<unsigned long long>(1, h->progress_host->evals),
                     h->progress_host->n_active, h->progress_host->max_needed);
-#ifdef MDRP_LO_TRACE
-        if (const char *path = getenv("MDRP_LO_TRACE_FILE")) {
-            unsigned int n_ev = 0;
-            unsigned long long *buf = nullptr;
-            HIPCHK(hipMemcpyFromSymbol(&n_ev, HIP_SYMBOL(g_lo_trace_n), sizeof n_ev));
-            HIPCHK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_lo_trace), sizeof buf));
-            if (buf && n_ev) {
-                std::vector<unsigned long long> host(8ull * n_ev);
-                HIPCHK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
-                if (FILE *f = fopen(path, "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-            }
-            n_ev = 0;
-            HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_lo_trace_n), &n_ev, sizeof n_ev));
-        }
-#endif
         it0 += super_len;
         if (h->progress_host->n_active == 0 || it0 >= ro->max_iterations) break;
         max_needed = h->progress_host->max_needed;
@@ -1010,8 +661,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     hipEvent_t f0, f1;
     if ((rc = get_events(h, &f0, &f1, 3))) return rc;
     HIPCHK(hipEventRecord(f0, s));
-    if (use_lme) { if ((rc = lme_final(h, s, rp, kind, est_shift, mask_dev, results_dev))) return rc; }
-    else if (classic)
+    if (classic)
         MDRP_CLASSIC_LM_DISPATCH(kc_final, final_threads, kind, dim3(batch), clm_list_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(), mask_dev, results_dev,
                                  (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr, clm_list_stride);
     else {
@@ -1021,19 +671,6 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     }
     HIPCHK(hipEventRecord(f1, s));
     HIPCHK(hipGetLastError());
-#ifdef MDRP_LO_TRACE
-    if (const char *path = getenv("MDRP_LO_TRACE_FILE")) { // per-pair timing of the (unfused) final refinements: <file>.final
-        HIPCHK(hipStreamSynchronize(s));
-        unsigned long long *buf = nullptr;
-        HIPCHK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(g_fin_trace), sizeof buf));
-        if (buf && !classic) {
-            std::vector<unsigned long long> host(8ull * std::min(batch, 65536));
-            HIPCHK(hipMemcpy(host.data(), buf, host.size() * 8, hipMemcpyDeviceToHost));
-            const std::string fp = std::string(path) + ".final";
-            if (FILE *f = fopen(fp.c_str(), "wb")) { fwrite(host.data(), 8, host.size(), f); fclose(f); }
-        }
-    }
-#endif
     return MDRP_OK;
 }
 
@@ -1049,6 +686,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     if (ro->progressive_sampling) { g_err = "progressive_sampling (PROSAC, RandomSampler::initialize_prosac) is not built"; return MDRP_ERR_UNSUPPORTED; }
     if (ro->real_focal_check && (kind == MDRP_SHARED_6PT || kind == MDRP_FUNDAMENTAL_7PT)) { g_err = "real_focal_check is not built"; return MDRP_ERR_UNSUPPORTED; }
     const int mps = kind == MDRP_RELPOSE_5PT ? 12 : (kind == MDRP_SHARED_6PT ? 16 : 4);
+    if (h->fuse_disabled && --h->fuse_retry_in <= 0) h->fuse_disabled = false; // once per API call (not per pass): the handle tries the fused tail again
     h->ev_used = 0; h->sweep_ms = 0; h->sweep_launches = 0; h->sweep_evals = 0; h->mfma_evals = 0; h->fp64_evals = 0; h->bound_evals = 0; h->count_launches = 0; h->count_ms = 0; h->last_batch = batch; h->lm_cost_evals = 0; h->lm_accum_evals = 0;
     int rc;
     if ((rc = h->results.ensure(sizeof(ResultDev) * std::max(batch, 1)))) return rc;
@@ -1073,13 +711,8 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
-    // the LM engine's problem table (lme_ensure in run_pass: max(batch, MDRP_LME_CAP or 48 per pair + 2048) problems) only where it runs
-    const bool budget_lme = kind <= 2 && env_int("MDRP_LM_ENGINE", 0) != 0; // (the same default as run_pass)
-    const size_t lme_fixed = budget_lme ? (size_t)std::max(env_int("MDRP_LME_CAP", 0), 2048) * lme_bytes_per_problem(n_max) : 0; // per pass, not per pair
-    const size_t per_pair_all = per_pair + (budget_lme ? 49 * lme_bytes_per_problem(n_max) : 0) /*LM engine: 48 problems per pair and pass*/ +
-                                (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
+    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
-    budget = budget > lme_fixed ? budget - lme_fixed : 0;
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
     per_pass = std::max(1, std::min(per_pass, env_int("MDRP_PAIRS_PER_PASS", per_pass))); // (tests: several passes on a small batch)
@@ -1100,10 +733,14 @@ int finish_timing(mdrp_handle *h) {
     h->lm_cost_evals = (int64_t)h->lm_stats_host[0]; h->lm_accum_evals = (int64_t)h->lm_stats_host[1];
     h->fin_cost_evals = (int64_t)h->lm_stats_host[2]; h->fin_accum_evals = (int64_t)h->lm_stats_host[3];
     h->fuse_gate_timeouts = (int64_t)h->lm_stats_host[4]; h->fuse_wait_timeouts = (int64_t)h->lm_stats_host[5];
+    if (!(h->fuse_gate_timeouts || h->fuse_wait_timeouts) && !h->fuse_disabled) h->fuse_backoff = 64; // a clean call (fused or not needed): the back-off starts over
     if ((h->fuse_gate_timeouts || h->fuse_wait_timeouts) && !h->fuse_disabled) {
-        // results are unaffected (the pass behind the LO launch refined what the waits gave up on), the call was slower than unfused
+        // results are unaffected (the pass behind the LO launch refined what the waits gave up on), the call was slower than unfused.
+        // Exponential back-off: 64, 128, ... 16384 unfused API calls after consecutive expired waits (a busy moment on a shared GPU costs 64 calls,
+        // a profiler that serialises every dispatch soon costs nothing)
         h->fuse_disabled = true;
-        h->fuse_retry_in = env_int("MDRP_FUSE_RETRY_CALLS", 64);
+        h->fuse_retry_in = h->fuse_backoff;
+        h->fuse_backoff = std::min(h->fuse_backoff * 2, 16384);
         if (!getenv("MDRP_QUIET"))
             fprintf(stderr, "[mdrp] fused tail: %lld gate / %lld final-refinement waits timed out (kernels of two streams did not overlap: "
                             "profiler or serialised dispatch?); this handle runs unfused for its next %d calls\n",
@@ -1139,13 +776,29 @@ extern "C" {
 const char *mdrp_last_error(void) { return g_err.c_str(); }
 // the build embeds a hash of the source files (mdrp_amd/build.py) so that a stale prebuilt library can be told from the tree
 int mdrp_abi_version(void) { return MDRP_ABI_VERSION; }
-const char *mdrp_version(void) { return "mdrp-hip 0.4 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
+const char *mdrp_version(void) { return "mdrp-hip 0.5 (gfx950) MDRP_SRC_HASH=" MDRP_SRC_HASH; }
 
 // HIP_VERSION of the toolchain this library was compiled with (the runtime is bound at load time: mdrp_amd/_capi.py compares the two)
 int mdrp_hip_build_version(void) { return HIP_VERSION; }
 
-int mdrp_create(int device, void *stream, mdrp_handle **out) { return create_handle(device, (hipStream_t)stream, stream == nullptr, out); }
-int mdrp_create_on_stream(int device, void *stream, mdrp_handle **out) { return create_handle(device, (hipStream_t)stream, false, out); }
+// the header's mdrp_create / mdrp_create_on_stream macros hand over the ABI the HOST was compiled against: another version, or another size of
+// mdrp_ransac_opt, is refused here — before any call could read option fields past the end of a smaller struct
+static int check_host_abi(int abi_version, int ransac_opt_bytes) {
+    if (abi_version == MDRP_ABI_VERSION && ransac_opt_bytes == (int)sizeof(mdrp_ransac_opt)) return MDRP_OK;
+    char buf[256];
+    snprintf(buf, sizeof buf, "host was compiled against ABI %#x (mdrp_ransac_opt %d bytes), this library speaks %#x (%d bytes): recompile the host against include/mdrp.h",
+             abi_version, ransac_opt_bytes, MDRP_ABI_VERSION, (int)sizeof(mdrp_ransac_opt));
+    g_err = buf;
+    return MDRP_ERR_INVALID;
+}
+int mdrp_create_(int device, void *stream, mdrp_handle **out, int abi_version, int ransac_opt_bytes) {
+    if (int rc = check_host_abi(abi_version, ransac_opt_bytes)) return rc;
+    return create_handle(device, (hipStream_t)stream, stream == nullptr, out);
+}
+int mdrp_create_on_stream_(int device, void *stream, mdrp_handle **out, int abi_version, int ransac_opt_bytes) {
+    if (int rc = check_host_abi(abi_version, ransac_opt_bytes)) return rc;
+    return create_handle(device, (hipStream_t)stream, false, out);
+}
 
 } // extern "C"
 
@@ -1166,23 +819,18 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     HIPCHK(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void **)&h->lme_live_host, sizeof(int32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->lm_stats_host, LM_STATS_BYTES, hipHostMallocDefault));
     std::memset(h->lm_stats_host, 0, LM_STATS_BYTES);
-    {   // high priority: the few long LO wavefronts should be placed first, the sweep fills the remaining slots
+    {   // high priority: the few long LO wavefronts should be placed first, the sweeps fill the remaining slots
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        const int prio = env_int("MDRP_AUX_PRIO", 1) ? prio_hi : prio_lo;
-        const int prio2 = env_int("MDRP_AUX2_PRIO", 1) ? prio_hi : prio_lo;
-        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio));
-        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio2));
+        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio_hi));
     }
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_counted, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_tables, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[0], hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[1], hipEventDisableTiming));
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < mdrp_handle::PARTS_MAX; ++j) HIPCHK(hipEventCreateWithFlags(&h->ev_part[i][j], hipEventDisableTiming));
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         HIPCHK(hipEventCreateWithFlags(&h->ev_solved[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&h->ev_scanned[i], hipEventDisableTiming));
@@ -1207,20 +855,17 @@ void mdrp_destroy(mdrp_handle *h) {
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
                       &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
-                      &h->lm_stats, &h->lme_probs, &h->lme_part, &h->lme_ipart, &h->lme_list, &h->lme_cnt, &h->lme_ctl, &h->lme_iota, &h->lme_pair_live, &h->lme_accpart, &h->tag_snap};
+                      &h->lm_stats};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
-    if (h->lme_live_host) (void)hipHostFree(h->lme_live_host);
     if (h->lm_stats_host) (void)hipHostFree(h->lm_stats_host);
     if (h->params_host) (void)hipHostFree(h->params_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
-    if (h->ev_counted) (void)hipEventDestroy(h->ev_counted);
     if (h->ev_tables) (void)hipEventDestroy(h->ev_tables);
     for (int i = 0; i < 2; ++i) if (h->ev_sampled[i]) (void)hipEventDestroy(h->ev_sampled[i]);
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < mdrp_handle::PARTS_MAX; ++j) if (h->ev_part[i][j]) (void)hipEventDestroy(h->ev_part[i][j]);
     for (int i = 0; i < mdrp_handle::NC_MAX; ++i) {
         if (h->ev_solved[i]) (void)hipEventDestroy(h->ev_solved[i]);
         if (h->ev_scanned[i]) (void)hipEventDestroy(h->ev_scanned[i]);
@@ -1360,10 +1005,6 @@ int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const
     HIPCHK(hipMemcpyAsync(h->unit_a.p, x1h, sizeof(double) * 3 * K * count, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(h->unit_b.p, x2h, sizeof(double) * 3 * K * count, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync(h->unit_e.p, 0, sizeof(Model) * M * count, s));
-#ifdef MDRP_5PT_STAGES
-    { const int stage = env_int("MDRP_5PT_STAGE", 99); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_5pt_stage), &stage, sizeof(int))); }
-    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventRecord(e0, s));
-#endif
     if (kind == MDRP_SHARED_6PT)
         hipLaunchKernelGGL(kc_solver_unit<CLASSIC_SHARED>, dim3((count + 63) / 64), dim3(64), 0, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
@@ -1374,10 +1015,6 @@ int mdrp_classic_solver_batch(mdrp_handle *h, int kind, const double *x1h, const
         hipLaunchKernelGGL(kc_solver_unit<CLASSIC_FUND>, dim3((count + 63) / 64), dim3(64), SOLVE7_LDS_BYTES, s, count, h->unit_a.as<double>(),
                            h->unit_b.as<double>(), h->unit_e.as<Model>(), h->unit_f.as<int32_t>());
     HIPCHK(hipGetLastError());
-#ifdef MDRP_5PT_STAGES
-    { HIPCHK(hipEventRecord(e1, s)); HIPCHK(hipEventSynchronize(e1)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
-      fprintf(stderr, "[mdrp] classic solver kernel: %d problems in %.3f ms (%.1f ns each)\n", count, ms, 1e6 * ms / count); }
-#endif
     HIPCHK(hipMemcpyAsync(out, h->unit_e.p, sizeof(Model) * M * count, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(n_out, h->unit_f.p, sizeof(int32_t) * count, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1594,21 +1231,6 @@ int mdrp_refine_models(mdrp_handle *h, int kind, mdrp_model *models, int count, 
     o.max_it = (int)std::min<uint64_t>(opt->max_iterations, 1u << 30); o.loss = opt->loss_type; o.loss_scale = opt->loss_scale;
     o.grad_tol = opt->gradient_tol; o.step_tol = opt->step_tol; o.lambda0 = opt->initial_lambda;
     o.lambda_min = opt->min_lambda; o.lambda_max = opt->max_lambda;
-    if (env_int("MDRP_LM_ENGINE", 0) != 0) {
-        // the phase-batched engine with all `count` problems on one pair (pair 0 = the packed records)
-        h->lme_mode = env_int("MDRP_LM_ENGINE", 0); h->lme_mode_final = 0;
-        if ((rc = lme_ensure(h, count, 1, nn)) || (rc = h->st.ensure(sizeof(PairState)))) return rc;
-        PairState ps;
-        std::memset(&ps, 0, sizeof ps);
-        ps.n = n;
-        HIPCHK(hipMemcpyAsync(h->st.p, &ps, sizeof ps, hipMemcpyHostToDevice, s));
-        int32_t *iota = h->lme_iota.as<int32_t>(), *total = h->lme_ctl.as<int32_t>() + LME_RING;
-        hipLaunchKernelGGL(k_lme_iota, dim3(1), dim3(64), 0, s, iota, 2, total, count, count);
-        const LmePhase ph = lme_phase(h, 1, nn, iota, total, 0, count, nullptr);
-        hipLaunchKernelGGL(k_lme_unit_init, dim3((count + 255) / 256), dim3(256), 0, s, ph, count, h->unit_e.as<Model>(), kind, n, scale_reproj, weight_sampson, o);
-        if ((rc = lme_run(h, s, ph, kind, (kind == MDRP_CALIB && estimate_shift) ? 1 : 0, o.loss, o.max_it, std::min(count, h->num_cu * 8), count, 8, 8, h->lme_mode == 2))) return rc;
-        hipLaunchKernelGGL(k_lme_unit_finish, dim3((count + 255) / 256), dim3(256), 0, s, ph, count, h->unit_e.as<Model>(), h->unit_a.as<double>());
-    } else
     MDRP_LM_DISPATCH(k_refine_unit, (count >= 2048 ? 64 : 256), kind, (kind == MDRP_CALIB && estimate_shift), dim3(count), lm_list_bytes(n), s,
                      count, h->unit_e.as<Model>(), h->pts.as<double>(), h->dep.as<double>(), n, scale_reproj, weight_sampson, o,
                      h->unit_a.as<double>(), lm_list_stride(n));

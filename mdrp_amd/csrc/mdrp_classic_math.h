@@ -384,14 +384,6 @@ MDRP_HD void quad_lin_mul_add(const double *q, const double *l, double s, double
 
 // ---------------------------------------------------------------- 5-point: essential matrices
 // x1h, x2h: the five sample bearings (unit vectors).  Es: up to 10 matrices, row-major, unit Frobenius norm.
-#if defined(__HIPCC__) && defined(MDRP_5PT_STAGES)
-__device__ int g_5pt_stage = 99; // experiment: stop after stage k (tools/stage_5pt.py)
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && defined(MDRP_5PT_STAGES)
-#define MDRP_5PT_STOP(k, sink) if (g_5pt_stage <= (k)) { Es[0][0] = (sink); return 0; }
-#else
-#define MDRP_5PT_STOP(k, sink)
-#endif
 // Caller-provided strided storage for the two dynamically indexed arrays of the solver: the 10 x 10 matrix that is LU-factorised
 // with partial pivoting (element (r, k) at C[(10 r + k) cs]) and, once that is dead, the root finder's interval stack (the two
 // may alias).  On the device both live in LDS, one column of 64 lanes per element (in scratch memory the solver spent 90 % of
@@ -409,7 +401,6 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         double N[36];
         epipolar_columns<5>(x1h, x2h, store.C, store.cs); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
         fullpiv_nullspace<5>(store.C, store.cs, N);
-        MDRP_5PT_STOP(1, N[0] + N[35])
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -468,7 +459,6 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         for (int k = 0; k < 10; ++k) { M5(k, 9) = det[k]; R[9][k] = det[10 + k]; }
 #undef SYM3
     }
-    MDRP_5PT_STOP(2, M5(0, 0) + M5(9, 9) + R[4][7])
     // P M = Lo Up, partial pivoting; the multipliers stay in the eliminated positions; perm[i] = original row now at position i
     int perm[10];
 #pragma unroll
@@ -553,10 +543,8 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) ab[i + j] += bx[r0][i] * by[r1][j];
         for (int i = 0; i < 7; ++i) for (int j = 0; j < 5; ++j) c[i + j] += sgn * ab[i] * b1[r2][j];
     }
-    MDRP_5PT_STOP(3, c[0] + c[10] + c[5])
     double roots[10];
     const int nr = real_roots_fast<10>(c, roots, store.rs);
-    MDRP_5PT_STOP(4, roots[0] + (double)nr)
     int n_out = 0;
     for (int s = 0; s < nr; ++s) {
         const double z = roots[s];

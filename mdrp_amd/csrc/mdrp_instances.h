@@ -7,11 +7,7 @@ namespace mdrp {
 #define MDRP_FINAL_PARAMS RunParams, PairState *, const double *, const double *, uint8_t *, ResultDev *, int, int, unsigned long long *, const int32_t *, int32_t *, \
                           unsigned long long, unsigned long long *
 #define MDRP_FINAL_LOSSES(X, K, S, T) X(K, S, T, 0) X(K, S, T, 1) X(K, S, T, 2) X(K, S, T, 3) X(K, S, T, 4) X(K, S, T, 5)
-#ifdef MDRP_FAST_BUILD
-#define MDRP_FINAL_KINDS(X, T) MDRP_FINAL_LOSSES(X, 0, false, T)
-#else
 #define MDRP_FINAL_KINDS(X, T) MDRP_FINAL_LOSSES(X, 0, false, T) MDRP_FINAL_LOSSES(X, 0, true, T) MDRP_FINAL_LOSSES(X, 1, false, T) MDRP_FINAL_LOSSES(X, 2, false, T)
-#endif
 #define MDRP_FINAL_ONE(K, S, T, L) MDRP_INST template __global__ void k_final<K, S, T, L>(MDRP_FINAL_PARAMS);
 
 #define MDRP_CLASSIC_KINDS_T(X, T) X(CLASSIC_RELPOSE, T) X(CLASSIC_SHARED, T) X(CLASSIC_FUND, T)

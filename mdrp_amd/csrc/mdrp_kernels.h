@@ -42,30 +42,16 @@
 namespace mdrp {
 
 constexpr int PT_STRIDE = 6;       // doubles per correspondence record
-#ifndef MDRP_TILE_PTS
 #define MDRP_TILE_PTS 512
-#endif
-#ifndef MDRP_SCORE_MINWAVES
 #define MDRP_SCORE_MINWAVES 4
-#endif
 constexpr int TILE_PTS = MDRP_TILE_PTS; // correspondences per LDS tile (48 B each)
 constexpr size_t SCORE_TILE_BYTES = (size_t)TILE_PTS * (PT_STRIDE * sizeof(double) + 4 * sizeof(float)); // + fp32 coordinates
-#ifndef MDRP_P1F_UNROLL
 #define MDRP_P1F_UNROLL 8
-#endif
-#ifndef MDRP_P1_UNROLL
 #define MDRP_P1_UNROLL 4
-#endif
 constexpr int PRUNE_EVERY = 4;     // bail-out test every PRUNE_EVERY groups of 32 records (power of two)
-#ifndef MDRP_DENSE_KEY
 #define MDRP_DENSE_KEY 40 // of 64 probe records
-#endif
-#ifndef MDRP_SOLVE_MINWAVES
 #define MDRP_SOLVE_MINWAVES 2
-#endif
-#ifndef MDRP_SCORE_THREADS
 #define MDRP_SCORE_THREADS 256
-#endif
 constexpr int SCORE_THREADS = MDRP_SCORE_THREADS; // waves of one workgroup share one LDS tile
 constexpr int LM_THREADS = 256;
 constexpr int MAX_NP = 9;
@@ -445,7 +431,7 @@ struct SampsonTerms { double C2, den; };
 // v_fmac_f64 here and has to copy the loop-invariant addend (an entry of E) with v_mov_b64 before every use:
 // 5 extra fp64-rate moves per Sampson evaluation (+25 % VALU work in the hot loop).
 __device__ __forceinline__ double fma3(double a, double b, double c) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(MDRP_NO_ASM_FMA)
+#if defined(__HIP_DEVICE_COMPILE__)
     double d;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
@@ -679,13 +665,11 @@ __device__ __forceinline__ void score_tile_dense(const double *__restrict__ recs
             }
         }
         pr.processed += g;
-#ifndef MDRP_NO_PRUNE
         if (pr.rec_score < DBL_MAX) {
             pr.dead = pr.dead || (((long long)cnt + (long long)(pr.n - pr.processed) <= pr.rec_cnt) &&
                                   (score + thr * (double)(pr.processed - cnt) >= pr.rec_score));
             if (__all(pr.dead)) { pr.wave_dead = true; return; }
         }
-#endif
     }
 }
 
@@ -756,13 +740,11 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
             }
         }
         pr.processed += g;
-#ifndef MDRP_NO_PRUNE
         if (pr.rec_score < DBL_MAX && ((p0 >> 5) & (PRUNE_EVERY - 1)) == PRUNE_EVERY - 1) {
             pr.dead = pr.dead || (((long long)cnt + (long long)(pr.n - pr.processed) <= pr.rec_cnt) &&
                                   (score + thr * (double)(pr.processed - cnt) >= pr.rec_score));
             if (__all(pr.dead)) { pr.wave_dead = true; return; }
         }
-#endif
     }
 }
 
@@ -773,9 +755,6 @@ __device__ __forceinline__ void score_tile(const double *__restrict__ recs, int 
 //   keep the record unless |C32| > tb,  tb >= T + 2e-6 * M  (5x margin on 7u = 4.2e-7); NaN keeps; tb = inf keeps all.
 // Survivors (~1-2 % of the records) are re-tested and scored exactly in fp64 by phase 2, so results are bit-identical.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-#ifdef MDRP_EXP_STATS
-__device__ unsigned long long *g_stats; // experiment counters (set by k_score from its totals pointer)
-#endif
 template <bool POSE>
 __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, const float4 *__restrict__ recs32, int npts,
                                                const double E[9], const float Ef[9], float tb, const Model *__restrict__ mp,
@@ -810,10 +789,6 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
                         const f32x2 e1 = __builtin_elementwise_fma(Ev[3], a, __builtin_elementwise_fma(Ev[4], b, Ev[5]));
                         const f32x2 e2 = __builtin_elementwise_fma(Ev[6], a, __builtin_elementwise_fma(Ev[7], b, Ev[8]));
                         const f32x2 C = __builtin_elementwise_fma(c, e0, __builtin_elementwise_fma(d, e1, e2));
-#ifdef MDRP_NO_ASM_MASK
-                        mask |= !(fabsf(C.x) > tb) ? (1u << j) : 0u;
-                        mask |= !(fabsf(C.y) > tb) ? (2u << j) : 0u;
-#else
                         // mask = 2 * mask + keep: compare into an SGPR pair, add-with-carry shifts it in (2 instructions per
                         // record instead of compare + select + constant move + or); record j lands in bit 31 - j
                         const float cx = C.x, cy = C.y;
@@ -822,12 +797,9 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
                         asm("v_cmp_ngt_f32_e64 %0, |%1|, %2" : "=s"(ky) : "v"(cy), "v"(tb));
                         asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(kx));
                         asm("v_addc_co_u32_e64 %0, %1, %0, %0, %2" : "+v"(mask), "=s"(co) : "s"(ky));
-#endif
                     }
                 }
-#ifndef MDRP_NO_ASM_MASK
                 mask = __brev(mask); // back to record j in bit j
-#endif
                 const int valid = g - q0; // records past the end of the tile hold stale LDS
                 if (valid < 32) mask &= (1u << valid) - 1u;
                 half[h] = mask;
@@ -835,17 +807,6 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
         }
         uint64_t m = (uint64_t)half[0] | ((uint64_t)half[1] << 32);
         if (pr.dead) m = 0;
-#ifdef MDRP_EXP_STATS
-        {
-            const int pc = __popcll(m);
-            int mx = pc, sm = pc, lv = pr.dead ? 0 : 1;
-            for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o, 64)); sm += __shfl_xor(sm, o, 64); lv += __shfl_xor(lv, o, 64); }
-            if ((threadIdx.x & 63) == 0) {
-                atomicAdd(&g_stats[0], (unsigned long long)sm); atomicAdd(&g_stats[1], (unsigned long long)mx);
-                atomicAdd(&g_stats[2], 1ull); atomicAdd(&g_stats[3], (unsigned long long)lv);
-            }
-        }
-#endif
         if (m) {
             double R[9], t[3];
             if (POSE) {
@@ -861,13 +822,11 @@ __device__ __forceinline__ void score_tile_f32(const double *__restrict__ recs, 
             }
         }
         pr.processed += g;
-#ifndef MDRP_NO_PRUNE
         if (pr.rec_score < DBL_MAX) {
             pr.dead = pr.dead || (((long long)cnt + (long long)(pr.n - pr.processed) <= pr.rec_cnt) &&
                                   (score + thr * (double)(pr.processed - cnt) >= pr.rec_score));
             if (__all(pr.dead)) { pr.wave_dead = true; return; }
         }
-#endif
     }
 }
 
@@ -899,9 +858,7 @@ __device__ __forceinline__ int plan_find(const int32_t *__restrict__ prefix, int
 // resident: every wavefront of the pair reads the same 64 N bytes).  Output tile: lane l holds hypothesis l & 15 against
 // correspondences 4 (l >> 4) .. + 3 of the group, so the four |C| > tb tests of a lane belong to ONE hypothesis and add into
 // one counter per tile.  Per 16 x 16 evaluations: one MFMA (16 cycles) + 4 x (v_cmp + v_addc).
-#ifndef MDRP_CNT_TILES
 #define MDRP_CNT_TILES 8
-#endif
 constexpr int CNT_TILES = MDRP_CNT_TILES;          // MFMA tiles (16 hypotheses) per wavefront: 4 or 8
 constexpr int CNT_ROUNDS = (16 * CNT_TILES) / 64;  // prologue / epilogue rounds of 64 hypotheses
 static_assert(CNT_TILES == 4 || CNT_TILES == 8, "a wavefront owns 64 or 128 hypotheses");
@@ -1183,9 +1140,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
 // true record candidates and near-ties, and only those reach the fp64 sweep.  Branch-free: ~23 fp32 instructions per
 // evaluation against ~12 (mostly fp64, divergent) of the exact sweep's survivors, and no second phase.
 constexpr int BND_THREADS = 256;
-#ifndef MDRP_BND_TILE
 #define MDRP_BND_TILE 256
-#endif
 constexpr int BND_TILE = MDRP_BND_TILE; // correspondences per LDS tile (16 B each, fp32); early-exit test and compaction per tile
 
 // E (or F) of a model as the scoring sweeps see it
@@ -1382,11 +1337,7 @@ MDRP_GLOBAL __launch_bounds__(256) void k_sort_tags(RunParams rp, const PairStat
     const size_t slot_base = (size_t)pair * rp.slot_stride;
     const uint32_t *src = tags + slot_base;
     uint32_t *dst = tags_sorted + slot_base;
-#ifdef MDRP_NO_CLASSIFY
-    const int dense_min = PROBE_PTS + 1;
-#else
     const int dense_min = ps.n >= 8 ? MDRP_DENSE_KEY : PROBE_PTS + 1;
-#endif
     for (int i = tid; i < cnt; i += 256) atomicAdd(&s_hist[min(src[i] >> 24, (uint32_t)PROBE_PTS)], 1);
     __syncthreads();
     if (tid < 64) { // exclusive prefix over the sparse keys
@@ -1451,9 +1402,6 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
                                                          int32_t *__restrict__ totals) {
     extern __shared__ double tile[]; // TILE_PTS * PT_STRIDE doubles, then TILE_PTS float4 (fp32 coordinates)
     float4 *tile32 = reinterpret_cast<float4 *>(tile + TILE_PTS * PT_STRIDE);
-#ifdef MDRP_EXP_STATS
-    g_stats = reinterpret_cast<unsigned long long *>(totals + 4);
-#endif
     const int total = totals[1];
     const int tid = threadIdx.x;
     for (int w = blockIdx.x; w < total; w += gridDim.x) {
@@ -1519,16 +1467,8 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
         }
         __syncthreads();
         if (!pr.wave_dead) {
-#ifdef MDRP_NO_BOUND
-            score_tile<POSE, false>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
-#else
             if (dense) score_tile_dense<POSE>(tile, npts, E, mp, thr, score, cnt, pr);
-#ifdef MDRP_NO_F32
-            else score_tile<POSE, true>(tile, npts, E, mp, thr, thr_dmax, score, cnt, pr);
-#else
             else score_tile_f32<POSE>(tile, tile32, npts, E, Ef, tb, mp, thr, score, cnt, pr);
-#endif
-#endif
         }
     }
     if (live) {
@@ -1679,13 +1619,9 @@ constexpr int LM_LIST_MAX_N = 8192; // u16 indices, <= 32 KiB of dynamic LDS (no
 // The compiler cannot prove uniformity of values that went through vector arithmetic; readfirstlane states it, and the
 // 25-34 doubles move from VGPRs to SGPRs, where VOP3 fp64 instructions read them directly.
 __device__ __forceinline__ double uniform_f64(double x) {
-#ifdef MDRP_NO_SGPR_STATE
-    return x;
-#else
     const unsigned long long b = __double_as_longlong(x);
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-#endif
 }
 __device__ __forceinline__ void lm_state_uniform(LmState &st) {
 #pragma unroll
@@ -1716,10 +1652,6 @@ struct LmShared {
     const double *logtab;      // LDS copy of the log table of lm_log1p (the Cauchy losses of the final refinements), or null: library log1p
     unsigned long long *stats; // [0] correspondences evaluated by cost sweeps, [1] by accumulate sweeps (or null): bench.py's fp64 roofline
     unsigned long long ev[2];  // ... collected here per problem, flushed by lm_flush_stats
-#ifdef MDRP_LO_TRACE
-    unsigned long long tloop;  // (MDRP_EXP_COSTSPLIT) ticks inside the record loop of lm_cost
-    unsigned long long ph[4];  // experiment build: wall-clock ticks of the last lm_refine in cost sweeps | normal-equation sweeps | total; iterations | accepted << 16
-#endif
 };
 // one pair of global atomics per LM problem (thread 0, after the problem's last barrier)
 __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
@@ -1730,9 +1662,7 @@ __device__ __forceinline__ void lm_flush_stats(LmShared &sh) {
     sh.ev[0] = 0; sh.ev[1] = 0;
 }
 
-#ifndef MDRP_LM_COST_UNROLL
 #define MDRP_LM_COST_UNROLL 1 // records per lane and trip of the cost sweep (lm_cost)
-#endif
 // IRLS weight of the Sampson row: ws^2 w(r^2) in the calibrated refiner, ws^2 w(ws r^2) in the two focal ones (the COST carries ws rho(r^2) in all
 // three) — see lm_accumulate_point.  The work lists of lm_cost and of the list engine (mdrp_lm.h) are built with the same expression.
 template <int KIND>
@@ -1844,9 +1774,6 @@ __device__ __forceinline__ double lm_cost(const Model &m, const double *__restri
         }
     };
     if (!mask || midx) evaluated = max(hi - lo, 0);
-#if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
-    const unsigned long long tl0 = wall_clock64();
-#endif
     // the next trip's records are requested before the current ones are consumed; two trips per loop iteration, the buffers swap roles
     // instead of being copied (a trip past `hi` is all padding: loads from a clamped index, nothing counted).  Requesting two trips ahead
     // (four rotating buffers) was measured 1-2 % slower.
@@ -1857,9 +1784,6 @@ __device__ __forceinline__ double lm_cost(const Model &m, const double *__restri
         A = fetch_trip(base + 128 * U);
         if (base + 64 * U < hi) step_trip(B, base + 64 * U);
     }
-#if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
-    if (threadIdx.x == 0) sh.tloop += wall_clock64() - tl0;
-#endif
     if (use_list && lane == 0) sh.count[buf][wave] = cnt;
     if (sh.stats && lane == 0 && evaluated) atomicAdd(&sh.ev[0], (unsigned long long)evaluated);
     double v[1] = {cost};
@@ -1917,9 +1841,6 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
         const double w = sampson_row_weight<KIND>(loss, o.loss_scale, o.mu, ws, ws2, r0 * r0);
         if (w != 0.0) lm_accumulate_row<KIND, SHIFT, 0x1C0u>(J0, r0, w, acc); // no scale / shift dependence (ws is a run-time weight: its product stays)
     }
-#ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     {
         double r1, r2, zf, J1[LM_NPAR], J2[LM_NPAR];
         lm_forward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.x, r1, r2, zf, J1, J2);
@@ -1930,9 +1851,6 @@ __device__ __forceinline__ void lm_accumulate_point(const LmState &stt, double2 
             lm_accumulate_row<KIND, SHIFT, 0x148u, LOSS == 1>(J2, r2, w, acc); // t.x, scale, shift2
         }
     }
-#ifdef MDRP_LM_FENCE // pins the term order for the scheduler; measured: no gain at 2 waves/SIMD
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     {
         double r3, r4, zb, J3[LM_NPAR], J4[LM_NPAR];
         lm_backward_term<true, KIND != 0>(stt, sqrt_sr, p01.x, p01.y, p23.x, p23.y, dd.y, r3, r4, zb, J3, J4);
@@ -2033,20 +1951,10 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
     Model cand = m;
     int it = 0;
     if (mask && sh.stride > 0 && sh.midx) lm_mask_index<T>(mask, n, sh);
-#ifdef MDRP_LO_TRACE
-    unsigned long long tr_c = 0, tr_a = 0, tr_t;
-    const unsigned long long tr_0 = wall_clock64();
-    int tr_acc = 0;
-#define MDRP_TR(x) x
-#else
-#define MDRP_TR(x)
-#endif
 #pragma unroll 1
     for (;;) {
         // cost of the model under evaluation: the start model on the first trip (into list buffer `cur`), a candidate step afterwards
-        MDRP_TR(tr_t = wall_clock64();)
         const double cost_new = lm_cost<KIND, T, LOSS>(cand, pts, dep, n, mask, sqrt_sr, ws, o, sh, first ? cur : cur ^ 1);
-        MDRP_TR(tr_c += wall_clock64() - tr_t;)
         if (first) { cost = cost_new; first = false; }
         else {
             if (cost_new < cost) {
@@ -2065,9 +1973,7 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
         }
         if (it >= o.max_it) break;
         if (recompute) {
-            MDRP_TR(tr_t = wall_clock64(); ++tr_acc;)
             lm_accumulate<KIND, SHIFT, T, LOSS>(m, pts, dep, n, mask, sqrt_sr, ws, ws2, o, acc, sh, cur);
-            MDRP_TR(tr_a += wall_clock64() - tr_t;)
             double gn = 0;
             int idx = 0;
 #pragma unroll
@@ -2097,11 +2003,6 @@ __device__ __forceinline__ void lm_refine(Model &m, const double *__restrict__ p
         if (KIND == 1) full[10] = full[9];
         lm_apply_step(m, full, KIND != 0, KIND == 0 && SHIFT, cand);
     }
-#if defined(MDRP_LO_TRACE) && defined(MDRP_EXP_COSTSPLIT)
-    if (threadIdx.x == 0) { tr_a = sh.tloop; sh.tloop = 0; } // the "normal equations" column then reads: ticks inside lm_cost's record loop
-#endif
-    MDRP_TR(if (threadIdx.x == 0) { sh.ph[0] = tr_c; sh.ph[1] = tr_a; sh.ph[2] = wall_clock64() - tr_0; sh.ph[3] = (unsigned long long)it | ((unsigned long long)tr_acc << 16); })
-#undef MDRP_TR
 }
 
 // workgroup-wide exact MSAC score of one model (score_model of the estimators); optional inlier mask output
@@ -2146,9 +2047,7 @@ __device__ __forceinline__ void block_score(int kind, const Model &m, const doub
 // ------------------------------------------------------------------------------------------------ LO
 // Persistent workgroups pop (pair, trigger) items; each refines the triggering minimal model (refine_model
 // @0x4fa550/@0x4fad60/@0x4fb0a0: 25 it, TRUNCATED) and rescoring it.
-#ifndef MDRP_LM_MINWAVES
 #define MDRP_LM_MINWAVES 2
-#endif
 // LO work plan of one chunk: the triggers the chunk's scan appended to each pair's list, as a prefix sum over the pairs.
 // The plan is frozen when it is built (begin/end per pair), so k_lo of this chunk can run on a second stream while the
 // next chunk's scan keeps appending triggers — the LO of the first, short chunk (most of a run's LO work: records fall
@@ -2354,11 +2253,6 @@ __device__ __forceinline__ void fuse_publish(const FuseTail &fz, const RunParams
     __hip_atomic_store(fz.ready + t, pair, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-#ifdef MDRP_LO_TRACE // experiment: per-problem timing of the LO kernels (tools/lo_trace.py)
-__device__ unsigned long long *g_lo_trace = nullptr; // 8 x u64 per problem
-__device__ unsigned int g_lo_trace_n = 0;
-__device__ unsigned long long *g_fin_trace = nullptr; // 8 x u64 per pair: pair | start | end | iterations of the inlier refinement | of the LO << 32 | ticks of the inlier refinement in cost sweeps | normal equations | whole LM | accepted steps
-#endif
 // LO of item w of the launch's plan (refine_model + score_model of the refined model), by the whole workgroup
 template <int KIND, bool SHIFT, int T>
 __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st, const double *__restrict__ pts, const double *__restrict__ dep,
@@ -2374,21 +2268,10 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
     LmOpt o;
     o.max_it = 25; o.loss = 1; o.loss_scale = ps.lo_loss_scale;
     o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
-#ifdef MDRP_EXP_SAMEPAIR // experiment (wrong results, timing only): every problem sweeps one of 8 pairs' records — what would a perfect L2 buy?
-    const double *pp = pts + (size_t)(pair & 7) * rp.n_max * PT_STRIDE;
-    const double *dd = dep + (size_t)(pair & 7) * rp.n_max * 2;
-#else
     const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     const double *dd = dep + (size_t)pair * rp.n_max * 2;
-#endif
-#ifdef MDRP_LO_TRACE
-    const unsigned long long t_start = wall_clock64();
-#endif
     // (a NaN model — the reference's P3P, k_solve — has a NaN cost: no step can be accepted, it comes back as it is)
     if (m.q[0] == m.q[0]) lm_refine<KIND, SHIFT, T, 1>(m, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // refine_model: always TRUNCATED
-#ifdef MDRP_LO_TRACE
-    else if (threadIdx.x == 0) sh.ph[0] = sh.ph[1] = sh.ph[2] = sh.ph[3] = 0; // (no LM ran: nothing to attribute)
-#endif
     double sc;
     int cn;
     block_score<T>(KIND, m, pp, ps.n, ps.sq_thr, sh.scratch, sc, cn, nullptr);
@@ -2402,16 +2285,6 @@ __device__ void lo_problem(const RunParams &rp, const PairState *__restrict__ st
             }
         }
     }
-#ifdef MDRP_LO_TRACE
-    if (threadIdx.x == 0 && g_lo_trace) {
-        const unsigned int k = atomicAdd(&g_lo_trace_n, 1u);
-        unsigned long long *e = g_lo_trace + 8ull * k;
-        e[0] = (unsigned long long)pair; e[1] = (unsigned long long)pos; e[2] = (unsigned long long)tr.cnt_ref; e[3] = (unsigned long long)cn;
-        e[4] = t_start; e[5] = wall_clock64();
-        e[6] = (sh.ph[0] & 0xFFFFFFFFull) | (sh.ph[1] << 32);                       // ticks in cost sweeps | in normal-equation sweeps
-        e[7] = (unsigned long long)(rp.chunk_off != 0) | (sh.ph[3] << 8) | (sh.ph[2] << 40); // chunk flag | iterations, accepted | ticks inside lm_refine
-    }
-#endif
 }
 
 template <int KIND, bool SHIFT, int T>
@@ -2424,9 +2297,6 @@ __global__ __launch_bounds__(T, MDRP_LM_MINWAVES) void k_lo(RunParams rp, const 
     __shared__ LmShared sh;
     __shared__ int s_item;
     if (threadIdx.x == 0) { sh.list = lm_dyn_list; sh.stride = list_stride; sh.midx = 0; sh.stats = lm_stats; sh.ev[0] = 0; sh.ev[1] = 0; sh.logtab = nullptr; }
-#ifdef MDRP_LO_TRACE
-    if (threadIdx.x == 0) sh.tloop = 0;
-#endif
     __syncthreads();
     const int total = plan[3 * (size_t)rp.batch + 1];
     if (fz.ready && threadIdx.x == 0) { // pairs without a trigger in this launch are ready as they are (earlier LO launches have ended: stream order)
@@ -2477,10 +2347,6 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
     }
     const double *pp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
     const double *dd = dep + (size_t)pair * rp.n_max * 2;
-#ifdef MDRP_LO_TRACE
-    const unsigned long long tf0 = wall_clock64();
-    unsigned long long tf_it = 0, tf_ph[4] = {0, 0, 0, 0};
-#endif
     // ransac<>'s last LO from the best model: 25 iterations, TRUNCATED, all records
     Model x = ps.best;
     {
@@ -2489,9 +2355,6 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         o.grad_tol = 1e-10; o.step_tol = 1e-8; o.lambda0 = 1e-3; o.lambda_min = 1e-10; o.lambda_max = 1e10;
         if (x.q[0] == x.q[0]) lm_refine<KIND, SHIFT, T, 1>(x, pp, dd, ps.n, nullptr, ps.scale_reproj, rp.weight_sampson, o, sh); // (NaN model: lo_problem)
     }
-#ifdef MDRP_LO_TRACE
-    if (threadIdx.x == 0) tf_it |= (sh.ph[3] & 0xFFFFull) << 32;
-#endif
     uint64_t num_inliers = ps.num_inliers;
     {
         double sc;
@@ -2510,9 +2373,6 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         o.max_it = rp.final_max_it; o.loss = FLOSS >= 0 ? FLOSS : rp.final_loss; o.loss_scale = ps.final_loss_scale;
         o.grad_tol = rp.grad_tol; o.step_tol = rp.step_tol; o.lambda0 = rp.lambda0; o.lambda_min = rp.lambda_min; o.lambda_max = rp.lambda_max;
         lm_refine<KIND, SHIFT, T, FLOSS>(x, pp, dd, ps.n, mask, ps.scale_reproj, rp.weight_sampson, o, sh);
-#ifdef MDRP_LO_TRACE
-        if (threadIdx.x == 0) { tf_it |= sh.ph[3] & 0xFFFFull; tf_ph[0] = sh.ph[0]; tf_ph[1] = sh.ph[1]; tf_ph[2] = sh.ph[2]; tf_ph[3] = sh.ph[3] >> 16; }
-#endif
     }
     if (KIND != 0) { x.f1 *= ps.norm; x.f2 *= ps.norm; }
     __syncthreads();
@@ -2524,13 +2384,6 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         results[pair] = res;
         lm_flush_stats(sh);
     }
-#ifdef MDRP_LO_TRACE
-    if (threadIdx.x == 0 && g_fin_trace) {
-        unsigned long long *e = g_fin_trace + 8ull * pair;
-        e[0] = (unsigned long long)pair; e[1] = tf0; e[2] = wall_clock64(); e[3] = tf_it;
-        e[4] = tf_ph[0]; e[5] = tf_ph[1]; e[6] = tf_ph[2]; e[7] = tf_ph[3];
-    }
-#endif
 }
 
 template <int KIND, bool SHIFT, int T, int FLOSS>

@@ -42,11 +42,8 @@ MDRP_HD void model_identity(Model &m) {
 // build takes the hardware seed and two Newton steps (<= 1.5 ulp instead of correctly rounded: the same class of difference as the FMA
 // contraction it already has against the oracle; every solution is Newton-polished against its own equations afterwards).  The host build of
 // this header — the CPU tests against the oracle — keeps the IEEE operations.  MDRP_SOLVER_IEEE_DIV=1 restores them on the device.
-#ifndef MDRP_SOLVER_IEEE_DIV
-#define MDRP_SOLVER_IEEE_DIV 0
-#endif
 MDRP_HD double sv_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
     return fma(fma(-x, y, 1.0), y, y);
@@ -55,14 +52,14 @@ MDRP_HD double sv_rcp(double x) {
 #endif
 }
 MDRP_HD double sv_div(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     return a * sv_rcp(b);
 #else
     return a / b;
 #endif
 }
 MDRP_HD double sv_rsqrt(double x) { // 1 / sqrt(x), x > 0
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rsq(x);
     const double h = 0.5 * x;
     y = y * fma(-h * y, y, 1.5);
@@ -72,7 +69,7 @@ MDRP_HD double sv_rsqrt(double x) { // 1 / sqrt(x), x > 0
 #endif
 }
 MDRP_HD double sv_sqrt(double x) { // sqrt(x) without the compiler's range scaling (the solvers' arguments are O(1) quantities)
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     double r = __builtin_amdgcn_rsq(x);
     r = r * fma(-0.5 * x * r, r, 1.5);
     const double g = x * r;
@@ -182,7 +179,7 @@ MDRP_HD int solve_cubic_real(double b, double c, double d, double &r0, double &r
         const double rr = sv_sqrt(-p * third);
         double arg = (rr > 0) ? sv_div(-0.5 * q, rr * rr * rr) : 0.0;
         arg = arg > 1 ? 1 : (arg < -1 ? -1 : arg);
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_SOLVER_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
         if (FAST) {
             const double ax = fabs(arg);
             double pa = -0.0012624911;
@@ -736,11 +733,8 @@ MDRP_HD int run_solver(int solver, const Sample3 &s, Model out[4]) {
 // hardware seed and two Newton steps: <= 1 ulp instead of correctly rounded, the same class of difference as the FMA contraction the
 // device build already has against the oracle (gated by the 3 x 1024-pair fixtures of tests/test_gpu_headline.py: masks and inlier
 // counts identical, models to 1e-8).  x = 0 gives NaN where the division gives inf; both end as "term truncated / row of weight zero".
-#ifndef MDRP_LM_IEEE_DIV
-#define MDRP_LM_IEEE_DIV 0
-#endif
 MDRP_HD double lm_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rcp(x);
     y = fma(fma(-x, y, 1.0), y, y);
     return fma(fma(-x, y, 1.0), y, y);
@@ -749,7 +743,7 @@ MDRP_HD double lm_rcp(double x) {
 #endif
 }
 MDRP_HD double lm_rsqrt(double x) {
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     double y = __builtin_amdgcn_rsq(x);
     const double h = 0.5 * x;
     y = y * fma(-h * y, y, 1.5);
@@ -766,7 +760,7 @@ MDRP_HD double loss_value(int type, double thr, double r2) {
     // the truncated losses are std::min(r2, t2) = (t2 < r2) ? t2 : r2 in the reference: a NaN residual makes the COST NaN (no LM step is ever accepted)
     case 1: case 5: return t2 < r2 ? t2 : r2;
     case 2: { const double r = sqrt(r2); return r <= thr ? r2 : thr * (2.0 * r - thr); }
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV // (1 / t^2 is invariant over a sweep: one reciprocal, products per record)
+#if defined(__HIP_DEVICE_COMPILE__)
     case 3: return t2 * log1p(r2 * lm_rcp(t2));
     case 4: return t2 * log1p((t2 < r2 ? t2 : r2) * lm_rcp(t2));
 #else
@@ -832,7 +826,7 @@ MDRP_HD double loss_weight(int type, double thr, double r2, double mu = 0.5) {
         return (1.0 - zbar) / rho;
     }
     case 2: { const double r = sqrt(r2); return r <= thr ? 1.0 : thr / r; }
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     case 3: { const double w = lm_rcp(1.0 + r2 * lm_rcp(t2)); return w > dmin ? w : dmin; }
     case 4: { if (!(r2 < t2)) return 0.0; const double w = lm_rcp(1.0 + r2 * lm_rcp(t2)); return w > dmin ? w : dmin; }
 #else
@@ -1236,7 +1230,7 @@ MDRP_HD void lm_apply_step(const Model &m, const double d[LM_NPAR], bool focal, 
 template <int N>
 MDRP_HD void chol_solve(const double *A, const double *b, double *x) {
     double L[N * N];
-#if defined(__HIP_DEVICE_COMPILE__) && !MDRP_LM_IEEE_DIV
+#if defined(__HIP_DEVICE_COMPILE__)
     double inv[N];
 #pragma unroll
     for (int i = 0; i < N; ++i)

@@ -81,8 +81,8 @@ class BatchPipeline:
 #       139 k at 16384 (the LM tails amortise inside a large call); chunks of 1024 / 2048 / 4096 pairs two in flight: 126 / 132 / 134 k at 8192.
 #   pageable host buffers (estimate_*_batch):  chunks of 1024 pairs two in flight win from ~8 k pairs on - 117.8 k against 109.1 k for one
 #       call at 8192 pairs (a chunk's H2D copy runs beside the previous chunk's kernels); at 4096 pairs one call is still ahead (103 k vs 100 k).
-# So: host batches of more than PIPELINE_MIN pairs are cut into chunks of PIPELINE_CHUNK pairs that go through a per-(thread, device)
-# BatchPipeline(depth 2); resident batches go through one call unless MDRP_PIPELINE_DEVICE=1.  Pairs are independent units and every
+# So: host batches of more than PIPELINE_MIN pairs are cut into chunks of PIPELINE_CHUNK pairs that go through one BatchPipeline(depth 2) per
+# device; resident batches always go through one call.  Pairs are independent units and every
 # summation order depends on the record index and list position only, so the records and masks are those of sequential chunk calls bit for
 # bit (tests/test_gpu_boundary.py::test_batch_pipeline_equals_sequential_calls, tests/test_gpu_headline.py::test_large_batches_...).
 def _env_int(name, dflt):
@@ -94,10 +94,8 @@ def _env_int(name, dflt):
 
 
 PIPELINE_MIN = _env_int("MDRP_PIPELINE_MIN", 6144)      # host batches up to this size go through one call on the thread's default handle
-PIPELINE_CHUNK = _env_int("MDRP_PIPELINE_CHUNK", 1024)  # pairs per chunk beyond that (0 = never split)
-PIPELINE_DEPTH = _env_int("MDRP_PIPELINE_DEPTH", 2)
-PIPELINE_DEVICE = _env_int("MDRP_PIPELINE_DEVICE", 0)   # 1: resident batches (estimate_batch_torch) are chunked as well (measured: slower)
-_auto_tls = threading.local()
+PIPELINE_CHUNK = 1024                                    # pairs per chunk beyond that
+PIPELINE_DEPTH = 2                                       # chunks in flight
 
 
 def chunk_bounds(batch, chunk=None):
@@ -111,14 +109,30 @@ def chunk_bounds(batch, chunk=None):
     return list(zip(cuts[:-1], cuts[1:]))
 
 
+_auto_pipes = {}            # device -> BatchPipeline, shared by every calling thread (submissions go through the pipeline's own pool: thread-safe)
+_auto_lock = threading.Lock()
+
+
 def _auto_pipe(device):
-    pipes = getattr(_auto_tls, "pipes", None)
-    if pipes is None:
-        pipes = _auto_tls.pipes = {}
-    p = pipes.get(device)
-    if p is None:
-        p = pipes[device] = BatchPipeline(depth=PIPELINE_DEPTH, device=device)
-    return p
+    """ONE pipeline per device for the whole process (one per calling thread leaked two handles with full scratch and two worker
+    threads for every short-lived thread of a server), closed at interpreter exit."""
+    with _auto_lock:
+        p = _auto_pipes.get(device)
+        if p is None:
+            if not _auto_pipes:
+                import atexit
+                atexit.register(close_auto_pipelines)
+            p = _auto_pipes[device] = BatchPipeline(depth=PIPELINE_DEPTH, device=device)
+        return p
+
+
+def close_auto_pipelines():
+    """release the handles (device scratch) and worker threads of the automatic pipelines; they are recreated on the next large batch"""
+    with _auto_lock:
+        pipes = list(_auto_pipes.values())
+        _auto_pipes.clear()
+    for p in pipes:
+        p.close()
 
 
 def estimate_host(kind, x1, x2, d1, d2, ro, bo, n_per_pair=None, cam1=None, cam2=None, device=0, want_mask=True):

@@ -658,17 +658,6 @@ def estimate_batch_torch(kind, points2D_1, points2D_2, depth_1, depth_2, cameras
     cams1 = cams2 = None
     if k == _capi.CALIB:
         cams1, cams2 = _camera_records(cameras1, B), _camera_records(cameras2, B)
-    if pipeline.PIPELINE_DEVICE and len(pipeline.chunk_bounds(B)) > 1:
-        # (MDRP_PIPELINE_DEVICE=1; measured slower than one call, mdrp_amd/pipeline.py) a large resident batch: chunks of pipeline.PIPELINE_CHUNK pairs, two in flight on the pipeline's own handles and streams.  The
-        # inputs were produced on `stream`: wait for them once; the records come back after every chunk's stream has drained, so later
-        # work on `stream` sees complete masks.
-        with torch.cuda.device(x1.device):
-            mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
-            stream.synchronize()
-            res = pipeline.estimate_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N, _capi.ransac_opt_from_dict(ransac_opt),
-                                           _capi.bundle_opt_from_dict(bundle_opt), None if n_per_pair is None else np.ascontiguousarray(n_per_pair, dtype=np.int32),
-                                           cams1, cams2, mask.data_ptr(), dev)
-        return res, mask
     with torch.cuda.device(x1.device):
         mask = torch.zeros((B, N), dtype=torch.uint8, device=x1.device)
         h.estimate_batch_device(k, x1.data_ptr(), x2.data_ptr(), d1.data_ptr(), d2.data_ptr(), B, N,

@@ -19,7 +19,9 @@ def test_library_exports_every_declared_symbol():
     assert "NEEDED" in dyn, dyn  # the dynamic section was really read (libstdc++, libc, ...)
     assert not [ln for ln in dyn.splitlines() if "NEEDED" in ln and "amdhip" in ln]
     hdr = open(os.path.join(ROOT, "include", "mdrp.h")).read()
-    declared = sorted(set(re.findall(r"\b(mdrp_[a-z_]+)\s*\(", hdr)))
+    macros = set(re.findall(r"#define\s+(mdrp_[a-z_]+)\(", hdr))  # mdrp_create / mdrp_create_on_stream: macros over the versioned entry points
+    assert macros == {"mdrp_create", "mdrp_create_on_stream"}
+    declared = sorted(set(re.findall(r"\b(mdrp_[a-z_]+)\s*\(", hdr)) - macros)
     assert declared, "no declarations parsed"
     for name in declared:
         assert hasattr(lib, name), name
@@ -102,3 +104,20 @@ def test_c_host_links_and_loads(tmp_path):
                     f"-Wl,-rpath,{os.path.join(rocm, 'lib')}", f"-Wl,-rpath,{libdir}", "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "mdrp-hip" in out.stdout and "create rc" in out.stdout, (out.stdout, out.stderr)
+
+
+def test_handle_creation_refuses_a_host_compiled_against_another_abi():
+    """mdrp_ransac_opt grew from 72 to 88 bytes in ABI 0.4 and nothing stopped a host compiled against 0.3 from passing the smaller
+    struct.  Since 0.5 the header's mdrp_create / mdrp_create_on_stream are macros over mdrp_create_ / mdrp_create_on_stream_ that hand over the
+    host's MDRP_ABI_VERSION and sizeof(mdrp_ransac_opt): a mismatch is MDRP_ERR_INVALID (1) with both versions in the message, before any device
+    is touched — so this runs without a GPU."""
+    lib = _capi.load_library()
+    h = C.c_void_p()
+    for fn in (lib.mdrp_create_, lib.mdrp_create_on_stream_):
+        assert fn(0, None, C.byref(h), 0x00000003, 72) == 1 and b"recompile" in lib.mdrp_last_error() and not h.value
+        assert fn(0, None, C.byref(h), _capi.ABI_VERSION, 72) == 1 and not h.value
+    # the matching ABI gets past the check: on this box (no GPU) the next refusal is MDRP_ERR_NO_DEVICE / a HIP error, never INVALID
+    rc = lib.mdrp_create_(0, None, C.byref(h), _capi.ABI_VERSION, C.sizeof(_capi.RansacOpt))
+    assert rc != 1
+    if rc == 0:
+        lib.mdrp_destroy(h)

@@ -700,22 +700,12 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
     ref, ref_mask = run()
     assert int(ref["iterations"].min()) == 4000 and int(ref["num_inliers"].min()) > 300
     for env in ({"MDRP_CHUNKS": "512"}, {"MDRP_CHUNKS": "256,1024"}, {"MDRP_CHUNKS": "512", "MDRP_LO_OVERLAP": "0"},
-                {"MDRP_CHUNKS": "128,256,512", "MDRP_LO_OVERLAP_WAVES": "4", "MDRP_LO_AFTER_SOLVE": "0", "MDRP_LO_AFTER_COUNT": "0"},
-                {"MDRP_CHUNKS": "128", "MDRP_BOUND": "0"}, {"MDRP_CHUNKS": "64,128", "MDRP_LO_AFTER_COUNT": "0"},
+                {"MDRP_CHUNKS": "128,256,512"}, {"MDRP_CHUNKS": "128", "MDRP_BOUND": "0"}, {"MDRP_CHUNKS": "64,128", "MDRP_LO_OVERLAP": "0"},
                 {"MDRP_CHUNKS": "512", "MDRP_LO_THREADS": "256", "MDRP_FINAL_THREADS": "64"},
                 {"MDRP_CHUNKS": "128", "MDRP_LO_THREADS": "64"}, {"MDRP_CHUNKS": "128", "MDRP_FINAL_THREADS": "64"},
-                {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "0"}, {"MDRP_CHUNKS": "128,1024", "MDRP_LM_ENGINE": "1"},
-                {"MDRP_CHUNKS": "128", "MDRP_SOLVE_PARTS": "2"}, {"MDRP_CHUNKS": "256", "MDRP_SOLVE_PARTS": "4", "MDRP_LO_AFTER_COUNT": "0"},
-                {"MDRP_CHUNKS": "128", "MDRP_LM_ENGINE": "2"}, {"MDRP_CHUNKS": "64,512", "MDRP_LM_ENGINE": "2", "MDRP_LME_CAP": "16"},
                 {"MDRP_CHUNKS": "128", "MDRP_FUSE_TAIL": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_FUSE_TAIL": "1"},
-                # one LO queue for the chip instead of one per XCD (lo_take): which workgroup refines which trigger is scheduling only
-                {"MDRP_CHUNKS": "128", "MDRP_LO_XCD": "0"}, {"MDRP_CHUNKS": "128,512", "MDRP_LO_XCD": "0", "MDRP_FUSE_TAIL": "0"},
-                {"MDRP_CHUNKS": "64,256", "MDRP_LO_XCD": "1", "MDRP_LO_OVERLAP_WAVES": "2"},
-                # the inlier-only final refinement over every record with a mask instead of the compacted inlier index (lm_mask_index)
-                {"MDRP_CHUNKS": "128", "MDRP_FINAL_MASK_INDEX": "0"}, {"MDRP_CHUNKS": "128", "MDRP_FINAL_MASK_INDEX": "1", "MDRP_FINAL_THREADS": "64"}):
-        for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_LO_OVERLAP_WAVES", "MDRP_LO_AFTER_SOLVE", "MDRP_LO_AFTER_COUNT", "MDRP_BOUND",
-                  "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_LM_ENGINE", "MDRP_FUSE_TAIL", "MDRP_LME_CAP", "MDRP_SOLVE_PARTS", "MDRP_LO_XCD",
-                  "MDRP_FINAL_MASK_INDEX"):
+                {"MDRP_CHUNKS": "64,256", "MDRP_FUSE_TAIL": "0", "MDRP_BOUND": "0"}):
+        for k in ("MDRP_CHUNKS", "MDRP_LO_OVERLAP", "MDRP_BOUND", "MDRP_LO_THREADS", "MDRP_FINAL_THREADS", "MDRP_FUSE_TAIL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -724,7 +714,7 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
             assert np.array_equal(res[f], ref[f]), (env, f)
         assert np.array_equal(mask, ref_mask), env
         # thread-count variants reduce in a different order: models agree to rounding, not bitwise
-        tol = 1e-9 if ("MDRP_LO_THREADS" in env or "MDRP_FINAL_THREADS" in env or "MDRP_LM_ENGINE" in env or "MDRP_FINAL_MASK_INDEX" in env) else 0.0
+        tol = 1e-9 if ("MDRP_LO_THREADS" in env or "MDRP_FINAL_THREADS" in env) else 0.0
         def flat(m):
             return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
         assert np.allclose(flat(res["model"]), flat(ref["model"]), rtol=tol, atol=tol), env
@@ -732,61 +722,12 @@ def test_schedule_does_not_change_results(handle, capi, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,es,rf", [(0, False, None), (0, True, None), (1, False, "shared"), (2, False, "varying")])
-@pytest.mark.parametrize("loss", ["TRUNCATED_CAUCHY", "CAUCHY", "TRUNCATED_LE_ZACH", "TRIVIAL"])
-def test_lm_engines_agree_on_every_estimator(capi, monkeypatch, kind, es, rf, loss):
-    """The three LM schedules — persistent kernels (0: the default), list engine (1), segment engine with dense sweeps (2) — run the same lm_impl<> arithmetic with different summation trees: integer statistics and masks identical, models
-    to 1e-9, on a ragged batch (pairs below the sample size and below one segment included) for every estimator and for final
-    losses with and without truncation / per-iteration state."""
-    from mdrp_amd import synth
-    B, N = 24, 900
-    ns = [N, 700, 257, 256, 255, 64, 5, 3, 2, 0, 300, 511] * 2
-    x1, x2 = np.zeros((B, N, 2)), np.zeros((B, N, 2))
-    d1, d2 = np.ones((B, N)), np.ones((B, N))
-    for i, n in enumerate(ns):
-        if n:
-            p = synth.make_pair(9500 + i, n, noise_px=0.5, depth_noise=0.02, outlier_frac=[0.4, 0.0, 0.2][i % 3], random_focal=rf,
-                                shift1=0.2 if es else 0.0, shift2=-0.1 if es else 0.0)
-            x1[i, :n], x2[i, :n], d1[i, :n], d2[i, :n] = p["x1"], p["x2"], p["d1"], p["d2"]
-    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
-    ro = capi.ransac_opt_from_dict({"max_iterations": 1200, "min_iterations": 1200, "max_epipolar_error": 2.0, "max_reproj_error": 16.0,
-                                    "monodepth_estimate_shift": es})
-    bo = capi.bundle_opt_from_dict({"loss_type": loss, "max_iterations": 40})
-    h = capi.Handle(0)
-    try:
-        out = []
-        for eng in ("0", "1", "2", "22"):  # "22": the final phase on the segment engine as well (default: LO phases only)
-            monkeypatch.setenv("MDRP_LM_ENGINE", eng[0])
-            monkeypatch.setenv("MDRP_LM_ENGINE_FINAL", "2" if eng == "22" else "1")
-            res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, np.array(ns, dtype=np.int32), cams if kind == 0 else None, cams if kind == 0 else None)
-            out.append((res.copy(), mask.copy()))
-    finally:
-        h.close()
-
-    def flat(m):
-        return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
-    (r0, m0) = out[0]
-    assert int(r0["refinements"].max()) > 3 and int(r0["num_inliers"].max()) > 400
-    for eng, (r, m) in zip(("1", "2", "22"), out[1:]):
-        for f in ("refinements", "iterations", "num_inliers"):
-            assert np.array_equal(r[f], r0[f]), (eng, f, r[f], r0[f])
-        assert np.array_equal(m, m0), eng
-        # summation trees differ: 1e-9 where the problem is well conditioned; pairs of a few dozen correspondences amplify the roundings
-        # (measured 2.4e-8 at n = 64), and a score that is zero up to rounding (n = 3: the minimal sample IS the data) has no relative scale
-        # ... and so does the calibrated estimator's 9-parameter LM with its two weakly observable shifts (measured 2e-8 at n = 900)
-        big = np.array(ns) >= 250
-        dm = np.abs(flat(r["model"]) - flat(r0["model"])).max(axis=1)
-        assert (dm[big] < (1e-7 if es else 1e-9)).all() and (dm < 1e-6).all(), (eng, dm)
-        assert np.allclose(r["model_score"], r0["model_score"], rtol=1e-8, atol=1e-12), eng
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("n_max", [900, 5440, 5441, 6000])
-def test_final_refinement_over_the_inlier_index_matches_the_masked_sweep(capi, monkeypatch, n_max):
+def test_final_refinement_over_the_inlier_index_at_and_beyond_the_list_limit(capi, monkeypatch, n_max):
     """The inlier-only final refinement (estimate_* tail @0x2247c3 / @0x223815) walks a compacted index of the inliers (lm_mask_index: a third LDS list,
-    N <= 5440) instead of evaluating every record under the mask: same arithmetic, another lane -> record assignment.  Integer statistics and masks
-    identical, models to 1e-9 — on ragged pairs (short ones, few inliers, N at and beyond the list limit) for the calibrated and the varying-focal estimator,
-    64 and 256 lanes per pair; beyond the limit both settings take the old path and must agree bit for bit."""
+    N <= 5440); beyond that size it evaluates every record under the mask.  Both paths, at and around the limit, with 64 and 256 lanes per pair, on ragged
+    pairs (short ones, few inliers) for the calibrated and the varying-focal estimator: integer statistics and masks identical between the two widths, models
+    to 1e-9 (another summation tree)."""
     from mdrp_amd import synth
     ns = [n_max, n_max - 1, 700, 257, 64, 5, 3, 0]
     B = len(ns)
@@ -802,22 +743,19 @@ def test_final_refinement_over_the_inlier_index_matches_the_masked_sweep(capi, m
         bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
         out = {}
         for threads in ("256", "64"):
-            for mi in ("0", "1"):
-                monkeypatch.setenv("MDRP_FINAL_THREADS", threads); monkeypatch.setenv("MDRP_FINAL_MASK_INDEX", mi)
-                h = capi.Handle(0)
-                res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, np.array(ns, dtype=np.int32), cams if kind == 0 else None, cams if kind == 0 else None)
-                out[(threads, mi)] = (res.copy(), mask.copy())
-                h.close()
+            monkeypatch.setenv("MDRP_FINAL_THREADS", threads)
+            h = capi.Handle(0)
+            res, mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, np.array(ns, dtype=np.int32), cams if kind == 0 else None, cams if kind == 0 else None)
+            out[threads] = (res.copy(), mask.copy())
+            h.close()
         def flat(m):
             return np.c_[m["q"], m["t"], m["scale"], m["shift1"], m["shift2"], m["f1"], m["f2"]]
-        for threads in ("256", "64"):
-            (r0, m0), (r1, m1) = out[(threads, "0")], out[(threads, "1")]
-            for f in ("refinements", "iterations", "num_inliers"):
-                assert np.array_equal(r0[f], r1[f]), (kind, threads, f)
-            assert np.array_equal(m0, m1), (kind, threads)
-            tol = 0.0 if n_max > 5440 else 1e-9
-            assert np.allclose(flat(r0["model"]), flat(r1["model"]), rtol=tol, atol=tol), (kind, threads)
-        assert int(out[("256", "1")][0]["num_inliers"][0]) > n_max // 3
+        (r0, m0), (r1, m1) = out["256"], out["64"]
+        for f in ("refinements", "iterations", "num_inliers"):
+            assert np.array_equal(r0[f], r1[f]), (kind, f)
+        assert np.array_equal(m0, m1), kind
+        assert np.allclose(flat(r0["model"]), flat(r1["model"]), rtol=1e-9, atol=1e-9), kind
+        assert int(r0["num_inliers"][0]) > n_max // 3
 
 
 @pytest.mark.gpu
