@@ -103,7 +103,9 @@ struct mdrp_handle {
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     hipStream_t aux_stream = nullptr;  // the second chunk's sampler + solver run here, beside the first chunk's sweep
-    hipStream_t aux_stream2 = nullptr; // the first chunk's LO runs here, beside the second chunk's solver and sweep
+    hipStream_t aux_stream2 = nullptr; // the sample tables and the super-chunk's LO launch run here
+    hipStream_t copy_stream = nullptr; // host-buffer calls: the H2D slices of the correspondences
+    hipEvent_t ev_copied = nullptr, ev_prepped = nullptr;
     DevBuf fuse;                       // fused tail: control words (64 B) | done_cnt[batch] | fin_done[batch] | ready[batch]
     static constexpr int NC_MAX = 8; // chunks of a super-chunk
     hipEvent_t ev_lo = nullptr, ev_tables = nullptr, ev_sampled[2] = {}, ev_solved[NC_MAX] = {}, ev_scanned[NC_MAX] = {};
@@ -239,9 +241,13 @@ int solver_for(int kind, int est_shift) {
 }
 
 // one pass = a contiguous range of pairs that fits the scratch budget
+// `host` (or null): the caller's HOST buffers of this pass; x1 ... d2 are then the handle's device staging buffers, still to be filled
+struct HostSrc { const double *x1, *x2, *d1, *d2; };
+constexpr int HOST_SLICE_PAIRS = 256; // pairs per H2D slice of a host-buffer call (24.6 MB at N = 2000: ~0.5 ms of PCIe per slice)
+
 int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
              int n_max, const int32_t *n_host, const mdrp_camera *cam1, const mdrp_camera *cam2, const mdrp_ransac_opt *ro,
-             const mdrp_bundle_opt *bo, int chunk_cap, uint8_t *mask_dev, ResultDev *results_dev) {
+             const mdrp_bundle_opt *bo, int chunk_cap, uint8_t *mask_dev, ResultDev *results_dev, const HostSrc *host) {
     hipStream_t s = h->stream;
     const int est_shift = (kind == MDRP_CALIB && ro->monodepth_estimate_shift) ? 1 : 0;
     const bool classic = kind >= MDRP_RELPOSE_5PT;              // non-monodepth baselines (mdrp_classic.h)
@@ -333,16 +339,22 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     rp.chunk_len = chunk_cap; rp.chunk_off = 0; rp.slot_stride = chunk_cap * mps; rp.super_len = chunk_cap; rp.chunk_start = 0;
     rp.mps = mps; rp.sample_sz = ssz;
 
-    if (classic)
-        hipLaunchKernelGGL(kc_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d_nper, d_table_of,
-                           d_cams1, d_cams2, ro->max_epipolar_error, bo->loss_scale, h->pts.as<double>(),
-                           h->st.as<PairState>(), h->rfrag.as<uint4>());
-    else
-        hipLaunchKernelGGL(k_prep, dim3(batch), dim3(256), 0, s, rp, x1, x2, d1, d2, d_nper,
-                           d_table_of, d_cams1, d_cams2, ro->max_epipolar_error,
-                           ro->max_reproj_error, bo->loss_scale, h->pts.as<double>(), h->dep.as<double>(), h->st.as<PairState>(),
-                           h->rfrag.as<uint4>());
-    HIPCHK(hipGetLastError());
+    // normalisation, record layout, MFMA fragments and pair states of the pairs [p0, p0 + pc) (one workgroup per pair, bases offset by p0)
+    auto launch_prep = [&](int p0, int pc) {
+        const size_t o2 = (size_t)2 * p0 * n_max, o1 = (size_t)p0 * n_max;
+        double *pts_p = h->pts.as<double>() + o1 * PT_STRIDE;
+        uint4 *rfrag_p = h->rfrag.as<uint4>() + (size_t)p0 * groups_max * 64;
+        if (classic)
+            hipLaunchKernelGGL(kc_prep, dim3(pc), dim3(256), 0, s, rp, x1 + o2, x2 + o2, d_nper + p0, d_table_of + p0, d_cams1 + p0, d_cams2 + p0,
+                               ro->max_epipolar_error, bo->loss_scale, pts_p, h->st.as<PairState>() + p0, rfrag_p);
+        else
+            hipLaunchKernelGGL(k_prep, dim3(pc), dim3(256), 0, s, rp, x1 + o2, x2 + o2, d1 + o1, d2 + o1, d_nper + p0, d_table_of + p0, d_cams1 + p0, d_cams2 + p0,
+                               ro->max_epipolar_error, ro->max_reproj_error, bo->loss_scale, pts_p, h->dep.as<double>() + 2 * o1, h->st.as<PairState>() + p0, rfrag_p);
+    };
+    if (!host) { // device-resident inputs: everything is there (host buffers: the copies and k_prep are issued slice by slice below)
+        launch_prep(0, batch);
+        HIPCHK(hipGetLastError());
+    }
 
     // Run-time knobs (DESIGN.md 10 lists all of them): the stream pipeline, the fp32 bound stage, lanes per LM problem.
     const bool lo_overlap = env_int("MDRP_LO_OVERLAP", 1) != 0; // three-stream pipeline; 0 = every kernel on the handle's stream
@@ -455,14 +467,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 presampled[c] = true;
             }
         }
-        auto issue_solve = [&](int c, hipStream_t st_) -> int {
+        // Every kernel of the front indexes its per-pair arrays as base[pair]: a RANGE of pairs [p0, p0 + pc) is the same launch on offset bases
+        // with rp.batch = pc (the plans are per-launch scratch).  The whole batch is the range [0, batch); the host-buffer path below runs the
+        // first chunk and the second chunk's solver slice by slice while later slices are still on their way over PCIe.
+        auto issue_solve = [&](int c, hipStream_t st_, int p0, int pc) -> int {
             RunParams r = rp;
-            r.chunk_len = (int)lens[c]; r.chunk_off = offs[c];
+            r.chunk_len = (int)lens[c]; r.chunk_off = offs[c]; r.batch = pc;
             const bool odd = c & 1;
-            uint32_t *tg = (odd ? h->tags2 : h->tags).as<uint32_t>();
+            const size_t so = (size_t)p0 * rp.slot_stride;
+            uint32_t *tg = (odd ? h->tags2 : h->tags).as<uint32_t>() + so;
             uint32_t *smp = (odd ? h->samples2 : h->samples).as<uint32_t>();
-            int32_t *mc = (odd ? h->model_count2 : h->model_count).as<int32_t>();
-            HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * batch, st_));
+            int32_t *mc = (odd ? h->model_count2 : h->model_count).as<int32_t>() + 2 * (size_t)p0;
+            HIPCHK(hipMemsetAsync(mc, 0, sizeof(int32_t) * 2 * pc, st_));
             if (c < 2 && presampled[c]) HIPCHK(hipStreamWaitEvent(st_, h->ev_sampled[c], 0));
             else launch_samples(st_, r.chunk_len, smp);
             hipEvent_t v0, v1;
@@ -470,22 +486,23 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if ((rc_ = get_events(h, &v0, &v1, 5))) return rc_;
             HIPCHK(hipEventRecord(v0, st_));
             struct Stop { hipEvent_t e; hipStream_t s; ~Stop() { (void)hipEventRecord(e, s); } } stop_{v1, st_}; // after the solver launch below
+            PairState *st_p = h->st.as<PairState>() + p0;
+            double *pts_p = h->pts.as<double>() + (size_t)p0 * n_max * PT_STRIDE;
+            Model *models_p = h->models.as<Model>() + so;
+            int32_t *inl_p = h->slot_inl.as<int32_t>() + so;
             if (classic) {
-                const dim3 sgrid((r.chunk_len + 63) / 64, batch);
+                const dim3 sgrid((r.chunk_len + 63) / 64, pc);
                 if (kind == MDRP_SHARED_6PT)
-                    hipLaunchKernelGGL(kc_solve<CLASSIC_SHARED>, sgrid, dim3(64), 0, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
-                                       h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_SHARED>, sgrid, dim3(64), 0, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
                 else if (kind == MDRP_RELPOSE_5PT)
-                    hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
-                                       h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
                 else
-                    hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), SOLVE7_LDS_BYTES, st_, r, h->st.as<PairState>(), smp, h->pts.as<double>(),
-                                       h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc);
+                    hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), SOLVE7_LDS_BYTES, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
                 return MDRP_OK;
             }
+            double *dep_p = h->dep.as<double>() + (size_t)p0 * n_max * 2;
 #define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
-    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, batch), dim3(256), 0, st_, r, h->st.as<PairState>(), smp,   \
-                       h->pts.as<double>(), h->dep.as<double>(), h->models.as<Model>(), h->slot_inl.as<int32_t>(), tg, mc, 0, r.chunk_len)
+    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, pc), dim3(256), 0, st_, r, st_p, smp, pts_p, dep_p, models_p, inl_p, tg, mc, 0, r.chunk_len)
             switch (r.solver) {
             case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
             case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;
@@ -495,81 +512,118 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
 #undef MDRP_SOLVE_LAUNCH
             return MDRP_OK;
         };
-        if ((rc = issue_solve(0, s))) return rc;
-        if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
-        for (int c = 0; c < n_chunks; ++c) {
-            const int len = (int)lens[c];
-            rp.chunk_len = len; rp.chunk_off = offs[c];
+        // count -> bound -> sort -> plan -> exact score -> scan of chunk c for the pairs [p0, p0 + pc), on the main stream
+        auto sweep_chunk = [&](int c, int p0, int pc) -> int {
+            RunParams r = rp;
+            r.chunk_len = (int)lens[c]; r.chunk_off = offs[c]; r.batch = pc;
+            const int len = r.chunk_len;
             const bool odd = c & 1;
-            uint32_t *tags_sc = (odd ? h->tags2_s : h->tags_s).as<uint32_t>();
-            int32_t *mcount_c = (odd ? h->model_count2 : h->model_count).as<int32_t>();
-            if (piped && c + 1 < n_chunks) {
+            const size_t so = (size_t)p0 * rp.slot_stride;
+            PairState *st_p = h->st.as<PairState>() + p0;
+            const double *pts_p = h->pts.as<double>() + (size_t)p0 * n_max * PT_STRIDE;
+            const Model *models_p = h->models.as<Model>() + so;
+            uint32_t *tags_sc = (odd ? h->tags2_s : h->tags_s).as<uint32_t>() + so;
+            int32_t *mcount_c = (odd ? h->model_count2 : h->model_count).as<int32_t>() + 2 * (size_t)p0;
+            uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>() + so;
+            uint32_t *tags_v = h->tags_v.as<uint32_t>() + so;
+            int32_t *surv1 = h->surv_count.as<int32_t>() + p0, *surv2 = h->surv2_count.as<int32_t>() + p0;
+            hipEvent_t e0, e1;
+            int rc_;
+            if ((rc_ = get_events(h, &e0, &e1, 0))) return rc_;
+            // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
+            unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
+            {
+                hipEvent_t c0, c1;
+                if ((rc_ = get_events(h, &c0, &c1, 1))) return rc_;
+                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
+                                   surv1, (const int32_t *)nullptr); // (also clears the survivor counters k_count appends to)
+                const dim3 cgrid((unsigned)pc * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
+                HIPCHK(hipEventRecord(c0, s));
+                MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, h->rfrag.as<uint4>() + (size_t)p0 * groups_max * 64, models_p,
+                                    tags_c, mcount_c, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr);
+                HIPCHK(hipEventRecord(c1, s));
+                h->count_launches++;
+            }
+            const uint32_t *surv_tags = tags_v;
+            const int32_t *surv_cnt = surv1;
+            if (use_bound && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
+                // fp32 lower bound of the score for k_count's survivors; its survivors go back into the chunk's tag list
+                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, surv1, 1, BND_THREADS, h->cplan.as<int32_t>(), surv2, (const int32_t *)nullptr);
+                const dim3 bgrid((unsigned)pc * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
+                unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
+                hipEvent_t b0, b1;
+                if ((rc_ = get_events(h, &b0, &b1, 4))) return rc_;
+                HIPCHK(hipEventRecord(b0, s));
+                MDRP_SWEEP_DISPATCH(k_bound, kind, bgrid, dim3(BND_THREADS), 0, s, r, st_p, pts_p, models_p, tags_v, surv1, h->cplan.as<int32_t>(), tags_c, surv2, bstats);
+                HIPCHK(hipEventRecord(b1, s));
+                surv_tags = tags_c; surv_cnt = surv2;
+            }
+            hipLaunchKernelGGL(k_sort_tags, dim3(pc), dim3(256), 0, s, r, st_p, mcount_c, surv_cnt, surv_tags, tags_sc);
+            int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2; // (the slice's plan uses the head of the buffer, `totals` stays where it is)
+            hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, mcount_c, plan, totals);
+            HIPCHK(hipEventRecord(e0, s));
+            const dim3 grid((unsigned)pc * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
+            MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, r, st_p, pts_p, models_p, tags_sc, mcount_c,
+                                h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, plan, totals);
+            HIPCHK(hipEventRecord(e1, s));
+            h->sweep_launches++;
+            Trigger *trig_p = h->triggers.as<Trigger>() + (size_t)p0 * trig_cap;
+            unsigned long long *scan_stats = reinterpret_cast<unsigned long long *>(cnt + 10);
+            if (mps == 16)
+                hipLaunchKernelGGL(k_scan<16>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
+            else if (mps == 12)
+                hipLaunchKernelGGL(k_scan<12>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
+            else
+                hipLaunchKernelGGL(k_scan<4>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
+            return MDRP_OK;
+        };
+        // ---- host buffers (MDRP_MEM_HOST): the correspondences arrive slice by slice on the copy stream; k_prep, the first chunk and the second
+        // chunk's solver of slice i run while slice i + 1 is on its way over PCIe
+        int c_first = 0; // chunks below this one have been swept already (by the sliced front)
+        bool solved1 = false;
+        if (host && it0 == 0) {
+            const bool sliced = piped && n_chunks >= 2 && batch >= 2 * HOST_SLICE_PAIRS;
+            const int sl = sliced ? HOST_SLICE_PAIRS : batch;
+            for (int p0 = 0; p0 < batch; p0 += sl) {
+                const int pc = std::min(sl, batch - p0);
+                const size_t o2 = (size_t)2 * p0 * n_max, o1 = (size_t)p0 * n_max, n2 = sizeof(double) * 2 * (size_t)pc * n_max, n1 = sizeof(double) * (size_t)pc * n_max;
+                hipStream_t cs = sliced ? h->copy_stream : s;
+                HIPCHK(hipMemcpyAsync(const_cast<double *>(x1) + o2, host->x1 + o2, n2, hipMemcpyHostToDevice, cs));
+                HIPCHK(hipMemcpyAsync(const_cast<double *>(x2) + o2, host->x2 + o2, n2, hipMemcpyHostToDevice, cs));
+                if (host->d1 && host->d2) {
+                    HIPCHK(hipMemcpyAsync(const_cast<double *>(d1) + o1, host->d1 + o1, n1, hipMemcpyHostToDevice, cs));
+                    HIPCHK(hipMemcpyAsync(const_cast<double *>(d2) + o1, host->d2 + o1, n1, hipMemcpyHostToDevice, cs));
+                }
+                if (sliced) { HIPCHK(hipEventRecord(h->ev_copied, cs)); HIPCHK(hipStreamWaitEvent(s, h->ev_copied, 0)); }
+                launch_prep(p0, pc);
+                if (!sliced) break;
+                HIPCHK(hipEventRecord(h->ev_prepped, s));
+                HIPCHK(hipStreamWaitEvent(aux, h->ev_prepped, 0));
+                if ((rc = issue_solve(1, aux, p0, pc))) return rc;   // the long solver of this slice beside the next slice's copy
+                if ((rc = issue_solve(0, s, p0, pc))) return rc;
+                if ((rc = sweep_chunk(0, p0, pc))) return rc;
+            }
+            if (sliced) {
+                HIPCHK(hipEventRecord(h->ev_solved[0], s)); HIPCHK(hipEventRecord(h->ev_scanned[0], s));
+                HIPCHK(hipEventRecord(h->ev_solved[1], aux));
+                c_first = 1; solved1 = true;
+            }
+        }
+        if (c_first == 0) {
+            if ((rc = issue_solve(0, s, 0, batch))) return rc;
+            if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
+        }
+        for (int c = c_first; c < n_chunks; ++c) {
+            rp.chunk_len = (int)lens[c]; rp.chunk_off = offs[c];
+            if (piped && c + 1 < n_chunks && !(c == 0 && solved1)) {
                 // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
                 HIPCHK(hipStreamWaitEvent(aux, c == 0 ? h->ev_solved[0] : h->ev_scanned[c - 1], 0));
-                if ((rc = issue_solve(c + 1, aux))) return rc;
+                if ((rc = issue_solve(c + 1, aux, 0, batch))) return rc;
                 HIPCHK(hipEventRecord(h->ev_solved[c + 1], aux));
             }
             if (piped && c > 0) HIPCHK(hipStreamWaitEvent(s, h->ev_solved[c], 0));
-            if (!piped && c > 0 && (rc = issue_solve(c, s))) return rc;
-            {
-                hipEvent_t e0, e1;
-                if ((rc = get_events(h, &e0, &e1, 0))) return rc;
-                // candidate counts on the matrix cores against the records of the chunks before this one; survivors only go on
-                const uint32_t *tags_c = (odd ? h->tags2 : h->tags).as<uint32_t>();
-                unsigned long long *cstats = reinterpret_cast<unsigned long long *>(cnt + 6);
-                {
-                    hipEvent_t c0, c1;
-                    if ((rc = get_events(h, &c0, &c1, 1))) return rc;
-                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
-                                       h->surv_count.as<int32_t>(), (const int32_t *)nullptr); // (also clears the survivor counters k_count appends to)
-                    const dim3 cgrid((unsigned)batch * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
-                    HIPCHK(hipEventRecord(c0, s));
-                    MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, rp, h->st.as<PairState>(), h->rfrag.as<uint4>(), h->models.as<Model>(),
-                                        tags_c, mcount_c, h->cplan.as<int32_t>(), h->tags_v.as<uint32_t>(),
-                                        h->surv_count.as<int32_t>(), cstats, (int32_t *)nullptr, (const int32_t *)nullptr);
-                    HIPCHK(hipEventRecord(c1, s));
-                    h->count_launches++;
-                }
-                const uint32_t *surv_tags = h->tags_v.as<uint32_t>();
-                const int32_t *surv_cnt = h->surv_count.as<int32_t>();
-                if (use_bound && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
-                    // fp32 lower bound of the score for k_count's survivors; its survivors go back into the chunk's tag list
-                    uint32_t *tags_b = (odd ? h->tags2 : h->tags).as<uint32_t>();
-                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, h->st.as<PairState>(), h->surv_count.as<int32_t>(), 1,
-                                       BND_THREADS, h->cplan.as<int32_t>(), h->surv2_count.as<int32_t>(), (const int32_t *)nullptr);
-                    const dim3 bgrid((unsigned)batch * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
-                    unsigned long long *bstats = reinterpret_cast<unsigned long long *>(cnt + 12);
-                    hipEvent_t b0, b1;
-                    if ((rc = get_events(h, &b0, &b1, 4))) return rc;
-                    HIPCHK(hipEventRecord(b0, s));
-                    MDRP_SWEEP_DISPATCH(k_bound, kind, bgrid, dim3(BND_THREADS), 0, s, rp, h->st.as<PairState>(), h->pts.as<double>(), h->models.as<Model>(),
-                                        h->tags_v.as<uint32_t>(), h->surv_count.as<int32_t>(), h->cplan.as<int32_t>(),
-                                        tags_b, h->surv2_count.as<int32_t>(), bstats);
-                    HIPCHK(hipEventRecord(b1, s));
-                    surv_tags = tags_b; surv_cnt = h->surv2_count.as<int32_t>();
-                }
-                hipLaunchKernelGGL(k_sort_tags, dim3(batch), dim3(256), 0, s, rp, h->st.as<PairState>(), mcount_c, surv_cnt, surv_tags, tags_sc);
-                int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2;
-                hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, batch, mcount_c, plan, totals);
-                HIPCHK(hipEventRecord(e0, s));
-                const dim3 grid((unsigned)batch * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
-                MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, rp, h->st.as<PairState>(), h->pts.as<double>(),
-                                    h->models.as<Model>(), tags_sc, mcount_c, h->slot_score.as<double>(), h->slot_inl.as<int32_t>(), plan, totals);
-                HIPCHK(hipEventRecord(e1, s));
-                h->sweep_launches++;
-            }
-            if (mps == 16)
-                hipLaunchKernelGGL(k_scan<16>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                                   h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
-                                   reinterpret_cast<unsigned long long *>(cnt + 10));
-            else if (mps == 12)
-                hipLaunchKernelGGL(k_scan<12>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                                   h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
-                                   reinterpret_cast<unsigned long long *>(cnt + 10));
-            else
-                hipLaunchKernelGGL(k_scan<4>, dim3(batch), dim3(64), 0, s, rp, h->st.as<PairState>(), h->slot_score.as<double>(),
-                                   h->slot_inl.as<int32_t>(), h->triggers.as<Trigger>(), trig_cap, mcount_c,
-                                   reinterpret_cast<unsigned long long *>(cnt + 10));
+            if (!piped && c > 0 && (rc = issue_solve(c, s, 0, batch))) return rc;
+            if ((rc = sweep_chunk(c, 0, batch))) return rc;
             if (c + 1 < n_chunks) { // (the solver of chunk c + 2 waits for this chunk's scan: it reuses this chunk's lists)
                 if (piped) HIPCHK(hipEventRecord(h->ev_scanned[c], s));
                 continue;
@@ -676,7 +730,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
 
 int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
                     int n_max, const int32_t *n_per_pair, const mdrp_camera *cam1, const mdrp_camera *cam2,
-                    const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev) {
+                    const mdrp_ransac_opt *ro, const mdrp_bundle_opt *bo, uint8_t *mask_dev, const HostSrc *host = nullptr) {
     const bool known_kind = kind >= 0 && kind <= 5;
     if (!h || batch < 0 || n_max < 0 || !known_kind || !ro || !bo) { g_err = "invalid argument"; return MDRP_ERR_INVALID; }
     if (kind == MDRP_SHARED_6PT && batch > 0 && !cam1) { g_err = "the 6-point estimator needs the principal point in cam1"; return MDRP_ERR_INVALID; }
@@ -718,10 +772,13 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     per_pass = std::max(1, std::min(per_pass, env_int("MDRP_PAIRS_PER_PASS", per_pass))); // (tests: several passes on a small batch)
     for (int p0 = 0; p0 < batch; p0 += per_pass) {
         const int nb = std::min(per_pass, batch - p0);
+        HostSrc hs{};
+        if (host) hs = HostSrc{host->x1 + (size_t)2 * p0 * n_max, host->x2 + (size_t)2 * p0 * n_max, host->d1 ? host->d1 + (size_t)p0 * n_max : nullptr,
+                               host->d2 ? host->d2 + (size_t)p0 * n_max : nullptr};
         rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 ? d1 + (size_t)p0 * n_max : nullptr,
                       d2 ? d2 + (size_t)p0 * n_max : nullptr, nb,
                       n_max, n_host.data() + p0, cam1 ? cam1 + p0 : nullptr, cam2 ? cam2 + p0 : nullptr, ro, bo, chunk_cap,
-                      mask + (size_t)p0 * n_max, h->results.as<ResultDev>() + p0);
+                      mask + (size_t)p0 * n_max, h->results.as<ResultDev>() + p0, host ? &hs : nullptr);
         if (rc) return rc;
     }
     return MDRP_OK;
@@ -827,6 +884,9 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
         HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamNonBlocking, prio_hi));
         HIPCHK(hipStreamCreateWithPriority(&h->aux_stream2, hipStreamNonBlocking, prio_hi));
     }
+    HIPCHK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_copied, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_prepped, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_lo, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_tables, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_sampled[0], hipEventDisableTiming));
@@ -863,6 +923,9 @@ void mdrp_destroy(mdrp_handle *h) {
     if (h->params_host) (void)hipHostFree(h->params_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
     if (h->aux_stream2) { (void)hipStreamSynchronize(h->aux_stream2); (void)hipStreamDestroy(h->aux_stream2); }
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->ev_copied) (void)hipEventDestroy(h->ev_copied);
+    if (h->ev_prepped) (void)hipEventDestroy(h->ev_prepped);
     if (h->ev_lo) (void)hipEventDestroy(h->ev_lo);
     if (h->ev_tables) (void)hipEventDestroy(h->ev_tables);
     for (int i = 0; i < 2; ++i) if (h->ev_sampled[i]) (void)hipEventDestroy(h->ev_sampled[i]);
@@ -917,21 +980,20 @@ int mdrp_estimate_batch(mdrp_handle *h, int kind, int mem_space, const double *x
     const size_t np = (size_t)batch * n_max;
     int rc;
     uint8_t *mask_dev = inlier_mask;
+    HostSrc hsrc{};
+    bool use_host = false;
     if (mem_space == MDRP_MEM_HOST) {
         if ((rc = h->in_x1.ensure(sizeof(double) * 2 * np + 16)) || (rc = h->in_x2.ensure(sizeof(double) * 2 * np + 16)) ||
             (rc = h->in_d1.ensure(sizeof(double) * np + 16)) || (rc = h->in_d2.ensure(sizeof(double) * np + 16)))
             return rc;
-        HIPCHK(hipMemcpyAsync(h->in_x1.p, x1, sizeof(double) * 2 * np, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipMemcpyAsync(h->in_x2.p, x2, sizeof(double) * 2 * np, hipMemcpyHostToDevice, h->stream));
-        if (d1 && d2) {
-            HIPCHK(hipMemcpyAsync(h->in_d1.p, d1, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
-            HIPCHK(hipMemcpyAsync(h->in_d2.p, d2, sizeof(double) * np, hipMemcpyHostToDevice, h->stream));
-            d1 = h->in_d1.as<double>(); d2 = h->in_d2.as<double>();
-        }
+        // the copies are issued by run_pass, slice by slice on the handle's copy stream, beside the first kernels of the slices before them
+        hsrc = HostSrc{x1, x2, (d1 && d2) ? d1 : nullptr, (d1 && d2) ? d2 : nullptr};
+        if (d1 && d2) { d1 = h->in_d1.as<double>(); d2 = h->in_d2.as<double>(); }
         x1 = h->in_x1.as<double>(); x2 = h->in_x2.as<double>();
+        use_host = true;
         mask_dev = nullptr; // handle-owned device mask, copied back below
     }
-    rc = estimate_device(h, kind, x1, x2, d1, d2, batch, n_max, n_per_pair, cam1, cam2, ropt, bopt, mask_dev);
+    rc = estimate_device(h, kind, x1, x2, d1, d2, batch, n_max, n_per_pair, cam1, cam2, ropt, bopt, mask_dev, use_host ? &hsrc : nullptr);
     if (rc) return rc;
     if (mem_space == MDRP_MEM_HOST && inlier_mask && np > 0)
         HIPCHK(hipMemcpyAsync(inlier_mask, h->mask.p, np, hipMemcpyDeviceToHost, h->stream));

@@ -226,6 +226,46 @@ def test_batches_larger_than_one_pass(monkeypatch):
         h.close()
 
 
+def test_host_buffer_call_in_h2d_slices_equals_the_resident_call():
+    """a host-buffer call of >= 512 pairs copies the correspondences in 256-pair slices on the handle's copy stream and runs k_prep,
+    the first chunk and the second chunk's solver of each slice beside the next slice's copy (mdrp_capi.hip run_pass).  Pairs are independent units:
+    records and masks must equal those of the SAME batch resident on the device bit for bit — ragged counts (incl. pairs below the sample size), per-pair
+    cameras, a last slice that is short (600 = 256 + 256 + 88), for a monodepth estimator and a classic one."""
+    import torch
+    from mdrp_amd import _capi, synth
+    B, N = 600, 640
+    rng = np.random.default_rng(77)
+    ns = rng.integers(200, N + 1, size=B).astype(np.int32)
+    ns[[5, 300, 599]] = [2, 0, 3]
+    x1, x2 = np.zeros((B, N, 2)), np.zeros((B, N, 2))
+    d1, d2 = np.ones((B, N)), np.ones((B, N))
+    for i in range(B):
+        n = int(ns[i])
+        if n:
+            p = synth.make_pair(8800 + i, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4)
+            x1[i, :n], x2[i, :n], d1[i, :n], d2[i, :n] = p["x1"], p["x2"], p["d1"], p["d2"]
+    cams = np.zeros(B, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 700.0 + rng.uniform(0, 200, B)
+    ro = _capi.ransac_opt_from_dict({"max_iterations": 1500, "min_iterations": 1500, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+    bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    dev = torch.device("cuda", 0)
+    h = _capi.Handle(0)
+    try:
+        for kind in (0, 5):
+            c = cams if kind == 0 else None
+            res_h, mask_h = h.estimate_batch(kind, x1, x2, d1 if kind == 0 else None, d2 if kind == 0 else None, ro, bo, ns, c, c)
+            t = [torch.from_numpy(a).to(dev) for a in (x1, x2, d1, d2)]
+            mask_d = torch.zeros((B, N), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize(dev)
+            h.estimate_batch_device(kind, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr() if kind == 0 else 0, t[3].data_ptr() if kind == 0 else 0, B, N, ro, bo, ns, c, c,
+                                    mask_d.data_ptr())
+            res_d = h.fetch_results(B)
+            assert res_h.tobytes() == res_d.tobytes(), kind
+            assert np.array_equal(mask_h, mask_d.cpu().numpy()), kind
+            assert int(res_h["num_inliers"].max()) > 200
+    finally:
+        h.close()
+
+
 def test_local_shard_through_the_device_gather_path_one_rank():
     """BASELINE configs[4]'s data path on ONE GPU: dist.estimate_local_shard_device — device-resident inputs,
     mdrp_estimate_batch_async, mdrp_copy_results_device into the rank's slot, all_gather_into_tensor over RCCL (a one-rank `nccl`
