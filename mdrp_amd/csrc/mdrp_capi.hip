@@ -577,10 +577,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 hipLaunchKernelGGL(k_scan<4>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
             return MDRP_OK;
         };
-        // ---- host buffers (MDRP_MEM_HOST): the correspondences arrive slice by slice on the copy stream; k_prep, the first chunk and the second
-        // chunk's solver of slice i run while slice i + 1 is on its way over PCIe
-        int c_first = 0; // chunks below this one have been swept already (by the sliced front)
-        bool solved1 = false;
+        // ---- host buffers (MDRP_MEM_HOST): the correspondences arrive slice by slice on the copy stream; k_prep and the second chunk's solver (the
+        // long one: 1.6 ms per 1024 pairs) of slice i run while slice i + 1 is on its way over PCIe
+        bool solved1 = false; // the second chunk's solver has been issued (slice by slice)
         if (host && it0 == 0) {
             const bool sliced = piped && n_chunks >= 2 && batch >= 2 * HOST_SLICE_PAIRS;
             const int sl = sliced ? HOST_SLICE_PAIRS : batch;
@@ -599,21 +598,15 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 if (!sliced) break;
                 HIPCHK(hipEventRecord(h->ev_prepped, s));
                 HIPCHK(hipStreamWaitEvent(aux, h->ev_prepped, 0));
-                if ((rc = issue_solve(1, aux, p0, pc))) return rc;   // the long solver of this slice beside the next slice's copy
-                if ((rc = issue_solve(0, s, p0, pc))) return rc;
-                if ((rc = sweep_chunk(0, p0, pc))) return rc;
+                if ((rc = issue_solve(1, aux, p0, pc))) return rc;   // the long solver of this slice beside the next slices' copies
             }
-            if (sliced) {
-                HIPCHK(hipEventRecord(h->ev_solved[0], s)); HIPCHK(hipEventRecord(h->ev_scanned[0], s));
-                HIPCHK(hipEventRecord(h->ev_solved[1], aux));
-                c_first = 1; solved1 = true;
-            }
+            // (the first chunk is NOT sliced: its exact sweep is a fixed ~0.5 ms of serial record loops per workgroup whatever the number of pairs -
+            // four slices cost four times that on the main stream, measured 10.3 ms per step against 9.6 with one sweep behind the last slice)
+            if (sliced) { HIPCHK(hipEventRecord(h->ev_solved[1], aux)); solved1 = true; }
         }
-        if (c_first == 0) {
-            if ((rc = issue_solve(0, s, 0, batch))) return rc;
-            if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
-        }
-        for (int c = c_first; c < n_chunks; ++c) {
+        if ((rc = issue_solve(0, s, 0, batch))) return rc;
+        if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
+        for (int c = 0; c < n_chunks; ++c) {
             rp.chunk_len = (int)lens[c]; rp.chunk_off = offs[c];
             if (piped && c + 1 < n_chunks && !(c == 0 && solved1)) {
                 // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
