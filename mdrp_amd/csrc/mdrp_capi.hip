@@ -569,12 +569,13 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             h->sweep_launches++;
             Trigger *trig_p = h->triggers.as<Trigger>() + (size_t)p0 * trig_cap;
             unsigned long long *scan_stats = reinterpret_cast<unsigned long long *>(cnt + 10);
-            if (mps == 16)
-                hipLaunchKernelGGL(k_scan<16>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
-            else if (mps == 12)
-                hipLaunchKernelGGL(k_scan<12>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
-            else
-                hipLaunchKernelGGL(k_scan<4>, dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats);
+            // (four iterations per lane where the chunk is long: a 9872-iteration chunk is 39 steps of one wavefront instead of 154)
+#define MDRP_SCAN(M, I) hipLaunchKernelGGL((k_scan<M, I>), dim3(pc), dim3(64), 0, s, r, st_p, h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, trig_p, trig_cap, mcount_c, scan_stats)
+            if (mps == 16) MDRP_SCAN(16, 1);
+            else if (mps == 12) MDRP_SCAN(12, 1);
+            else if (len >= 1024) MDRP_SCAN(4, 4);
+            else MDRP_SCAN(4, 1);
+#undef MDRP_SCAN
             return MDRP_OK;
         };
         // ---- host buffers (MDRP_MEM_HOST): the correspondences arrive slice by slice on the copy stream; k_prep and the second chunk's solver (the

@@ -1480,9 +1480,11 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
 }
 
 // ------------------------------------------------------------------------------------------------ scan
-// One wave per pair walks the chunk's slots in iteration order, 64 iterations per step: per-lane local records ->
-// wave exclusive prefix (max count, min score) -> per-lane replay against the true running records.
-template <int MPS = 4>
+// One wave per pair walks the chunk's slots in iteration order, 64 * IPL iterations per step (a lane owns IPL consecutive iterations): per-lane
+// local records -> wave exclusive prefix (max count, min score) -> per-lane replay against the true running records.
+// IPL (round 6): with one iteration per lane the 154 steps of a 9872-iteration chunk were 154 dependent memory round trips of one wavefront per
+// SIMD (0.13 ms, on the critical path in front of the LO launch); four iterations per lane keep four times the loads in flight per step.
+template <int MPS = 4, int IPL = 1>
 __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict__ st, const double *__restrict__ slot_score,
                                              const int32_t *__restrict__ slot_inl, Trigger *__restrict__ triggers,
                                              int trig_cap, const int32_t *__restrict__ model_count,
@@ -1498,41 +1500,46 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
     static_assert(MPS % 4 == 0, "slots of an iteration are read as 16-byte groups");
     constexpr int NG = MPS / 4;
     const size_t slot_base = (size_t)pair * rp.slot_stride + (size_t)rp.chunk_off * MPS;
-    // one wavefront walks ~150 steps of 64 iterations: the slots of the next step are requested before this step is
-    // examined, and a step in which no lane beats the running records (most of them) skips the prefix and the replay
-    struct Slots { int4 c[NG]; double2 s01[NG], s23[NG]; };
+    // the slots of the next step are requested before this step is examined, and a step in which no lane beats the running records
+    // (most of them) skips the prefix and the replay
+    struct Slots { int4 c[IPL][NG]; double2 s01[IPL][NG], s23[IPL][NG]; };
     auto fetch = [&](int it0) {
         Slots r;
-        const int it = it0 + lane;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (it < rp.chunk_len) {
-                r.c[g] = *reinterpret_cast<const int4 *>(slot_inl + slot_base + (size_t)it * MPS + 4 * g);
-                const double2 *sp = reinterpret_cast<const double2 *>(slot_score + slot_base + (size_t)it * MPS + 4 * g);
-                r.s01[g] = sp[0]; r.s23[g] = sp[1]; // empty slots hold stale scores: masked by the count below
-            } else { r.c[g] = make_int4(-1, -1, -1, -1); r.s01[g] = r.s23[g] = make_double2(DBL_MAX, DBL_MAX); }
+        for (int j = 0; j < IPL; ++j) {
+            const int it = it0 + IPL * lane + j;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (it < rp.chunk_len) {
+                    r.c[j][g] = *reinterpret_cast<const int4 *>(slot_inl + slot_base + (size_t)it * MPS + 4 * g);
+                    const double2 *sp = reinterpret_cast<const double2 *>(slot_score + slot_base + (size_t)it * MPS + 4 * g);
+                    r.s01[j][g] = sp[0]; r.s23[j][g] = sp[1]; // empty slots hold stale scores: masked by the count below
+                } else { r.c[j][g] = make_int4(-1, -1, -1, -1); r.s01[j][g] = r.s23[j][g] = make_double2(DBL_MAX, DBL_MAX); }
+            }
         }
         return r;
     };
     Slots nxt = fetch(0);
-    for (int it0 = 0; it0 < rp.chunk_len; it0 += 64) {
-        const int it = it0 + lane;
+    for (int it0 = 0; it0 < rp.chunk_len; it0 += 64 * IPL) {
         const Slots cur = nxt;
-        if (it0 + 64 < rp.chunk_len) nxt = fetch(it0 + 64);
-        int c[MPS];
-        double s[MPS];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            c[4 * g] = cur.c[g].x; c[4 * g + 1] = cur.c[g].y; c[4 * g + 2] = cur.c[g].z; c[4 * g + 3] = cur.c[g].w;
-            s[4 * g] = c[4 * g] >= 0 ? cur.s01[g].x : DBL_MAX; s[4 * g + 1] = c[4 * g + 1] >= 0 ? cur.s01[g].y : DBL_MAX;
-            s[4 * g + 2] = c[4 * g + 2] >= 0 ? cur.s23[g].x : DBL_MAX; s[4 * g + 3] = c[4 * g + 3] >= 0 ? cur.s23[g].y : DBL_MAX;
-        }
-        if (c[0] == -3) { c[0] = 0; s[0] = nan_score; } // k_solve's NaN model of the iteration (the reference's P3P): no inlier, every residual counts thr
+        if (it0 + 64 * IPL < rp.chunk_len) nxt = fetch(it0 + 64 * IPL);
+        int c[IPL][MPS];
+        double s[IPL][MPS];
         long long lc = -1;
         double ls = DBL_MAX;
 #pragma unroll
-        for (int k = 0; k < MPS; ++k) if (c[k] >= 0) { lc = max(lc, (long long)c[k]); ls = fmin(ls, s[k]); }
-        if (__all(lc <= run_cnt && !(ls < run_score))) continue; // nothing in these 64 iterations improves a record
+        for (int j = 0; j < IPL; ++j) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                c[j][4 * g] = cur.c[j][g].x; c[j][4 * g + 1] = cur.c[j][g].y; c[j][4 * g + 2] = cur.c[j][g].z; c[j][4 * g + 3] = cur.c[j][g].w;
+                s[j][4 * g] = c[j][4 * g] >= 0 ? cur.s01[j][g].x : DBL_MAX; s[j][4 * g + 1] = c[j][4 * g + 1] >= 0 ? cur.s01[j][g].y : DBL_MAX;
+                s[j][4 * g + 2] = c[j][4 * g + 2] >= 0 ? cur.s23[j][g].x : DBL_MAX; s[j][4 * g + 3] = c[j][4 * g + 3] >= 0 ? cur.s23[j][g].y : DBL_MAX;
+            }
+            if (c[j][0] == -3) { c[j][0] = 0; s[j][0] = nan_score; } // k_solve's NaN model of the iteration (the reference's P3P): no inlier, every residual counts thr
+#pragma unroll
+            for (int k = 0; k < MPS; ++k) if (c[j][k] >= 0) { lc = max(lc, (long long)c[j][k]); ls = fmin(ls, s[j][k]); }
+        }
+        if (__all(lc <= run_cnt && !(ls < run_score))) continue; // nothing in these iterations improves a record
         // exclusive prefix over lanes
         long long pc = lc;
         double psn = ls;
@@ -1549,30 +1556,43 @@ __global__ __launch_bounds__(64) void k_scan(RunParams rp, PairState *__restrict
         if (lane == 0) { ec = -1; es = DBL_MAX; }
         long long bc = max(run_cnt, ec);
         double bs = fmin(run_score, es);
-        // replay this iteration's models in order against the true running records
-        int k_ref = -1, k_min = -1, cnt_min = 0, cnt_ref = 0;
-        double score_min = 0;
+        // replay this lane's iterations, and each iteration's models, in order against the true running records
+        int k_ref[IPL], k_min[IPL], cnt_min[IPL], cnt_ref[IPL], mine = 0;
+        double score_min[IPL];
 #pragma unroll
-        for (int k = 0; k < MPS; ++k) {
-            if (c[k] >= 0) {
-                const bool more = (long long)c[k] > bc, better = s[k] < bs;
-                if (more || better) {
-                    if (more) bc = c[k];
-                    if (better) { bs = s[k]; k_min = k; score_min = s[k]; cnt_min = c[k]; }
-                    k_ref = k; cnt_ref = c[k];
+        for (int j = 0; j < IPL; ++j) {
+            k_ref[j] = -1; k_min[j] = -1; cnt_min[j] = 0; cnt_ref[j] = 0; score_min[j] = 0;
+#pragma unroll
+            for (int k = 0; k < MPS; ++k) {
+                if (c[j][k] >= 0) {
+                    const bool more = (long long)c[j][k] > bc, better = s[j][k] < bs;
+                    if (more || better) {
+                        if (more) bc = c[j][k];
+                        if (better) { bs = s[j][k]; k_min[j] = k; score_min[j] = s[j][k]; cnt_min[j] = c[j][k]; }
+                        k_ref[j] = k; cnt_ref[j] = c[j][k];
+                    }
                 }
             }
+            mine += k_ref[j] >= 0;
         }
-        const unsigned long long ball = __ballot(k_ref >= 0);
-        if (k_ref >= 0) {
-            const int pos = ntrig + __popcll(ball & ((1ull << lane) - 1ull));
-            if (pos < trig_cap) {
-                Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
-                tr.iter = (uint32_t)(rp.chunk_off + it); tr.k_ref = k_ref; tr.k_min = k_min; tr.cnt_min = cnt_min; tr.score_min = score_min;
-                tr.ref_score = DBL_MAX; tr.ref_cnt = 0; tr.cnt_ref = cnt_ref;
+        // triggers in iteration order: this lane's come after those of the lanes below it
+        int before = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(before, o, 64); if (lane >= o) before += v; }
+        const int step_total = __shfl(before, 63, 64);
+        int pos = ntrig + before - mine;
+#pragma unroll
+        for (int j = 0; j < IPL; ++j) {
+            if (k_ref[j] >= 0) {
+                if (pos < trig_cap) {
+                    Trigger &tr = triggers[(size_t)pair * trig_cap + pos];
+                    tr.iter = (uint32_t)(rp.chunk_off + it0 + IPL * lane + j); tr.k_ref = k_ref[j]; tr.k_min = k_min[j]; tr.cnt_min = cnt_min[j]; tr.score_min = score_min[j];
+                    tr.ref_score = DBL_MAX; tr.ref_cnt = 0; tr.cnt_ref = cnt_ref[j];
+                }
+                ++pos;
             }
         }
-        ntrig += __popcll(ball);
+        ntrig += step_total;
         run_cnt = max(run_cnt, tot_c);
         run_score = fmin(run_score, tot_s);
     }

@@ -57,6 +57,38 @@ def test_solvers_vs_oracle_and_reference(handle, capi, po, golden, kind):
         assert checked_ref == len(n) - len(REFERENCE_NAN_SOLUTIONS[kind]) and agree_ref == checked_ref, (agree_ref, checked_ref)
 
 
+def test_reference_nan_p3p_samples_never_have_a_real_pose_on_the_device(handle, capi, po):
+    """k_solve evaluates the reference's NaN-pose predicate (p3p_reference_nan) only on lanes whose own P3P found no pose; the oracle — like the
+    reference — evaluates it first and lets it override real roots.  The two agree as long as `predicate true` implies `the device solver finds nothing`.
+    Checked here on 60 000 minimal samples drawn the way the estimator draws them (headline generator, outliers and noise included; degenerate and
+    near-degenerate triples from tiny N): the oracle's predicate (orc_p3p_reference_nan, sqrt-and-divide arithmetic) on every sample against the device
+    solver's solution count through mdrp_solver_batch — no sample may have both, and the predicate fires often enough for the check to mean something."""
+    import ctypes as C
+    from mdrp_amd import synth
+    lib = po.lib()
+    lib.orc_p3p_reference_nan.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.orc_p3p_reference_nan.restype = C.c_int
+    rng = np.random.default_rng(2024)
+    X1, X2, D1, D2 = [], [], [], []
+    for k, n in enumerate((2000, 2000, 400, 60, 12, 5)):
+        b = synth.make_batch(31000 + 100 * k, 20, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
+        for j in range(20):
+            idx = np.stack([rng.choice(n, 3, replace=False) for _ in range(500)])
+            X1.append(b["x1"][j][idx]); X2.append(b["x2"][j][idx]); D1.append(b["d1"][j][idx]); D2.append(b["d2"][j][idx])
+    x1 = np.concatenate(X1) / 800.0; x2 = np.concatenate(X2) / 800.0; d1 = np.concatenate(D1); d2 = np.concatenate(D2)
+    S = len(d1)
+    x1h = np.concatenate([x1, np.ones((S, 3, 1))], axis=2); x2h = np.concatenate([x2, np.ones((S, 3, 1))], axis=2)
+    out, n_dev = handle.solver_batch(0, x1h, x2h, d1, d2)
+    xb = np.ascontiguousarray(x2h / np.linalg.norm(x2h, axis=2, keepdims=True))  # unit bearings of image 2 (sqrt and divide, as the oracle's caller forms them)
+    Xp = np.ascontiguousarray(x1h * d1[:, :, None])                                # back-projected points of image 1
+    dp = C.POINTER(C.c_double)
+    pred = np.array([lib.orc_p3p_reference_nan(xb[i].ctypes.data_as(dp), Xp[i].ctypes.data_as(dp)) for i in range(S)], dtype=bool)
+    both = np.nonzero(pred & (n_dev > 0))[0]
+    assert S == 60000 and pred.sum() > 300, (S, int(pred.sum()))
+    assert len(both) == 0, (len(both), both[:10], n_dev[both[:10]])
+    print(f"reference-NaN P3P samples: {int(pred.sum())} of {S}; none of them has a real pose on the device (solutions on the others: mean {n_dev[~pred].mean():.2f})")
+
+
 # ---------------------------------------------------------------------------------------------- scoring sweep
 def test_score_sweep_vs_reference_golden(handle, capi, po, golden):
     g = golden("scoring")
