@@ -119,6 +119,7 @@ struct mdrp_handle {
     DevBuf tags_s, tags2_s; // survivor lists ordered by candidate density (k_sort_tags)
     DevBuf tags2, model_count2, samples2; // odd chunks of a super-chunk (chunk c + 1 is solved beside the sweep of chunk c)
     DevBuf tags_v, surv_count; // survivors of k_count (unsorted, with density keys) and their number per pair
+    DevBuf tags_und, und_part, und_count; // k_count's two phases: hypotheses phase A left undecided, their partial candidate counts, their number per pair (stride 2)
     DevBuf rfrag;              // MFMA A fragments of the correspondences (k_prep): [pair][ceil(n_max/16)][64] x 16 B
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
@@ -301,6 +302,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->samples2.ensure(sizeof(uint32_t) * ssz * (size_t)n_tables * chunk_cap))) return rc;
     if ((rc = h->tags_v.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
+    if ((rc = h->tags_und.ensure(sizeof(uint32_t) * slots)) || (rc = h->und_part.ensure(sizeof(int32_t) * slots)) || (rc = h->und_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
     if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
     if ((rc = h->surv2_count.ensure(sizeof(int32_t) * batch))) return rc;
     const size_t groups_max = ((size_t)n_max + 15) / 16;
@@ -535,12 +537,26 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             {
                 hipEvent_t c0, c1;
                 if ((rc_ = get_events(h, &c0, &c1, 1))) return rc_;
+                // phase A: every hypothesis over the pair's leading tiles (all tiles where the records do not allow a split); phase B: the undecided
+                // ones over the rest (k_count, mdrp_kernels.h).  A run's first chunk has no record: phase A is the whole count, no phase B.
+                const bool two_phase = !(it0 == 0 && c == 0);
+                uint32_t *tags_u = h->tags_und.as<uint32_t>() + so;
+                int32_t *und_part = h->und_part.as<int32_t>() + so, *und_cnt = h->und_count.as<int32_t>() + 2 * (size_t)p0;
+                const uint4 *rfrag_p = h->rfrag.as<uint4>() + (size_t)p0 * groups_max * 64;
                 hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
-                                   surv1, (const int32_t *)nullptr); // (also clears the survivor counters k_count appends to)
+                                   surv1, (const int32_t *)nullptr, two_phase ? und_cnt : (int32_t *)nullptr); // (also clears the counters k_count appends to)
                 const dim3 cgrid((unsigned)pc * (unsigned)((len * mps + CNT_WG_MODELS - 1) / CNT_WG_MODELS));
                 HIPCHK(hipEventRecord(c0, s));
-                MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, h->rfrag.as<uint4>() + (size_t)p0 * groups_max * 64, models_p,
-                                    tags_c, mcount_c, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr);
+                MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, rfrag_p, models_p,
+                                    tags_c, mcount_c, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr,
+                                    two_phase ? 1 : 0, tags_u, und_part, und_cnt, (const int32_t *)nullptr);
+                if (two_phase) {
+                    hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, und_cnt, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
+                                       (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
+                    MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, rfrag_p, models_p,
+                                        tags_u, und_cnt, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr,
+                                        2, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, und_part);
+                }
                 HIPCHK(hipEventRecord(c1, s));
                 h->count_launches++;
             }
@@ -759,7 +775,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
-    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
+    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * 3 * sizeof(uint32_t) /*tags_v, tags_und, und_part*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
@@ -908,7 +924,7 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->params, &h->fuse, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
+                      &h->tags_v, &h->surv_count, &h->tags_und, &h->und_part, &h->und_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
                       &h->lm_stats};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -897,7 +897,7 @@ __device__ __forceinline__ int plan_block_scan(int v, int &total, int *s_w) {
 // begin (or null): the plan covers list entries [begin[stride p], counts[stride p]) of every pair — a sub-range of a list that is still growing
 MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const PairState *__restrict__ st, const int32_t *__restrict__ counts, int stride,
                                                              int per_wg, int32_t *__restrict__ plan, int32_t *__restrict__ zero_a,
-                                                             const int32_t *__restrict__ begin = nullptr) {
+                                                             const int32_t *__restrict__ begin = nullptr, int32_t *__restrict__ zero_b2 = nullptr /*[2 * batch], stride 2*/) {
     __shared__ int s_w[PLAN_THREADS / 64 + 1];
     int run = 0;
     for (int p0 = 0; p0 < batch; p0 += PLAN_THREADS) {
@@ -905,12 +905,33 @@ MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const P
         const int b = (p < batch && st[p].active) ? (counts[stride * p] - (begin ? begin[stride * p] : 0) + per_wg - 1) / per_wg : 0;
         int tot;
         const int ex = plan_block_scan(b, tot, s_w);
-        if (p < batch) { plan[p] = run + ex; if (zero_a) zero_a[p] = 0; }
+        if (p < batch) { plan[p] = run + ex; if (zero_a) zero_a[p] = 0; if (zero_b2) zero_b2[2 * p] = 0; }
         run += tot;
     }
     if (threadIdx.x == 0) plan[batch] = run;
 }
 
+// Two-phase count (round 6).  A garbage hypothesis keeps ~5 % of the correspondences as candidates; with cand_A candidates among the first R_A
+// records its total is at most cand_A + (N - R_A), and once THAT bound passes both record tests the hypothesis is retired without its remaining
+// N - R_A evaluations.  Phase A sweeps the pair's first T_A tiles (256 records each) for every hypothesis and retires what is decided; the few
+// that are not (true candidates, partial fits: ~8 % at 50 % outliers) go on an `undecided` list with their partial counts, and phase B — a second
+// launch over that list only — sweeps the remaining tiles and applies the unchanged test to the exact total.  T_A is a per-pair function of the
+// pair state alone (count_split_tiles: the point where a hypothesis with 1/16 candidates is decided), so both launches agree on it; any T_A gives
+// the same decisions for every hypothesis that reaches the final test, and the early ones are implied by it (cand <= cand_A + N - R_A).
+// Pairs whose records do not allow a split (no record yet; T_A within one tile of the end) are counted in full by phase A, as before.
+__device__ __forceinline__ int count_split_tiles(const PairState &ps, int n_tiles) {
+    if (!(ps.best_min_score < DBL_MAX) || n_tiles < 4) return n_tiles;
+    const double rec_score = ps.best_min_score * (1.0 + 1e-12);
+    long long bar = (long long)floor((double)ps.n - rec_score / ps.sq_thr); // thr (n - c) >= rec_score  for  c <= bar  (heuristic here; the decisions use the exact expression)
+    if (bar > (long long)ps.best_min_cnt) bar = (long long)ps.best_min_cnt;
+    if (bar <= 0) return n_tiles;
+    const long long ra = (((long long)ps.n - bar) * 16 + 14) / 15 + 32;     // a hypothesis with <= 1/16 candidates is decided after this many records
+    const int ta = (int)((ra + 255) >> 8);
+    return ta + 2 > n_tiles ? n_tiles : ta;
+}
+
+// PHASE 0: the whole sweep in one launch (unit path).  1: phase A (tags / model_count = the chunk's tag lists; undecided -> tags_und / und_part / und_count).
+// 2: phase B (tags / model_count = the undecided lists, part_in = their partial counts).
 template <bool POSE, bool RAWF = false> // RAWF: the model IS a fundamental matrix (first nine doubles, row-major) — 7-point baseline
 __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const PairState *__restrict__ st, const uint4 *__restrict__ rfrag,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags,
@@ -918,7 +939,9 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
                                                           uint32_t *__restrict__ tags_surv,
                                                           int32_t *__restrict__ surv_count, unsigned long long *__restrict__ stats,
                                                           int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/,
-                                                          const int32_t *__restrict__ tag_begin = nullptr /*or: entries [tag_begin[2 p], model_count[2 p]) of the tag lists*/) {
+                                                          const int32_t *__restrict__ tag_begin = nullptr /*or: entries [tag_begin[2 p], model_count[2 p]) of the tag lists*/,
+                                                          int phase = 0, uint32_t *__restrict__ tags_und = nullptr, int32_t *__restrict__ und_part = nullptr,
+                                                          int32_t *__restrict__ und_count = nullptr, const int32_t *__restrict__ part_in = nullptr) {
     // LDS: first the B fragments of the workgroup's 512 hypotheses (prologue), then the A-fragment tiles of the sweep
     constexpr int A_TILE_GROUPS = 16;                                   // 16 groups = 256 correspondences = 16 KiB per tile
     __shared__ uint4 s_lds[2 * A_TILE_GROUPS * 64];                     // 32 KiB: two tiles (double buffer)
@@ -940,11 +963,12 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     // ---- prologue: 64 lanes build the B fragments of 64 hypotheses per round (wave-private LDS); the loads of both rounds
     // are issued before the arithmetic of the first (tag -> model is a dependent pair of L2 round trips)
     uint32_t slot_r[CNT_ROUNDS] = {};
+    int part_r[CNT_ROUNDS] = {}; // phase B: candidates counted by phase A
     double mq[CNT_ROUNDS][4], mt[CNT_ROUNDS][3], mf[CNT_ROUNDS][2], ms[CNT_ROUNDS][2];
 #pragma unroll
     for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
-        if (i < cnt) slot_r[r] = tags_p[i] & 0xFFFFFFu;
+        if (i < cnt) { slot_r[r] = tags_p[i] & 0xFFFFFFu; if (phase == 2) part_r[r] = part_in[slot_base + tbeg + i]; }
     }
 #pragma unroll
     for (int r = 0; r < CNT_ROUNDS; ++r) {
@@ -1048,6 +1072,8 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const int G = (n + 15) >> 4;
     const uint4 *A = rfrag + (size_t)pair * ((rp.n_max + 15) >> 4) * 64;
     const int n_tiles = (G + A_TILE_GROUPS - 1) / A_TILE_GROUPS;
+    const int t_split = phase == 0 ? n_tiles : count_split_tiles(ps, n_tiles);
+    const int t_lo = phase == 2 ? t_split : 0, t_hi = phase == 1 ? t_split : n_tiles; // this launch sweeps the tiles [t_lo, t_hi)
     uint4 stage[4];
     auto fetch = [&](int tile) { // 256 threads x 4 x 16 B = one tile; past the last group: zeros (C = 0: never an outlier)
         const int g0 = tile * A_TILE_GROUPS;
@@ -1061,13 +1087,14 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
 #pragma unroll
         for (int k = 0; k < 4; ++k) s_lds[buf * A_TILE_GROUPS * 64 + k * CNT_THREADS + tid] = stage[k];
     };
-    fetch(0);
-    commit(0);
+    if (t_lo >= t_hi) return; // (phase B of a pair that was not split: nothing on its undecided list either; uniform per workgroup)
+    fetch(t_lo);
+    commit(t_lo & 1);
     __syncthreads();
     // every tile is swept as 16 groups (zero rows past the end cost nothing but their share of the last tile)
-    for (int tile = 0; tile < n_tiles; ++tile) {
+    for (int tile = t_lo; tile < t_hi; ++tile) {
         const int buf = tile & 1;
-        if (tile + 1 < n_tiles) fetch(tile + 1);
+        if (tile + 1 < t_hi) fetch(tile + 1);
         if (!idle) {
             const uint4 *T = s_lds + buf * A_TILE_GROUPS * 64 + lane;
             uint4 f0 = T[0], f1 = T[64];
@@ -1089,13 +1116,16 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
                 }
             }
         }
-        if (tile + 1 < n_tiles) commit(buf ^ 1); // the other buffer was last read before the previous barrier
+        if (tile + 1 < t_hi) commit(buf ^ 1); // the other buffer was last read before the previous barrier
         __syncthreads();
     }
     if (idle) return;
     // ---- epilogue: totals per hypothesis, retirement, survivor list
     uint32_t *s_out = reinterpret_cast<uint32_t *>(&s_frag[wave][0][0]); // wave-private, fragments are in registers now
-    const int pad = n_tiles * A_TILE_GROUPS * 16 - n; // zero rows past the end always count as candidates
+    const int swept = (t_hi - t_lo) * A_TILE_GROUPS * 16, real = min(max(n - t_lo * A_TILE_GROUPS * 16, 0), swept);
+    const int pad = swept - real; // zero rows past the end always count as candidates
+    const bool split_a = phase == 1 && t_hi < n_tiles;             // phase A of a split pair: totals are not known yet
+    const int rest = split_a ? n - t_hi * A_TILE_GROUPS * 16 : 0;  // records phase B still has to sweep
 #pragma unroll
     for (int t = 0; t < CNT_TILES; ++t) {
         float o = cand[t];
@@ -1111,24 +1141,29 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     for (int r = 0; r < CNT_ROUNDS; ++r) {
         const int i = m0 + 64 * r + lane;
         const bool live = i < cnt;
-        const int cnd = live ? (int)s_out[64 * r + lane] : 0;
+        const int cnd_here = live ? (int)s_out[64 * r + lane] + part_r[r] : 0;
+        const int cnd = cnd_here + rest; // phase A of a split pair: the most the total can still become
         if (cand_out && live) cand_out[i] = cnd;
         const bool surv = live && ((long long)cnd > rec_cnt || thr * (double)(n - cnd) < rec_score); // else: its slot keeps k_solve's -2
         const unsigned long long ball = __ballot(surv);
         if (ball) {
             int base = 0;
             const int first = __ffsll((long long)ball) - 1;
-            if (lane == first) base = atomicAdd(&surv_count[pair], __popcll(ball));
+            if (lane == first) base = atomicAdd(split_a ? &und_count[2 * pair] : &surv_count[pair], __popcll(ball));
             base = __shfl(base, first, 64);
             if (surv) {
-                const uint32_t key = (uint32_t)min(PROBE_PTS, (int)(((long long)cnd * PROBE_PTS + n - 1) / n));
-                tags_surv[slot_base + base + __popcll(ball & ((1ull << lane) - 1ull))] = slot_r[r] | (key << 24);
+                const size_t at = slot_base + base + __popcll(ball & ((1ull << lane) - 1ull));
+                if (split_a) { tags_und[at] = slot_r[r]; und_part[at] = cnd_here; } // undecided: phase B finishes its count
+                else {
+                    const uint32_t key = (uint32_t)min(PROBE_PTS, (int)(((long long)cnd * PROBE_PTS + n - 1) / n));
+                    tags_surv[at] = slot_r[r] | (key << 24);
+                }
             }
         }
     }
     if (stats && lane == 0 && wave == 0 && blk == 0) { // per pair, once: evaluations the CPU loop would do, and those the MFMA sweep does
-        atomicAdd(&stats[0], (unsigned long long)cnt * (unsigned long long)n);
-        atomicAdd(&stats[1], (unsigned long long)(((cnt + 15) / 16) * 16) * (unsigned long long)(n_tiles * A_TILE_GROUPS * 16));
+        if (phase != 2) atomicAdd(&stats[0], (unsigned long long)cnt * (unsigned long long)n);
+        atomicAdd(&stats[1], (unsigned long long)(((cnt + 15) / 16) * 16) * (unsigned long long)swept);
     }
 }
 
