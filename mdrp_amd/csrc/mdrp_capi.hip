@@ -119,7 +119,8 @@ struct mdrp_handle {
     DevBuf tags_s, tags2_s; // survivor lists ordered by candidate density (k_sort_tags)
     DevBuf tags2, model_count2, samples2; // odd chunks of a super-chunk (chunk c + 1 is solved beside the sweep of chunk c)
     DevBuf tags_v, surv_count; // survivors of k_count (unsorted, with density keys) and their number per pair
-    DevBuf tags_und, und_part, und_count; // k_count's two phases: hypotheses phase A left undecided, their partial candidate counts, their number per pair (stride 2)
+    DevBuf cand_stat; // [2 batch] u64: candidates | evaluations of the run's first chunk per pair (k_count's split point)
+    DevBuf und_count; // k_count's two phases: hypotheses phase A left undecided, per pair (stride 2); the list itself and the partial counts alias the sorted tag lists
     DevBuf rfrag;              // MFMA A fragments of the correspondences (k_prep): [pair][ceil(n_max/16)][64] x 16 B
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
@@ -248,7 +249,7 @@ constexpr int HOST_SLICE_PAIRS = 256; // pairs per H2D slice of a host-buffer ca
 
 int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const double *d1, const double *d2, int batch,
              int n_max, const int32_t *n_host, const mdrp_camera *cam1, const mdrp_camera *cam2, const mdrp_ransac_opt *ro,
-             const mdrp_bundle_opt *bo, int chunk_cap, uint8_t *mask_dev, ResultDev *results_dev, const HostSrc *host) {
+             const mdrp_bundle_opt *bo, int chunk_cap, uint8_t *mask_dev, ResultDev *results_dev, const HostSrc *host, int batch_call) {
     hipStream_t s = h->stream;
     const int est_shift = (kind == MDRP_CALIB && ro->monodepth_estimate_shift) ? 1 : 0;
     const bool classic = kind >= MDRP_RELPOSE_5PT;              // non-monodepth baselines (mdrp_classic.h)
@@ -302,7 +303,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     if ((rc = h->samples2.ensure(sizeof(uint32_t) * ssz * (size_t)n_tables * chunk_cap))) return rc;
     if ((rc = h->tags_v.ensure(sizeof(uint32_t) * slots))) return rc;
     if ((rc = h->surv_count.ensure(sizeof(int32_t) * batch))) return rc;
-    if ((rc = h->tags_und.ensure(sizeof(uint32_t) * slots)) || (rc = h->und_part.ensure(sizeof(int32_t) * slots)) || (rc = h->und_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
+    if ((rc = h->cand_stat.ensure(sizeof(unsigned long long) * 2 * batch))) return rc;
+    if ((rc = h->und_count.ensure(sizeof(int32_t) * 2 * batch))) return rc;
     if ((rc = h->cplan.ensure(sizeof(int32_t) * ((size_t)batch + 1)))) return rc;
     if ((rc = h->surv2_count.ensure(sizeof(int32_t) * batch))) return rc;
     const size_t groups_max = ((size_t)n_max + 15) / 16;
@@ -363,8 +365,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const bool use_bound = env_int("MDRP_BOUND", 1) != 0;       // fp32 lower-bound stage between k_count and the fp64 sweep
     // lanes per LO problem: one wavefront when there are many short problems; four when the batch is small or the pairs are large (N = 5000:
     // a one-wavefront problem is 4 ms long and the launch ends with its stragglers — 45.6 against 43.9 ms per 1024 varying-focal pairs)
-    const int lo_threads = env_int("MDRP_LO_THREADS", (batch >= 128 && n_max < 4096) ? 64 : 256);
-    const int final_threads = env_int("MDRP_FINAL_THREADS", batch >= 4096 ? 64 : 256);
+    // (chosen from the CALL's batch, not this pass's: the lane count fixes the LM's summation tree, and how a call is cut into passes depends on the
+    // memory that happens to be free — a pair must get the same record whatever pass it falls into)
+    const int lo_threads = env_int("MDRP_LO_THREADS", (batch_call >= 128 && n_max < 4096) ? 64 : 256);
+    const int final_threads = env_int("MDRP_FINAL_THREADS", batch_call >= 4096 ? 64 : 256);
     // the inlier-only final refinement walks a compacted index of the inliers instead of masking every record (where the three lists fit 32 KiB of LDS)
     const int mask_index = lm_mask_index_on(n_max);
     // work lists of the classic LM (mdrp_classic.h ClmList)
@@ -434,6 +438,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         for (int c = 0; c < n_chunks; ++c) super_len += lens[c];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
         HIPCHK(hipMemsetAsync(h->counters.p, 0, COUNTERS_BYTES, s));
+        if (it0 == 0) HIPCHK(hipMemsetAsync(h->cand_stat.p, 0, sizeof(unsigned long long) * 2 * batch, s));
         // Three-stream pipeline over the chunks of a super-chunk (the benchmark shape: 128 | 9872 iterations):
         //   main:  prep solve0 count0 sort0 score0 scan0 | (wait solve1) count1 bound1 sort1 score1 scan1 | gate, final refinements (fused tail) | walk
         //   aux :       (after solve0) solve1 ...
@@ -540,8 +545,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 // phase A: every hypothesis over the pair's leading tiles (all tiles where the records do not allow a split); phase B: the undecided
                 // ones over the rest (k_count, mdrp_kernels.h).  A run's first chunk has no record: phase A is the whole count, no phase B.
                 const bool two_phase = !(it0 == 0 && c == 0);
-                uint32_t *tags_u = h->tags_und.as<uint32_t>() + so;
-                int32_t *und_part = h->und_part.as<int32_t>() + so, *und_cnt = h->und_count.as<int32_t>() + 2 * (size_t)p0;
+                unsigned long long *cand_stat = h->cand_stat.as<unsigned long long>() + 2 * (size_t)p0;
+                // The undecided list lives where this chunk's SORTED list will be written once the counts are done (k_sort_tags, below), the partial counts
+                // in the other parity's sorted list, whose last reader was the previous chunk's exact sweep: no scratch of their own.
+                uint32_t *tags_u = tags_sc;
+                int32_t *und_part = reinterpret_cast<int32_t *>((odd ? h->tags_s : h->tags2_s).as<uint32_t>() + so), *und_cnt = h->und_count.as<int32_t>() + 2 * (size_t)p0;
                 const uint4 *rfrag_p = h->rfrag.as<uint4>() + (size_t)p0 * groups_max * 64;
                 hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, mcount_c, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
                                    surv1, (const int32_t *)nullptr, two_phase ? und_cnt : (int32_t *)nullptr); // (also clears the counters k_count appends to)
@@ -549,13 +557,13 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 HIPCHK(hipEventRecord(c0, s));
                 MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, rfrag_p, models_p,
                                     tags_c, mcount_c, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr,
-                                    two_phase ? 1 : 0, tags_u, und_part, und_cnt, (const int32_t *)nullptr);
+                                    1, tags_u, und_part, und_cnt, (const int32_t *)nullptr, cand_stat);
                 if (two_phase) {
                     hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, und_cnt, 2, CNT_WG_MODELS, h->cplan.as<int32_t>(),
                                        (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
                     MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, rfrag_p, models_p,
                                         tags_u, und_cnt, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr,
-                                        2, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, und_part);
+                                        2, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, und_part, cand_stat);
                 }
                 HIPCHK(hipEventRecord(c1, s));
                 h->count_launches++;
@@ -775,7 +783,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
-    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * 3 * sizeof(uint32_t) /*tags_v, tags_und, und_part*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
+    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
@@ -788,7 +796,7 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
         rc = run_pass(h, kind, x1 + (size_t)2 * p0 * n_max, x2 + (size_t)2 * p0 * n_max, d1 ? d1 + (size_t)p0 * n_max : nullptr,
                       d2 ? d2 + (size_t)p0 * n_max : nullptr, nb,
                       n_max, n_host.data() + p0, cam1 ? cam1 + p0 : nullptr, cam2 ? cam2 + p0 : nullptr, ro, bo, chunk_cap,
-                      mask + (size_t)p0 * n_max, h->results.as<ResultDev>() + p0, host ? &hs : nullptr);
+                      mask + (size_t)p0 * n_max, h->results.as<ResultDev>() + p0, host ? &hs : nullptr, batch);
         if (rc) return rc;
     }
     return MDRP_OK;
@@ -924,7 +932,7 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->params, &h->fuse, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->tags_und, &h->und_part, &h->und_count, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
+                      &h->tags_v, &h->surv_count, &h->und_count, &h->cand_stat, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
                       &h->lm_stats};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -919,13 +919,19 @@ MDRP_GLOBAL __launch_bounds__(PLAN_THREADS) void k_count_plan(int batch, const P
 // pair state alone (count_split_tiles: the point where a hypothesis with 1/16 candidates is decided), so both launches agree on it; any T_A gives
 // the same decisions for every hypothesis that reaches the final test, and the early ones are implied by it (cand <= cand_A + N - R_A).
 // Pairs whose records do not allow a split (no record yet; T_A within one tile of the end) are counted in full by phase A, as before.
-__device__ __forceinline__ int count_split_tiles(const PairState &ps, int n_tiles) {
-    if (!(ps.best_min_score < DBL_MAX) || n_tiles < 4) return n_tiles;
+// cand_stat[2 pair] / [2 pair + 1]: candidates and evaluations of the hypotheses a FULL count of this call has seen for the pair so far (the run's
+// first chunk: 128 iterations of mostly garbage) — the pair's own garbage candidate rate (5 % for calibrated poses at 50 % outliers, 10-15 % for the
+// focal estimators' fundamental matrices), from which the split point follows.
+__device__ __forceinline__ int count_split_tiles(const PairState &ps, int n_tiles, const unsigned long long *__restrict__ cand_stat, int pair) {
+    if (!(ps.best_min_score < DBL_MAX) || n_tiles < 4 || !cand_stat) return n_tiles;
+    const unsigned long long cs = cand_stat[2 * pair], es = cand_stat[2 * pair + 1];
+    if (es == 0) return n_tiles;
     const double rec_score = ps.best_min_score * (1.0 + 1e-12);
     long long bar = (long long)floor((double)ps.n - rec_score / ps.sq_thr); // thr (n - c) >= rec_score  for  c <= bar  (heuristic here; the decisions use the exact expression)
     if (bar > (long long)ps.best_min_cnt) bar = (long long)ps.best_min_cnt;
     if (bar <= 0) return n_tiles;
-    const long long ra = (((long long)ps.n - bar) * 16 + 14) / 15 + 32;     // a hypothesis with <= 1/16 candidates is decided after this many records
+    const double g = fmin(0.5, 1.1 * (double)cs / (double)es + 0.005);      // garbage candidate rate, with a margin: a hypothesis at that rate is decided after ra records
+    const long long ra = (long long)((double)((long long)ps.n - bar) / (1.0 - g)) + 32;
     const int ta = (int)((ra + 255) >> 8);
     return ta + 2 > n_tiles ? n_tiles : ta;
 }
@@ -933,7 +939,7 @@ __device__ __forceinline__ int count_split_tiles(const PairState &ps, int n_tile
 // PHASE 0: the whole sweep in one launch (unit path).  1: phase A (tags / model_count = the chunk's tag lists; undecided -> tags_und / und_part / und_count).
 // 2: phase B (tags / model_count = the undecided lists, part_in = their partial counts).
 template <bool POSE, bool RAWF = false> // RAWF: the model IS a fundamental matrix (first nine doubles, row-major) — 7-point baseline
-__global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const PairState *__restrict__ st, const uint4 *__restrict__ rfrag,
+__global__ __launch_bounds__(CNT_THREADS, 4) void k_count(RunParams rp, const PairState *__restrict__ st, const uint4 *__restrict__ rfrag,
                                                           const Model *__restrict__ models, const uint32_t *__restrict__ tags,
                                                           const int32_t *__restrict__ model_count, const int32_t *__restrict__ plan,
                                                           uint32_t *__restrict__ tags_surv,
@@ -941,7 +947,8 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
                                                           int32_t *__restrict__ cand_out /*unit path: [models] candidate counts, or null*/,
                                                           const int32_t *__restrict__ tag_begin = nullptr /*or: entries [tag_begin[2 p], model_count[2 p]) of the tag lists*/,
                                                           int phase = 0, uint32_t *__restrict__ tags_und = nullptr, int32_t *__restrict__ und_part = nullptr,
-                                                          int32_t *__restrict__ und_count = nullptr, const int32_t *__restrict__ part_in = nullptr) {
+                                                          int32_t *__restrict__ und_count = nullptr, const int32_t *__restrict__ part_in = nullptr,
+                                                          unsigned long long *__restrict__ cand_stat = nullptr /*[2 batch]: see count_split_tiles*/) {
     // LDS: first the B fragments of the workgroup's 512 hypotheses (prologue), then the A-fragment tiles of the sweep
     constexpr int A_TILE_GROUPS = 16;                                   // 16 groups = 256 correspondences = 16 KiB per tile
     __shared__ uint4 s_lds[2 * A_TILE_GROUPS * 64];                     // 32 KiB: two tiles (double buffer)
@@ -1072,7 +1079,7 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
     const int G = (n + 15) >> 4;
     const uint4 *A = rfrag + (size_t)pair * ((rp.n_max + 15) >> 4) * 64;
     const int n_tiles = (G + A_TILE_GROUPS - 1) / A_TILE_GROUPS;
-    const int t_split = phase == 0 ? n_tiles : count_split_tiles(ps, n_tiles);
+    const int t_split = phase == 0 ? n_tiles : count_split_tiles(ps, n_tiles, cand_stat, pair);
     const int t_lo = phase == 2 ? t_split : 0, t_hi = phase == 1 ? t_split : n_tiles; // this launch sweeps the tiles [t_lo, t_hi)
     uint4 stage[4];
     auto fetch = [&](int tile) { // 256 threads x 4 x 16 B = one tile; past the last group: zeros (C = 0: never an outlier)
@@ -1143,6 +1150,10 @@ __global__ __launch_bounds__(CNT_THREADS, 3) void k_count(RunParams rp, const Pa
         const bool live = i < cnt;
         const int cnd_here = live ? (int)s_out[64 * r + lane] + part_r[r] : 0;
         const int cnd = cnd_here + rest; // phase A of a split pair: the most the total can still become
+        if (cand_stat && phase == 1 && !split_a && rec_cnt == 0 && !(ps.best_min_score < DBL_MAX)) { // the run's first chunk (no record yet): the pair's candidate statistics
+            const int tot = wave_sum_i(cnd_here), lv = __popcll(__ballot(live));
+            if (lane == 0 && lv) { atomicAdd(&cand_stat[2 * pair], (unsigned long long)tot); atomicAdd(&cand_stat[2 * pair + 1], (unsigned long long)lv * (unsigned long long)n); }
+        }
         if (cand_out && live) cand_out[i] = cnd;
         const bool surv = live && ((long long)cnd > rec_cnt || thr * (double)(n - cnd) < rec_score); // else: its slot keeps k_solve's -2
         const unsigned long long ball = __ballot(surv);
