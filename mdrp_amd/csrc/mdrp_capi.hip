@@ -344,19 +344,19 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     rp.mps = mps; rp.sample_sz = ssz;
 
     // normalisation, record layout, MFMA fragments and pair states of the pairs [p0, p0 + pc) (one workgroup per pair, bases offset by p0)
-    auto launch_prep = [&](int p0, int pc) {
+    auto launch_prep = [&](int p0, int pc, hipStream_t ps_) {
         const size_t o2 = (size_t)2 * p0 * n_max, o1 = (size_t)p0 * n_max;
         double *pts_p = h->pts.as<double>() + o1 * PT_STRIDE;
         uint4 *rfrag_p = h->rfrag.as<uint4>() + (size_t)p0 * groups_max * 64;
         if (classic)
-            hipLaunchKernelGGL(kc_prep, dim3(pc), dim3(256), 0, s, rp, x1 + o2, x2 + o2, d_nper + p0, d_table_of + p0, d_cams1 + p0, d_cams2 + p0,
+            hipLaunchKernelGGL(kc_prep, dim3(pc), dim3(256), 0, ps_, rp, x1 + o2, x2 + o2, d_nper + p0, d_table_of + p0, d_cams1 + p0, d_cams2 + p0,
                                ro->max_epipolar_error, bo->loss_scale, pts_p, h->st.as<PairState>() + p0, rfrag_p);
         else
-            hipLaunchKernelGGL(k_prep, dim3(pc), dim3(256), 0, s, rp, x1 + o2, x2 + o2, d1 + o1, d2 + o1, d_nper + p0, d_table_of + p0, d_cams1 + p0, d_cams2 + p0,
+            hipLaunchKernelGGL(k_prep, dim3(pc), dim3(256), 0, ps_, rp, x1 + o2, x2 + o2, d1 + o1, d2 + o1, d_nper + p0, d_table_of + p0, d_cams1 + p0, d_cams2 + p0,
                                ro->max_epipolar_error, ro->max_reproj_error, bo->loss_scale, pts_p, h->dep.as<double>() + 2 * o1, h->st.as<PairState>() + p0, rfrag_p);
     };
     if (!host) { // device-resident inputs: everything is there (host buffers: the copies and k_prep are issued slice by slice below)
-        launch_prep(0, batch);
+        launch_prep(0, batch, s);
         HIPCHK(hipGetLastError());
     }
 
@@ -605,6 +605,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // ---- host buffers (MDRP_MEM_HOST): the correspondences arrive slice by slice on the copy stream; k_prep and the second chunk's solver (the
         // long one: 1.6 ms per 1024 pairs) of slice i run while slice i + 1 is on its way over PCIe
         bool solved1 = false; // the second chunk's solver has been issued (slice by slice)
+        int swept0 = 0;       // pairs whose first chunk the sliced front has swept already
         if (host && it0 == 0) {
             const bool sliced = piped && n_chunks >= 2 && batch >= 2 * HOST_SLICE_PAIRS;
             const int sl = sliced ? HOST_SLICE_PAIRS : batch;
@@ -618,21 +619,31 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     HIPCHK(hipMemcpyAsync(const_cast<double *>(d1) + o1, host->d1 + o1, n1, hipMemcpyHostToDevice, cs));
                     HIPCHK(hipMemcpyAsync(const_cast<double *>(d2) + o1, host->d2 + o1, n1, hipMemcpyHostToDevice, cs));
                 }
-                if (sliced) { HIPCHK(hipEventRecord(h->ev_copied, cs)); HIPCHK(hipStreamWaitEvent(s, h->ev_copied, 0)); }
-                launch_prep(p0, pc);
-                if (!sliced) break;
-                HIPCHK(hipEventRecord(h->ev_prepped, s));
-                HIPCHK(hipStreamWaitEvent(aux, h->ev_prepped, 0));
-                if ((rc = issue_solve(1, aux, p0, pc))) return rc;   // the long solver of this slice beside the next slices' copies
+                if (!sliced) { launch_prep(p0, pc, s); break; }
+                // k_prep and the long solver of the slice on the solver stream, beside the next slices' copies (the main stream sweeps the first chunk)
+                HIPCHK(hipEventRecord(h->ev_copied, cs)); HIPCHK(hipStreamWaitEvent(aux, h->ev_copied, 0));
+                if (p0 == 0) HIPCHK(hipStreamWaitEvent(aux, h->ev_tables, 0)); // (the per-call parameters were uploaded on the main stream)
+                launch_prep(p0, pc, aux);
+                HIPCHK(hipEventRecord(h->ev_prepped, aux));
+                if ((rc = issue_solve(1, aux, p0, pc))) return rc;
+                // The first chunk is swept in TWO parts only: everything but the last slice as soon as the last-but-one slice is prepared (beside the
+                // last slice's copy), the last slice behind its own k_prep.  (Its exact sweep is a fixed ~0.5 ms of serial record loops per workgroup
+                // whatever the number of pairs: one sweep per slice cost four times that on the main stream, 10.3 ms per step against 10.0.)
+                const bool last = p0 + sl >= batch, last_but_one = !last && p0 + 2 * sl >= batch;
+                if (last_but_one || last) HIPCHK(hipStreamWaitEvent(s, h->ev_prepped, 0)); // (the prep of this slice and, by stream order, of every slice before it)
+                if (last_but_one) { swept0 = p0 + pc; if ((rc = issue_solve(0, s, 0, swept0)) || (rc = sweep_chunk(0, 0, swept0))) return rc; }
+                if (last) { if ((rc = issue_solve(0, s, swept0, batch - swept0)) || (rc = sweep_chunk(0, swept0, batch - swept0))) return rc; swept0 = batch; }
             }
-            // (the first chunk is NOT sliced: its exact sweep is a fixed ~0.5 ms of serial record loops per workgroup whatever the number of pairs -
-            // four slices cost four times that on the main stream, measured 10.3 ms per step against 9.6 with one sweep behind the last slice)
             if (sliced) { HIPCHK(hipEventRecord(h->ev_solved[1], aux)); solved1 = true; }
         }
-        if ((rc = issue_solve(0, s, 0, batch))) return rc;
+        if (swept0 < batch && (rc = issue_solve(0, s, 0, batch))) return rc;
         if (piped) HIPCHK(hipEventRecord(h->ev_solved[0], s));
         for (int c = 0; c < n_chunks; ++c) {
             rp.chunk_len = (int)lens[c]; rp.chunk_off = offs[c];
+            if (c == 0 && swept0 >= batch) { // (the sliced front has swept the first chunk already)
+                if (piped) HIPCHK(hipEventRecord(h->ev_scanned[0], s));
+                continue;
+            }
             if (piped && c + 1 < n_chunks && !(c == 0 && solved1)) {
                 // the sampler tables advance in chunk order; chunk c + 1 reuses the lists chunk c - 1 was swept from
                 HIPCHK(hipStreamWaitEvent(aux, c == 0 ? h->ev_solved[0] : h->ev_scanned[c - 1], 0));

@@ -11,7 +11,7 @@ O=$R/gpurun_out/${TAG}_$W
 mkdir -p $O $R/profiles
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --extra-configs 0 --workload $W --batch $B > $O/bench_prof.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o kt -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --extra-configs 0 --c5-share 0 --latency 0 --workload $W --batch $B > $O/bench_prof.log 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 python3 $R/tools/rocpd_summary.py "$DB" > $O/kernel_stats.txt
 python3 $R/tools/rocpd_timeline.py "$DB" 40 > $O/timeline.txt
@@ -22,13 +22,13 @@ for C in "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE GRBM_GUI_ACTIVE" \
   i=$((i+1)); rm -rf /tmp/pmc_$i
   # counter collection serialises kernel dispatches: the fused tail (last LO launch and final refinements side by side) cannot
   # overlap then and would only show its bounded waits - the PMC passes profile the same kernels in the unfused order
-  MDRP_FUSE_TAIL=0 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$i -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --extra-configs 0 --workload $W --batch $B > $O/pmc_$i.log 2>&1
+  MDRP_FUSE_TAIL=0 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_$i -o c -- python3 $R/bench.py --steps 1 --warmup 1 --cpu-pairs 0 --host-steps 0 --inflight 1 --extra-configs 0 --c5-share 0 --latency 0 --workload $W --batch $B > $O/pmc_$i.log 2>&1
   F=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$F" ]; then grep -E "Counter_Name|mdrp::" "$F" > $O/pmc_$i.csv; else echo "pass $i: no counters"; tail -3 $O/pmc_$i.log; fi
 done
 python3 $R/tools/pmc_json.py $W $B 2 $O/pmc_1.csv $O/pmc_2.csv $O/pmc_3.csv $O/pmc_4.csv > $O/pmc.json
 cp $O/pmc.json $R/profiles/${TAG}_pmc_$W.json   # so that the bench line below cites this round's PMC passes
-cd $R && python3 bench.py --workload $W --batch $B --extra-configs 0 --cpu-pairs ${CPU_PAIRS:-0} > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400
+cd $R && python3 bench.py --workload $W --batch $B --extra-configs 0 --c5-share 0 --latency 0 --cpu-pairs ${CPU_PAIRS:-0} > $O/bench.json 2> $O/bench.err; tail -1 $O/bench.json | cut -c1-400
 cp $O/kernel_stats.txt $R/profiles/${TAG}_${W}_kernel_stats.txt; cp $O/timeline.txt $R/profiles/${TAG}_${W}_timeline.txt
 tail -1 $O/bench.json > $R/profiles/${TAG}_${W}_bench.json
 mkdir -p $R/gpurun_out/profiles_$TAG; cp $R/profiles/${TAG}_*${W}* $R/gpurun_out/profiles_$TAG/
