@@ -582,13 +582,24 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 HIPCHK(hipEventRecord(b1, s));
                 surv_tags = tags_c; surv_cnt = surv2;
             }
-            hipLaunchKernelGGL(k_sort_tags, dim3(pc), dim3(256), 0, s, r, st_p, mcount_c, surv_cnt, surv_tags, tags_sc);
             int32_t *plan = h->plan.as<int32_t>(), *totals = plan + 2 * (size_t)batch + 2; // (the slice's plan uses the head of the buffer, `totals` stays where it is)
-            hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, mcount_c, plan, totals);
-            HIPCHK(hipEventRecord(e0, s));
-            const dim3 grid((unsigned)pc * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
-            MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, r, st_p, pts_p, models_p, tags_sc, mcount_c,
-                                h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, plan, totals);
+            if (batch_call <= SCORE_WAVE_MAX_PAIRS) {
+                // few pairs: one WAVEFRONT per hypothesis (k_score_w) — a lane per hypothesis is a 0.3 ms serial record loop however few there are
+                hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, surv_cnt, 1, SCW_THREADS / 64, plan, (int32_t *)nullptr, (const int32_t *)nullptr, (int32_t *)nullptr);
+                hipLaunchKernelGGL(k_sort_tags, dim3(pc), dim3(256), 0, s, r, st_p, mcount_c, surv_cnt, surv_tags, tags_sc);
+                HIPCHK(hipEventRecord(e0, s));
+                const long long ub = (long long)pc * ((len * mps + SCW_THREADS / 64 - 1) / (SCW_THREADS / 64));
+                const dim3 grid((unsigned)std::min<long long>(ub, (long long)h->num_cu * 32));
+                MDRP_SWEEP_DISPATCH(k_score_w, kind, grid, dim3(SCW_THREADS), 0, s, r, st_p, pts_p, models_p, tags_sc, mcount_c,
+                                    h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, plan);
+            } else {
+                hipLaunchKernelGGL(k_sort_tags, dim3(pc), dim3(256), 0, s, r, st_p, mcount_c, surv_cnt, surv_tags, tags_sc);
+                hipLaunchKernelGGL(k_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, mcount_c, plan, totals);
+                HIPCHK(hipEventRecord(e0, s));
+                const dim3 grid((unsigned)pc * (unsigned)((len * mps + SCORE_THREADS - 1) / SCORE_THREADS));
+                MDRP_SWEEP_DISPATCH(k_score, kind, grid, dim3(SCORE_THREADS), tile_bytes, s, r, st_p, pts_p, models_p, tags_sc, mcount_c,
+                                    h->slot_score.as<double>() + so, h->slot_inl.as<int32_t>() + so, plan, totals);
+            }
             HIPCHK(hipEventRecord(e1, s));
             h->sweep_launches++;
             Trigger *trig_p = h->triggers.as<Trigger>() + (size_t)p0 * trig_cap;

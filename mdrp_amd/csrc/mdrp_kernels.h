@@ -1525,6 +1525,85 @@ __global__ __launch_bounds__(SCORE_THREADS, MDRP_SCORE_MINWAVES) void k_score(Ru
     } // item loop
 }
 
+// ------------------------------------------------------------------------------------------------ score, one wavefront per hypothesis
+// Small batches (round 6).  k_score gives every hypothesis a LANE that walks the pair's records in a serial loop: ~0.3 ms for N = 2000 whatever
+// the number of hypotheses — with one image pair per call (what /root/reference/eval.py does) the two exact sweeps of a run were 0.6 of its 1.7 ms,
+// on a chip that was 99 % idle.  Here a WAVEFRONT owns a hypothesis and its lanes take 64 records per trip (coalesced 48-byte loads, the same
+// score_point arithmetic per record).  The MSAC score is a sum in RECORD ORDER (compute_sampson_msac_score @0x4f61d0 adds as it goes, and scores
+// are compared with `<`): the inliers' r^2 of a trip are compacted in lane order into LDS and added one after the other, so the sum — and the
+// early exit against the records of earlier chunks (struct Prune) — is k_score's bit for bit.  Twice the instructions per hypothesis, none of the
+// latency: used where the hypotheses would not fill the chip anyway (mdrp_capi.hip: calls of at most SCORE_WAVE_MAX_PAIRS pairs).
+constexpr int SCORE_WAVE_MAX_PAIRS = 128;
+constexpr int SCW_THREADS = 256; // four hypotheses per workgroup
+template <bool POSE, bool RAWF = false>
+__global__ __launch_bounds__(SCW_THREADS) void k_score_w(RunParams rp, const PairState *__restrict__ st, const double *__restrict__ pts,
+                                                         const Model *__restrict__ models, const uint32_t *__restrict__ tags /*sorted: k_sort_tags*/,
+                                                         const int32_t *__restrict__ model_count, double *__restrict__ slot_score,
+                                                         int32_t *__restrict__ slot_inl, const int32_t *__restrict__ plan /*k_count_plan over the survivors, 4 per workgroup*/) {
+    __shared__ double s_r2[SCW_THREADS / 64][64];
+    const int total = plan[rp.batch];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int w = blockIdx.x; w < total; w += gridDim.x) {
+        const int pair = plan_find(plan, rp.batch, w);
+        const int i = (w - plan[pair]) * (SCW_THREADS / 64) + wave; // this wavefront's hypothesis in the pair's sorted list
+        const int cnt_sparse = model_count[2 * pair], cnt_dense = model_count[2 * pair + 1];
+        if (i >= cnt_sparse + cnt_dense) continue; // (wave-uniform)
+        const PairState &ps = st[pair];
+        const int n = ps.n;
+        const double thr = ps.sq_thr;
+        const size_t slot_base = (size_t)pair * rp.slot_stride;
+        const uint32_t slot = tags[slot_base + (i < cnt_sparse ? i : rp.slot_stride - 1 - (i - cnt_sparse))];
+        const Model m = models[slot_base + slot];
+        double E[9], R[9], t[3] = {m.t[0], m.t[1], m.t[2]};
+#pragma unroll
+        for (int q = 0; q < 9; ++q) R[q] = 0;
+        if (RAWF) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) E[q] = reinterpret_cast<const double *>(&m)[q];
+        } else {
+            double Em[9];
+            quat_to_R(m.q, R);
+            essential_from_Rt(R, m.t, Em);
+            if (POSE) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) E[q] = Em[q];
+            } else fundamental_from_E(Em, m.f1, m.f2, E);
+        }
+        const long long rec_cnt = (long long)ps.best_min_cnt;
+        const double rec_score = ps.best_min_score < DBL_MAX ? ps.best_min_score * (1.0 + 1e-12) : DBL_MAX;
+        const double *gp = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+        double score = 0;
+        int cnt = 0;
+        bool pruned = false;
+        for (int t0 = 0; t0 < n; t0 += 64) {
+            const int r = t0 + lane;
+            double s1 = 0;
+            int c1 = 0;
+            if (r < n) score_point<POSE>(gp + (size_t)r * PT_STRIDE, E, R, t, thr, s1, c1); // s1 = 0 + r^2 of an inlier
+            const unsigned long long ball = __ballot(c1 != 0);
+            if (ball) {
+                if (c1) s_r2[wave][__popcll(ball & lt)] = s1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int k = __popcll(ball);
+                for (int j = 0; j < k; ++j) score += s_r2[wave][j]; // in record order, one after the other (every lane the same sum)
+                cnt += k;
+                __builtin_amdgcn_wave_barrier(); // (the next trip overwrites the buffer)
+            }
+            // k_score's bail-out (Prune), tested where its dense path tests it: after every 128 records and at the end of a 512-record tile
+            const int processed = min(t0 + 64, n);
+            if (rec_score < DBL_MAX && ((processed & 127) == 0 || processed == n) &&
+                (long long)cnt + (long long)(n - processed) <= rec_cnt && score + thr * (double)(processed - cnt) >= rec_score) { pruned = true; break; }
+        }
+        if (lane == 0) {
+            slot_score[slot_base + slot] = pruned ? DBL_MAX : score + thr * (double)(n - cnt);
+            slot_inl[slot_base + slot] = pruned ? -2 : cnt;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // One wave per pair walks the chunk's slots in iteration order, 64 * IPL iterations per step (a lane owns IPL consecutive iterations): per-lane
 // local records -> wave exclusive prefix (max count, min score) -> per-lane replay against the true running records.

@@ -791,6 +791,39 @@ def test_final_refinement_over_the_inlier_index_at_and_beyond_the_list_limit(cap
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,rf", [(0, None), (2, "varying"), (5, None)])
+def test_wave_per_hypothesis_scoring_equals_lane_per_hypothesis(capi, monkeypatch, kind, rf):
+    """Calls of at most 128 pairs score their hypotheses with one WAVEFRONT each (k_score_w: 64 records per trip, the inliers' r^2 added in record
+    order through LDS); larger calls with one LANE each (k_score).  Same arithmetic, same order of the sum, equivalent bail-outs: 100 ragged pairs
+    estimated as a call of their own and as the first half of a 200-pair call must give the same records and masks BIT FOR BIT (the lanes per LO
+    problem are pinned: they too depend on the size of the call)."""
+    from mdrp_amd import synth
+    monkeypatch.setenv("MDRP_LO_THREADS", "64")
+    B, N = 200, 900
+    ns = [N, 700, 257, 64, 63, 5, 3, 2, 0, 450] * (B // 10)
+    x1, x2 = np.zeros((B, N, 2)), np.zeros((B, N, 2))
+    d1, d2 = np.ones((B, N)), np.ones((B, N))
+    for i, n in enumerate(ns):
+        if n:
+            p = synth.make_pair(12000 + i, n, noise_px=0.5, depth_noise=0.02, outlier_frac=[0.5, 0.0, 0.3][i % 3], random_focal=rf)
+            x1[i, :n], x2[i, :n], d1[i, :n], d2[i, :n] = p["x1"], p["x2"], p["d1"], p["d2"]
+    cams = np.zeros(B, dtype=capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+    ro = capi.ransac_opt_from_dict({"max_iterations": 3000, "min_iterations": 3000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+    bo = capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    c = cams if kind == 0 else None
+    npp = np.array(ns, dtype=np.int32)
+    h = capi.Handle(0)
+    try:
+        big, big_mask = h.estimate_batch(kind, x1, x2, d1, d2, ro, bo, npp, c, c)
+        small, small_mask = h.estimate_batch(kind, x1[:100], x2[:100], d1[:100], d2[:100], ro, bo, npp[:100], None if c is None else c[:100], None if c is None else c[:100])
+    finally:
+        h.close()
+    assert int(small["num_inliers"].max()) > 400 and int(small["refinements"].max()) > 3
+    assert small.tobytes() == big[:100].tobytes(), np.nonzero(small["model_score"] != big[:100]["model_score"])[0][:10]
+    assert np.array_equal(small_mask, big_mask[:100])
+
+
+@pytest.mark.gpu
 def test_device_resident_batch_matches_host_batch(capi):
     """poselib.estimate_batch_torch (tensors already on the GPU, current torch stream) == the host-buffer batch API"""
     import torch
