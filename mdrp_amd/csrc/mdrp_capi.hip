@@ -570,7 +570,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             }
             const uint32_t *surv_tags = tags_v;
             const int32_t *surv_cnt = surv1;
-            if (use_bound && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
+            // (calls of a few pairs skip the fp32 stage: its lane-per-hypothesis record loop is 0.1 ms of latency, and k_score_w takes k_count's survivors at once)
+            if (use_bound && batch_call > 16 && !(it0 == 0 && c == 0)) { // a run's first chunk has no records yet: nothing to retire
                 // fp32 lower bound of the score for k_count's survivors; its survivors go back into the chunk's tag list
                 hipLaunchKernelGGL(k_count_plan, dim3(1), dim3(PLAN_THREADS), 0, s, pc, st_p, surv1, 1, BND_THREADS, h->cplan.as<int32_t>(), surv2, (const int32_t *)nullptr);
                 const dim3 bgrid((unsigned)pc * (unsigned)((len * mps + BND_THREADS - 1) / BND_THREADS));
