@@ -480,13 +480,11 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     const PairState &ps = st[pair];
     if (!ps.active) return;
     const bool live = it < it_end;
-    const int lane = threadIdx.x & 63;
-    const size_t slot_base = (size_t)pair * rp.slot_stride;
-    unsigned vmask = 0;  // bit k: slot k of this iteration holds a model
+    int n = 0;
     bool nan_model = false;
-    Model out[SOLVER == SOLVER_P3P ? 1 : 4];
-    auto load_sample_at = [&](int it_, Sample3 &s) {
-        const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it_) * 3;
+    Model out[4];
+    auto load_sample = [&](Sample3 &s) {
+        const uint32_t *sm = samples + ((size_t)ps.table * rp.chunk_len + it) * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const size_t idx = (size_t)pair * rp.n_max + sm[k];
@@ -495,92 +493,27 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
             s.d1[k] = dep[2 * idx]; s.d2[k] = dep[2 * idx + 1];
         }
     };
-    auto load_sample = [&](Sample3 &s) { load_sample_at(it, s); };
-    if constexpr (SOLVER == SOLVER_P3P) {
-        // The P3P's candidates are cheap (cubic, line pair: a fifth of the kernel), finishing one is not (Newton polish, rigid alignment, quaternion,
-        // the 96-byte store: four fifths) — and of a sample's four candidate slots 1.2 hold a positive candidate on average, while a wavefront in
-        // lock step pays for all four as soon as ONE of its 64 samples fills the slot.  So the wavefront pools its candidates: every lane lists
-        // its positive ones in LDS (sample, slot, scaled depths), and lane j finishes candidate j, j + 64, ... of the pool, whoever's it is —
-        // re-reading that sample (L2) and writing the pose straight to the owner's model slot.  Every candidate is finished with the arithmetic
-        // of solver_calib_p3p (p3p_polish, p3p_pose: pure functions of sample and candidate), so the models are the same bit for bit; a model
-        // now stays in the slot of its CANDIDATE (slots without one are empty) instead of being packed to the front — the order within an
-        // iteration, which score_models<> walks, is the same.
-        struct Cand { double l[3]; int who; int pad_; }; // who = 4 * owner lane + slot
-        __shared__ Cand s_cand[256 / 64][256];
-        __shared__ unsigned char s_ok[256 / 64][256];
-        const int wave = threadIdx.x >> 6;
-        unsigned cmask = 0;
-        double C4[4][3];
-        if (live) {
-            Sample3 s;
-            load_sample(s);
-            P3pSetup su;
-            p3p_setup(s, su);
-            cmask = p3p_candidates(su.m01, su.m02, su.m12, su.a01, su.a02, su.a12, C4);
-        }
-        const int mine = __popc(cmask);
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        const int total = __shfl(incl, 63, 64), first = incl - mine;
-        {
-            int j = first;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if ((cmask >> c) & 1u) { Cand &d = s_cand[wave][j]; d.l[0] = C4[c][0]; d.l[1] = C4[c][1]; d.l[2] = C4[c][2]; d.who = 4 * lane + c; ++j; }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i0 = 0; i0 < total; i0 += 64) {
-            const int id = i0 + lane;
-            if (id < total) {
-                const Cand d = s_cand[wave][id];
-                const int it_o = it - lane + (d.who >> 2), c = d.who & 3;
-                Sample3 so;
-                load_sample_at(it_o, so);
-                P3pSetup su;
-                p3p_setup(so, su);
-                double lam[3] = {d.l[0], d.l[1], d.l[2]};
-                const bool ok = p3p_polish(su.m01, su.m02, su.m12, su.a01, su.a02, su.a12, lam);
-                if (ok) {
-                    p3p_pose(su, so.d2[0] * so.x2[0][0], lam, out[0]);
-                    models[slot_base + (size_t)(rp.chunk_off + it_o) * 4 + c] = out[0];
-                }
-                s_ok[wave][id] = ok ? 1 : 0;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            int j = first;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if ((cmask >> c) & 1u) { if (s_ok[wave][j]) vmask |= 1u << c; ++j; }
-        }
+    if (live) {
+        Sample3 s;
+        load_sample(s);
+        n = run_solver(SOLVER, s, out);
         // The reference's P3P emits NaN poses for ~3 % of the samples (p3p_reference_nan: exactly predictable).  A NaN hypothesis scores N * thr with
         // no inlier: it can only be a record while nothing has been scored yet — then it costs the reference one LO, and it is the run's answer if no
         // sample ever gives a real pose.  It needs no sweep: slot state -3 tells k_scan its (count, score) = (0, N * thr); it is not on the tag list.
+    }
+    if (SOLVER == SOLVER_P3P) {
         // ... and it only matters BEFORE the first real pose of the run: a lane asks only if no earlier iteration of its own wavefront has one
         // (k_scan decides exactly; this merely keeps ~80 % of the wavefronts — those whose first sample has a pose — out of the predicate)
-        const unsigned long long valid = __ballot(live && vmask != 0);
+        const unsigned long long valid = __ballot(live && n > 0);
         const int first_valid = valid ? __ffsll((long long)valid) - 1 : 64;
-        if (live && lane < first_valid) {
+        if (live && (int)(threadIdx.x & 63) < first_valid) {
             Sample3 s; // read again (L2): kept live across the solver it would cost the kernel its third wavefront per SIMD
             load_sample(s);
             nan_model = p3p_reference_nan(s);
         }
-    } else {
-        if (live) {
-            Sample3 s;
-            load_sample(s);
-            const int n_ = run_solver(SOLVER, s, out);
-            vmask = (1u << n_) - 1u; // these solvers pack their models to the front
-        }
     }
-    const int n = __popc(vmask);
     // wave-aggregated append to the pair's tag list: one atomic per wave (k_sort_tags orders and classifies the list)
+    const int lane = threadIdx.x & 63;
     int pre = n;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -592,12 +525,12 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     if (lane == 63 && tot > 0) base = atomicAdd(&model_count[2 * pair], tot);
     base = __shfl(base, 63, 64);
     if (!live) return;
-    const size_t slot0 = slot_base + (size_t)(rp.chunk_off + it) * 4;
+    const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * 4;
     int pos = base + pre - n;
-    const size_t tag_base = slot_base;
+    const size_t tag_base = (size_t)pair * rp.slot_stride;
     // slot states of the iteration in one 16-byte store: -1 = empty, -2 = "no record" — the default of every live slot:
     // k_count / k_bound retire most hypotheses without touching their slots again, k_score overwrites the survivors'
-    *reinterpret_cast<int4 *>(slot_inl + slot0) = make_int4(nan_model ? -3 : ((vmask & 1u) ? -2 : -1), (vmask & 2u) ? -2 : -1, (vmask & 4u) ? -2 : -1, (vmask & 8u) ? -2 : -1);
+    *reinterpret_cast<int4 *>(slot_inl + slot0) = make_int4(nan_model ? -3 : (n > 0 ? -2 : -1), n > 1 ? -2 : -1, n > 2 ? -2 : -1, n > 3 ? -2 : -1);
     if (nan_model) {
         Model m;
         model_identity(m);
@@ -607,8 +540,8 @@ __global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if ((vmask >> k) & 1u) {
-            if (SOLVER != SOLVER_P3P) models[slot0 + k] = out[k];
+        if (k < n) {
+            models[slot0 + k] = out[k];
             tags[tag_base + pos] = (uint32_t)((rp.chunk_off + it) * 4 + k);
             ++pos;
         }

@@ -314,39 +314,9 @@ MDRP_HD double linepair_quality(const double D1[6], const double D2[6], double g
     return sv_div(mx, nrm);
 }
 
-// ---------------------------------------------------------------- minimal solvers (inputs: 3 correspondences)
-// x1,x2: normalised image points (x,y) per correspondence, homogeneous z = 1 implied.
-struct Sample3 {
-    double x1[3][2], x2[3][2], d1[3], d2[3];
-};
-
-// The P3P in four pieces (round 6), so that k_solve can hand the expensive ones — Newton polish and pose extraction, 80 % of the kernel, needed by
-// 1.2 of the 4 candidate slots of a sample on average — to whichever lanes of the wavefront are free (mdrp_kernels.h k_solve<SOLVER_P3P>):
-//   p3p_setup       back-projected points, unit bearings, their cosines and squared distances
-//   p3p_candidates  cubic, line pair, the <= 4 candidate depth triples, scaled and sign-fixed; bit c of the result: candidate c is positive
-//   p3p_polish      Newton on the three distance equations (<= 5 steps), positivity of the polished depths
-//   p3p_pose        rigid alignment of the scaled bearings to the points, quaternion, scale from the first correspondence's x component
-// solver_calib_p3p runs them one after the other per candidate: the same values in the same order as the single-function solver of rounds 1-5
-// (every piece is a pure function of its arguments).
-struct P3pSetup { double m01, m02, m12, a01, a02, a12, X[9], xb[9]; };
-
-MDRP_HD void p3p_setup(const Sample3 &s, P3pSetup &ps) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double inv = sv_rsqrt(s.x2[i][0] * s.x2[i][0] + s.x2[i][1] * s.x2[i][1] + 1.0);
-        ps.X[3 * i] = s.d1[i] * s.x1[i][0]; ps.X[3 * i + 1] = s.d1[i] * s.x1[i][1]; ps.X[3 * i + 2] = s.d1[i];
-        ps.xb[3 * i] = s.x2[i][0] * inv; ps.xb[3 * i + 1] = s.x2[i][1] * inv; ps.xb[3 * i + 2] = inv;
-    }
-    double d01[3], d02[3], d12[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { d01[c] = ps.X[c] - ps.X[3 + c]; d02[c] = ps.X[c] - ps.X[6 + c]; d12[c] = ps.X[3 + c] - ps.X[6 + c]; }
-    ps.m01 = dot3(ps.xb, ps.xb + 3); ps.m02 = dot3(ps.xb, ps.xb + 6); ps.m12 = dot3(ps.xb + 3, ps.xb + 6);
-    ps.a01 = dot3(d01, d01); ps.a02 = dot3(d02, d02); ps.a12 = dot3(d12, d12);
-}
-
-// one candidate (tau:sigma) on a line spanned by u,v -> scaled, sign-fixed depths; returns whether they are positive
-MDRP_HD bool p3p_candidate(double tau, double sig, const double u[3], const double v[3], double m01, double m02, double m12,
-                           double a01, double a02, double a12, double lam[3]) {
+// one candidate (tau:sigma) on a line spanned by u,v -> scaled, sign-fixed, polished depths; returns validity
+MDRP_HD bool p3p_finish(double tau, double sig, const double u[3], const double v[3], double m01, double m02, double m12,
+                        double a01, double a02, double a12, double lam[3]) {
     double l0 = sig * u[0] + tau * v[0], l1 = sig * u[1] + tau * v[1], l2 = sig * u[2] + tau * v[2];
     double qv, av;
     if (a12 >= a01 && a12 >= a02) { qv = l1 * l1 + l2 * l2 - 2 * m12 * l1 * l2; av = a12; }
@@ -357,13 +327,6 @@ MDRP_HD bool p3p_candidate(double tau, double sig, const double u[3], const doub
     if (l0 < 0) sc = -sc;
     l0 *= sc; l1 *= sc; l2 *= sc;
     if (!(l0 > 0 && l1 > 0 && l2 > 0)) return false;
-    lam[0] = l0; lam[1] = l1; lam[2] = l2;
-    return true;
-}
-
-// Newton on the three distance equations from a positive candidate; returns whether the polished depths are positive
-MDRP_HD bool p3p_polish(double m01, double m02, double m12, double a01, double a02, double a12, double lam[3]) {
-    double l0 = lam[0], l1 = lam[1], l2 = lam[2];
     const double tol = 1e-15 * (a01 + a02 + a12);
     for (int it = 0; it < 5; ++it) {
         const double r0 = l0 * l0 + l1 * l1 - 2 * m01 * l0 * l1 - a01;
@@ -383,14 +346,14 @@ MDRP_HD bool p3p_polish(double m01, double m02, double m12, double a01, double a
     return true;
 }
 
-// candidate depth triples C[c] (c = 2 * line + intersection) and the mask of the positive ones
-MDRP_HD unsigned p3p_candidates(double m01, double m02, double m12, double a01, double a02, double a12, double C4[4][3]) {
+// returns number of depth triples written to L (<= 4)
+MDRP_HD int p3p_depths(double m01, double m02, double m12, double a01, double a02, double a12, double L[4][3]) {
     const double D1[6] = {a12, -a12 * m01, 0.0, a12 - a01, a01 * m12, -a01};
     const double D2[6] = {a12, 0.0, -a12 * m02, -a02, a02 * m12, a12 - a02};
     double A1[6], A2[6];
     sym_adj(D1, A1); sym_adj(D2, A2);
     const double c3 = sym_det(D2), c2 = sym_trprod(A2, D1), c1 = sym_trprod(A1, D2), c0 = sym_det(D1);
-    if (!(fabs(c3) > 1e-300)) return 0u;
+    if (!(fabs(c3) > 1e-300)) return 0;
     const double ic3 = sv_rcp(c3);
     double g0, g1, g2;
     const int nr = solve_cubic_real<true>(c2 * ic3, c1 * ic3, c0 * ic3, g0, g1, g2);
@@ -400,7 +363,7 @@ MDRP_HD unsigned p3p_candidates(double m01, double m02, double m12, double a01, 
         if (q1 > best) { best = q1; g = g1; }
         if (q2 > best) { best = q2; g = g2; }
     }
-    if (!(best > 0)) return 0u;
+    if (!(best > 0)) return 0;
     double C[6], B[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) C[i] = D1[i] + g * D2[i];
@@ -430,7 +393,7 @@ MDRP_HD unsigned p3p_candidates(double m01, double m02, double m12, double a01, 
     double Dq[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) Dq[i] = useD2 ? D2[i] : D1[i];
-    unsigned mask = 0u;
+    int n = 0;
 #pragma unroll
     for (int li = 0; li < 2; ++li) {
         const double l0 = li ? lb[0] : la[0], l1 = li ? lb[1] : la[1], l2 = li ? lb[2] : la[2];
@@ -449,41 +412,50 @@ MDRP_HD unsigned p3p_candidates(double m01, double m02, double m12, double a01, 
         if (disc >= 0) {
             const double sq = sv_sqrt(disc);
             const double qq = -(qb + (qb >= 0 ? sq : -sq));
-            if (p3p_candidate(qq, qa, u, v, m01, m02, m12, a01, a02, a12, C4[2 * li])) mask |= 1u << (2 * li);
-            if (p3p_candidate(qc, qq, u, v, m01, m02, m12, a01, a02, a12, C4[2 * li + 1])) mask |= 2u << (2 * li);
+            double lam[3];
+            if (n < 4 && p3p_finish(qq, qa, u, v, m01, m02, m12, a01, a02, a12, lam)) { L[n][0] = lam[0]; L[n][1] = lam[1]; L[n][2] = lam[2]; ++n; }
+            if (n < 4 && p3p_finish(qc, qq, u, v, m01, m02, m12, a01, a02, a12, lam)) { L[n][0] = lam[0]; L[n][1] = lam[1]; L[n][2] = lam[2]; ++n; }
         }
     }
-    return mask;
+    return n;
 }
 
-// pose of one polished depth triple: X_k = d1_k (x1_k, 1) against lam_k * bearing_k; scale from the first correspondence (x component)
-MDRP_HD void p3p_pose(const P3pSetup &ps, double d2x /* d2[0] * x2[0].x */, const double lam[3], Model &out) {
-    double Y[9], R[9];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) Y[3 * i + c] = lam[i] * ps.xb[3 * i + c];
-    model_identity(out);
-    align3(ps.X, Y, R, out.t);
-    R_to_quat(R, out.q);
-    double Rq[9];
-    quat_to_R(out.q, Rq);
-    const double px = Rq[0] * ps.X[0] + Rq[1] * ps.X[1] + Rq[2] * ps.X[2] + out.t[0];
-    out.scale = sv_div(px, d2x);
-}
+// ---------------------------------------------------------------- minimal solvers (inputs: 3 correspondences)
+// x1,x2: normalised image points (x,y) per correspondence, homogeneous z = 1 implied.
+struct Sample3 {
+    double x1[3][2], x2[3][2], d1[3], d2[3];
+};
 
 // a-6': P3P on X_k = d1_k (x1_k,1) and unit bearings of image 2; scale from the first correspondence (x component)
 MDRP_HD int solver_calib_p3p(const Sample3 &s, Model out[4]) {
-    P3pSetup ps;
-    p3p_setup(s, ps);
-    double C4[4][3];
-    const unsigned mask = p3p_candidates(ps.m01, ps.m02, ps.m12, ps.a01, ps.a02, ps.a12, C4);
-    int n = 0;
+    double X[9], xb[9];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        if ((mask >> c) & 1u) {
-            double lam[3] = {C4[c][0], C4[c][1], C4[c][2]};
-            if (p3p_polish(ps.m01, ps.m02, ps.m12, ps.a01, ps.a02, ps.a12, lam)) { p3p_pose(ps, s.d2[0] * s.x2[0][0], lam, out[n]); ++n; }
+    for (int i = 0; i < 3; ++i) {
+        const double inv = sv_rsqrt(s.x2[i][0] * s.x2[i][0] + s.x2[i][1] * s.x2[i][1] + 1.0);
+        X[3 * i] = s.d1[i] * s.x1[i][0]; X[3 * i + 1] = s.d1[i] * s.x1[i][1]; X[3 * i + 2] = s.d1[i];
+        xb[3 * i] = s.x2[i][0] * inv; xb[3 * i + 1] = s.x2[i][1] * inv; xb[3 * i + 2] = inv;
+    }
+    double d01[3], d02[3], d12[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d01[c] = X[c] - X[3 + c]; d02[c] = X[c] - X[6 + c]; d12[c] = X[3 + c] - X[6 + c]; }
+    double L[4][3];
+    const int n = p3p_depths(dot3(xb, xb + 3), dot3(xb, xb + 6), dot3(xb + 3, xb + 6), dot3(d01, d01), dot3(d02, d02),
+                             dot3(d12, d12), L);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < n) {
+            double Y[9], R[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) Y[3 * i + c] = L[k][i] * xb[3 * i + c];
+            model_identity(out[k]);
+            align3(X, Y, R, out[k].t);
+            R_to_quat(R, out[k].q);
+            double Rq[9];
+            quat_to_R(out[k].q, Rq);
+            const double px = Rq[0] * X[0] + Rq[1] * X[1] + Rq[2] * X[2] + out[k].t[0];
+            out[k].scale = sv_div(px, s.d2[0] * s.x2[0][0]);
         }
     }
     return n;
