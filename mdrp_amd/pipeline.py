@@ -75,16 +75,18 @@ class BatchPipeline:
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
-# Large batches through the drop-in entry points (VERDICT r04 item 5).  Measured through the Python entry points (tools/entry_rate.py,
-# profiles/r05_python_entry_points.txt; headline pairs, one MI355X):
-#   resident tensors (estimate_batch_torch):   ONE call is always the fastest - 126 k pairs/s at 2048 pairs, 132 k at 4096, 137 k at 8192,
-#       139 k at 16384 (the LM tails amortise inside a large call); chunks of 1024 / 2048 / 4096 pairs two in flight: 126 / 132 / 134 k at 8192.
-#   pageable host buffers (estimate_*_batch):  chunks of 1024 pairs two in flight win from ~8 k pairs on - 117.8 k against 109.1 k for one
-#       call at 8192 pairs (a chunk's H2D copy runs beside the previous chunk's kernels); at 4096 pairs one call is still ahead (103 k vs 100 k).
-# So: host batches of more than PIPELINE_MIN pairs are cut into chunks of PIPELINE_CHUNK pairs that go through one BatchPipeline(depth 2) per
-# device; resident batches always go through one call.  Pairs are independent units and every
-# summation order depends on the record index and list position only, so the records and masks are those of sequential chunk calls bit for
-# bit (tests/test_gpu_boundary.py::test_batch_pipeline_equals_sequential_calls, tests/test_gpu_headline.py::test_large_batches_...).
+# Large batches through the drop-in entry points.  Measured through the Python entry points (tools/entry_rate.py,
+# profiles/r06_python_entry_points.txt; headline pairs, one MI355X):
+#   resident tensors (estimate_batch_torch):   ONE call is always the fastest - 145 k pairs/s at 8192 and 16384 pairs (the LM tails amortise
+#       inside a large call).
+#   pageable host buffers (estimate_*_batch):  rounds 4-5 cut batches beyond 6144 pairs into 1024-pair chunks, two in flight, to hide the H2D
+#       copies (110-115 k pairs/s at 8192-16384 against 109 k for one call then).  Since round 6 a host-buffer call copies in 256-pair slices on
+#       its own copy stream beside the first kernels of the slices before (mdrp_capi.hip run_pass): ONE call is ahead there as well - 124.8 k
+#       against 110.4 k at 8192 pairs, 120.9 k against 114.7 k at 16384.  The automatic chunking is therefore OFF by default
+#       (PIPELINE_MIN = 0: never); MDRP_PIPELINE_MIN=<pairs> switches it on for batches beyond that size, BatchPipeline stays for callers that
+#       have several independent batches to keep in flight.
+# Pairs are independent units and every summation order depends on the record index and list position only, so chunked results are those of
+# sequential chunk calls bit for bit (tests/test_gpu_boundary.py::test_batch_pipeline_equals_sequential_calls, tests/test_gpu_headline.py).
 def _env_int(name, dflt):
     import os
     try:
@@ -93,15 +95,15 @@ def _env_int(name, dflt):
         return dflt
 
 
-PIPELINE_MIN = _env_int("MDRP_PIPELINE_MIN", 6144)      # host batches up to this size go through one call on the thread's default handle
-PIPELINE_CHUNK = 1024                                    # pairs per chunk beyond that
+PIPELINE_MIN = _env_int("MDRP_PIPELINE_MIN", 0)         # host batches beyond this size are chunked; 0 = never (the default)
+PIPELINE_CHUNK = 1024                                    # pairs per chunk
 PIPELINE_DEPTH = 2                                       # chunks in flight
 
 
 def chunk_bounds(batch, chunk=None):
     """[lo, hi) of the chunks a batch of `batch` pairs is cut into: `chunk` pairs each, a short remainder (< chunk / 4) joins the last one"""
     chunk = PIPELINE_CHUNK if chunk is None else chunk
-    if chunk <= 0 or batch <= max(PIPELINE_MIN, chunk):
+    if PIPELINE_MIN <= 0 or chunk <= 0 or batch <= max(PIPELINE_MIN, chunk):
         return [(0, batch)]
     cuts = list(range(0, batch, chunk)) + [batch]
     if len(cuts) > 2 and cuts[-1] - cuts[-2] < chunk // 4:

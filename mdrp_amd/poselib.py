@@ -213,8 +213,9 @@ def estimate_monodepth_relative_pose_batch(points2D_1, points2D_2, depth_1, dept
     """B calibrated pairs at once.  cameras1/2: one Camera|dict for all pairs, or a list of B.  Returns
     (list[MonoDepthTwoViewGeometry], list[info dict]) — or, with as_arrays=True, (records, inlier masks, n_per_pair) as numpy arrays
     (_capi.RESULT_DTYPE; (B, N) uint8): building B Python objects and B lists of N bools costs more than the estimate itself beyond
-    a few thousand pairs.  Host batches of more than pipeline.PIPELINE_MIN (6144) pairs are cut into 1024-pair chunks that run two
-    in flight, a chunk's H2D copy beside the previous chunk's kernels (mdrp_amd.pipeline; results identical to sequential chunk calls)."""
+    a few thousand pairs.  A host batch is ONE call whatever its size: the C side copies the correspondences in 256-pair slices on a copy stream
+    beside the first kernels of the slices before them (MDRP_PIPELINE_MIN=<pairs> brings back the chunked two-in-flight path of rounds 4-5,
+    mdrp_amd.pipeline; results identical to sequential chunk calls)."""
     x1, x2, d1, d2, ns = _stack(points2D_1, points2D_2, depth_1, depth_2)
     B = len(ns)
 

@@ -202,7 +202,7 @@ def test_headline_step_soak_is_bit_identical(capi):
         db.close()
 
 
-def test_large_batches_are_pipelined_by_the_entry_points(capi, golden):
+def test_large_batches_are_pipelined_by_the_entry_points(capi, golden, monkeypatch):
     """8192 headline pairs (the 1024-pair bench batch eight times over) in ONE call of the drop-in entry points.
     `estimate_monodepth_relative_pose_batch(..., as_arrays=True)` from host buffers cuts the batch into 1024-pair chunks that run two in flight
     (mdrp_amd.pipeline: a chunk's H2D copy beside the previous chunk's kernels); the same chunking on resident tensors (pipeline.estimate_device)
@@ -218,6 +218,7 @@ def test_large_batches_are_pipelined_by_the_entry_points(capi, golden):
     b = synth.make_batch(0, 1024, n, noise_px=0.5, depth_noise=0.02, outlier_frac=0.5)
     x1, x2, d1, d2 = (np.ascontiguousarray(np.concatenate([b[k]] * rep)) for k in ("x1", "x2", "d1", "d2"))
     B = len(x1)
+    monkeypatch.setattr(pipeline, "PIPELINE_MIN", 6144)  # (MDRP_PIPELINE_MIN=6144; off by default since round 6: one host call copies in slices by itself)
     assert pipeline.chunk_bounds(B) == [(1024 * i, 1024 * (i + 1)) for i in range(8)]
     cam = {"model": "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": [800.0, 0.0, 0.0]}
     bo = {"loss_type": "TRUNCATED_CAUCHY"}

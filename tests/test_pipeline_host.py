@@ -5,7 +5,9 @@ import pytest
 from mdrp_amd import _capi, pipeline, poselib
 
 
-def test_chunk_bounds_cover_the_batch_in_order():
+def test_chunk_bounds_cover_the_batch_in_order(monkeypatch):
+    assert pipeline.PIPELINE_MIN == 0 and pipeline.chunk_bounds(100000) == [(0, 100000)]  # the default since round 6: a host batch is ONE call (it copies in slices itself)
+    monkeypatch.setattr(pipeline, "PIPELINE_MIN", 6144)  # MDRP_PIPELINE_MIN=6144: the chunking of rounds 4-5
     for B in (0, 1, 1024, 6144, 6145, 8192, 9000, 12500, 100000):
         for chunk in (None, 512, 1024, 4096):
             b = pipeline.chunk_bounds(B, chunk)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """pairs/s through the Python drop-in entry points for a large batch: B headline pairs (the 1024-pair bench batch repeated) in ONE call of
 estimate_batch_torch (resident tensors) and estimate_monodepth_relative_pose_batch(as_arrays=True) (pageable host buffers).  The chunking knobs
-MDRP_PIPELINE_MIN / MDRP_PIPELINE_CHUNK / MDRP_PIPELINE_DEPTH are read when mdrp_amd.pipeline is imported: one process per setting.
+MDRP_PIPELINE_MIN is read when mdrp_amd.pipeline is imported: one process per setting.
     python tools/entry_rate.py [B] [repeats]"""
 import os
 import sys
