@@ -22,7 +22,7 @@ def tables():
 def test_every_kernel_family_is_in_the_library(tables):
     regs, _ = tables
     for fam, count in (("mdrp::k_final<", 48), ("mdrp::k_lo<", 8), ("mdrp::kc_final<", 6), ("mdrp::kc_lo<", 6), ("mdrp::k_solve<", 4), ("mdrp::k_count<", 3),
-                       ("mdrp::k_bound<", 3), ("mdrp::k_score<", 3)):
+                       ("mdrp::k_bound<", 3), ("mdrp::k_score<", 3), ("mdrp::k_score_w<", 3)):
         assert sum(1 for k in regs if k.startswith(fam)) == count, fam
 
 
@@ -46,7 +46,13 @@ def test_lm_kernels_keep_two_wavefronts_per_simd_and_spill_nothing_into_their_sw
 
 
 def test_sweep_kernels_do_not_spill(tables):
-    regs, _ = tables
+    regs, sites = tables
     for k, r in regs.items():
-        if k.startswith(("mdrp::k_count<", "mdrp::k_bound<", "mdrp::k_score<", "mdrp::k_scan<", "mdrp::k_prep", "mdrp::k_samples")):
+        if k.startswith(("mdrp::k_bound<", "mdrp::k_score<", "mdrp::k_score_w<", "mdrp::k_scan<", "mdrp::k_prep", "mdrp::k_samples")):
             assert r.get("vgpr_spill", 0) == 0 and r.get("scratch", 0) == 0, (k, r)
+        if k.startswith("mdrp::k_count<"):
+            # the MFMA count must keep FOUR wavefronts per SIMD (128 VGPRs): the two-phase version of round 6 first compiled to 138 registers, three
+            # wavefronts, and lost a quarter of its throughput on every shape.  Held at 128 by its launch bounds, it spills a dozen registers of the
+            # prologue / epilogue; none of the accesses may sit inside a loop (the sweep is a hand-ordered MFMA pipeline)
+            assert r["vgpr"] <= 128 and r["waves_per_simd"] >= 4, (k, r)
+            assert r.get("vgpr_spill", 0) <= 16 and sites[k]["scratch_in_inner_loops"] == 0 and sites[k]["scratch_in_sweep_loops"] == 0, (k, r, sites[k])
