@@ -564,6 +564,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                     MDRP_SWEEP_DISPATCH(k_count, kind, cgrid, dim3(CNT_THREADS), 0, s, r, st_p, rfrag_p, models_p,
                                         tags_u, und_cnt, h->cplan.as<int32_t>(), tags_v, surv1, cstats, (int32_t *)nullptr, (const int32_t *)nullptr,
                                         2, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, und_part, cand_stat);
+                    h->count_launches++; // (mdrp_stats::count_launches counts kernel launches: a rocprof summary shows the same number)
                 }
                 HIPCHK(hipEventRecord(c1, s));
                 h->count_launches++;
