@@ -711,12 +711,15 @@ def test_full_size_properties(handle, capi):
 
 
 @pytest.mark.gpu
-def test_schedule_does_not_change_results(handle, capi, monkeypatch):
+@pytest.mark.parametrize("B,N", [(12, 700), (12, 2300), (136, 2300)])
+def test_schedule_does_not_change_results(handle, capi, monkeypatch, B, N):
     """The chunk split (and with it which hypotheses k_count / k_bound retire against which records), the three-stream
     pipeline, the fp32 bound stage and the LO grid are scheduling only: every setting must reproduce the same records bit
-    for bit (single chunk on one stream, where nothing is ever retired, is the plain sequential schedule)."""
+    for bit (single chunk on one stream, where nothing is ever retired, is the plain sequential schedule).
+    N = 2300 (nine 256-record tiles): k_count's TWO-PHASE retirement is active in every chunked schedule (phase A over the leading tiles,
+    phase B for the undecided hypotheses) and absent from the single-chunk reference run; N = 700 (three tiles) never splits.
+    B = 12: the small-call path (k_score_w, no fp32 stage); B = 136: k_bound and the lane-per-hypothesis k_score."""
     from mdrp_amd import synth
-    B, N = 12, 700
     b = synth.make_batch(4000, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=0.4)
     cams = np.zeros(B, dtype=capi.CAMERA_DTYPE)
     cams["params"][:, 0] = 800.0
