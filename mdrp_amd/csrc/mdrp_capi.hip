@@ -125,6 +125,7 @@ struct mdrp_handle {
     DevBuf cplan;              // work plan of k_count / k_bound
     DevBuf surv2_count;        // survivors of k_bound per pair
     DevBuf lo_mask;            // 5-point LO: inlier subset of the refined model, one row per LO workgroup
+    DevBuf red5;               // 5-point solver: the Reduce5 blocks between its two kernels, [pair][ceil(chunk / 64)][76][64] doubles
     DevBuf lm_stats;                  // six u64: correspondences evaluated by the LM cost / accumulate sweeps of the LO kernel | of the final kernel |
                                       // fused tail: gate time-outs | final-refinement wait time-outs
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
@@ -386,6 +387,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const bool fuse_env = env_int("MDRP_FUSE_TAIL", ((kind == MDRP_CALIB && est_shift) || h->fuse_disabled) ? 0 : 1) != 0;
     bool final_done = false;
     // the 5-point LO keeps the inlier subset of the model it refines: one row per LO workgroup and chunk (LOs of two chunks overlap)
+    if (kind == MDRP_RELPOSE_5PT && (rc = h->red5.ensure(sizeof(double) * (size_t)batch * ((size_t)(chunk_cap + 63) / 64) * RED5_STRIDE * 64))) return rc;
     const size_t lo_mask_rows = (size_t)h->num_cu * 8; // kc_lo launches num_cu * (8 | 2) workgroups
     if ((kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) && (rc = h->lo_mask.ensure(lo_mask_rows * (size_t)std::max(n_max, 1)))) return rc;
     int32_t *cnt = h->counters.as<int32_t>();
@@ -501,8 +503,12 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 const dim3 sgrid((r.chunk_len + 63) / 64, pc);
                 if (kind == MDRP_SHARED_6PT)
                     hipLaunchKernelGGL(kc_solve<CLASSIC_SHARED>, sgrid, dim3(64), 0, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
-                else if (kind == MDRP_RELPOSE_5PT)
-                    hipLaunchKernelGGL(kc_solve<CLASSIC_RELPOSE>, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
+                else if (kind == MDRP_RELPOSE_5PT) {
+                    // two kernels (mdrp_classic.h): the elimination at three wavefronts per CU, roots and poses at six
+                    double *red5 = h->red5.as<double>() + (size_t)p0 * sgrid.x * RED5_STRIDE * 64;
+                    hipLaunchKernelGGL(kc_solve5_reduce, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, st_p, smp, pts_p, red5);
+                    hipLaunchKernelGGL(kc_solve5_roots, sgrid, dim3(64), SOLVE5B_LDS_BYTES, st_, r, st_p, smp, pts_p, red5, models_p, inl_p, tg, mc);
+                }
                 else
                     hipLaunchKernelGGL(kc_solve<CLASSIC_FUND>, sgrid, dim3(64), SOLVE7_LDS_BYTES, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
                 return MDRP_OK;
@@ -807,7 +813,8 @@ int estimate_device(mdrp_handle *h, int kind, const double *x1, const double *x2
     HIPCHK(hipMemGetInfo(&free_b, &total_b));
     const size_t per_pair = (size_t)chunk_cap * mps * (sizeof(Model) + sizeof(double) + 2 * sizeof(int32_t) + 4 * sizeof(uint32_t) /*tag lists*/) +
                             (size_t)chunk_cap * (sizeof(Trigger) + 8) + (size_t)n_max * (PT_STRIDE + 2) * sizeof(double) + 1024;
-    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/;
+    const size_t per_pair_all = per_pair + (size_t)chunk_cap * mps * sizeof(uint32_t) /*tags_v*/ + ((size_t)n_max + 15) / 16 * 1024 /*rfrag*/ +
+                                (kind == MDRP_RELPOSE_5PT ? ((size_t)chunk_cap + 63) / 64 * RED5_STRIDE * 64 * sizeof(double) : 0) /*red5*/;
     size_t budget = std::min<size_t>((size_t)(0.5 * (double)free_b), (size_t)96 << 30);
     int per_pass = (int)std::max<size_t>(1, std::min<size_t>((size_t)batch, budget / per_pair_all));
     per_pass = std::min(per_pass, 65535); // k_solve / k_probe put the pair index on grid.y
@@ -941,7 +948,7 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_score<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, tile_bytes));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_solve<CLASSIC_RELPOSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE5_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_solve5_reduce), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE5_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(kc_solver_unit<CLASSIC_RELPOSE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SOLVE5_LDS_BYTES));
     *out = h;
     return MDRP_OK;
@@ -956,7 +963,7 @@ void mdrp_destroy(mdrp_handle *h) {
     DevBuf *bufs[] = {&h->pts, &h->dep, &h->st, &h->samples, &h->params, &h->fuse, &h->models, &h->slot_score, &h->slot_inl, &h->tags, &h->model_count, &h->triggers, &h->work_pair,
                       &h->counters, &h->results, &h->mask, &h->in_x1, &h->in_x2, &h->in_d1, &h->in_d2, &h->unit_a,
                       &h->unit_b, &h->unit_c, &h->unit_d, &h->unit_e, &h->unit_f, &h->plan, &h->tags2, &h->model_count2, &h->samples2, &h->tags_s, &h->tags2_s,
-                      &h->tags_v, &h->surv_count, &h->und_count, &h->cand_stat, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
+                      &h->tags_v, &h->surv_count, &h->und_count, &h->cand_stat, &h->red5, &h->rfrag, &h->cplan, &h->surv2_count, &h->lo_mask,
                       &h->lm_stats};
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

@@ -163,6 +163,135 @@ __device__ __forceinline__ Solve5Store lds_solve5_store() {
     return Solve5Store{C, 64, RootStack{lo, hi, cc, ilo, ihi, 64}};
 }
 
+// ------------------------------------------------------------------------------------------------ 5-point solver in two kernels (round 6)
+// kc_solve<CLASSIC_RELPOSE> did everything per sample in one kernel: the elimination (10 x 10 LU in LDS, R in 200 registers) fixed it at 512 registers
+// and 51 KB of LDS per wavefront = three wavefronts per CU for its whole length, while four fifths of its instructions (Sturm isolation of the
+// degree-10 polynomial's roots, their polishing, the decomposition of up to ten essential matrices) need neither.
+//   kc_solve5_reduce   one lane per sample: null space, ten cubic constraints, LU, the three rows of B(z)  -> Reduce5 (75 doubles) to global memory,
+//                      lane-interleaved per 64 samples (element k of lane l at [(76 block + k) 64 + l]: every store is one 512-byte row)
+//   kc_solve5_roots    one lane per sample: det B(z), its real roots, (x, y, z) per root parked in LDS (the interval stack is dead by then);
+//                      then the wavefront's solutions (0-10 per sample, ~3 on average) are decomposed by whichever lane is free, 64 at a time
+//                      (round 4's pooling: the lock-step version ran max-over-lanes trips with a third of the lanes active): essential matrix from
+//                      the owner's null space (read back from the Reduce5 block), motion_from_essential, 4 x 5 cheirality tests, model store.  A pose
+//                      goes into slot `root index` of its sample (at most one decomposition of an essential matrix has all five points in front of
+//                      both cameras): k_scan walks the slots of an iteration in order and skips empty ones, so the order of the reference is kept
+//                      without counting.  25.6 KB of LDS per wavefront.
+// Same expressions, same order: the models are those of the one-kernel solver bit for bit.
+constexpr int RED5_STRIDE = REDUCE5_DOUBLES + 1;                                        // + 1: "the elimination succeeded"
+constexpr size_t SOLVE5B_LDS_BYTES = (size_t)64 * 50 * sizeof(double);                  // the root finder's stack: lo 12 | hi 12 | cc 6 | ilo 10 | ihi 10 columns
+__device__ __forceinline__ void gather5(const uint32_t *__restrict__ sm, const double *__restrict__ pts_pair, double (*x1h)[3], double (*x2h)[3]) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double *p = pts_pair + (size_t)sm[k] * PT_STRIDE;
+        const double2 p01 = *reinterpret_cast<const double2 *>(p), p23 = *reinterpret_cast<const double2 *>(p + 2),
+                      p45 = *reinterpret_cast<const double2 *>(p + 4);
+        x1h[k][0] = p01.x * p45.x; x1h[k][1] = p01.y * p45.x; x1h[k][2] = p45.x;
+        x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
+    }
+}
+
+MDRP_GLOBAL __launch_bounds__(64) void kc_solve5_reduce(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+                                                         const double *__restrict__ pts, double *__restrict__ red /*[pair][block][RED5_STRIDE][64]*/) {
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int it = blockIdx.x * 64 + lane;
+    const PairState &ps = st[pair];
+    if (!ps.active || it >= rp.chunk_len) return;
+    double x1h[5][3], x2h[5][3];
+    gather5(samples + ((size_t)ps.table * rp.chunk_len + it) * 5, pts + (size_t)pair * rp.n_max * PT_STRIDE, x1h, x2h);
+    Reduce5 r5;
+    const bool ok = relpose_5pt_reduce(x1h, x2h, lds_solve5_store(), r5);
+    double *dst = red + ((size_t)pair * gridDim.x + blockIdx.x) * RED5_STRIDE * 64 + lane;
+    const double *src = &r5.El[0][0][0];
+    static_assert(sizeof(Reduce5) == REDUCE5_DOUBLES * sizeof(double), "Reduce5 is 75 packed doubles");
+#pragma unroll
+    for (int k = 0; k < REDUCE5_DOUBLES; ++k) dst[(size_t)k * 64] = src[k];
+    dst[(size_t)REDUCE5_DOUBLES * 64] = ok ? 1.0 : 0.0;
+}
+
+MDRP_GLOBAL __launch_bounds__(64, 2) void kc_solve5_roots(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+                                                            const double *__restrict__ pts, const double *__restrict__ red, Model *__restrict__ models,
+                                                            int32_t *__restrict__ slot_inl, uint32_t *__restrict__ tags, int32_t *__restrict__ model_count) {
+    constexpr int MPS = ClassicTraits<CLASSIC_RELPOSE>::MPS;
+    extern __shared__ double solve5_lds[];
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int it = blockIdx.x * 64 + lane;
+    const PairState &ps = st[pair];
+    if (!ps.active) return;
+    const bool live = it < rp.chunk_len;
+    const size_t slot0 = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + it) * MPS;
+    const size_t tag_base = (size_t)pair * rp.slot_stride;
+    const double *blk = red + ((size_t)pair * gridDim.x + blockIdx.x) * RED5_STRIDE * 64;
+    const double *pts_pair = pts + (size_t)pair * rp.n_max * PT_STRIDE;
+    int ne = 0;
+    if (live) {
+        if (blk[(size_t)REDUCE5_DOUBLES * 64 + lane] != 0.0) {
+            double bx[3][4], by[3][4], b1[3][5];
+            {
+                const double *src = blk + (size_t)36 * 64 + lane; // behind El
+                double *dx = &bx[0][0], *dy = &by[0][0], *d1 = &b1[0][0];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) dx[k] = src[(size_t)k * 64];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) dy[k] = src[(size_t)(12 + k) * 64];
+#pragma unroll
+                for (int k = 0; k < 15; ++k) d1[k] = src[(size_t)(24 + k) * 64];
+            }
+            // (x, y) of a root are computed after the root finder has returned: its interval stack is dead, the solutions are parked straight in this
+            // lane's LDS column for whichever lane decomposes them
+            relpose_5pt_roots_xyz(bx, by, b1, lds_solve5_store().rs, [&](double x, double y, double z) {
+                if (ne < MAX_MODELS_5PT) { solve5_lds[(3 * ne) * 64 + lane] = x; solve5_lds[(3 * ne + 1) * 64 + lane] = y; solve5_lds[(3 * ne + 2) * 64 + lane] = z; ++ne; }
+            });
+        }
+#pragma unroll
+        for (int g = 0; g < MPS / 4; ++g) *reinterpret_cast<int4 *>(slot_inl + slot0 + 4 * g) = make_int4(-1, -1, -1, -1);
+    }
+    int pre = ne;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(pre, o, 64);
+        if (lane >= o) pre += v;
+    }
+    const int total = __shfl(pre, 63, 64);
+    int *codes = reinterpret_cast<int *>(solve5_lds + 30 * 64); // 640 items: ten more columns behind the thirty of the solutions
+    for (int r = 0; r < ne; ++r) codes[pre - ne + r] = lane * 16 + r;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const int i = i0 + lane;
+        bool found = false;
+        int src_it = 0, root = 0;
+        if (i < total) {
+            const int code = codes[i];
+            const int src = code >> 4;
+            root = code & 15;
+            src_it = blockIdx.x * 64 + src;
+            double El[3][3][4], e[9], x1h[5][3], x2h[5][3];
+            {
+                const double *sp = blk + src;
+                double *de = &El[0][0][0];
+#pragma unroll
+                for (int k = 0; k < 36; ++k) de[k] = sp[(size_t)k * 64];
+            }
+            essential_from_xyz(El, solve5_lds[(3 * root) * 64 + src], solve5_lds[(3 * root + 1) * 64 + src], solve5_lds[(3 * root + 2) * 64 + src], e);
+            gather5(samples + ((size_t)ps.table * rp.chunk_len + src_it) * 5, pts_pair, x1h, x2h);
+            const size_t dst = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + src_it) * MPS + root;
+            motion_from_essential_emit(e, x1h, x2h, 5, [&](const Model &m) {
+                if (!found) { models[dst] = m; slot_inl[dst] = -2; found = true; }
+                // (a second decomposition with all five points in front of both cameras would need exactly singular geometry)
+            });
+        }
+        const unsigned long long fb = __ballot(found);
+        if (fb) {
+            int base = 0;
+            const int first = __ffsll((long long)fb) - 1;
+            if (lane == first) base = atomicAdd(&model_count[2 * pair], __popcll(fb));
+            base = __shfl(base, first, 64);
+            if (found) tags[tag_base + base + __popcll(fb & ((1ull << lane) - 1ull))] = (uint32_t)((rp.chunk_off + src_it) * MPS + root);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample (64-lane workgroups: the solvers live in scratch-backed arrays and their trip counts
 // diverge with the number of real roots).  Same slot / tag conventions as k_solve with MPS slots per sample.
@@ -193,72 +322,7 @@ __global__ __launch_bounds__(64) void kc_solve(RunParams rp, const PairState *__
             x2h[k][0] = p23.x * p45.y; x2h[k][1] = p23.y * p45.y; x2h[k][2] = p45.y;
         }
     };
-    if (CK == CLASSIC_RELPOSE) {
-        // Round 4: the essential matrices of the wavefront's 64 samples (0-10 each, ~3 on average) are decomposed by whichever lane is
-        // free, not by the lane that found them.  Each lane parks its matrices in its own LDS column (the LU storage is dead by then),
-        // a table of (source lane, root) codes is built with one prefix sum, and the lanes walk that table 64 items at a time: every
-        // trip of motion_from_essential + 4 x 5 cheirality tests has all lanes busy, where the round-3 kernel ran max-over-lanes trips
-        // with a third of the lanes active (30 % of the solver's time).  A pose goes into slot `root index` of its
-        // sample (at most one decomposition of an essential matrix has all five points in front of both cameras): k_scan walks the
-        // slots of an iteration in order and skips empty ones, so the order of the reference is kept without counting.
-        extern __shared__ double solve5_lds[];
-        int ne = 0;
-        if (live) {
-            double x1h[K][3], x2h[K][3];
-            gather(it, x1h, x2h);
-            relpose_5pt_emit(x1h, x2h, lds_solve5_store(), [&](const double *e) {
-                if (ne < MAX_MODELS_5PT) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) solve5_lds[(9 * ne + k) * 64 + lane] = e[k];
-                    ++ne;
-                }
-            });
-#pragma unroll
-            for (int g = 0; g < MPS / 4; ++g) *reinterpret_cast<int4 *>(slot_inl + slot0 + 4 * g) = make_int4(-1, -1, -1, -1);
-        }
-        int pre = ne;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int v = __shfl_up(pre, o, 64);
-            if (lane >= o) pre += v;
-        }
-        const int total = __shfl(pre, 63, 64);
-        int *codes = reinterpret_cast<int *>(solve5_lds + 90 * 64); // 640 items fit the ten spare elements of the 64 columns
-        for (int r = 0; r < ne; ++r) codes[pre - ne + r] = lane * 16 + r;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i0 = 0; i0 < total; i0 += 64) {
-            const int i = i0 + lane;
-            bool found = false;
-            int src_it = 0, root = 0;
-            if (i < total) {
-                const int code = codes[i];
-                const int src = code >> 4;
-                root = code & 15;
-                src_it = blockIdx.x * 64 + src;
-                double e[9], x1h[K][3], x2h[K][3];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) e[k] = solve5_lds[(9 * root + k) * 64 + src];
-                gather(src_it, x1h, x2h);
-                const size_t dst = (size_t)pair * rp.slot_stride + (size_t)(rp.chunk_off + src_it) * MPS + root;
-                motion_from_essential_emit(e, x1h, x2h, 5, [&](const Model &m) {
-                    if (!found) { models[dst] = m; slot_inl[dst] = -2; found = true; }
-                    // (a second decomposition with all five points in front of both cameras would need exactly singular geometry;
-                    //  the round-3 kernel would have given it the next slot)
-                });
-            }
-            const unsigned long long fb = __ballot(found);
-            if (fb) {
-                int base = 0;
-                const int first = __ffsll((long long)fb) - 1;
-                if (lane == first) base = atomicAdd(&model_count[2 * pair], __popcll(fb));
-                base = __shfl(base, first, 64);
-                if (found) tags[tag_base + base + __popcll(fb & ((1ull << lane) - 1ull))] = (uint32_t)((rp.chunk_off + src_it) * MPS + root);
-            }
-        }
-        return;
-    }
+    static_assert(CK != CLASSIC_RELPOSE, "the 5-point solver runs as kc_solve5_reduce + kc_solve5_roots");
     if (live) {
         double x1h[K][3], x2h[K][3];
         gather(it, x1h, x2h);

@@ -389,14 +389,16 @@ MDRP_HD void quad_lin_mul_add(const double *q, const double *l, double s, double
 // may alias).  On the device both live in LDS, one column of 64 lanes per element (in scratch memory the solver spent 90 % of
 // its time waiting for them); on the host they are plain local arrays.
 struct Solve5Store { double *C; int cs; RootStack rs; };
-// emit(const double E[9]) is called for every essential matrix, in the order of the roots: the device solver hands each one straight
-// on to motion_from_essential and to the model slots (ten matrices and ten poses held in arrays cost the kernel 420 registers)
-template <class Emit>
-MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Emit &&emit) {
-    double Es[1][9]; // (only the experiment hooks below write here)
-    (void)Es;
+// Round 6: the solver in two halves, so that the device can run them as two kernels (mdrp_classic.h kc_solve5_reduce / kc_solve5_roots) — the
+// elimination needs the 10 x 10 LU in LDS and R in registers (512 registers, 51 KB per wavefront: three wavefronts per CU), the root finder and the
+// pose extraction need neither.  What passes from one half to the other is Reduce5 (75 doubles): the null space as linear polynomials and the
+// three rows of B(z).  Every value is computed by the same expressions as in rounds 1-5; relpose_5pt_emit below is the two halves back to back.
+struct Reduce5 { double El[3][3][4], bx[3][4], by[3][4], b1[3][5]; };
+constexpr int REDUCE5_DOUBLES = 36 + 12 + 12 + 15;
+
+MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Reduce5 &red) {
     // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]: the only copy of the null space that is kept
-    double El[3][3][4];
+    double (&El)[3][3][4] = red.El;
     {
         double N[36];
         epipolar_columns<5>(x1h, x2h, store.C, store.cs); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
@@ -467,7 +469,7 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         int piv = col;
         double pv = fabs(M5(col, col));
         for (int r = col + 1; r < 10; ++r) { const double v = fabs(M5(r, col)); if (v > pv) { pv = v; piv = r; } }
-        if (!(pv > 0.0)) return 0;
+        if (!(pv > 0.0)) return false;
         if (piv != col) {
 #pragma unroll
             for (int k = 0; k < 10; ++k) { const double t = M5(col, k); M5(col, k) = M5(piv, k); M5(piv, k) = t; }
@@ -496,7 +498,7 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
     }
     // rows 4..9 of X, two at a time: forward / back substitution of e_t, then w R; each pair (<x2 z>, <x2>), (<xyz>, <xy>),
     // (<y2 z>, <y2>) gives one row  u - z v  of  B(z) [x y 1]' = 0
-    double bx[3][4], by[3][4], b1[3][5];
+    double (&bx)[3][4] = red.bx, (&by)[3][4] = red.by, (&b1)[3][5] = red.b1;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         double uv[2][10];
@@ -532,6 +534,24 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         b1[i][4] = -v[6]; b1[i][3] = u[6] - v[7]; b1[i][2] = u[7] - v[8]; b1[i][1] = u[8] - v[9]; b1[i][0] = u[9];
     }
 #undef M5
+    return true;
+}
+
+// the essential matrix of one solution (x, y, z) of the null-space coordinates, unit Frobenius norm
+MDRP_HD void essential_from_xyz(const double El[3][3][4], double x, double y, double z, double e[9]) {
+    double nrm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { e[3 * i + j] = x * El[i][j][0] + y * El[i][j][1] + z * El[i][j][2] + El[i][j][3]; nrm += e[3 * i + j] * e[3 * i + j]; }
+    nrm = 1.0 / sqrt(nrm);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) e[k] *= nrm;
+}
+
+// det B(z) = 0 -> real roots z (Sturm, ascending), then (x, y) from two rows of B(z): emit_xyz(x, y, z) per solution, in the order of the roots
+template <class EmitXyz>
+MDRP_HD int relpose_5pt_roots_xyz(const double bx[3][4], const double by[3][4], const double b1[3][5], const RootStack &rs, EmitXyz &&emit_xyz) {
     double c[11];
     for (int k = 0; k < 11; ++k) c[k] = 0.0;
     constexpr int PERM[6][4] = {{0, 1, 2, 1}, {0, 2, 1, -1}, {1, 0, 2, -1}, {1, 2, 0, 1}, {2, 0, 1, 1}, {2, 1, 0, -1}};
@@ -544,7 +564,7 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         for (int i = 0; i < 7; ++i) for (int j = 0; j < 5; ++j) c[i + j] += sgn * ab[i] * b1[r2][j];
     }
     double roots[10];
-    const int nr = real_roots_fast<10>(c, roots, store.rs);
+    const int nr = real_roots_fast<10>(c, roots, rs);
     int n_out = 0;
     for (int s = 0; s < nr; ++s) {
         const double z = roots[s];
@@ -565,18 +585,23 @@ MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], con
         const double det = B[r0][0] * B[r1][1] - B[r0][1] * B[r1][0];
         const double x = (-B[r0][2] * B[r1][1] + B[r0][1] * B[r1][2]) / det;
         const double y = (-B[r0][0] * B[r1][2] + B[r0][2] * B[r1][0]) / det;
-        double e[9], nrm = 0.0;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { e[3 * i + j] = x * El[i][j][0] + y * El[i][j][1] + z * El[i][j][2] + El[i][j][3]; nrm += e[3 * i + j] * e[3 * i + j]; }
-        nrm = 1.0 / sqrt(nrm);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) e[k] *= nrm;
-        emit(e);
+        emit_xyz(x, y, z);
         ++n_out;
     }
     return n_out;
+}
+
+// emit(const double E[9]) is called for every essential matrix, in the order of the roots: the device solver hands each one straight
+// on to motion_from_essential and to the model slots (ten matrices and ten poses held in arrays cost the kernel 420 registers)
+template <class Emit>
+MDRP_HD int relpose_5pt_emit(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Emit &&emit) {
+    Reduce5 red;
+    if (!relpose_5pt_reduce(x1h, x2h, store, red)) return 0;
+    return relpose_5pt_roots_xyz(red.bx, red.by, red.b1, store.rs, [&](double x, double y, double z) {
+        double e[9];
+        essential_from_xyz(red.El, x, y, z, e);
+        emit(e);
+    });
 }
 MDRP_HD int relpose_5pt_E(const double (*x1h)[3], const double (*x2h)[3], double (*Es)[9], const Solve5Store &store) {
     int n = 0;

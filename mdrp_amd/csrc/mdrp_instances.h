@@ -16,8 +16,8 @@ namespace mdrp {
 #define MDRP_KC_FINAL_ONE(CK, T) MDRP_INST template __global__ void kc_final<CK, T>(RunParams, PairState *, const double *, uint8_t *, ResultDev *, const int32_t *, int32_t *, \
                                                                                      unsigned long long, unsigned long long *, int);
 #define MDRP_KC_REFINE_ONE(CK, T) MDRP_INST template __global__ void kc_refine_unit<CK, T>(int, Model *, const double *, int, LmOpt, double *);
-#define MDRP_KC_SOLVE_ONE(CK) MDRP_INST template __global__ void kc_solve<CK>(RunParams, const PairState *, const uint32_t *, const double *, Model *, int32_t *, uint32_t *, int32_t *); \
-                              MDRP_INST template __global__ void kc_solver_unit<CK>(int, const double *, const double *, Model *, int32_t *);
+#define MDRP_KC_SOLVE_ONE(CK) MDRP_INST template __global__ void kc_solve<CK>(RunParams, const PairState *, const uint32_t *, const double *, Model *, int32_t *, uint32_t *, int32_t *);
+#define MDRP_KC_UNIT_ONE(CK) MDRP_INST template __global__ void kc_solver_unit<CK>(int, const double *, const double *, Model *, int32_t *);
 #define MDRP_KC_SAMPLES_ONE(K) MDRP_INST template __global__ void kc_samples<K>(int, const int32_t *, uint64_t *, int, uint32_t *);
 
 #define MDRP_INSTANCES_FINAL_64 MDRP_FINAL_KINDS(MDRP_FINAL_ONE, 64)
@@ -26,6 +26,7 @@ namespace mdrp {
     MDRP_CLASSIC_KINDS_T(MDRP_KC_LO_ONE, 64) MDRP_CLASSIC_KINDS_T(MDRP_KC_LO_ONE, 256)                                              \
     MDRP_CLASSIC_KINDS_T(MDRP_KC_FINAL_ONE, 64) MDRP_CLASSIC_KINDS_T(MDRP_KC_FINAL_ONE, 256)                                        \
     MDRP_CLASSIC_KINDS_T(MDRP_KC_REFINE_ONE, 64) MDRP_CLASSIC_KINDS_T(MDRP_KC_REFINE_ONE, 256)                                      \
-    MDRP_KC_SOLVE_ONE(CLASSIC_RELPOSE) MDRP_KC_SOLVE_ONE(CLASSIC_SHARED) MDRP_KC_SOLVE_ONE(CLASSIC_FUND)                            \
+    MDRP_KC_SOLVE_ONE(CLASSIC_SHARED) MDRP_KC_SOLVE_ONE(CLASSIC_FUND) /* (the 5-point solver: kc_solve5_reduce + kc_solve5_roots, main unit) */ \
+    MDRP_KC_UNIT_ONE(CLASSIC_RELPOSE) MDRP_KC_UNIT_ONE(CLASSIC_SHARED) MDRP_KC_UNIT_ONE(CLASSIC_FUND)                               \
     MDRP_KC_SAMPLES_ONE(5) MDRP_KC_SAMPLES_ONE(6) MDRP_KC_SAMPLES_ONE(7)
 } // namespace mdrp
