@@ -404,11 +404,17 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     // leading chunk lengths of the first super-chunk; the last chunk takes the rest.  The first chunk has no records to
     // retire anything against, so it is scored exactly in full: keep it short.  Every later chunk goes through k_count /
     // k_bound against the records of the chunks before it.  Measured on the benchmark shape: "128" 84.5 k pairs/s, "64" 82 k,
-    // "256" 82.5 k, "512" 82 k, "256,768" 79 k (every chunk costs ~10 launches and a solver hand-over)
+    // "256" 82.5 k, "512" 82 k, "256,768" 79 k (every chunk costs ~10 launches and a solver hand-over).  The 7-point estimator gets a second leading
+    // chunk: at 50 % outliers one sample in 128 is outlier-free, so the records after 128 iterations are often those of a poor model and the rest of
+    // the run would be counted and bounded against a bar that retires little (round 6: k_bound 5.7 ms of a 16.4 ms step; with "128,1024" the bar
+    // the last 8848 iterations meet is that of 1152: 62.3 -> 87.3 k pairs/s; "128,512" 86.6 k, "256,1024" 87.6 k, "128,3300,3300" 78.3 k)
     std::vector<uint64_t> lead;
     {
         const char *e = getenv("MDRP_CHUNKS");
-        std::string spec = e ? e : "128";
+        // (round 6, with the two-phase count: the focal estimators and the scale + shift solver — more models per sample, a looser bar from 128
+        // iterations — gain 4 % with a first chunk of 256: shared focal 123.0 -> 128.0 k, shift 112.2 -> 116.6 k, varying focal 29.2 -> 29.7 k; the
+        // calibrated P3P path is flat between 128 and 384)
+        std::string spec = e ? e : (kind == MDRP_FUNDAMENTAL_7PT ? "128,1024" : (classic || rp.solver == SOLVER_P3P ? "128" : "256"));
         size_t pos = 0;
         while (pos < spec.size() && (int)lead.size() < mdrp_handle::NC_MAX - 1) {
             const size_t q = spec.find(',', pos);
@@ -504,9 +510,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                 if (kind == MDRP_SHARED_6PT)
                     hipLaunchKernelGGL(kc_solve<CLASSIC_SHARED>, sgrid, dim3(64), 0, st_, r, st_p, smp, pts_p, models_p, inl_p, tg, mc);
                 else if (kind == MDRP_RELPOSE_5PT) {
-                    // two kernels (mdrp_classic.h): the elimination at three wavefronts per CU, roots and poses at six
+                    // three kernels (mdrp_classic.h): null space and roots + poses at six wavefronts per CU, the elimination between them at three
                     double *red5 = h->red5.as<double>() + (size_t)p0 * sgrid.x * RED5_STRIDE * 64;
-                    hipLaunchKernelGGL(kc_solve5_reduce, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, st_p, smp, pts_p, red5);
+                    hipLaunchKernelGGL(kc_solve5_null, sgrid, dim3(64), SOLVE5N_LDS_BYTES, st_, r, st_p, smp, pts_p, red5);
+                    hipLaunchKernelGGL(kc_solve5_reduce, sgrid, dim3(64), SOLVE5_LDS_BYTES, st_, r, st_p, red5);
                     hipLaunchKernelGGL(kc_solve5_roots, sgrid, dim3(64), SOLVE5B_LDS_BYTES, st_, r, st_p, smp, pts_p, red5, models_p, inl_p, tg, mc);
                 }
                 else

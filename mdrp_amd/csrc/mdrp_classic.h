@@ -148,10 +148,10 @@ __global__ __launch_bounds__(SAMP_THREADS) void kc_samples(int n_tables, const i
     if (threadIdx.x == 0) table_state[t] = state;
 }
 
-// LDS storage of the 5-point solver: the 10 x 10 matrix of its LU factorisation, one 64-lane column per element, and — in the
-// same bytes, once the factorisation is dead — the root finder's interval stack (dynamic LDS of the launch: SOLVE5_LDS_BYTES;
-// one wavefront per workgroup, three workgroups per CU)
-constexpr size_t SOLVE5_LDS_BYTES = (size_t)64 * 100 * sizeof(double);
+// LDS storage of the 5-point solver: columns 2..9 of the 10 x 10 matrix of its LU factorisation (columns 0 and 1 are in registers,
+// mdrp_classic_math.h relpose_5pt_eliminate), one 64-lane column per element, and — in the same bytes, once the factorisation is dead —
+// the root finder's interval stack (dynamic LDS of the launch: SOLVE5_LDS_BYTES = 40 KB; one wavefront per workgroup, four workgroups per CU)
+constexpr size_t SOLVE5_LDS_BYTES = (size_t)64 * 80 * sizeof(double);
 constexpr size_t SOLVE7_LDS_BYTES = (size_t)64 * 63 * sizeof(double); // the 9 x 7 constraint matrix of the 7-point null space
 __device__ __forceinline__ Solve5Store lds_solve5_store() {
     extern __shared__ double solve5_lds[];
@@ -159,26 +159,29 @@ __device__ __forceinline__ Solve5Store lds_solve5_store() {
     double *C = solve5_lds + lane;
     double *lo = solve5_lds + lane, *hi = lo + 12 * 64;
     int *cc = reinterpret_cast<int *>(solve5_lds + 24 * 64) + lane; // 12 ints per lane = 6 double columns
-    double *ilo = solve5_lds + 30 * 64 + lane, *ihi = ilo + 10 * 64;
-    return Solve5Store{C, 64, RootStack{lo, hi, cc, ilo, ihi, 64}};
+    return Solve5Store{C, 64, RootStack{lo, hi, cc, lo + 11 * 64, hi + 11 * 64, 64, -64}}; // isolated intervals: down from the stack's last entry
 }
 
 // ------------------------------------------------------------------------------------------------ 5-point solver in two kernels (round 6)
 // kc_solve<CLASSIC_RELPOSE> did everything per sample in one kernel: the elimination (10 x 10 LU in LDS, R in 200 registers) fixed it at 512 registers
 // and 51 KB of LDS per wavefront = three wavefronts per CU for its whole length, while four fifths of its instructions (Sturm isolation of the
 // degree-10 polynomial's roots, their polishing, the decomposition of up to ten essential matrices) need neither.
-//   kc_solve5_reduce   one lane per sample: null space, ten cubic constraints, LU, the three rows of B(z)  -> Reduce5 (75 doubles) to global memory,
-//                      lane-interleaved per 64 samples (element k of lane l at [(76 block + k) 64 + l]: every store is one 512-byte row)
+//   kc_solve5_null     one lane per sample: the null space of the five epipolar constraints as linear polynomials (36 doubles)
+//   kc_solve5_reduce   one lane per sample: ten cubic constraints, LU (40 KB of LDS, 512 registers: four wavefronts per CU), the three rows of B(z)
+//                      (39 doubles)  -> with the null space: Reduce5 in global
+//                      memory, lane-interleaved per 64 samples (element k of lane l at [(76 block + k) 64 + l]: every access is one 512-byte row)
 //   kc_solve5_roots    one lane per sample: det B(z), its real roots, (x, y, z) per root parked in LDS (the interval stack is dead by then);
 //                      then the wavefront's solutions (0-10 per sample, ~3 on average) are decomposed by whichever lane is free, 64 at a time
 //                      (round 4's pooling: the lock-step version ran max-over-lanes trips with a third of the lanes active): essential matrix from
 //                      the owner's null space (read back from the Reduce5 block), motion_from_essential, 4 x 5 cheirality tests, model store.  A pose
 //                      goes into slot `root index` of its sample (at most one decomposition of an essential matrix has all five points in front of
 //                      both cameras): k_scan walks the slots of an iteration in order and skips empty ones, so the order of the reference is kept
-//                      without counting.  25.6 KB of LDS per wavefront.
-// Same expressions, same order: the models are those of the one-kernel solver bit for bit.
+//                      without counting.  17.5 KB of LDS per wavefront (eight per CU; 25.6 KB = six until the isolated intervals moved into the stack's arrays).
+// Same expressions, same order as the one-kernel solver; the last bits of the elimination depend on whether the compiler sees where the null space
+// comes from (-ffp-contract=fast), which is why the inlined path (unit entry point, tests) hides it: relpose_5pt_reduce, tools/ubench/solve5_split_bits.hip.
 constexpr int RED5_STRIDE = REDUCE5_DOUBLES + 1;                                        // + 1: "the elimination succeeded"
-constexpr size_t SOLVE5B_LDS_BYTES = (size_t)64 * 50 * sizeof(double);                  // the root finder's stack: lo 12 | hi 12 | cc 6 | ilo 10 | ihi 10 columns
+// the root finder's stack and isolated intervals: lo 12 | hi 12 | cc 6 columns; then the solutions: 30 columns and 640 codes (5): 17.5 KB, eight wavefronts per CU
+constexpr size_t SOLVE5B_LDS_BYTES = (size_t)64 * 35 * sizeof(double);
 __device__ __forceinline__ void gather5(const uint32_t *__restrict__ sm, const double *__restrict__ pts_pair, double (*x1h)[3], double (*x2h)[3]) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -190,22 +193,43 @@ __device__ __forceinline__ void gather5(const uint32_t *__restrict__ sm, const d
     }
 }
 
-MDRP_GLOBAL __launch_bounds__(64) void kc_solve5_reduce(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
-                                                         const double *__restrict__ pts, double *__restrict__ red /*[pair][block][RED5_STRIDE][64]*/) {
+// (the null space first, in a kernel of its own: a full-pivoting Householder QR of the 9 x 5 constraint matrix in 23 KB of LDS and a few dozen
+// registers — six wavefronts per CU instead of the three the elimination behind it is held to)
+constexpr size_t SOLVE5N_LDS_BYTES = (size_t)64 * 45 * sizeof(double);
+MDRP_GLOBAL __launch_bounds__(64, 2) void kc_solve5_null(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+                                                           const double *__restrict__ pts, double *__restrict__ red /*[pair][block][RED5_STRIDE][64]*/) {
+    extern __shared__ double solve5_lds[];
     const int pair = blockIdx.y, lane = threadIdx.x;
     const int it = blockIdx.x * 64 + lane;
     const PairState &ps = st[pair];
     if (!ps.active || it >= rp.chunk_len) return;
-    double x1h[5][3], x2h[5][3];
+    double x1h[5][3], x2h[5][3], El[3][3][4];
     gather5(samples + ((size_t)ps.table * rp.chunk_len + it) * 5, pts + (size_t)pair * rp.n_max * PT_STRIDE, x1h, x2h);
-    Reduce5 r5;
-    const bool ok = relpose_5pt_reduce(x1h, x2h, lds_solve5_store(), r5);
+    relpose_5pt_nullspace(x1h, x2h, solve5_lds + lane, 64, El);
     double *dst = red + ((size_t)pair * gridDim.x + blockIdx.x) * RED5_STRIDE * 64 + lane;
-    const double *src = &r5.El[0][0][0];
-    static_assert(sizeof(Reduce5) == REDUCE5_DOUBLES * sizeof(double), "Reduce5 is 75 packed doubles");
+    const double *src = &El[0][0][0];
 #pragma unroll
-    for (int k = 0; k < REDUCE5_DOUBLES; ++k) dst[(size_t)k * 64] = src[k];
-    dst[(size_t)REDUCE5_DOUBLES * 64] = ok ? 1.0 : 0.0;
+    for (int k = 0; k < 36; ++k) dst[(size_t)k * 64] = src[k];
+}
+
+MDRP_GLOBAL __launch_bounds__(64) void kc_solve5_reduce(RunParams rp, const PairState *__restrict__ st, double *__restrict__ red /*[pair][block][RED5_STRIDE][64]*/) {
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    const int it = blockIdx.x * 64 + lane;
+    const PairState &ps = st[pair];
+    if (!ps.active || it >= rp.chunk_len) return;
+    double *blk = red + ((size_t)pair * gridDim.x + blockIdx.x) * RED5_STRIDE * 64 + lane;
+    Reduce5 r5;
+    static_assert(sizeof(Reduce5) == REDUCE5_DOUBLES * sizeof(double), "Reduce5 is 75 packed doubles");
+    {
+        double *de = &r5.El[0][0][0];
+#pragma unroll
+        for (int k = 0; k < 36; ++k) de[k] = blk[(size_t)k * 64];
+    }
+    const bool ok = relpose_5pt_eliminate(lds_solve5_store(), r5);
+    const double *src = &r5.bx[0][0];
+#pragma unroll
+    for (int k = 36; k < REDUCE5_DOUBLES; ++k) blk[(size_t)k * 64] = src[k - 36];
+    blk[(size_t)REDUCE5_DOUBLES * 64] = ok ? 1.0 : 0.0;
 }
 
 MDRP_GLOBAL __launch_bounds__(64, 2) void kc_solve5_roots(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,

@@ -229,7 +229,11 @@ MDRP_HD int real_roots(const double *coef /*ascending powers, degree D*/, double
 // constant, so the 66 coefficients of a degree-10 chain live in registers instead of scratch memory (the dynamic version spends
 // half of the 5-point solver's time in scratch round trips).  The interval stack is caller-provided strided storage (LDS on the
 // device).  A chain that drops a degree (or a vanishing leading coefficient) goes to the generic routine above — same results.
-struct RootStack { double *lo, *hi; int *cc; double *ilo, *ihi; int stride; }; // stack: D + 2 entries each; isolating intervals: D each
+// stack: D + 2 entries each (lo, hi, cc: entry i at [i stride]); isolating intervals: entry j at ilo / ihi [j istride].  The two may share their
+// storage — the stack growing from entry 0, the isolated intervals down from entry D + 1 (ilo = lo + (D + 1) stride, istride = -stride): every
+// interval on the stack holds at least one root that is not isolated yet, so the two together never need more than D entries (the device does this:
+// the root kernel's LDS is what bounds its occupancy).
+struct RootStack { double *lo, *hi; int *cc; double *ilo, *ihi; int stride, istride; };
 template <int D>
 MDRP_HD constexpr int chain_off(int i) { return i * (D + 1) - i * (i - 1) / 2; }
 template <int D>
@@ -278,17 +282,17 @@ MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &
 #pragma unroll
         for (int k = 0; k <= D; ++k) if (k < m) ch[chain_off<D>(i) + k] = r[k] * inv;
     }
-    if (!generic) return real_roots<D>(coef, roots);
     double bound = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) bound = fmax(bound, fabs(ch[k]));
     bound += 1.0;
-    const int ss = st.stride;
+    const int ss = st.stride, is = st.istride;
     // phase 1 — isolation only: every trip of the loop is one Sturm evaluation for every lane (the root polishing used to sit
     // inside this loop: a wavefront then paid for both branches on every trip).  Isolating intervals come out in ascending order.
     int sp = 1, ni = 0;
     st.lo[0] = -bound; st.hi[0] = bound;
     st.cc[0] = sturm_changes_static<D>(ch, -bound) | (sturm_changes_static<D>(ch, bound) << 8);
+    if (!generic) sp = 0;
     while (sp > 0 && ni < D) {
         --sp;
         const double lo = st.lo[sp * ss], hi = st.hi[sp * ss];
@@ -296,9 +300,12 @@ MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &
         const int clo = packed & 0xFF, chi = (packed >> 8) & 0xFF, depth = packed >> 16;
         const int n = clo - chi;
         if (n <= 0) continue;
-        if (n == 1) { st.ilo[ni * ss] = lo; st.ihi[ni * ss] = hi; ++ni; continue; }
+        // (sign counts that do not add up — an interval claiming more roots than the polynomial has left — could outgrow the D + 2 entries: the
+        // generic path then; never seen, and before round 6 it would have written past the arrays)
+        if (sp + ni + (n == 1 ? 1 : 2) > D + 2) { generic = false; break; }
+        if (n == 1) { st.ilo[ni * is] = lo; st.ihi[ni * is] = hi; ++ni; continue; }
         if (depth > 200 || hi - lo < 1e-15 * fmax(1.0, fmax(fabs(lo), fabs(hi)))) { // multiple / unresolvable cluster
-            for (int i = 0; i < n && ni < D; ++i) { st.ilo[ni * ss] = 0.5 * (lo + hi); st.ihi[ni * ss] = 0.5 * (lo + hi); ++ni; }
+            for (int i = 0; i < n && ni < D && sp + ni < D + 2; ++i) { st.ilo[ni * is] = 0.5 * (lo + hi); st.ihi[ni * is] = 0.5 * (lo + hi); ++ni; }
             continue;
         }
         const double mid = 0.5 * (lo + hi);
@@ -306,6 +313,7 @@ MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &
         if (cm - chi > 0) { st.lo[sp * ss] = mid; st.hi[sp * ss] = hi; st.cc[sp * ss] = cm | (chi << 8) | ((depth + 1) << 16); ++sp; }
         if (clo - cm > 0) { st.lo[sp * ss] = lo; st.hi[sp * ss] = mid; st.cc[sp * ss] = clo | (cm << 8) | ((depth + 1) << 16); ++sp; }
     }
+    if (!generic) return real_roots<D>(coef, roots); // (a chain with a vanishing leading coefficient; the overflow above)
     // phase 2 — one root per trip: bisection on the sign of p down to a tight bracket, then safeguarded Newton
     auto peval = [&](double x) {
         double v = ch[D];
@@ -314,7 +322,7 @@ MDRP_HD int real_roots_fast(const double *coef, double *roots, const RootStack &
         return v;
     };
     for (int j = 0; j < ni; ++j) {
-        double a = st.ilo[j * ss], b = st.ihi[j * ss];
+        double a = st.ilo[j * is], b = st.ihi[j * is];
         if (a == b) { roots[j] = a; continue; }
         double fa = peval(a);
         for (int it = 0; it < 200; ++it) {
@@ -396,26 +404,34 @@ struct Solve5Store { double *C; int cs; RootStack rs; };
 struct Reduce5 { double El[3][3][4], bx[3][4], by[3][4], b1[3][5]; };
 constexpr int REDUCE5_DOUBLES = 36 + 12 + 12 + 15;
 
-MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Reduce5 &red) {
-    // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]: the only copy of the null space that is kept
+// E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]: the only copy of the null space that is kept
+MDRP_HD void relpose_5pt_nullspace(const double (*x1h)[3], const double (*x2h)[3], double *C /*9 x 5 constraint matrix, strided*/, int cs, double El[3][3][4]) {
+    double N[36];
+    epipolar_columns<5>(x1h, x2h, C, cs);
+    fullpiv_nullspace<5>(C, cs, N);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) El[i][j][k] = N[k * 9 + 3 * j + i];
+}
+
+// red.El in; red.bx / by / b1 out
+MDRP_HD bool relpose_5pt_eliminate(const Solve5Store &store, Reduce5 &red) {
     double (&El)[3][3][4] = red.El;
-    {
-        double N[36];
-        epipolar_columns<5>(x1h, x2h, store.C, store.cs); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
-        fullpiv_nullspace<5>(store.C, store.cs, N);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) El[i][j][k] = N[k * 9 + 3 * j + i];
-    }
     // The ten cubic constraints split into  L m_left + R m_right = 0  (ten eliminated monomials | [x y 1] (x) powers of z).  Only rows
-    // 4..9 of X = L^-1 R are needed:  X_i = w_i R  with  L' w_i = e_i.  L' lives in the caller's strided storage (LDS on the
-    // device: LU with partial pivoting needs dynamic row indices), R stays in registers (statically indexed: it is never permuted).
-    double *const M = store.C; // M(r, k) = L(k, r): element at M[(10 r + k) cs]
+    // 4..9 of X = L^-1 R are needed:  X_i = w_i R  with  L' w_i = e_i.  M = L' (M(r, k) = L(k, r): row = monomial, column = constraint) is
+    // LU-factorised with partial pivoting: the ROW index of a swap is data dependent, everything else is static once the column loop is
+    // unrolled.  Columns 2..9 live in the caller's strided storage (LDS on the device: element (r, k) at M[(8 r + k - 2) cs]), columns 0
+    // and 1 in registers with their swaps as select chains — 80 elements = 40 KB per wavefront instead of 100 = 51 KB is a fourth
+    // wavefront per CU for this kernel (round 6).  R stays in registers (statically indexed: it is never permuted).
+    double *const M = store.C;
     const int cs = store.cs;
-#define M5(r, k) M[(10 * (r) + (k)) * cs]
+    double mc[2][10]; // columns 0 and 1 of M
+#define M5(r, k) M[(8 * (r) + (k) - 2) * cs]
+    auto mget = [&](int r, int k) -> double { return k < 2 ? mc[k][r] : M5(r, k); }; // r, k: constants after unrolling
+    auto mset = [&](int r, int k, double v) { if (k < 2) mc[k][r] = v; else M5(r, k) = v; };
     double R[10][10];
     {
         double EEs[6][10], tr[10]; // E E' is symmetric: entry (i, j) at sym(i, j)
@@ -446,7 +462,7 @@ MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], 
                 for (int k = 0; k < 3; ++k) quad_lin_mul_add(EEs[SYM3(i, k)], El[k][j], 2.0, row);
                 quad_lin_mul_add(tr, El[i][j], -1.0, row);
 #pragma unroll
-                for (int k = 0; k < 10; ++k) { M5(k, 3 * i + j) = row[k]; R[3 * i + j][k] = row[10 + k]; }
+                for (int k = 0; k < 10; ++k) { mset(k, 3 * i + j, row[k]); R[3 * i + j][k] = row[10 + k]; }
             }
         double det[20], m[10];
 #pragma unroll
@@ -465,36 +481,43 @@ MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], 
     int perm[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) perm[i] = i;
+#pragma unroll
     for (int col = 0; col < 10; ++col) {
         int piv = col;
-        double pv = fabs(M5(col, col));
-        for (int r = col + 1; r < 10; ++r) { const double v = fabs(M5(r, col)); if (v > pv) { pv = v; piv = r; } }
+        double pv = fabs(mget(col, col));
+#pragma unroll
+        for (int r = 0; r < 10; ++r) if (r > col) { const double v = fabs(mget(r, col)); if (v > pv) { pv = v; piv = r; } }
         if (!(pv > 0.0)) return false;
         if (piv != col) {
 #pragma unroll
-            for (int k = 0; k < 10; ++k) { const double t = M5(col, k); M5(col, k) = M5(piv, k); M5(piv, k) = t; }
+            for (int k = 2; k < 10; ++k) { const double t = M5(col, k); M5(col, k) = M5(piv, k); M5(piv, k) = t; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double top = mc[c][col];
+                double low = top;
+#pragma unroll
+                for (int r = 0; r < 10; ++r) if (r > col && r == piv) { low = mc[c][r]; mc[c][r] = top; }
+                mc[c][col] = low;
+            }
             int pp = 0;
 #pragma unroll
             for (int i = 0; i < 10; ++i) if (i == piv) pp = perm[i];
-            int pc = 0;
-#pragma unroll
-            for (int i = 0; i < 10; ++i) if (i == col) pc = perm[i];
+            const int pc = perm[col];
 #pragma unroll
             for (int i = 0; i < 10; ++i) perm[i] = (i == piv) ? pc : ((i == col) ? pp : perm[i]);
         }
         double prow[10];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) prow[k] = M5(col, k);
-        double diag = 0.0;
+        for (int k = 0; k < 10; ++k) prow[k] = k >= col ? mget(col, k) : 0.0;
+        const double inv = 1.0 / prow[col];
 #pragma unroll
-        for (int k = 0; k < 10; ++k) if (k == col) diag = prow[k];
-        const double inv = 1.0 / diag;
-        for (int r = col + 1; r < 10; ++r) {
-            const double f = M5(r, col) * inv;
-            M5(r, col) = f;
+        for (int r = 0; r < 10; ++r)
+            if (r > col) {
+                const double f = mget(r, col) * inv;
+                mset(r, col, f);
 #pragma unroll
-            for (int k = 0; k < 10; ++k) if (k > col) M5(r, k) -= f * prow[k];
-        }
+                for (int k = 0; k < 10; ++k) if (k > col) mset(r, k, mget(r, k) - f * prow[k]);
+            }
     }
     // rows 4..9 of X, two at a time: forward / back substitution of e_t, then w R; each pair (<x2 z>, <x2>), (<xyz>, <xy>),
     // (<y2 z>, <y2>) gives one row  u - z v  of  B(z) [x y 1]' = 0
@@ -510,15 +533,15 @@ MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], 
             for (int a = 0; a < 10; ++a) {
                 double v = (perm[a] == t) ? 1.0 : 0.0;
 #pragma unroll
-                for (int k = 0; k < 10; ++k) if (k < a) v -= M5(a, k) * y[k];
+                for (int k = 0; k < 10; ++k) if (k < a) v -= mget(a, k) * y[k];
                 y[a] = v;
             }
 #pragma unroll
             for (int a = 9; a >= 0; --a) {
                 double v = y[a];
 #pragma unroll
-                for (int k = 0; k < 10; ++k) if (k > a) v -= M5(a, k) * y[k];
-                y[a] = v / M5(a, a);
+                for (int k = 0; k < 10; ++k) if (k > a) v -= mget(a, k) * y[k];
+                y[a] = v / mget(a, a);
             }
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
@@ -535,6 +558,22 @@ MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], 
     }
 #undef M5
     return true;
+}
+
+MDRP_HD bool relpose_5pt_reduce(const double (*x1h)[3], const double (*x2h)[3], const Solve5Store &store, Reduce5 &red) {
+    relpose_5pt_nullspace(x1h, x2h, store.C, store.cs, red.El); // the 9 x 5 constraint matrix borrows the LU storage (dead before it is built)
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The device runs the two parts as separate kernels (mdrp_classic.h): there the elimination reads the null space from memory.  Inlined behind the
+    // null space, -ffp-contract=fast forms other fused multiply-adds in it (tools/ubench/solve5_split_bits.hip: the three rows of B(z) differ in their
+    // last bits on 70 % of random samples); hiding where the 36 values come from makes this path compute what the kernels compute, bit for bit.
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) asm volatile("" : "+v"(red.El[i][j][k]));
+#endif
+    return relpose_5pt_eliminate(store, red);
 }
 
 // the essential matrix of one solution (x, y, z) of the null-space coordinates, unit Frobenius norm
@@ -1043,7 +1082,7 @@ MDRP_HD int solver_relpose_6pt(const double (*x1h)[3], const double (*x2h)[3], M
 struct Solve5Local {
     double C[100], lo[12], hi[12], ilo[10], ihi[10];
     int cc[12];
-    MDRP_HD Solve5Store store() { return Solve5Store{C, 1, RootStack{lo, hi, cc, ilo, ihi, 1}}; }
+    MDRP_HD Solve5Store store() { return Solve5Store{C, 1, RootStack{lo, hi, cc, ilo, ihi, 1, 1}}; }
 };
 
 // ---------------------------------------------------------------- 7-point
