@@ -152,7 +152,7 @@ __global__ __launch_bounds__(SAMP_THREADS) void kc_samples(int n_tables, const i
 // mdrp_classic_math.h relpose_5pt_eliminate), one 64-lane column per element, and — in the same bytes, once the factorisation is dead —
 // the root finder's interval stack (dynamic LDS of the launch: SOLVE5_LDS_BYTES = 40 KB; one wavefront per workgroup, four workgroups per CU)
 constexpr size_t SOLVE5_LDS_BYTES = (size_t)64 * 80 * sizeof(double);
-constexpr size_t SOLVE7_LDS_BYTES = (size_t)64 * 63 * sizeof(double); // the 9 x 7 constraint matrix of the 7-point null space
+constexpr size_t SOLVE7_LDS_BYTES = (size_t)64 * 36 * sizeof(double); // columns 0..3 of the 9 x 7 constraint matrix of the 7-point null space (4..6: registers)
 __device__ __forceinline__ Solve5Store lds_solve5_store() {
     extern __shared__ double solve5_lds[];
     const int lane = threadIdx.x & 63;
@@ -193,9 +193,9 @@ __device__ __forceinline__ void gather5(const uint32_t *__restrict__ sm, const d
     }
 }
 
-// (the null space first, in a kernel of its own: a full-pivoting Householder QR of the 9 x 5 constraint matrix in 23 KB of LDS and a few dozen
-// registers — six wavefronts per CU instead of the three the elimination behind it is held to)
-constexpr size_t SOLVE5N_LDS_BYTES = (size_t)64 * 45 * sizeof(double);
+// (the null space first, in a kernel of its own: a full-pivoting Householder QR of the 9 x 5 constraint matrix, three of its columns in 14 KB of
+// LDS and two in registers — eight wavefronts per CU instead of the four the elimination behind it is held to)
+constexpr size_t SOLVE5N_LDS_BYTES = (size_t)64 * 27 * sizeof(double); // columns 0..2 of the 9 x 5 constraint matrix (3, 4: registers)
 MDRP_GLOBAL __launch_bounds__(64, 2) void kc_solve5_null(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
                                                            const double *__restrict__ pts, double *__restrict__ red /*[pair][block][RED5_STRIDE][64]*/) {
     extern __shared__ double solve5_lds[];

@@ -105,6 +105,138 @@ MDRP_HD void fullpiv_nullspace(double *A, int as, double *N /*[9 - M][9]*/) {
 #undef AQ
 }
 
+// The same factorisation of the 9 x M epipolar constraint matrix (column p = kron(x1[p], x2[p]): entry 3 j + i multiplies E(i, j)) with its
+// last RC columns in registers and only the first M - RC in the caller's strided storage (element (r, c) at A[(9 c + r) as]).  The device keeps the
+// matrix in LDS, one 64-lane column per element, and that allocation is what bounds the occupancy of the 7-point solver and of the 5-point null
+// space kernel (63 columns = 32 KB: five wavefronts per CU; 36 = 18 KB: eight).  Only the two swaps of a step address the matrix with data-dependent
+// indices: on the register columns they are select chains, between a stored and a register column an exchange.  Same operations on the same values in
+// the same order as fullpiv_nullspace<M> behind epipolar_columns<M> (tests/hostmath pins both against the oracle).
+template <int K> struct StepC { static constexpr int value = K; };
+template <int M, int RC>
+MDRP_HD void epipolar_nullspace(const double (*x1h)[3], const double (*x2h)[3], double *A, int as, double *N /*[9 - M][9]*/) {
+    constexpr int NN = 9 - M, ML = M - RC;
+    double rc[RC][9];
+#define AQ(r, c) A[(9 * (c) + (r)) * as]
+    auto get = [&](int r, int c) __attribute__((always_inline)) -> double { return c < ML ? AQ(r, c) : rc[c - ML][r]; }; // r, c: constants after unrolling
+    auto set = [&](int r, int c, double v) __attribute__((always_inline)) { if (c < ML) AQ(r, c) = v; else rc[c - ML][r] = v; };
+#pragma unroll
+    for (int p = 0; p < M; ++p)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) set(3 * j + i, p, x1h[p][j] * x2h[p][i]);
+    double tau[M];
+    int rt[M];
+    double ess[M][9];
+    const double prec = 2.220446049250313e-16 * (double)M;
+    double biggest = 0.0;
+    bool degenerate = false;
+    // one elimination step with the step number as a compile-time constant (a `#pragma unroll` over the steps is only a request: at M = 7 the body
+    // is past the compiler's threshold, the loop stays rolled and every array it indexes with k moves to scratch memory)
+    auto step = [&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        tau[k] = 0.0; rt[k] = k;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) ess[k][r] = 0.0;
+        if (degenerate) return;
+        int br = k, bc = k;
+        double big = -1.0;
+#pragma unroll
+        for (int c = k; c < M; ++c)
+#pragma unroll
+            for (int r = k; r < 9; ++r) {
+                const double v = fabs(get(r, c));
+                if (v > big) { big = v; br = r; bc = c; }
+            }
+        if (k == 0) biggest = big;
+        if (big <= biggest * prec) { degenerate = true; return; }
+        rt[k] = br;
+        if (br != k) {
+#pragma unroll
+            for (int c = k; c < M; ++c) {
+                if (c < ML) { const double t = AQ(k, c); AQ(k, c) = AQ(br, c); AQ(br, c) = t; }
+                else {
+                    const double top = rc[c - ML][k];
+                    double low = top;
+#pragma unroll
+                    for (int r = 0; r < 9; ++r) if (r > k && r == br) { low = rc[c - ML][r]; rc[c - ML][r] = top; }
+                    rc[c - ML][k] = low;
+                }
+            }
+        }
+        if (bc != k) {
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                const double tk = get(r, k);
+                double tb = tk;
+                if (k < ML && bc < ML) { tb = AQ(r, bc); AQ(r, bc) = tk; } // both stored
+                else {
+#pragma unroll
+                    for (int j = 0; j < RC; ++j) if (ML + j > k && ML + j == bc) { tb = rc[j][r]; rc[j][r] = tk; }
+                }
+                set(r, k, tb);
+            }
+        }
+        double col[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) col[r] = (r >= k) ? get(r, k) : 0.0;
+        double tail = 0.0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (r > k) tail += col[r] * col[r];
+        const double c0 = col[k];
+        double beta;
+        if (tail <= 2.2250738585072014e-308) {
+            beta = c0;
+        } else {
+            beta = sqrt(c0 * c0 + tail);
+            if (c0 >= 0.0) beta = -beta;
+            const double inv = 1.0 / (c0 - beta);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) ess[k][r] = col[r] * inv;
+            tau[k] = (beta - c0) / beta;
+        }
+#pragma unroll
+        for (int c = k + 1; c < M; ++c) {
+            double tmp = 0.0;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) tmp += ess[k][r] * get(r, c);
+            tmp += get(k, c);
+            set(k, c, get(k, c) - tau[k] * tmp);
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) set(r, c, get(r, c) - tau[k] * ess[k][r] * tmp);
+        }
+    };
+    step(StepC<0>{}); step(StepC<1>{}); step(StepC<2>{}); step(StepC<3>{}); step(StepC<4>{});
+    if constexpr (M > 5) step(StepC<5>{});
+    if constexpr (M > 6) step(StepC<6>{});
+    static_assert(M >= 5 && M <= 7, "five to seven constraints");
+#pragma unroll
+    for (int j = 0; j < NN; ++j) {
+        double q[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) q[r] = (r == M + j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = M - 1; k >= 0; --k) {
+            double tmp = q[k];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) tmp += ess[k][r] * q[r];
+            q[k] -= tau[k] * tmp;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k) q[r] -= tau[k] * ess[k][r] * tmp;
+            const double qk = q[k];
+            double qr = qk;
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k && r == rt[k]) qr = q[r];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) if (r > k && r == rt[k]) q[r] = qk;
+            q[k] = qr;
+        }
+#pragma unroll
+        for (int r = 0; r < 9; ++r) N[9 * j + r] = q[r];
+    }
+#undef AQ
+}
+
 // epipolar constraint columns kron(x1, x2): entry 3 j + i multiplies E(i, j)  (x2' E x1 = 0)
 template <int M>
 MDRP_HD void epipolar_columns(const double (*x1h)[3], const double (*x2h)[3], double *A /*9 x M col-major, strided*/, int as) {
@@ -405,10 +537,9 @@ struct Reduce5 { double El[3][3][4], bx[3][4], by[3][4], b1[3][5]; };
 constexpr int REDUCE5_DOUBLES = 36 + 12 + 12 + 15;
 
 // E(i, j) = x N0 + y N1 + z N2 + N3 as linear polynomials [x, y, z, 1]: the only copy of the null space that is kept
-MDRP_HD void relpose_5pt_nullspace(const double (*x1h)[3], const double (*x2h)[3], double *C /*9 x 5 constraint matrix, strided*/, int cs, double El[3][3][4]) {
+MDRP_HD void relpose_5pt_nullspace(const double (*x1h)[3], const double (*x2h)[3], double *C /*columns 0..2 of the 9 x 5 constraint matrix, strided*/, int cs, double El[3][3][4]) {
     double N[36];
-    epipolar_columns<5>(x1h, x2h, C, cs);
-    fullpiv_nullspace<5>(C, cs, N);
+    epipolar_nullspace<5, 2>(x1h, x2h, C, cs, N); // 27 elements in C
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -430,8 +561,8 @@ MDRP_HD bool relpose_5pt_eliminate(const Solve5Store &store, Reduce5 &red) {
     const int cs = store.cs;
     double mc[2][10]; // columns 0 and 1 of M
 #define M5(r, k) M[(8 * (r) + (k) - 2) * cs]
-    auto mget = [&](int r, int k) -> double { return k < 2 ? mc[k][r] : M5(r, k); }; // r, k: constants after unrolling
-    auto mset = [&](int r, int k, double v) { if (k < 2) mc[k][r] = v; else M5(r, k) = v; };
+    auto mget = [&](int r, int k) __attribute__((always_inline)) -> double { return k < 2 ? mc[k][r] : M5(r, k); }; // r, k: constants after unrolling
+    auto mset = [&](int r, int k, double v) __attribute__((always_inline)) { if (k < 2) mc[k][r] = v; else M5(r, k) = v; };
     double R[10][10];
     {
         double EEs[6][10], tr[10]; // E E' is symmetric: entry (i, j) at sym(i, j)
@@ -1089,10 +1220,9 @@ struct Solve5Local {
 // A fundamental matrix travels in the first nine doubles of a Model, row-major (q[0..3], t[0..2], scale, shift1).
 MDRP_HD double *model_F(Model &m) { return m.q; }
 MDRP_HD const double *model_F(const Model &m) { return m.q; }
-MDRP_HD int solver_fundamental_7pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[3]*/, double *A /*63 doubles, strided*/, int as) {
+MDRP_HD int solver_fundamental_7pt(const double (*x1h)[3], const double (*x2h)[3], Model *out /*[3]*/, double *A /*36 doubles, strided*/, int as) {
     double N[18];
-    epipolar_columns<7>(x1h, x2h, A, as);
-    fullpiv_nullspace<7>(A, as, N);
+    epipolar_nullspace<7, 3>(x1h, x2h, A, as, N); // columns 0..3 of the 9 x 7 constraint matrix in A
     const double *N0 = N, *N1 = N + 9;
     // det(r A + B), A = mat(N0), B = mat(N1), vec index of (i, j) = 3 j + i
     double c[4] = {0, 0, 0, 0};
