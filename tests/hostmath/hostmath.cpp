@@ -206,6 +206,22 @@ int hm_relpose_7pt(const double *x1h, const double *x2h, double *out /*3*12*/) {
     std::memcpy(out, m, sizeof(Model) * n);
     return n;
 }
+// the null space of M epipolar constraints, by the stored-matrix factorisation (which = 0) and by the one with trailing columns in registers (which = 1)
+int hm_nullspace(int M, int which, const double *x1h, const double *x2h, double *N /*[9 - M][9]*/) {
+    const double(*a)[3] = reinterpret_cast<const double(*)[3]>(x1h);
+    const double(*b)[3] = reinterpret_cast<const double(*)[3]>(x2h);
+    double A[63];
+    if (which == 0) {
+        if (M == 5) { epipolar_columns<5>(a, b, A, 1); fullpiv_nullspace<5>(A, 1, N); }
+        else if (M == 7) { epipolar_columns<7>(a, b, A, 1); fullpiv_nullspace<7>(A, 1, N); }
+        else return 1;
+    } else {
+        if (M == 5) epipolar_nullspace<5, 2>(a, b, A, 1, N);
+        else if (M == 7) epipolar_nullspace<7, 3>(a, b, A, 1, N);
+        else return 1;
+    }
+    return 0;
+}
 int hm_real_roots10(const double *c, double *roots) { return real_roots<10>(c, roots); }
 int hm_real_roots10_fast(const double *c, double *roots) {
     Solve5Local loc;

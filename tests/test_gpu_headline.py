@@ -440,7 +440,8 @@ GPU_MINUS_ORACLE_LO_BASELINES = {
     # 5-point: a degree-10 root at the edge of existence, found by the device's elimination order (LU in LDS) and not by the oracle's (Gauss-Jordan), sets a
     # record: one more LO, nothing else changes (the class of DESIGN.md 8a; 6 of 3840 pairs in the stress campaign).  On pair 939 the reference has it too.
     # (Until the null space moved into a kernel of its own — other fused multiply-adds in the elimination's last bits, DESIGN.md 8a — pairs 553 and 864
-    # were in this list as well, against the reference; now the LO count equals the reference's on every pair of the batch.)
+    # were in this list as well, against the reference: the batch's LO count now differs from the reference's on 11 pairs instead of 13 — the oracle's
+    # own differences, stored in the fixture as `oracle_refinements`.)
     "relpose_5pt_n2000_i10k": {939: 1},
     "fundamental_7pt_n2000_i10k": {},
     "shared_6pt_n2000_i10k": {},

@@ -196,6 +196,33 @@ def test_device_solvers_equal_oracle_on_random_samples(hm):
             assert all(fund_diff(out[k], ref[k]) < 1e-10 for k in range(n)), trial
 
 
+def test_null_space_with_register_columns_equals_the_stored_factorisation(hm):
+    """epipolar_nullspace<M, RC> (the device's: trailing constraint columns in registers, swaps as select chains) against epipolar_columns<M> +
+    fullpiv_nullspace<M> (everything in the strided matrix): the same operations on the same values, so on the host — no fused multiply-adds — the
+    two null spaces are equal bit for bit; generic samples, samples with repeated points (rank-deficient: the `degenerate` exit) and samples whose
+    largest entries sit in the trailing columns (the pivot search then picks a register column in the first step)."""
+    rng = np.random.default_rng(5)
+
+    def unit(x):
+        h = np.c_[x, np.ones(len(x))]
+        return np.ascontiguousarray(h / np.linalg.norm(h, axis=1, keepdims=True))
+
+    for trial in range(900):
+        M = 5 if trial % 2 == 0 else 7
+        x1 = rng.uniform(-1, 1, (M, 2))
+        x2 = x1 + rng.normal(size=(M, 2)) * (0.1 if trial % 4 < 2 else 1.0)
+        if trial % 9 == 4:
+            x1[1], x2[1] = x1[0], x2[0]                      # two identical constraints
+        if trial % 9 == 7:
+            x1[-1] *= 30.0; x2[-2] *= 30.0                    # the largest entries in the last columns
+        a, b = unit(x1), unit(x2)
+        if trial % 9 == 7:
+            a[-1] *= 50.0                                     # (not unit bearings: the factorisation does not care)
+        n0, n1 = np.zeros((9 - M, 9)), np.zeros((9 - M, 9))
+        assert hm.hm_nullspace(M, 0, P(a), P(b), P(n0)) == 0 and hm.hm_nullspace(M, 1, P(a), P(b), P(n1)) == 0
+        assert n0.tobytes() == n1.tobytes(), (trial, M, np.abs(n0 - n1).max())
+
+
 # ---------------------------------------------------------------------------------------------- 6-point, shared focal
 def _sixpt_residual(sol, a, b):
     """how well a solution (q, t, f) reproduces the six epipolar constraints: max |x2' F x1| / |F| with F = K^-1' [t]x R K^-1
