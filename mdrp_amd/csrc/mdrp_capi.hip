@@ -522,7 +522,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             }
             double *dep_p = h->dep.as<double>() + (size_t)p0 * n_max * 2;
 #define MDRP_SOLVE_LAUNCH(S)                                                                                                   \
-    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + 255) / 256, pc), dim3(256), 0, st_, r, st_p, smp, pts_p, dep_p, models_p, inl_p, tg, mc, 0, r.chunk_len)
+    hipLaunchKernelGGL(k_solve<S>, dim3((r.chunk_len + solve_threads(S) - 1) / solve_threads(S), pc), dim3(solve_threads(S)), 0, st_, r, st_p, smp, pts_p, dep_p, models_p, inl_p, tg, mc, 0, r.chunk_len)
             switch (r.solver) {
             case SOLVER_P3P: MDRP_SOLVE_LAUNCH(SOLVER_P3P); break;
             case SOLVER_SHIFT: MDRP_SOLVE_LAUNCH(SOLVER_SHIFT); break;

@@ -469,14 +469,22 @@ constexpr int PROBE_PTS = 64; // scale of the candidate-density key: key = candi
 // ------------------------------------------------------------------------------------------------ solve
 // One lane per minimal sample.  Models go to models[pair][iter][k]; live slots are appended to the pair's tag list
 // with ONE atomic per wave (wave-aggregated prefix sum); model_count[2 * pair] counts them.
+// Nothing in the kernel is shared between wavefronts, so the workgroup size only decides how slots are refilled: with one wavefront per workgroup a
+// finished wavefront is replaced at once instead of when the slowest of four has finished (the solvers' run time varies with the number of
+// roots): the kernel alone is 25 % shorter (P3P 1.66 -> 1.25 ms, shared focal 1.52 -> 1.30, shift 1.85 -> 1.30).  But the long solver launch runs
+// BESIDE the first chunk's exact sweep, and the faster it takes the chip's slots the later that sweep's lane-per-hypothesis loops (0.5 ms of latency
+// that nothing shortens) get going: A/B on one box, three runs each — shared focal 8.05-8.27 -> 7.82-7.95 ms per step, shift solver 8.72-8.86 ->
+// 8.81-8.89, calibrated P3P 8.33-8.49 -> 8.49-8.74 (its first sweep then ends 0.6 ms after the solver instead of inside it; stream priorities
+// change nothing).  So: one wavefront per workgroup for the focal solvers, four for the calibrated ones.
+constexpr int solve_threads(int solver) { return solver == SOLVER_P3P || solver == SOLVER_SHIFT ? 256 : 64; }
 template <int SOLVER> // one solver per kernel (host dispatch): a runtime switch made every launch carry the registers of the largest
-__global__ __launch_bounds__(256, MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
+__global__ __launch_bounds__(solve_threads(SOLVER), MDRP_SOLVE_MINWAVES) void k_solve(RunParams rp, const PairState *__restrict__ st, const uint32_t *__restrict__ samples,
                                                const double *__restrict__ pts, const double *__restrict__ dep,
                                                Model *__restrict__ models, int32_t *__restrict__ slot_inl,
                                                uint32_t *__restrict__ tags, int32_t *__restrict__ model_count,
                                                int it_begin, int it_end /*iterations [it_begin, it_end) of the chunk: one launch solves a sub-range*/) {
     const int pair = blockIdx.y;
-    const int it = it_begin + blockIdx.x * 256 + threadIdx.x;
+    const int it = it_begin + blockIdx.x * solve_threads(SOLVER) + threadIdx.x;
     const PairState &ps = st[pair];
     if (!ps.active) return;
     const bool live = it < it_end;
