@@ -227,4 +227,10 @@ int hm_real_roots10_fast(const double *c, double *roots) {
     Solve5Local loc;
     return real_roots_fast<10>(c, roots, loc.store().rs);
 }
+// the device's storage: the isolated intervals in the free end of the interval stack's own arrays (mdrp_classic.h lds_solve5_store)
+int hm_real_roots10_fast_shared(const double *c, double *roots) {
+    double lo[12], hi[12];
+    int cc[12];
+    return real_roots_fast<10>(c, roots, RootStack{lo, hi, cc, lo + 11, hi + 11, 1, -1});
+}
 }

@@ -196,6 +196,38 @@ def test_device_solvers_equal_oracle_on_random_samples(hm):
             assert all(fund_diff(out[k], ref[k]) < 1e-10 for k in range(n)), trial
 
 
+def test_root_finder_with_shared_interval_storage_equals_separate_arrays(hm):
+    """real_roots_fast<10> with the isolated intervals stored in the free end of the interval stack's arrays (the device's layout: what bounds the
+    root kernel's LDS) against the same routine with separate arrays: the same roots bit for bit — also with all ten roots real (stack and isolated
+    intervals then meet: 10 of the 12 shared entries), with clustered and with repeated roots."""
+    rng = np.random.default_rng(17)
+    seen10 = 0
+    for trial in range(1500):
+        mode = trial % 5
+        if mode == 0:
+            c = rng.normal(size=11)
+        elif mode == 1:                                   # ten real roots
+            c = np.poly(rng.uniform(-3, 3, 10))[::-1] * rng.uniform(0.1, 10)
+        elif mode == 2:                                   # clusters
+            c = np.poly(np.r_[rng.uniform(-2, 2, 4), 0.7 + 1e-6 * rng.normal(size=3), -1.1 + 1e-9 * rng.normal(size=3)])[::-1]
+        elif mode == 3:                                   # repeated roots and a complex pair
+            r = rng.uniform(-2, 2, 3)
+            c = np.real(np.poly(np.r_[r, r, r[:2], 0.3 + 0.9j, 0.3 - 0.9j]))[::-1]
+        else:                                             # a few real roots among complex pairs
+            z = rng.normal(size=4) + 1j * rng.uniform(0.2, 2, 4)
+            c = np.real(np.poly(np.r_[z, z.conj(), rng.uniform(-4, 4, 2)]))[::-1]
+        c = np.ascontiguousarray(c, dtype=np.float64)
+        ra, rb = np.zeros(10), np.zeros(10)
+        na, nb = hm.hm_real_roots10_fast(P(c), P(ra)), hm.hm_real_roots10_fast_shared(P(c), P(rb))
+        assert na == nb and ra[:na].tobytes() == rb[:nb].tobytes(), (trial, na, nb, ra, rb)
+        assert np.all(np.diff(ra[:na]) >= 0), (trial, ra[:na])
+        seen10 += na == 10
+        if mode == 1:
+            want = np.sort(np.roots(c[::-1]).real)
+            assert na == 10 and np.allclose(ra, want, rtol=1e-6, atol=1e-6), (trial, ra, want)
+    assert seen10 >= 250
+
+
 def test_null_space_with_register_columns_equals_the_stored_factorisation(hm):
     """epipolar_nullspace<M, RC> (the device's: trailing constraint columns in registers, swaps as select chains) against epipolar_columns<M> +
     fullpiv_nullspace<M> (everything in the strided matrix): the same operations on the same values, so on the host — no fused multiply-adds — the
