@@ -411,10 +411,16 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     std::vector<uint64_t> lead;
     {
         const char *e = getenv("MDRP_CHUNKS");
-        // (round 6, with the two-phase count: the focal estimators and the scale + shift solver — more models per sample, a looser bar from 128
-        // iterations — gain 4 % with a first chunk of 256: shared focal 123.0 -> 128.0 k, shift 112.2 -> 116.6 k, varying focal 29.2 -> 29.7 k; the
-        // calibrated P3P path is flat between 128 and 384)
-        std::string spec = e ? e : (kind == MDRP_FUNDAMENTAL_7PT ? "128,1024" : (classic || rp.solver == SOLVER_P3P ? "128" : "256"));
+        // Round 6, with the two-phase count: at 50 % outliers the step is flat in the first chunk's length from 128 to 512 iterations (calibrated P3P
+        // 8.45-8.49 / 8.44-8.55 / 8.40-8.41 / 8.51-8.66 ms at 128 / 256 / 384 / 512; shared focal 8.05 -> 7.99 at 256 or 384) — what a longer first
+        // chunk costs in exact scoring it returns as a tighter bar — but NOT at other outlier ratios: one 3-point sample in 64 is outlier-free at
+        // 75 % outliers, one in 300 at 85 %, and a pair whose first chunk holds none sends the whole rest of its run through the fp32 bound and the
+        // exact sweep: 75 % outliers 124 k pairs/s with 128, 142 k with 256, 147 k with 384; 85 %: 78 k / 93 k / 104 k (136 k with 1024).  The
+        // outlier-free shape pays for it the other way round (every hypothesis of the first chunk is a good one and is scored in full: 72.3 k with
+        // 128, 71.1 k with 256, 69.5 k with 384).  Default: 256 for the 3-point estimators where the run is long enough to pay for it (a sixteenth of
+        // the iterations that certainly run, between 128 and 256), 512 for the 5-point one (solver-bound: flat), 128,1024 for the 7-point one
+        // (above); MDRP_CHUNKS=384 or 128,1024 for data with fewer than one inlier in four.
+        std::string spec = e ? e : (kind == MDRP_FUNDAMENTAL_7PT ? "128,1024" : (kind == MDRP_RELPOSE_5PT ? "512" : "128"));
         size_t pos = 0;
         while (pos < spec.size() && (int)lead.size() < mdrp_handle::NC_MAX - 1) {
             const size_t q = spec.find(',', pos);
@@ -423,6 +429,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (q == std::string::npos) break;
             pos = q + 1;
         }
+        if (!e && !classic) lead.assign(1, std::min<uint64_t>(256, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
     }
     uint64_t max_needed = 0;
     rp.slot_stride = chunk_cap * mps;
