@@ -53,7 +53,8 @@ class Stats(C.Structure):
                 ("lo_ms", C.c_double), ("lo_launches", C.c_int64), ("final_ms", C.c_double), ("final_launches", C.c_int64),
                 ("bound_ms", C.c_double), ("bound_launches", C.c_int64), ("solve_ms", C.c_double), ("solve_launches", C.c_int64),
                 ("lm_cost_evals", C.c_int64), ("lm_accum_evals", C.c_int64), ("final_cost_evals", C.c_int64), ("final_accum_evals", C.c_int64),
-                ("fuse_gate_timeouts", C.c_int64), ("fuse_wait_timeouts", C.c_int64)]  # ABI 0.3 (mdrp_last_stats_sized)
+                ("fuse_gate_timeouts", C.c_int64), ("fuse_wait_timeouts", C.c_int64),  # ABI 0.3 (mdrp_last_stats_sized)
+                ("first_chunk", C.c_int64)]  # ABI 0.5
 
 
 class Result(C.Structure):

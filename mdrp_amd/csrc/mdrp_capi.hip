@@ -74,7 +74,10 @@ struct Progress {
     unsigned long long evals_mfma;  // evaluations executed by k_count on the matrix cores (padded to 16 x 16 tiles)
     unsigned long long evals_sweep; // evaluations handed to the fp64 sweep (survivors * n)
     unsigned long long evals_bound; // evaluations executed by k_bound in fp32 (k_count's survivors * n)
+    int32_t inl_sum16, n_sum16;     // final refinements: sums over the pairs of (inliers of the result) / 16 and N / 16 (RunParams::inl_stat)
 };
+static_assert(sizeof(Progress) == 14 * sizeof(int32_t), "Progress ends where the LO queue heads begin");
+constexpr int CNT_INL_STAT = 14; // int32 index of Progress::inl_sum16 in the `counters` buffer
 constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
 constexpr int CNT_XCD_HEAD = 32; // int32 index of the per-XCD LO queue heads: [chunk][8] at LO_XCD_STRIDE ints (lo_take, mdrp_kernels.h)
 constexpr size_t COUNTERS_BYTES = sizeof(int32_t) * (CNT_XCD_HEAD + 8 * LO_XCD_STRIDE);
@@ -130,6 +133,8 @@ struct mdrp_handle {
                                       // fused tail: gate time-outs | final-refinement wait time-outs
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
     int64_t fuse_gate_timeouts = 0, fuse_wait_timeouts = 0; // of the last call
+    int64_t first_chunk = 0;                                // of the last call (mdrp_stats::first_chunk)
+    double seen_inlier_ratio[3] = {-1.0, -1.0, -1.0};       // per monodepth estimator: inlier ratio of the results of its last call that measured one
     bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, run unfused ...
     int fuse_retry_in = 0;            // ... for this many API calls, then try the fused tail again (a busy moment on a shared GPU is not a profiler)
     int fuse_backoff = 64;            // ... doubled after every consecutive expired wait (capped), reset by a call whose fused tail ran through
@@ -391,6 +396,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
     const size_t lo_mask_rows = (size_t)h->num_cu * 8; // kc_lo launches num_cu * (8 | 2) workgroups
     if ((kind == MDRP_RELPOSE_5PT || kind == MDRP_SHARED_6PT) && (rc = h->lo_mask.ensure(lo_mask_rows * (size_t)std::max(n_max, 1)))) return rc;
     int32_t *cnt = h->counters.as<int32_t>();
+    rp.inl_stat = classic ? nullptr : cnt + CNT_INL_STAT;
     const size_t tile_bytes = SCORE_TILE_BYTES;
 
     uint64_t it0 = 0;
@@ -429,7 +435,18 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (q == std::string::npos) break;
             pos = q + 1;
         }
-        if (!e && !classic) lead.assign(1, std::min<uint64_t>(256, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
+        if (!e && !classic) {
+            lead.assign(1, std::min<uint64_t>(256, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
+            // ... and where the handle's previous call with this estimator (kind 0..2 here) has measured the inlier ratio r of its results: ~6 outlier-free samples
+            // expected in the first chunk, 6 / r^3 iterations between 256 and 1024 (r = 0.5: 256; 0.25: 384; 0.15: 1024), 128 for (nearly)
+            // outlier-free data (r > 0.72) — the lengths the sweeps above found best at 0, 50, 75 and 85 % outliers.  A long run only (the first
+            // chunk stays under an eighth of it).
+            if (h->seen_inlier_ratio[kind] >= 0.0 && certain >= 8192) {
+                const double r = std::max(h->seen_inlier_ratio[kind], 0.05);
+                const double want = 6.0 / (r * r * r);
+                lead[0] = want <= 16.0 ? 128 : (uint64_t)std::min(1024.0, std::max(256.0, std::ceil(want / 64.0) * 64.0));
+            }
+        }
     }
     uint64_t max_needed = 0;
     rp.slot_stride = chunk_cap * mps;
@@ -451,6 +468,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         }
         uint64_t super_len = 0;
         for (int c = 0; c < n_chunks; ++c) super_len += lens[c];
+        if (it0 == 0) h->first_chunk = (int64_t)lens[0];
         rp.chunk_start = it0; rp.super_len = (int)super_len;
         HIPCHK(hipMemsetAsync(h->counters.p, 0, COUNTERS_BYTES, s));
         if (it0 == 0) HIPCHK(hipMemsetAsync(h->cand_stat.p, 0, sizeof(unsigned long long) * 2 * batch, s));
@@ -763,6 +781,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
         h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
         h->bound_evals += (int64_t)h->progress_host->evals_bound;
+        if (final_done && h->progress_host->n_sum16 > 0) { // (fused tail: the final refinements are behind this read-back; otherwise they are still to come)
+            h->seen_inlier_ratio[kind] = (double)h->progress_host->inl_sum16 / (double)h->progress_host->n_sum16;
+        }
         if (getenv("MDRP_DEBUG"))
             fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu (mfma %llu, fp32 bound %llu, fp64 sweep %llu = %.2f %%) active %d max_needed %llu\n",
                     (unsigned long long)it0, (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->evals_mfma,
@@ -1085,6 +1106,7 @@ int mdrp_last_stats_sized(mdrp_handle *h, mdrp_stats *out, size_t out_size) {
     out->lm_cost_evals = h->lm_cost_evals; out->lm_accum_evals = h->lm_accum_evals;
     out->final_cost_evals = h->fin_cost_evals; out->final_accum_evals = h->fin_accum_evals;
     out->fuse_gate_timeouts = h->fuse_gate_timeouts; out->fuse_wait_timeouts = h->fuse_wait_timeouts;
+    out->first_chunk = h->first_chunk;
     std::memcpy(caller, &full, std::min(out_size, sizeof full)); // a caller compiled against an older, shorter struct gets its prefix
     return MDRP_OK;
 }

@@ -110,6 +110,7 @@ struct RunParams {
     // user bundle options (final refinement)
     int final_max_it, final_loss;
     double grad_tol, step_tol, lambda0, lambda_min, lambda_max;
+    int32_t *inl_stat;  // [2]: sums over the pairs of (inliers of the result) / 16 and N / 16 — the host sizes the NEXT call's first chunk from their ratio
 };
 
 // ------------------------------------------------------------------------------------------------ reductions: cross-lane sums (gfx950)
@@ -2535,6 +2536,7 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         res.refinements = ps.refinements + 1; res.iterations = ps.iterations; res.num_inliers = num_inliers;
         res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
         results[pair] = res;
+        if (rp.inl_stat) { atomicAdd(&rp.inl_stat[0], (int32_t)(num_inliers >> 4)); atomicAdd(&rp.inl_stat[1], (int32_t)(ps.n >> 4)); }
         lm_flush_stats(sh);
     }
 }

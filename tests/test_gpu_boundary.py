@@ -266,6 +266,47 @@ def test_host_buffer_call_in_h2d_slices_equals_the_resident_call():
         h.close()
 
 
+def test_first_chunk_follows_the_inlier_ratio_of_the_previous_call_and_changes_no_result():
+    """The first chunk of a run (scored exactly in full: no bar yet) is sized from the inlier ratio of the handle's previous call with the same estimator
+    (mdrp_capi.hip run_pass; mdrp_stats::first_chunk): 256 iterations on a fresh handle, 6 / r^3 between 256 and 1024 afterwards (128 for nearly
+    outlier-free data) — r = 0.2 (80 % outliers): 768; r = 0.5: 256; r = 1: 128 — for runs of at least 8192 certain iterations, per estimator, never under MDRP_CHUNKS.  Records and masks of the same
+    batch are identical whatever the length was."""
+    from mdrp_amd import _capi, synth
+    B, N = 48, 600
+    ro = _capi.ransac_opt_from_dict({"max_iterations": 8192, "min_iterations": 8192, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+    ro_short = _capi.ransac_opt_from_dict({"max_iterations": 2000, "min_iterations": 2000, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
+    bo = _capi.bundle_opt_from_dict({"loss_type": "TRUNCATED_CAUCHY"})
+    cams = np.zeros(B, dtype=_capi.CAMERA_DTYPE); cams["params"][:, 0] = 800.0
+
+    def batch(of, rf=None):
+        b = synth.make_batch(4200, B, N, noise_px=0.5, depth_noise=0.02, outlier_frac=of, random_focal=rf)
+        return b["x1"], b["x2"], b["d1"], b["d2"]
+
+    dirty, half, clean, shared = batch(0.8), batch(0.5), batch(0.0), batch(0.8, "shared")
+    h = _capi.Handle(0)
+    try:
+        def run(kind, data, opt=ro):
+            c = cams if kind == 0 else None
+            res, mask = h.estimate_batch(kind, *data, opt, bo, None, c, c)
+            return res.tobytes(), mask.tobytes(), int(h.last_stats()["first_chunk"])
+        r1 = run(0, dirty)
+        assert r1[2] == 256                                    # fresh handle
+        r2 = run(0, dirty)
+        assert 512 <= r2[2] <= 896 and r2[:2] == r1[:2], r2[2]  # r ~ 0.2: 6 / r^3 = 750 -> 768 (0.19 ... 0.22: 896 ... 576); the same records and masks
+        assert run(0, dirty, ro_short)[2] == 128                # a short run keeps a sixteenth of its certain iterations, at least 128
+        r3 = run(1, shared)
+        assert r3[2] == 256                                    # another estimator: its own history
+        r4 = run(0, half)
+        assert r4[2] == r2[2]                                  # (sized by the calibrated call before it)
+        r5 = run(0, half)
+        assert r5[2] == 256 and r5[:2] == r4[:2], r5[2]         # r ~ 0.5: 48 -> 256
+        run(0, clean)
+        assert run(0, clean)[2] == 128                          # r ~ 1: 6 -> 128
+        assert 512 <= run(1, shared)[2] <= 896                  # the shared-focal estimator's second call
+    finally:
+        h.close()
+
+
 def test_local_shard_through_the_device_gather_path_one_rank():
     """BASELINE configs[4]'s data path on ONE GPU: dist.estimate_local_shard_device — device-resident inputs,
     mdrp_estimate_batch_async, mdrp_copy_results_device into the rank's slot, all_gather_into_tensor over RCCL (a one-rank `nccl`
