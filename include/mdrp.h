@@ -258,9 +258,9 @@ typedef struct {
     int64_t fuse_wait_timeouts;
     /* ---- appended in ABI 0.5 (mdrp_last_stats_sized only) ----
      * Iterations of the first chunk of the last call — the part of a run that is scored exactly in full because nothing has set a bar yet.  The
-     * monodepth estimators size it from the inlier ratio of the handle's PREVIOUS call with the same estimator (a pair whose first chunk holds no
-     * outlier-free sample has no bar for the rest of its run: 128 iterations where half of the correspondences are inliers, 1024 where one in seven
-     * is), 256 without one; MDRP_CHUNKS overrides.  Results do not depend on it. */
+     * monodepth estimators size it from the inlier ratios of the results of the handle's PREVIOUS call with the same estimator (a pair whose first
+     * chunk holds no outlier-free sample has no bar for the rest of its run: 256 iterations where half of the correspondences are inliers, 1024
+     * where one in seven is, 128 where all are), 256 without one; MDRP_CHUNKS overrides.  Results do not depend on it. */
     int64_t first_chunk;
 } mdrp_stats;
 /* writes min(out_size, sizeof(mdrp_stats)) bytes: pass sizeof(mdrp_stats) of the header the caller was compiled against */

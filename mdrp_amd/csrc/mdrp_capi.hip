@@ -74,10 +74,10 @@ struct Progress {
     unsigned long long evals_mfma;  // evaluations executed by k_count on the matrix cores (padded to 16 x 16 tiles)
     unsigned long long evals_sweep; // evaluations handed to the fp64 sweep (survivors * n)
     unsigned long long evals_bound; // evaluations executed by k_bound in fp32 (k_count's survivors * n)
-    int32_t inl_sum16, n_sum16;     // final refinements: sums over the pairs of (inliers of the result) / 16 and N / 16 (RunParams::inl_stat)
+    int32_t wish_sum, wish_pairs;   // final refinements: sum over the pairs of first_chunk_wish(inlier ratio of the result), number of pairs (RunParams::inl_stat)
 };
 static_assert(sizeof(Progress) == 14 * sizeof(int32_t), "Progress ends where the LO queue heads begin");
-constexpr int CNT_INL_STAT = 14; // int32 index of Progress::inl_sum16 in the `counters` buffer
+constexpr int CNT_INL_STAT = 14; // int32 index of Progress::wish_sum in the `counters` buffer
 constexpr int CNT_LO_HEAD = 16; // int32 index of the LO queue heads (one per chunk) in the `counters` buffer
 constexpr int CNT_XCD_HEAD = 32; // int32 index of the per-XCD LO queue heads: [chunk][8] at LO_XCD_STRIDE ints (lo_take, mdrp_kernels.h)
 constexpr size_t COUNTERS_BYTES = sizeof(int32_t) * (CNT_XCD_HEAD + 8 * LO_XCD_STRIDE);
@@ -134,7 +134,7 @@ struct mdrp_handle {
     unsigned long long *lm_stats_host = nullptr; // pinned copy, valid after finish_timing
     int64_t fuse_gate_timeouts = 0, fuse_wait_timeouts = 0; // of the last call
     int64_t first_chunk = 0;                                // of the last call (mdrp_stats::first_chunk)
-    double seen_inlier_ratio[3] = {-1.0, -1.0, -1.0};       // per monodepth estimator: inlier ratio of the results of its last call that measured one
+    double seen_wish[3] = {-1.0, -1.0, -1.0};               // per monodepth estimator: mean first_chunk_wish over the results of its last call that measured it
     bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, run unfused ...
     int fuse_retry_in = 0;            // ... for this many API calls, then try the fused tail again (a busy moment on a shared GPU is not a profiler)
     int fuse_backoff = 64;            // ... doubled after every consecutive expired wait (capped), reset by a call whose fused tail ran through
@@ -437,15 +437,13 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         }
         if (!e && !classic) {
             lead.assign(1, std::min<uint64_t>(256, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
-            // ... and where the handle's previous call with this estimator (kind 0..2 here) has measured the inlier ratio r of its results: ~6 outlier-free samples
-            // expected in the first chunk, 6 / r^3 iterations between 256 and 1024 (r = 0.5: 256; 0.25: 384; 0.15: 1024), 128 for (nearly)
-            // outlier-free data (r > 0.72) — the lengths the sweeps above found best at 0, 50, 75 and 85 % outliers.  A long run only (the first
-            // chunk stays under an eighth of it).
-            if (h->seen_inlier_ratio[kind] >= 0.0 && certain >= 8192) {
-                const double r = std::max(h->seen_inlier_ratio[kind], 0.05);
-                const double want = 6.0 / (r * r * r);
-                lead[0] = want <= 16.0 ? 128 : (uint64_t)std::min(1024.0, std::max(256.0, std::ceil(want / 64.0) * 64.0));
-            }
+            // ... and where the handle's previous call with this estimator (kind 0..2 here) has results to go by: the mean over its pairs of what each
+            // would have liked (first_chunk_wish, mdrp_kernels.h: 6 / r^3 iterations for the pair's inlier ratio r, between 256 and 1024; 128 for nearly
+            // outlier-free pairs) — the lengths the sweeps above found best at 0, 50, 75 and 85 % outliers, and for a batch that mixes them (20 / 50 / 70 /
+            // 85 % by pair: 93.7 k pairs/s at 128, 101 k at 256, 105 k at 384-512, 104 k at 1024).  A long run only (the first chunk stays under an
+            // eighth of it).
+            if (h->seen_wish[kind] >= 0.0 && certain >= 8192)
+                lead[0] = (uint64_t)std::min(1024.0, std::max(128.0, std::ceil(h->seen_wish[kind] / 64.0) * 64.0));
         }
     }
     uint64_t max_needed = 0;
@@ -781,9 +779,8 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         h->mfma_evals += (int64_t)h->progress_host->evals_mfma;
         h->fp64_evals += (int64_t)h->progress_host->evals_sweep;
         h->bound_evals += (int64_t)h->progress_host->evals_bound;
-        if (final_done && h->progress_host->n_sum16 > 0) { // (fused tail: the final refinements are behind this read-back; otherwise they are still to come)
-            h->seen_inlier_ratio[kind] = (double)h->progress_host->inl_sum16 / (double)h->progress_host->n_sum16;
-        }
+        if (final_done && h->progress_host->wish_pairs > 0) // (fused tail: the final refinements are behind this read-back; otherwise they are still to come)
+            h->seen_wish[kind] = (double)h->progress_host->wish_sum / (double)h->progress_host->wish_pairs;
         if (getenv("MDRP_DEBUG"))
             fprintf(stderr, "[mdrp] super-chunk start %llu len %llu (%d chunks): evals %llu (mfma %llu, fp32 bound %llu, fp64 sweep %llu = %.2f %%) active %d max_needed %llu\n",
                     (unsigned long long)it0, (unsigned long long)super_len, n_chunks, h->progress_host->evals, h->progress_host->evals_mfma,

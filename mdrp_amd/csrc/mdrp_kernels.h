@@ -110,8 +110,19 @@ struct RunParams {
     // user bundle options (final refinement)
     int final_max_it, final_loss;
     double grad_tol, step_tol, lambda0, lambda_min, lambda_max;
-    int32_t *inl_stat;  // [2]: sums over the pairs of (inliers of the result) / 16 and N / 16 — the host sizes the NEXT call's first chunk from their ratio
+    int32_t *inl_stat;  // [2]: sum over the pairs of first_chunk_wish(inlier ratio of the result), and their number — the host sizes the NEXT call's first chunk from the mean
 };
+
+// The first chunk of a run is scored exactly in full (nothing has set a bar yet); everything behind it meets the bar it leaves, and a pair whose
+// first chunk holds no outlier-free sample has none.  With r the pair's inlier ratio and k its sample size: 6 / r^k iterations — six such samples
+// expected — between 256 and 1024; 128 where (nearly) every sample is one.  Measured at 0 / 50 / 75 / 85 % outliers (mdrp_capi.hip run_pass).
+MDRP_HD int32_t first_chunk_wish(double r, int k) {
+    if (!(r > 0.05)) r = 0.05;
+    double p = r;
+    for (int i = 1; i < k; ++i) p *= r;
+    const double want = 6.0 / p;
+    return want <= 16.0 ? 128 : (want >= 1024.0 ? 1024 : (want <= 256.0 ? 256 : (int32_t)want));
+}
 
 // ------------------------------------------------------------------------------------------------ reductions: cross-lane sums (gfx950)
 template <int CTRL>
@@ -2536,7 +2547,10 @@ __device__ __forceinline__ void final_pair(const RunParams &rp, const PairState 
         res.refinements = ps.refinements + 1; res.iterations = ps.iterations; res.num_inliers = num_inliers;
         res.inlier_ratio = ps.inlier_ratio; res.model_score = ps.model_score;
         results[pair] = res;
-        if (rp.inl_stat) { atomicAdd(&rp.inl_stat[0], (int32_t)(num_inliers >> 4)); atomicAdd(&rp.inl_stat[1], (int32_t)(ps.n >> 4)); }
+        if (rp.inl_stat) { // what this pair would have liked as the run's first chunk: ~6 outlier-free samples expected in it (first_chunk_wish)
+            atomicAdd(&rp.inl_stat[0], first_chunk_wish((double)num_inliers / (double)ps.n, 3));
+            atomicAdd(&rp.inl_stat[1], 1);
+        }
         lm_flush_stats(sh);
     }
 }

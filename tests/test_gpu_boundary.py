@@ -267,10 +267,11 @@ def test_host_buffer_call_in_h2d_slices_equals_the_resident_call():
 
 
 def test_first_chunk_follows_the_inlier_ratio_of_the_previous_call_and_changes_no_result():
-    """The first chunk of a run (scored exactly in full: no bar yet) is sized from the inlier ratio of the handle's previous call with the same estimator
-    (mdrp_capi.hip run_pass; mdrp_stats::first_chunk): 256 iterations on a fresh handle, 6 / r^3 between 256 and 1024 afterwards (128 for nearly
-    outlier-free data) — r = 0.2 (80 % outliers): 768; r = 0.5: 256; r = 1: 128 — for runs of at least 8192 certain iterations, per estimator, never under MDRP_CHUNKS.  Records and masks of the same
-    batch are identical whatever the length was."""
+    """The first chunk of a run (scored exactly in full: no bar yet) is sized from the results of the handle's previous call with the same estimator
+    (mdrp_capi.hip run_pass; mdrp_stats::first_chunk): 256 iterations on a fresh handle; afterwards the mean over the previous call's pairs of
+    6 / r^3 (r: the pair's inlier ratio; between 256 and 1024, 128 for a nearly outlier-free pair) — 80 % outliers: ~750; 50 %: 256; none: 128 — for
+    runs of at least 8192 certain iterations, per estimator, never under MDRP_CHUNKS.  Records and masks of the same batch are identical whatever
+    the length was."""
     from mdrp_amd import _capi, synth
     B, N = 48, 600
     ro = _capi.ransac_opt_from_dict({"max_iterations": 8192, "min_iterations": 8192, "max_epipolar_error": 2.0, "max_reproj_error": 16.0})
