@@ -121,7 +121,7 @@ def test_every_pair_of_the_bench_batch_vs_oracle_fixture(capi, golden, workload)
 GPU_MINUS_ORACLE_LO = {
     "calib_p3p_n2000_i10k": {},
     "calib_shift_n2000_i10k": {},
-    "shared_n2000_i10k": {957: -1},
+    "shared_n2000_i10k": {957: -1},  # (here the HIP path agrees with the REFERENCE and the oracle does not: right by an accident of contraction, not by construction)
     "varying_n5000_i10k": {},
 }
 # pairs whose final MODEL differs from the reference's by more than north_star's 1e-6: the reference's relpose_monodepth_3pt returns a NaN
