@@ -424,9 +424,9 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
         // exact sweep: 75 % outliers 124 k pairs/s with 128, 142 k with 256, 147 k with 384; 85 %: 78 k / 93 k / 104 k (136 k with 1024).  The
         // outlier-free shape pays for it the other way round (every hypothesis of the first chunk is a good one and is scored in full: 72.3 k with
         // 128, 71.1 k with 256, 69.5 k with 384).  Default: 256 for the 3-point estimators where the run is long enough to pay for it (a sixteenth of
-        // the iterations that certainly run, between 128 and 256), 512 for the 5-point one (solver-bound: flat), 128,1024 for the 7-point one
+        // the iterations that certainly run, between 128 and 256), up to 512 for the 5-point one by the same rule (solver-bound: flat), 128,1024 for the 7-point one
         // (above); MDRP_CHUNKS=384 or 128,1024 for data with fewer than one inlier in four.
-        std::string spec = e ? e : (kind == MDRP_FUNDAMENTAL_7PT ? "128,1024" : (kind == MDRP_RELPOSE_5PT ? "512" : "128"));
+        std::string spec = e ? e : (kind == MDRP_FUNDAMENTAL_7PT ? "128,1024" : "128");
         size_t pos = 0;
         while (pos < spec.size() && (int)lead.size() < mdrp_handle::NC_MAX - 1) {
             const size_t q = spec.find(',', pos);
@@ -435,6 +435,7 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (q == std::string::npos) break;
             pos = q + 1;
         }
+        if (!e && kind == MDRP_RELPOSE_5PT) lead.assign(1, std::min<uint64_t>(512, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
         if (!e && !classic) {
             lead.assign(1, std::min<uint64_t>(256, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
             // ... and where the handle's previous call with this estimator (kind 0..2 here) has results to go by: the mean over its pairs of what each

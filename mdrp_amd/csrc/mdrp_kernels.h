@@ -113,17 +113,6 @@ struct RunParams {
     int32_t *inl_stat;  // [2]: sum over the pairs of first_chunk_wish(inlier ratio of the result), and their number — the host sizes the NEXT call's first chunk from the mean
 };
 
-// The first chunk of a run is scored exactly in full (nothing has set a bar yet); everything behind it meets the bar it leaves, and a pair whose
-// first chunk holds no outlier-free sample has none.  With r the pair's inlier ratio and k its sample size: 6 / r^k iterations — six such samples
-// expected — between 256 and 1024; 128 where (nearly) every sample is one.  Measured at 0 / 50 / 75 / 85 % outliers (mdrp_capi.hip run_pass).
-MDRP_HD int32_t first_chunk_wish(double r, int k) {
-    if (!(r > 0.05)) r = 0.05;
-    double p = r;
-    for (int i = 1; i < k; ++i) p *= r;
-    const double want = 6.0 / p;
-    return want <= 16.0 ? 128 : (want >= 1024.0 ? 1024 : (want <= 256.0 ? 256 : (int32_t)want));
-}
-
 // ------------------------------------------------------------------------------------------------ reductions: cross-lane sums (gfx950)
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {

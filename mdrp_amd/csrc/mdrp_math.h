@@ -1300,4 +1300,15 @@ MDRP_HD void draw_sample3(uint64_t n, uint64_t &state, uint32_t &i0, uint32_t &i
     do { i2 = (uint32_t)((uint64_t)(int64_t)splitmix_int(state) % n); } while (i2 == i0 || i2 == i1);
 }
 
+// The first chunk of a run is scored exactly in full (nothing has set a bar yet); everything behind it meets the bar it leaves, and a pair whose
+// first chunk holds no outlier-free sample has none.  With r the pair's inlier ratio and k its sample size: 6 / r^k iterations — six such samples
+// expected — between 256 and 1024; 128 where (nearly) every sample is one.  Measured at 0 / 50 / 75 / 85 % outliers (mdrp_capi.hip run_pass).
+MDRP_HD int32_t first_chunk_wish(double r, int k) {
+    if (!(r > 0.05)) r = 0.05;
+    double p = r;
+    for (int i = 1; i < k; ++i) p *= r;
+    const double want = 6.0 / p;
+    return want <= 16.0 ? 128 : (want >= 1024.0 ? 1024 : (want <= 256.0 ? 256 : (int32_t)want));
+}
+
 } // namespace mdrp

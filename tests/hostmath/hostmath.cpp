@@ -182,6 +182,7 @@ extern "C" int hm_bound_check(const double *E, const double *x1, const double *x
     return (*lb <= (double)exact) && (cu >= ce);
 }
 
+extern "C" int hm_first_chunk_wish(double r, int k) { return first_chunk_wish(r, k); }
 // ---- non-monodepth baselines (mdrp_classic_math.h)
 #include "../../mdrp_amd/csrc/mdrp_classic_math.h"
 extern "C" {

@@ -273,3 +273,18 @@ def test_filters_are_conservative_for_model_matrices_of_any_magnitude(hm):
             cu, ce = C.c_long(), C.c_long()
             assert hm.hm_bound_check(P(E), P(x1), P(x2), C.c_long(n), C.c_double(thr), C.byref(lb), C.byref(ex), C.byref(cu), C.byref(ce)) == 1, (e, kind, lb.value, ex.value)
     assert judged >= 20  # ... and across the ordinary magnitudes the count filter still retires something
+
+
+def test_first_chunk_wish_of_a_pair(hm):
+    """mdrp_math.h first_chunk_wish: what a pair of inlier ratio r (sample size k) would like as the first chunk of its run — 6 / r^k iterations between
+    256 and 1024, 128 when nearly every sample is outlier-free; the host averages it over the pairs of a call to size the next one's (mdrp_capi.hip)."""
+    import ctypes as C
+    hm.hm_first_chunk_wish.restype = C.c_int
+    hm.hm_first_chunk_wish.argtypes = [C.c_double, C.c_int]
+    w = lambda r, k=3: hm.hm_first_chunk_wish(r, k)
+    assert [w(1.0), w(0.8), w(0.72), w(0.7)] == [128, 128, 256, 256]     # 6 / r^3 <= 16 up to r = 0.721
+    assert [w(0.5), w(0.3), w(0.25), w(0.2), w(0.18), w(0.15), w(0.0)] == [256, 256, 384, 749, 1024, 1024, 1024]  # (0.2^3 rounds up: 6 / 0.008000000000000002)
+    assert w(float("nan")) == 1024
+    assert [w(0.5, 5), w(0.5, 7), w(0.9, 7)] == [256, 768, 128]
+    assert all(w(a) >= w(b) for a, b in zip(np.linspace(0.01, 0.71, 80), np.linspace(0.02, 0.72, 80)))  # monotone below the cut-off
+
