@@ -31,12 +31,26 @@ def oracle_case(a):
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 777
+    ref_file = sys.argv[3] if len(sys.argv) > 3 else None   # tests/tools/gen_options_ref_table.py: the REFERENCE BINARY's results instead of the oracle's
     t = poc.table(seed, cases)
     jobs = [(name, j, t[j]) for name in OPTIONS_NAMES for j in range(cases)]
     t0 = time.time()
-    with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:   # before the GPU is touched
-        orc = {(r[0], r[1]): r for r in pool.map(oracle_case, jobs, chunksize=8)}
+    if ref_file:
+        g = np.load(ref_file)
+        assert int(g["seed"]) == seed and int(g["cases"]) >= cases, "reference table of another seed / size"
+        orc = {}
+        for name in OPTIONS_NAMES:
+            kind = OPTIONS_KINDS[name][0]
+            for j in range(cases):
+                st = g[name + "_stats"][j]
+                m = g[name + "_model"][j][:int(g[name + "_model_len"][j])]
+                n = int(t[j][0])
+                orc[(name, j)] = (name, j, np.r_[m, 1.0, 1.0] if kind == 0 else m, (int(st[0]), int(st[1]), int(st[2])), np.packbits(np.unpackbits(g[name + "_mask"][j])[:n]))
+    else:
+        with mp.get_context("fork").Pool(min(32, os.cpu_count() or 1)) as pool:   # before the GPU is touched
+            orc = {(r[0], r[1]): r for r in pool.map(oracle_case, jobs, chunksize=8)}
     t_orc = time.time() - t0
+    against = "the REFERENCE BINARY" if ref_file else "the oracle"
     from mdrp_amd import _capi as capi
     h = capi.default_handle(0)
     t0 = time.time()
@@ -61,8 +75,8 @@ def main():
             same += ok; lo += int(r["refinements"]) != st[0]
             if not ok:
                 bad.append(j)
-        print(f"{name}: {same} / {cases} cases identical to the oracle (iterations, inliers, mask, model 1e-6); LO count differs on {lo}; not identical: {bad}", flush=True)
-    print(f"oracle {t_orc:.0f} s on the host cores, HIP path {time.time() - t0:.0f} s ({4 * cases} calls of one pair)")
+        print(f"{name}: {same} / {cases} cases identical to {against} (iterations, inliers, mask, model 1e-6); LO count differs on {lo}; not identical: {bad}", flush=True)
+    print(f"{'reference table loaded in' if ref_file else 'oracle'} {t_orc:.0f} s on the host cores, HIP path {time.time() - t0:.0f} s ({4 * cases} calls of one pair)")
 
 
 if __name__ == "__main__":
