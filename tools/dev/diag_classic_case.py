@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""GPU box.  One case of tests/tools/stress_options_classic.py in detail:  python tools/dev/diag_classic_case.py NAME SEED REF.npz J [J ...]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+import stress_options_classic as soc  # noqa: E402
+from helpers import CLASSIC_OPTIONS_KINDS as KINDS, classic_options_cameras, classic_options_pair  # noqa: E402
+from oracle import pyorc as po  # noqa: E402
+
+
+def main():
+    import mdrp_amd.poselib as poselib
+    from mdrp_amd import _capi
+    name, seed, ref = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    g = np.load(ref)
+    t = soc.case_table(seed, int(g["cases"]))
+    kind = KINDS[name]
+    loss_name = {v: k for k, v in _capi.LOSS_TYPES.items()}
+    for j in [int(a) for a in sys.argv[4:]]:
+        row = t[j]; n = int(row[0])
+        p = classic_options_pair(name, j, row)
+        ro = {"max_iterations": int(row[5]), "min_iterations": int(row[6]), "max_epipolar_error": float(row[3]), "seed": int(row[4])}
+        bo = {"max_iterations": int(row[9]), "loss_type": loss_name[int(row[7])], "loss_scale": float(row[8]), "gradient_tol": 1e-10}
+        c1, c2 = classic_options_cameras(row)
+        if kind == 3:
+            cams = [{"model": "PINHOLE" if c[0] else "SIMPLE_PINHOLE", "width": 1600, "height": 1200, "params": c[1]} for c in (c1, c2)]
+            pose, info = poselib.estimate_relative_pose(p["x1"], p["x2"], cams[0], cams[1], ro, bo)
+            m = np.r_[pose.q, pose.t]
+        elif kind == 4:
+            pair, info = poselib.estimate_shared_focal_relative_pose(p["x1"], p["x2"], (float(row[12]), float(row[13])), ro, bo)
+            m = np.r_[pair.pose.q, pair.pose.t, pair.camera1.params[0]]
+        else:
+            F, info = poselib.estimate_fundamental(p["x1"], p["x2"], ro, bo)
+            m = np.asarray(F).reshape(-1)
+        oro = po.ransac_opt(**ro)
+        obo = po.bundle_opt(max_iterations=int(row[9]), loss_type=int(row[7]), loss_scale=float(row[8]), gradient_tol=1e-10)
+        cc = (po.cam_flat(*c1), po.cam_flat(*c2)) if kind == 3 else (None, None)
+        mo, st, mask = po.estimate_classic(kind, p["x1"], p["x2"], oro, obo, cc[0], cc[1], pp=(float(row[12]), float(row[13])))
+        mo = np.asarray(mo, float).reshape(-1)
+        r, ist = g[f"{name}_model"][j], g[f"{name}_istats"][j]
+        diff = soc.fund_diff if kind == 5 else (lambda a, b: soc.pose_diff(a[:7], b[:7]))
+        print(f"case {j}: N {n} options {ro} {bo}")
+        print(f"  reference (LO, it, inl) {tuple(int(x) for x in ist)} model {r[:8]}")
+        print(f"  oracle    {(st.refinements, st.iterations, st.num_inliers)} model {mo[:8]}  diff to reference {diff(mo, r):.2e}")
+        print(f"  hip       {(info['refinements'], info['iterations'], info['num_inliers'])} model {m[:8]}  diff to reference {diff(m, r):.2e}, to oracle {diff(m, mo):.2e}; "
+              f"mask bits vs reference {int((np.array(info['inliers'], dtype=np.uint8) != np.unpackbits(g[f'{name}_mask'][j])[:n]).sum())}")
+
+
+if __name__ == "__main__":
+    main()
