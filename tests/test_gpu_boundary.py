@@ -304,6 +304,10 @@ def test_first_chunk_follows_the_inlier_ratio_of_the_previous_call_and_changes_n
         run(0, clean)
         assert run(0, clean)[2] == 128                          # r ~ 1: 6 -> 128
         assert 512 <= run(1, shared)[2] <= 896                  # the shared-focal estimator's second call
+        # the comparison rows keep fixed schedules: 5-point a sixteenth of the certain iterations up to 512, 7-point 128 (| 1024 | rest)
+        cl = lambda kind, opt: (h.estimate_batch(kind, half[0], half[1], None, None, opt, bo, None, cams if kind == 3 else None, cams if kind == 3 else None),
+                                int(h.last_stats()["first_chunk"]))[1]
+        assert [cl(3, ro), cl(3, ro_short), cl(5, ro), cl(5, ro_short)] == [512, 128, 128, 128]
     finally:
         h.close()
 
