@@ -135,6 +135,8 @@ struct mdrp_handle {
     int64_t fuse_gate_timeouts = 0, fuse_wait_timeouts = 0; // of the last call
     int64_t first_chunk = 0;                                // of the last call (mdrp_stats::first_chunk)
     double seen_wish[3] = {-1.0, -1.0, -1.0};               // per monodepth estimator: mean first_chunk_wish over the results of its last call that measured it
+    int32_t *wish_host = nullptr; hipEvent_t ev_wish = nullptr; // unfused runs: the two sums are copied behind the final refinements and read by the next call
+    int wish_kind = -1;                                     // ... of this estimator, once ev_wish has completed (-1: nothing pending)
     bool fuse_disabled = false;       // a bounded wait of the fused tail expired on this handle: streams do not overlap here, run unfused ...
     int fuse_retry_in = 0;            // ... for this many API calls, then try the fused tail again (a busy moment on a shared GPU is not a profiler)
     int fuse_backoff = 64;            // ... doubled after every consecutive expired wait (capped), reset by a call whose fused tail ran through
@@ -434,6 +436,10 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
             if (v > 0) lead.push_back((uint64_t)v);
             if (q == std::string::npos) break;
             pos = q + 1;
+        }
+        if (h->wish_kind >= 0 && hipEventQuery(h->ev_wish) == hipSuccess) { // an unfused run's sums have arrived
+            if (h->wish_host[1] > 0) h->seen_wish[h->wish_kind] = (double)h->wish_host[0] / (double)h->wish_host[1];
+            h->wish_kind = -1;
         }
         if (!e && kind == MDRP_RELPOSE_5PT) lead.assign(1, std::min<uint64_t>(512, std::max<uint64_t>(128, certain / 16 / 64 * 64)));
         if (!e && !classic) {
@@ -805,6 +811,11 @@ int run_pass(mdrp_handle *h, int kind, const double *x1, const double *x2, const
                          h->lm_stats.as<unsigned long long>() + 2, (const int32_t *)nullptr, (int32_t *)nullptr, 0ull, (unsigned long long *)nullptr);
     }
     HIPCHK(hipEventRecord(f1, s));
+    if (rp.inl_stat && h->wish_kind < 0) { // (the fused tail's sums came with the progress record; these arrive when the stream gets here: the next call looks)
+        HIPCHK(hipMemcpyAsync(h->wish_host, rp.inl_stat, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(h->ev_wish, s));
+        h->wish_kind = kind;
+    }
     HIPCHK(hipGetLastError());
     return MDRP_OK;
 }
@@ -959,6 +970,8 @@ static int create_handle(int device, hipStream_t stream, bool own_stream, mdrp_h
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipHostMalloc((void **)&h->progress_host, sizeof(Progress), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&h->lm_stats_host, LM_STATS_BYTES, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&h->wish_host, 2 * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_wish, hipEventDisableTiming));
     std::memset(h->lm_stats_host, 0, LM_STATS_BYTES);
     {   // high priority: the few long LO wavefronts should be placed first, the sweeps fill the remaining slots
         int prio_lo = 0, prio_hi = 0;
@@ -1001,6 +1014,8 @@ void mdrp_destroy(mdrp_handle *h) {
     for (DevBuf *b : bufs) b->release();
     for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (h->progress_host) (void)hipHostFree(h->progress_host);
+    if (h->wish_host) (void)hipHostFree(h->wish_host);
+    if (h->ev_wish) (void)hipEventDestroy(h->ev_wish);
     if (h->lm_stats_host) (void)hipHostFree(h->lm_stats_host);
     if (h->params_host) (void)hipHostFree(h->params_host);
     if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }

@@ -304,6 +304,12 @@ def test_first_chunk_follows_the_inlier_ratio_of_the_previous_call_and_changes_n
         run(0, clean)
         assert run(0, clean)[2] == 128                          # r ~ 1: 6 -> 128
         assert 512 <= run(1, shared)[2] <= 896                  # the shared-focal estimator's second call
+        # the shift solver runs its final refinements unfused, behind the last progress record: its sums arrive with an event the next call looks at
+        ro_shift = _capi.ransac_opt_from_dict({"max_iterations": 8192, "min_iterations": 8192, "max_epipolar_error": 2.0, "max_reproj_error": 16.0,
+                                               "monodepth_estimate_shift": True})
+        run(0, clean)                                          # (the calibrated estimators share one history: back to 128 ...)
+        assert run(0, dirty, ro_shift)[2] == 128
+        assert 512 <= run(0, dirty, ro_shift)[2] <= 896         # ... and up again from the shift solver's own results
         # the comparison rows keep fixed schedules: 5-point a sixteenth of the certain iterations up to 512, 7-point 128 (| 1024 | rest)
         cl = lambda kind, opt: (h.estimate_batch(kind, half[0], half[1], None, None, opt, bo, None, cams if kind == 3 else None, cams if kind == 3 else None),
                                 int(h.last_stats()["first_chunk"]))[1]
