@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""GPU box.  One case of tests/tools/stress_options_classic.py in detail:  python tools/dev/diag_classic_case.py NAME SEED REF.npz J [J ...]"""
+"""GPU box.  One case of tests/tools/stress_options_classic.py in detail:  python tests/tools/diag_classic_case.py NAME SEED REF.npz J [J ...]"""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")  # tests/tools -> repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 import stress_options_classic as soc  # noqa: E402
 from helpers import CLASSIC_OPTIONS_KINDS as KINDS, classic_options_cameras, classic_options_pair  # noqa: E402

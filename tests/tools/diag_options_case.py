@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""GPU box.  One case of tests/tools/stress_options.py in detail:  python tools/dev/diag_options_case.py NAME SEED CASES J [J ...]
+"""GPU box.  One case of tests/tools/stress_options.py in detail:  python tests/tools/diag_options_case.py NAME SEED CASES J [J ...]
 prints options, the oracle's and the HIP path's statistics, the model difference and the number of differing mask bits."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")  # tests/tools -> repository root
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 from helpers import OPTIONS_KINDS, options_cameras, options_dicts, options_pair, model_diff  # noqa: E402
 import probe_options_campaign as poc  # noqa: E402
