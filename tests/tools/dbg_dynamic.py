@@ -1,3 +1,4 @@
+"""GPU box.  One dynamic-stopping fixture case by case: reference statistics, the HIP path and the oracle side by side:  python tests/tools/dbg_dynamic.py [name]"""
 import sys, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
